@@ -1,0 +1,30 @@
+"""Build libp2p_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libp2p_hip.so")
+SOURCES = [os.path.join(CSRC, "p2p_kernels.hip"), os.path.join(CSRC, "p2p_host.cpp")]
+DEPS = SOURCES + [os.path.join(CSRC, "p2p_device.h"), os.path.join(HERE, "..", "include", "p2p_hip.h")]
+# -ffp-contract=off: the coordinate maths must round exactly where NumPy rounds (no fused a*b+c
+# unless written as fmaf).  IEEE divide / sqrt are hipcc's default for fp32.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-Wall"]
+
+
+def build(force=False, verbose=False):
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    tmp = OUT + ".tmp.%d" % os.getpid()
+    cmd = [hipcc] + FLAGS + ["-o", tmp] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(tmp, OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

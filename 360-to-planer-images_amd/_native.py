@@ -1,0 +1,321 @@
+"""ctypes binding of libp2p_hip.so (the C ABI declared in include/p2p_hip.h).
+
+There is NO CPU fallback: if the shared library is missing this module raises at
+load time, and if no HIP device is usable every compute call raises P2PError
+(P2P_ERR_NO_DEVICE).  Build the library with `python -c "import __graft_entry__ as g; g.build()"`
+or `python 360-to-planer-images_amd/_build.py`.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libp2p_hip.so")
+
+P2P_OK = 0
+P2P_ERR_INVALID, P2P_ERR_NO_DEVICE, P2P_ERR_HIP, P2P_ERR_OOM, P2P_ERR_STATE = -1, -2, -3, -4, -5
+BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_101 = 0, 1, 2, 3, 4
+FLAG_KEEP_COORDS = 1
+
+# every symbol include/p2p_hip.h declares (tests check the library exports exactly these)
+ABI_SYMBOLS = (
+    "p2p_version", "p2p_last_error", "p2p_device_count",
+    "p2p_remap_views_u8", "p2p_remap_views_maps_u8", "p2p_remap_maps_u8",
+    "p2p_build_pitch_map", "p2p_build_yaw_row",
+    "p2p_ctx_create", "p2p_ctx_destroy", "p2p_ctx_synchronize",
+    "p2p_job_create", "p2p_job_destroy", "p2p_job_set_pano", "p2p_job_set_maps", "p2p_job_run",
+    "p2p_job_get_views", "p2p_job_kernel_ms", "p2p_job_kernel_ms_last", "p2p_job_device_out", "p2p_job_get_coords",
+    "p2p_job_get_yaw_tables",
+)
+
+
+class P2PError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libp2p_hip: %s (status %d)" % (message, code))
+        self.code = code
+
+
+class JobDesc(ctypes.Structure):
+    _fields_ = [
+        ("pw", ctypes.c_int32), ("ph", ctypes.c_int32), ("n_panos", ctypes.c_int32),
+        ("n_yaw", ctypes.c_int32), ("yaw_deg", ctypes.POINTER(ctypes.c_int32)),
+        ("n_pitch", ctypes.c_int32), ("pitch_deg", ctypes.POINTER(ctypes.c_int32)),
+        ("fov_deg", ctypes.c_int32), ("ow", ctypes.c_int32), ("oh", ctypes.c_int32),
+        ("flags", ctypes.c_int32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load libp2p_hip.so once.  Raises OSError (with build instructions) if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(
+            "%s is missing: the HIP extension has not been built and there is no CPU fallback. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` in the repository root." % LIB_PATH
+        )
+    L = ctypes.CDLL(LIB_PATH)
+    c_int, c_i64, c_vp, c_dbl = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_double
+    L.p2p_version.restype = ctypes.c_char_p
+    L.p2p_version.argtypes = []
+    L.p2p_last_error.restype = ctypes.c_char_p
+    L.p2p_last_error.argtypes = []
+    L.p2p_device_count.restype = c_int
+    L.p2p_device_count.argtypes = []
+    L.p2p_remap_views_u8.restype = c_int
+    L.p2p_remap_views_u8.argtypes = [c_vp, c_int, c_int, c_i64, c_vp, c_int, c_vp, c_int, c_int,
+                                     c_int, c_int, c_vp, c_int, c_int]
+    L.p2p_remap_views_maps_u8.restype = c_int
+    L.p2p_remap_views_maps_u8.argtypes = [c_vp, c_int, c_int, c_i64, c_vp, c_int, c_vp, c_vp, c_int,
+                                          c_int, c_int, c_vp, c_int]
+    L.p2p_remap_maps_u8.restype = c_int
+    L.p2p_remap_maps_u8.argtypes = [c_vp, c_int, c_int, c_i64, c_int, c_vp, c_vp, c_int, c_int, c_vp,
+                                    c_int, c_vp, c_int]
+    L.p2p_build_pitch_map.restype = c_int
+    L.p2p_build_pitch_map.argtypes = [c_int, c_int, c_dbl, c_dbl, c_int, c_int, c_vp, c_vp, c_int]
+    L.p2p_build_yaw_row.restype = c_int
+    L.p2p_build_yaw_row.argtypes = [c_int, c_dbl, c_vp, c_int]
+    L.p2p_ctx_create.restype = c_int
+    L.p2p_ctx_create.argtypes = [c_int, ctypes.POINTER(c_vp)]
+    L.p2p_ctx_destroy.restype = None
+    L.p2p_ctx_destroy.argtypes = [c_vp]
+    L.p2p_ctx_synchronize.restype = c_int
+    L.p2p_ctx_synchronize.argtypes = [c_vp]
+    L.p2p_job_create.restype = c_int
+    L.p2p_job_create.argtypes = [c_vp, ctypes.POINTER(JobDesc), ctypes.POINTER(c_vp)]
+    L.p2p_job_destroy.restype = None
+    L.p2p_job_destroy.argtypes = [c_vp]
+    L.p2p_job_set_pano.restype = c_int
+    L.p2p_job_set_pano.argtypes = [c_vp, c_int, c_vp, c_i64]
+    L.p2p_job_set_maps.restype = c_int
+    L.p2p_job_set_maps.argtypes = [c_vp, c_vp, c_vp, c_vp]
+    L.p2p_job_run.restype = c_int
+    L.p2p_job_run.argtypes = [c_vp]
+    L.p2p_job_get_views.restype = c_int
+    L.p2p_job_get_views.argtypes = [c_vp, c_int, c_vp]
+    L.p2p_job_kernel_ms.restype = c_int
+    L.p2p_job_kernel_ms.argtypes = [c_vp, ctypes.POINTER(ctypes.c_float)]
+    L.p2p_job_kernel_ms_last.restype = c_int
+    L.p2p_job_kernel_ms_last.argtypes = [c_vp, c_vp, c_int]
+    L.p2p_job_device_out.restype = c_vp
+    L.p2p_job_device_out.argtypes = [c_vp, ctypes.POINTER(c_i64)]
+    L.p2p_job_get_coords.restype = c_int
+    L.p2p_job_get_coords.argtypes = [c_vp, c_vp]
+    L.p2p_job_get_yaw_tables.restype = c_int
+    L.p2p_job_get_yaw_tables.argtypes = [c_vp, c_vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != P2P_OK:
+        raise P2PError(rc, lib().p2p_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    return lib().p2p_device_count()
+
+
+def version():
+    return lib().p2p_version().decode()
+
+
+def _i32(seq):
+    a = np.ascontiguousarray(np.asarray(seq, dtype=np.int64))
+    if a.ndim != 1:
+        raise ValueError("angle lists must be one-dimensional")
+    if a.size and (a.min() < -(2**31) or a.max() >= 2**31):
+        raise ValueError("angle out of int32 range")
+    return a.astype(np.int32)
+
+
+def as_image(a, what="image"):
+    a = np.asarray(a)
+    if a.dtype != np.uint8:
+        raise TypeError("%s must be uint8 (got %s)" % (what, a.dtype))
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("%s must have shape (H, W, 3), got %s" % (what, a.shape))
+    if a.strides[2] != 1 or a.strides[1] != 3 or a.strides[0] < 3 * a.shape[1]:
+        a = np.ascontiguousarray(a)
+    return a
+
+
+def remap_views(pano, yaw_deg, pitch_deg, fov_deg, ow, oh, device=0):
+    """p2p_remap_views_u8 -> uint8 [n_yaw][n_pitch][oh][ow][3]."""
+    pano = as_image(pano, "pano_image")
+    yaw, pitch = _i32(yaw_deg), _i32(pitch_deg)
+    ph, pw = pano.shape[:2]
+    out = np.empty((yaw.size, pitch.size, int(oh), int(ow), 3), dtype=np.uint8)
+    check(lib().p2p_remap_views_u8(pano.ctypes.data, pw, ph, pano.strides[0],
+                                   yaw.ctypes.data, yaw.size, pitch.ctypes.data, pitch.size,
+                                   int(fov_deg), int(ow), int(oh), out.ctypes.data, int(device), 0))
+    return out
+
+
+def remap_views_maps(pano, yaw_rows, U, V, device=0):
+    """p2p_remap_views_maps_u8: caller float maps.  yaw_rows [n_yaw][pw]; U, V [n_pitch][oh][ow]."""
+    pano = as_image(pano, "pano_image")
+    ph, pw = pano.shape[:2]
+    yaw_rows = np.ascontiguousarray(yaw_rows, dtype=np.float32)
+    U = np.ascontiguousarray(U, dtype=np.float32)
+    V = np.ascontiguousarray(V, dtype=np.float32)
+    if yaw_rows.ndim != 2 or yaw_rows.shape[1] != pw:
+        raise ValueError("yaw_rows must be [n_yaw][pano_width]")
+    if U.ndim != 3 or U.shape != V.shape:
+        raise ValueError("U and V must both be [n_pitch][oh][ow]")
+    n_pitch, oh, ow = U.shape
+    out = np.empty((yaw_rows.shape[0], n_pitch, oh, ow, 3), dtype=np.uint8)
+    check(lib().p2p_remap_views_maps_u8(pano.ctypes.data, pw, ph, pano.strides[0],
+                                        yaw_rows.ctypes.data, yaw_rows.shape[0],
+                                        U.ctypes.data, V.ctypes.data, n_pitch, ow, oh,
+                                        out.ctypes.data, int(device)))
+    return out
+
+
+def remap_maps(src, U, V, border=BORDER_CONSTANT, border_value=None, device=0):
+    """p2p_remap_maps_u8 == cv2.remap(src, U, V, INTER_LINEAR, borderMode=border)."""
+    src = np.asarray(src)
+    if src.dtype != np.uint8:
+        raise TypeError("src must be uint8")
+    squeeze = src.ndim == 2
+    if squeeze:
+        src = src[:, :, None]
+    if src.ndim != 3 or src.shape[2] not in (1, 3, 4):
+        raise ValueError("src must be (H, W), (H, W, 1), (H, W, 3) or (H, W, 4)")
+    src = np.ascontiguousarray(src)
+    sh, sw, cn = src.shape
+    U = np.ascontiguousarray(U, dtype=np.float32)
+    V = np.ascontiguousarray(V, dtype=np.float32)
+    if U.ndim != 2 or U.shape != V.shape:
+        raise ValueError("U and V must be two 2-D arrays of one shape")
+    oh, ow = U.shape
+    out = np.empty((oh, ow, cn), dtype=np.uint8)
+    bv = None
+    if border_value is not None:
+        bv = np.zeros(4, dtype=np.uint8)
+        bv[:cn] = np.asarray(border_value, dtype=np.uint8).ravel()[:cn]
+    check(lib().p2p_remap_maps_u8(src.ctypes.data, sw, sh, src.strides[0], cn, U.ctypes.data, V.ctypes.data,
+                                  ow, oh, out.ctypes.data, int(border),
+                                  None if bv is None else bv.ctypes.data, int(device)))
+    return out[:, :, 0] if squeeze else out
+
+
+def build_pitch_map(ow, oh, fov_rad, pitch_rad, pw, ph, device=0):
+    U = np.empty((int(oh), int(ow)), dtype=np.float32)
+    V = np.empty_like(U)
+    check(lib().p2p_build_pitch_map(int(ow), int(oh), float(fov_rad), float(pitch_rad), int(pw), int(ph),
+                                    U.ctypes.data, V.ctypes.data, int(device)))
+    return U, V
+
+
+def build_yaw_row(pw, yaw_rad, device=0):
+    row = np.empty(int(pw), dtype=np.float32)
+    check(lib().p2p_build_yaw_row(int(pw), float(yaw_rad), row.ctypes.data, int(device)))
+    return row
+
+
+class Context:
+    """p2p_ctx: one device, one HIP stream."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        check(lib().p2p_ctx_create(int(device), ctypes.byref(self._h)))
+        self.device = int(device)
+
+    def synchronize(self):
+        check(lib().p2p_ctx_synchronize(self._h))
+
+    def close(self):
+        if self._h:
+            lib().p2p_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Job:
+    """p2p_job: n_panos resident panoramas of one size x (yaw x pitch) views, outputs resident in HBM."""
+
+    def __init__(self, ctx, pw, ph, n_panos, yaw_deg, pitch_deg, fov_deg, ow, oh, flags=0):
+        self.ctx = ctx
+        self._yaw, self._pitch = _i32(yaw_deg), _i32(pitch_deg)
+        d = JobDesc(int(pw), int(ph), int(n_panos),
+                    self._yaw.size, self._yaw.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                    self._pitch.size, self._pitch.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                    int(fov_deg), int(ow), int(oh), int(flags))
+        self._h = ctypes.c_void_p()
+        check(lib().p2p_job_create(ctx._h, ctypes.byref(d), ctypes.byref(self._h)))
+        self.pw, self.ph, self.n_panos = int(pw), int(ph), int(n_panos)
+        self.n_yaw, self.n_pitch, self.ow, self.oh = self._yaw.size, self._pitch.size, int(ow), int(oh)
+
+    def set_pano(self, index, pano):
+        pano = as_image(pano, "pano_image")
+        if pano.shape[:2] != (self.ph, self.pw):
+            raise ValueError("panorama is %s, job expects (%d, %d)" % (pano.shape[:2], self.ph, self.pw))
+        check(lib().p2p_job_set_pano(self._h, int(index), pano.ctypes.data, pano.strides[0]))
+
+    def set_maps(self, yaw_rows, U, V):
+        U = np.ascontiguousarray(U, dtype=np.float32)
+        V = np.ascontiguousarray(V, dtype=np.float32)
+        if U.shape != (self.n_pitch, self.oh, self.ow) or V.shape != U.shape:
+            raise ValueError("U, V must be [n_pitch][oh][ow]")
+        rows_p = None
+        if yaw_rows is not None:
+            yaw_rows = np.ascontiguousarray(yaw_rows, dtype=np.float32)
+            if yaw_rows.shape != (self.n_yaw, self.pw):
+                raise ValueError("yaw_rows must be [n_yaw][pw]")
+            rows_p = yaw_rows.ctypes.data
+        check(lib().p2p_job_set_maps(self._h, rows_p, U.ctypes.data, V.ctypes.data))
+
+    def run(self):
+        check(lib().p2p_job_run(self._h))
+
+    def kernel_ms(self):
+        ms = ctypes.c_float()
+        check(lib().p2p_job_kernel_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def kernel_ms_last(self, n):
+        out = np.empty(int(n), dtype=np.float32)
+        check(lib().p2p_job_kernel_ms_last(self._h, out.ctypes.data, int(n)))
+        return out
+
+    def get_views(self, index=0):
+        out = np.empty((self.n_yaw, self.n_pitch, self.oh, self.ow, 3), dtype=np.uint8)
+        check(lib().p2p_job_get_views(self._h, int(index), out.ctypes.data))
+        return out
+
+    def get_coords(self):
+        out = np.empty((self.n_pitch, self.oh, self.ow, 2), dtype=np.int32)
+        check(lib().p2p_job_get_coords(self._h, out.ctypes.data))
+        return out
+
+    def get_yaw_tables(self):
+        out = np.empty((self.n_yaw, self.pw), dtype=np.uint32)
+        check(lib().p2p_job_get_yaw_tables(self._h, out.ctypes.data))
+        return out
+
+    def device_out(self):
+        n = ctypes.c_int64()
+        p = lib().p2p_job_device_out(self._h, ctypes.byref(n))
+        return p, n.value
+
+    def close(self):
+        if self._h:
+            lib().p2p_job_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

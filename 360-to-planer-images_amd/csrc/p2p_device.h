@@ -1,0 +1,66 @@
+// p2p_device.h -- structures and launchers shared by the device code (p2p_kernels.hip) and the
+// host side of the C ABI (p2p_host.cpp).  Not part of the public ABI (that is include/p2p_hip.h).
+#ifndef P2P_DEVICE_H
+#define P2P_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace p2p {
+
+constexpr int TILE_W = 32;          // output tile of one workgroup
+constexpr int TILE_H = 8;
+constexpr int VIEWS_BLOCK = TILE_W * TILE_H;
+constexpr int LDS_TILE_CAP = 4096;  // dwords of yaw-resampled panorama footprint per LDS buffer
+
+// scalars of precompute_pitch_mapping (P:114-175) that NumPy evaluates once, on the host, in
+// float64 and then uses as float32
+struct MapGeom {
+    float half_w, half_h;  // W / 2.0, H / 2.0          (P:129-130)
+    float focal;           // 0.5 * W / tan(FOV / 2)    (P:119, cast at P:131)
+    float pw_f, ph_f;      // panorama size as float32  (P:167-173)
+};
+
+struct PitchConst {
+    float c, s;  // cos / sin of the pitch angle, float64 -> float32 (R_pitch dtype, P:142-149)
+};
+
+struct ViewsParams {
+    const uint8_t* src;      // [n_panos] panoramas, each ph rows of src_pitch bytes (BGR interleaved)
+    size_t pano_stride;      // bytes between panoramas
+    int src_pitch;           // bytes between rows (>= 3 * pw)
+    int pw, ph;
+    const uint32_t* ytab;    // [n_yaw][pw] packed yaw-table entries: 3*ix | fx << 20
+    int n_yaw, n_pitch, n_panos;
+    int pairs_per_block;     // (panorama, yaw) pairs looped over by one workgroup
+    const PitchConst* pitch; // [n_pitch]
+    const float* mapU;       // [n_pitch][oh][ow] caller maps (HOST_MAPS) or nullptr
+    const float* mapV;
+    MapGeom geom;
+    int ow, oh;
+    uint8_t* out;            // [n_panos][n_yaw][n_pitch][oh][ow][3]
+    int32_t* coords;         // optional [n_pitch][oh][ow][2] dump of (sx, sy)
+};
+
+struct RemapParams {
+    const uint8_t* src;
+    int sw, sh, src_pitch;
+    const float* U;
+    const float* V;
+    uint8_t* dst;
+    int ow, oh;
+    int border;
+    uint8_t cval[4];
+};
+
+hipError_t launch_yaw_tables(uint32_t* packed, float* rows, int pw, int n_yaw, const double* yaw_rad,
+                             hipStream_t st);
+hipError_t launch_yaw_pack(uint32_t* packed, const float* rows, size_t n, hipStream_t st);
+hipError_t launch_pitch_map(float* U, float* V, int ow, int oh, const MapGeom& g, float c, float s,
+                            hipStream_t st);
+hipError_t launch_remap_views(const ViewsParams& P, bool host_maps, hipStream_t st);
+hipError_t launch_remap_maps(const RemapParams& P, int cn, hipStream_t st);
+
+}  // namespace p2p
+#endif

@@ -1,0 +1,641 @@
+// p2p_host.cpp -- host side of the C ABI declared in include/p2p_hip.h: argument checking,
+// device buffers, streams, events and kernel launches.  No pixel or map arithmetic happens on
+// the CPU here; the only host maths is the handful of float64 scalars NumPy also evaluates once
+// per call (np.radians, focal length, cos/sin of the pitch: P:64-68, P:85, P:119, P:142-149).
+#include "../../include/p2p_hip.h"
+#include "p2p_device.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? P2P_ERR_OOM : P2P_ERR_HIP, "%s: %s", #expr, \
+                        hipGetErrorString(e_));                                               \
+    } while (0)
+
+constexpr double kPi = 3.141592653589793;  // NPY_PI
+inline double deg2rad(double d) { return d * (kPi / 180.0); }  // np.radians
+
+constexpr size_t kSlack = 256;  // bytes past a panorama: the 8-byte pixel-pair loads may overrun by 5
+
+int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+}  // namespace
+
+struct p2p_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct p2p_job {
+    p2p_ctx* ctx = nullptr;
+    p2p_job_desc d{};
+    std::vector<int32_t> yaw, pitch;
+    uint8_t* d_src = nullptr;
+    size_t pano_stride = 0;
+    int src_pitch = 0;
+    uint8_t* d_out = nullptr;
+    size_t out_bytes = 0;
+    uint32_t* d_ytab = nullptr;
+    double* d_yaw_rad = nullptr;
+    p2p::PitchConst* d_pitch = nullptr;
+    float* d_mapU = nullptr;
+    float* d_mapV = nullptr;
+    float* d_rows = nullptr;
+    int32_t* d_coords = nullptr;
+    p2p::MapGeom geom{};
+    bool host_maps = false;
+    bool ran = false;
+    std::vector<char> pano_set;
+    // ring of event pairs: one per p2p_job_run, so a caller can time K back-to-back launches
+    // without synchronising between them (bench.py's roofline figure)
+    std::vector<hipEvent_t> ev_ring;  // 2 * kEvRing events, created on first run
+    long long runs = 0;
+};
+
+static constexpr int kEvRing = 256;
+
+namespace {
+
+int use_device(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(P2P_ERR_NO_DEVICE, "no HIP device is available (hipGetDeviceCount found none)");
+    if (device < 0 || device >= n)
+        return fail(P2P_ERR_NO_DEVICE, "device %d out of range (have %d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    return P2P_OK;
+}
+
+bool dims_ok(int w, int h) { return w >= 1 && h >= 1 && w < 32767 && h < 32767; }
+
+// one context per (thread, device) for the one-shot entry points
+struct ThreadCtxs {
+    std::map<int, p2p_ctx*> m;
+    ~ThreadCtxs()
+    {
+        for (auto& kv : m)
+            p2p_ctx_destroy(kv.second);
+    }
+};
+thread_local ThreadCtxs g_tctx;
+
+int thread_ctx(int device, p2p_ctx** out)
+{
+    auto it = g_tctx.m.find(device);
+    if (it != g_tctx.m.end()) {
+        HIP_TRY(hipSetDevice(device));
+        *out = it->second;
+        return P2P_OK;
+    }
+    p2p_ctx* c = nullptr;
+    int rc = p2p_ctx_create(device, &c);
+    if (rc != P2P_OK)
+        return rc;
+    g_tctx.m[device] = c;
+    *out = c;
+    return P2P_OK;
+}
+
+int choose_pairs_per_block(const p2p_job_desc& d)
+{
+    const int tiles = ((d.ow + p2p::TILE_W - 1) / p2p::TILE_W) * ((d.oh + p2p::TILE_H - 1) / p2p::TILE_H);
+    const long long base = (long long)tiles * d.n_pitch;
+    const int n_pairs = d.n_panos * d.n_yaw;
+    int forced = env_int("P2P_PAIRS_PER_BLOCK", 0);
+    if (forced > 0)
+        return forced > n_pairs ? n_pairs : forced;
+    // keep >= ~8 workgroups per CU in flight, otherwise amortise the map maths over many pairs
+    const long long target = 256LL * 8;
+    long long z = (target + base - 1) / base;
+    if (z < 1) z = 1;
+    if (z > n_pairs) z = n_pairs;
+    int ppb = (int)((n_pairs + z - 1) / z);
+    const int cap = env_int("P2P_MAX_PAIRS_PER_BLOCK", 16);
+    if (ppb > cap) ppb = cap;
+    return ppb < 1 ? 1 : ppb;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* p2p_version(void) { return "0.1.0-gfx950"; }
+const char* p2p_last_error(void) { return g_err; }
+
+int p2p_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n < 0 ? 0 : n;
+}
+
+int p2p_ctx_create(int device, p2p_ctx** out)
+{
+    if (!out)
+        return fail(P2P_ERR_INVALID, "p2p_ctx_create: out is NULL");
+    *out = nullptr;
+    int rc = use_device(device);
+    if (rc != P2P_OK)
+        return rc;
+    p2p_ctx* c = new (std::nothrow) p2p_ctx();
+    if (!c)
+        return fail(P2P_ERR_OOM, "host allocation failed");
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e != hipSuccess) {
+        p2p_ctx_destroy(c);
+        return fail(P2P_ERR_HIP, "stream/event creation: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return P2P_OK;
+}
+
+void p2p_ctx_destroy(p2p_ctx* c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamDestroy(c->stream);
+    }
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+}
+
+int p2p_ctx_synchronize(p2p_ctx* c)
+{
+    if (!c)
+        return fail(P2P_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return P2P_OK;
+}
+
+void p2p_job_destroy(p2p_job* j)
+{
+    if (!j)
+        return;
+    if (j->ctx) {
+        (void)hipSetDevice(j->ctx->device);
+        (void)hipStreamSynchronize(j->ctx->stream);
+    }
+    (void)hipFree(j->d_src);
+    (void)hipFree(j->d_out);
+    (void)hipFree(j->d_ytab);
+    (void)hipFree(j->d_yaw_rad);
+    (void)hipFree(j->d_pitch);
+    (void)hipFree(j->d_mapU);
+    (void)hipFree(j->d_mapV);
+    (void)hipFree(j->d_rows);
+    (void)hipFree(j->d_coords);
+    for (hipEvent_t e : j->ev_ring)
+        (void)hipEventDestroy(e);
+    delete j;
+}
+
+int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out)
+{
+    if (!ctx || !desc || !out)
+        return fail(P2P_ERR_INVALID, "p2p_job_create: NULL argument");
+    *out = nullptr;
+    const p2p_job_desc& d = *desc;
+    if (!dims_ok(d.pw, d.ph))
+        return fail(P2P_ERR_INVALID, "panorama %dx%d: both sides must be in 1..32766 (cv::remap asserts < SHRT_MAX)", d.pw, d.ph);
+    if (!dims_ok(d.ow, d.oh))
+        return fail(P2P_ERR_INVALID, "output %dx%d: both sides must be in 1..32766", d.ow, d.oh);
+    if (d.n_panos < 1 || d.n_yaw < 1 || d.n_pitch < 1 || !d.yaw_deg || !d.pitch_deg)
+        return fail(P2P_ERR_INVALID, "need at least one panorama, yaw and pitch");
+    for (int i = 0; i < d.n_pitch; ++i)
+        if (d.pitch_deg[i] < 1 || d.pitch_deg[i] > 179)
+            return fail(P2P_ERR_INVALID, "Pitch angle must be between 1 and 179 degrees, got %d.", d.pitch_deg[i]);
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    p2p_job* j = new (std::nothrow) p2p_job();
+    if (!j)
+        return fail(P2P_ERR_OOM, "host allocation failed");
+    j->ctx = ctx;
+    j->d = d;
+    j->yaw.assign(d.yaw_deg, d.yaw_deg + d.n_yaw);
+    j->pitch.assign(d.pitch_deg, d.pitch_deg + d.n_pitch);
+    j->d.yaw_deg = j->yaw.data();
+    j->d.pitch_deg = j->pitch.data();
+    j->pano_set.assign(d.n_panos, 0);
+
+    j->src_pitch = (3 * d.pw + 15) & ~15;
+    j->pano_stride = (((size_t)j->src_pitch * d.ph + kSlack) + 255) & ~(size_t)255;
+    j->out_bytes = (size_t)d.n_panos * d.n_yaw * d.n_pitch * d.oh * d.ow * 3;
+
+    // scalars NumPy evaluates in float64 once per map (P:64-68, P:119, P:129-131, P:142-149)
+    const double fov_rad = deg2rad((double)d.fov_deg);
+    j->geom.half_w = (float)(d.ow / 2.0);
+    j->geom.half_h = (float)(d.oh / 2.0);
+    j->geom.focal = (float)((0.5 * d.ow) / std::tan(fov_rad / 2));
+    j->geom.pw_f = (float)d.pw;
+    j->geom.ph_f = (float)d.ph;
+    std::vector<p2p::PitchConst> pc(d.n_pitch);
+    for (int i = 0; i < d.n_pitch; ++i) {
+        double pr = deg2rad((double)j->pitch[i]);
+        pc[i].c = (float)std::cos(pr);
+        pc[i].s = (float)std::sin(pr);
+    }
+    std::vector<double> yr(d.n_yaw);
+    for (int i = 0; i < d.n_yaw; ++i)
+        yr[i] = deg2rad((double)j->yaw[i]);  // P:85
+
+    hipError_t e = hipMalloc((void**)&j->d_src, j->pano_stride * d.n_panos);
+    if (e == hipSuccess) e = hipMalloc((void**)&j->d_out, j->out_bytes + 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&j->d_ytab, (size_t)d.n_yaw * d.pw * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&j->d_yaw_rad, (size_t)d.n_yaw * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&j->d_pitch, (size_t)d.n_pitch * sizeof(p2p::PitchConst));
+    if (e == hipSuccess && (d.flags & P2P_FLAG_KEEP_COORDS))
+        e = hipMalloc((void**)&j->d_coords, (size_t)d.n_pitch * d.oh * d.ow * 2 * sizeof(int32_t));
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(j->d_yaw_rad, yr.data(), yr.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(j->d_pitch, pc.data(), pc.size() * sizeof(p2p::PitchConst), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = p2p::launch_yaw_tables(j->d_ytab, nullptr, d.pw, d.n_yaw, j->d_yaw_rad, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);  // yr / pc are stack-lifetime host buffers
+    if (e != hipSuccess) {
+        p2p_job_destroy(j);
+        return fail(e == hipErrorOutOfMemory ? P2P_ERR_OOM : P2P_ERR_HIP, "p2p_job_create: %s", hipGetErrorString(e));
+    }
+    *out = j;
+    return P2P_OK;
+}
+
+int p2p_job_set_pano(p2p_job* j, int index, const uint8_t* pano, int64_t row_stride)
+{
+    if (!j || !pano)
+        return fail(P2P_ERR_INVALID, "p2p_job_set_pano: NULL argument");
+    if (index < 0 || index >= j->d.n_panos)
+        return fail(P2P_ERR_INVALID, "panorama index %d out of range", index);
+    if (row_stride < (int64_t)3 * j->d.pw)
+        return fail(P2P_ERR_INVALID, "row_stride %lld < 3*pw", (long long)row_stride);
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    HIP_TRY(hipMemcpy2DAsync(j->d_src + (size_t)index * j->pano_stride, (size_t)j->src_pitch, pano,
+                             (size_t)row_stride, (size_t)3 * j->d.pw, (size_t)j->d.ph,
+                             hipMemcpyHostToDevice, j->ctx->stream));
+    // the caller may release `pano` when we return
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+    j->pano_set[index] = 1;
+    return P2P_OK;
+}
+
+int p2p_job_set_maps(p2p_job* j, const float* yaw_rows, const float* U, const float* V)
+{
+    if (!j || !U || !V)
+        return fail(P2P_ERR_INVALID, "p2p_job_set_maps: NULL argument");
+    const p2p_job_desc& d = j->d;
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    const size_t n_map = (size_t)d.n_pitch * d.oh * d.ow;
+    if (!j->d_mapU) HIP_TRY(hipMalloc((void**)&j->d_mapU, n_map * sizeof(float)));
+    if (!j->d_mapV) HIP_TRY(hipMalloc((void**)&j->d_mapV, n_map * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(j->d_mapU, U, n_map * sizeof(float), hipMemcpyHostToDevice, j->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(j->d_mapV, V, n_map * sizeof(float), hipMemcpyHostToDevice, j->ctx->stream));
+    if (yaw_rows) {
+        const size_t n = (size_t)d.n_yaw * d.pw;
+        // the yaw stage's taps must stay inside the row, as P:105's clip guarantees
+        for (size_t k = 0; k < n; ++k)
+            if (!(yaw_rows[k] >= 0.0f && yaw_rows[k] <= (float)(d.pw - 1)))
+                return fail(P2P_ERR_INVALID, "yaw_rows[%zu] = %g outside [0, pw-1] (P:105 clips it)", k, (double)yaw_rows[k]);
+        if (!j->d_rows) HIP_TRY(hipMalloc((void**)&j->d_rows, n * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(j->d_rows, yaw_rows, n * sizeof(float), hipMemcpyHostToDevice, j->ctx->stream));
+        HIP_TRY(p2p::launch_yaw_pack(j->d_ytab, j->d_rows, n, j->ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+    j->host_maps = true;
+    return P2P_OK;
+}
+
+int p2p_job_run(p2p_job* j)
+{
+    if (!j)
+        return fail(P2P_ERR_INVALID, "job is NULL");
+    for (int i = 0; i < j->d.n_panos; ++i)
+        if (!j->pano_set[i])
+            return fail(P2P_ERR_STATE, "panorama %d was never set", i);
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    p2p::ViewsParams P{};
+    P.src = j->d_src;
+    P.pano_stride = j->pano_stride;
+    P.src_pitch = j->src_pitch;
+    P.pw = j->d.pw;
+    P.ph = j->d.ph;
+    P.ytab = j->d_ytab;
+    P.n_yaw = j->d.n_yaw;
+    P.n_pitch = j->d.n_pitch;
+    P.n_panos = j->d.n_panos;
+    P.pairs_per_block = choose_pairs_per_block(j->d);
+    P.pitch = j->d_pitch;
+    P.mapU = j->d_mapU;
+    P.mapV = j->d_mapV;
+    P.geom = j->geom;
+    P.ow = j->d.ow;
+    P.oh = j->d.oh;
+    P.out = j->d_out;
+    P.coords = j->d_coords;
+    if (j->ev_ring.empty()) {
+        j->ev_ring.resize(2 * kEvRing, nullptr);
+        for (auto& e : j->ev_ring)
+            HIP_TRY(hipEventCreate(&e));
+    }
+    const int slot = (int)(j->runs % kEvRing);
+    HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
+    HIP_TRY(p2p::launch_remap_views(P, j->host_maps, j->ctx->stream));
+    HIP_TRY(hipEventRecord(j->ev_ring[2 * slot + 1], j->ctx->stream));
+    j->runs++;
+    j->ran = true;
+    return P2P_OK;
+}
+
+int p2p_job_kernel_ms(p2p_job* j, float* ms)
+{
+    if (!j || !ms)
+        return fail(P2P_ERR_INVALID, "NULL argument");
+    if (!j->ran)
+        return fail(P2P_ERR_STATE, "p2p_job_run has not been called");
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    const int slot = (int)((j->runs - 1) % kEvRing);
+    HIP_TRY(hipEventSynchronize(j->ev_ring[2 * slot + 1]));
+    HIP_TRY(hipEventElapsedTime(ms, j->ev_ring[2 * slot], j->ev_ring[2 * slot + 1]));
+    return P2P_OK;
+}
+
+int p2p_job_kernel_ms_last(p2p_job* j, float* ms, int n)
+{
+    if (!j || !ms || n < 1)
+        return fail(P2P_ERR_INVALID, "bad argument");
+    if (j->runs < n || n > kEvRing)
+        return fail(P2P_ERR_STATE, "only %lld runs recorded (ring holds %d)", j->runs, kEvRing);
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+    for (int k = 0; k < n; ++k) {
+        const int slot = (int)((j->runs - n + k) % kEvRing);
+        HIP_TRY(hipEventElapsedTime(&ms[k], j->ev_ring[2 * slot], j->ev_ring[2 * slot + 1]));
+    }
+    return P2P_OK;
+}
+
+int p2p_job_get_views(p2p_job* j, int index, uint8_t* out)
+{
+    if (!j || !out)
+        return fail(P2P_ERR_INVALID, "NULL argument");
+    if (index < 0 || index >= j->d.n_panos)
+        return fail(P2P_ERR_INVALID, "panorama index %d out of range", index);
+    if (!j->ran)
+        return fail(P2P_ERR_STATE, "p2p_job_run has not been called");
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    const size_t per = j->out_bytes / j->d.n_panos;
+    HIP_TRY(hipMemcpyAsync(out, j->d_out + per * index, per, hipMemcpyDeviceToHost, j->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+    return P2P_OK;
+}
+
+void* p2p_job_device_out(p2p_job* j, int64_t* bytes)
+{
+    if (!j)
+        return nullptr;
+    if (bytes)
+        *bytes = (int64_t)j->out_bytes;
+    return j->d_out;
+}
+
+int p2p_job_get_coords(p2p_job* j, int32_t* sxsy)
+{
+    if (!j || !sxsy)
+        return fail(P2P_ERR_INVALID, "NULL argument");
+    if (!j->d_coords)
+        return fail(P2P_ERR_STATE, "job was not created with P2P_FLAG_KEEP_COORDS");
+    if (!j->ran)
+        return fail(P2P_ERR_STATE, "p2p_job_run has not been called");
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    const size_t n = (size_t)j->d.n_pitch * j->d.oh * j->d.ow * 2 * sizeof(int32_t);
+    HIP_TRY(hipMemcpyAsync(sxsy, j->d_coords, n, hipMemcpyDeviceToHost, j->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+    return P2P_OK;
+}
+
+int p2p_job_get_yaw_tables(p2p_job* j, uint32_t* packed)
+{
+    if (!j || !packed)
+        return fail(P2P_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    const size_t n = (size_t)j->d.n_yaw * j->d.pw * sizeof(uint32_t);
+    HIP_TRY(hipMemcpyAsync(packed, j->d_ytab, n, hipMemcpyDeviceToHost, j->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+    return P2P_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// one-shot entry points
+// ------------------------------------------------------------------------------------------
+static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride,
+                         const int32_t* yaw_deg, int n_yaw, const int32_t* pitch_deg, int n_pitch,
+                         int fov_deg, int ow, int oh, uint8_t* out, int device, int flags,
+                         const float* yaw_rows, const float* U, const float* V)
+{
+    if (!pano || !out)
+        return fail(P2P_ERR_INVALID, "NULL image pointer");
+    if (n_yaw == 0 || n_pitch == 0)
+        return P2P_OK;
+    p2p_ctx* ctx = nullptr;
+    int rc = thread_ctx(device, &ctx);
+    if (rc != P2P_OK)
+        return rc;
+    std::vector<int32_t> dummy_yaw, dummy_pitch;
+    if (!yaw_deg) {  // caller-supplied rows: degrees are irrelevant
+        dummy_yaw.assign(n_yaw, 0);
+        yaw_deg = dummy_yaw.data();
+    }
+    if (!pitch_deg) {
+        dummy_pitch.assign(n_pitch, 90);
+        pitch_deg = dummy_pitch.data();
+    }
+    p2p_job_desc d{};
+    d.pw = pw; d.ph = ph; d.n_panos = 1;
+    d.n_yaw = n_yaw; d.yaw_deg = yaw_deg;
+    d.n_pitch = n_pitch; d.pitch_deg = pitch_deg;
+    d.fov_deg = fov_deg; d.ow = ow; d.oh = oh; d.flags = flags;
+    p2p_job* j = nullptr;
+    rc = p2p_job_create(ctx, &d, &j);
+    if (rc != P2P_OK)
+        return rc;
+    rc = p2p_job_set_pano(j, 0, pano, row_stride);
+    if (rc == P2P_OK && U)
+        rc = p2p_job_set_maps(j, yaw_rows, U, V);
+    if (rc == P2P_OK)
+        rc = p2p_job_run(j);
+    if (rc == P2P_OK)
+        rc = p2p_job_get_views(j, 0, out);
+    p2p_job_destroy(j);
+    return rc;
+}
+
+int p2p_remap_views_u8(const uint8_t* pano, int pw, int ph, int64_t row_stride,
+                       const int32_t* yaw_deg, int n_yaw, const int32_t* pitch_deg, int n_pitch,
+                       int fov_deg, int ow, int oh, uint8_t* out, int device, int flags)
+{
+    if (n_yaw < 0 || n_pitch < 0 || (n_yaw > 0 && !yaw_deg) || (n_pitch > 0 && !pitch_deg))
+        return fail(P2P_ERR_INVALID, "bad yaw/pitch list");
+    return views_oneshot(pano, pw, ph, row_stride, yaw_deg, n_yaw, pitch_deg, n_pitch, fov_deg, ow, oh,
+                         out, device, flags & ~P2P_FLAG_KEEP_COORDS, nullptr, nullptr, nullptr);
+}
+
+int p2p_remap_views_maps_u8(const uint8_t* pano, int pw, int ph, int64_t row_stride,
+                            const float* yaw_rows, int n_yaw, const float* U, const float* V,
+                            int n_pitch, int ow, int oh, uint8_t* out, int device)
+{
+    if (n_yaw < 0 || n_pitch < 0 || (n_yaw > 0 && !yaw_rows) || (n_pitch > 0 && (!U || !V)))
+        return fail(P2P_ERR_INVALID, "bad map arguments");
+    return views_oneshot(pano, pw, ph, row_stride, nullptr, n_yaw, nullptr, n_pitch, 90, ow, oh, out,
+                         device, 0, yaw_rows, U, V);
+}
+
+int p2p_remap_maps_u8(const uint8_t* src, int sw, int sh, int64_t row_stride, int cn,
+                      const float* U, const float* V, int ow, int oh, uint8_t* out,
+                      int border_mode, const uint8_t* border_value, int device)
+{
+    if (!src || !U || !V || !out)
+        return fail(P2P_ERR_INVALID, "NULL pointer");
+    if (cn != 1 && cn != 3 && cn != 4)
+        return fail(P2P_ERR_INVALID, "cn must be 1, 3 or 4 (got %d)", cn);
+    if (!dims_ok(sw, sh) || !dims_ok(ow, oh))
+        return fail(P2P_ERR_INVALID, "image sides must be in 1..32766 (cv::remap asserts < SHRT_MAX)");
+    if (border_mode < P2P_BORDER_CONSTANT || border_mode > P2P_BORDER_REFLECT_101)
+        return fail(P2P_ERR_INVALID, "unsupported border mode %d", border_mode);
+    if (row_stride < (int64_t)sw * cn)
+        return fail(P2P_ERR_INVALID, "row_stride too small");
+    p2p_ctx* ctx = nullptr;
+    int rc = thread_ctx(device, &ctx);
+    if (rc != P2P_OK)
+        return rc;
+    const int pitch = (sw * cn + 15) & ~15;
+    const size_t n_map = (size_t)ow * oh;
+    uint8_t *d_src = nullptr, *d_dst = nullptr;
+    float *d_U = nullptr, *d_V = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_src); (void)hipFree(d_dst); (void)hipFree(d_U); (void)hipFree(d_V);
+    };
+    hipError_t e = hipMalloc((void**)&d_src, (size_t)pitch * sh + kSlack);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_dst, n_map * cn);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_U, n_map * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_V, n_map * sizeof(float));
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(d_src, pitch, src, (size_t)row_stride, (size_t)sw * cn, sh, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_U, U, n_map * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_V, V, n_map * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        p2p::RemapParams P{};
+        P.src = d_src; P.sw = sw; P.sh = sh; P.src_pitch = pitch;
+        P.U = d_U; P.V = d_V; P.dst = d_dst; P.ow = ow; P.oh = oh; P.border = border_mode;
+        for (int k = 0; k < 4; ++k)
+            P.cval[k] = (border_value && k < cn) ? border_value[k] : 0;
+        e = p2p::launch_remap_maps(P, cn, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_dst, n_map * cn, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? P2P_ERR_OOM : P2P_ERR_HIP, "p2p_remap_maps_u8: %s", hipGetErrorString(e));
+    return P2P_OK;
+}
+
+int p2p_build_pitch_map(int ow, int oh, double fov_rad, double pitch_rad, int pw, int ph,
+                        float* U, float* V, int device)
+{
+    if (!U || !V)
+        return fail(P2P_ERR_INVALID, "NULL pointer");
+    if (!dims_ok(ow, oh) || pw < 1 || ph < 1)
+        return fail(P2P_ERR_INVALID, "bad sizes");
+    p2p_ctx* ctx = nullptr;
+    int rc = thread_ctx(device, &ctx);
+    if (rc != P2P_OK)
+        return rc;
+    p2p::MapGeom g{};
+    g.half_w = (float)(ow / 2.0);
+    g.half_h = (float)(oh / 2.0);
+    g.focal = (float)((0.5 * ow) / std::tan(fov_rad / 2));  // P:119, cast to float32 at P:131
+    g.pw_f = (float)pw;
+    g.ph_f = (float)ph;
+    const double pr = pitch_rad;
+    const size_t n = (size_t)ow * oh;
+    float *dU = nullptr, *dV = nullptr;
+    hipError_t e = hipMalloc((void**)&dU, n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&dV, n * sizeof(float));
+    if (e == hipSuccess) e = p2p::launch_pitch_map(dU, dV, ow, oh, g, (float)std::cos(pr), (float)std::sin(pr), ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(U, dU, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(V, dV, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dU);
+    (void)hipFree(dV);
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? P2P_ERR_OOM : P2P_ERR_HIP, "p2p_build_pitch_map: %s", hipGetErrorString(e));
+    return P2P_OK;
+}
+
+int p2p_build_yaw_row(int pw, double yaw_rad, float* U_row, int device)
+{
+    if (!U_row)
+        return fail(P2P_ERR_INVALID, "NULL pointer");
+    if (pw < 1 || pw >= 32767)
+        return fail(P2P_ERR_INVALID, "bad panorama width %d", pw);
+    p2p_ctx* ctx = nullptr;
+    int rc = thread_ctx(device, &ctx);
+    if (rc != P2P_OK)
+        return rc;
+    const double yr = yaw_rad;  // np.radians(yaw_angle), P:85
+    double* d_yr = nullptr;
+    float* d_row = nullptr;
+    hipError_t e = hipMalloc((void**)&d_yr, sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_row, (size_t)pw * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_yr, &yr, sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = p2p::launch_yaw_tables(nullptr, d_row, pw, 1, d_yr, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(U_row, d_row, (size_t)pw * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_yr);
+    (void)hipFree(d_row);
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? P2P_ERR_OOM : P2P_ERR_HIP, "p2p_build_yaw_row: %s", hipGetErrorString(e));
+    return P2P_OK;
+}
+
+}  // extern "C"

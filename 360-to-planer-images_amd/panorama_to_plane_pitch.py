@@ -1,0 +1,316 @@
+#!/usr/bin/env python3
+"""Host-side mirror of the reference tool app/panorama_to_plane-pitch.py ("P") on top of the
+MI355X library libp2p_hip.so: same function names, argument order, defaults, file naming,
+logging format and error behaviour, so a user of the reference can switch files.
+
+    reference interface (P:line)                      here
+    ------------------------------------------------  -------------------------------------------
+    get_version                         P:22-27       get_version
+    get_yaw_mapping / get_pitch_mapping P:42-73       same names, same cache keys (device-built maps)
+    precompute_yaw_mapping              P:79-108      p2p_build_yaw_row  (one row, broadcast)
+    precompute_pitch_mapping            P:114-175     p2p_build_pitch_map
+    process_yaw_and_pitchs              P:181-221     p2p_remap_views_u8 (both remaps, one kernel)
+    process_single_image                P:227-280     one resident job per image (all yaws x pitches)
+    main                                P:286-356     same walk / logging / error swallowing
+    check_pitch                         P:362-376     same messages
+    CLI                                 P:382-488     same flags and defaults (+ additive --device)
+
+All pixel and map arithmetic runs on the GPU.  There is no CPU fallback: without the built
+library or without a HIP device the calls raise.
+Image files are decoded / encoded with Pillow (cv2 is not a dependency here); arrays keep
+cv2's BGR channel order at the API boundary because the reference hands BGR arrays around
+(P:243-244) -- the kernel itself is channel-agnostic.
+"""
+import argparse
+import logging
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+if __package__ in (None, ""):  # executed as a script: make the sibling module importable
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _native  # type: ignore
+else:
+    from . import _native
+
+VERSION = "0.3.2"  # the reference release this file mirrors (P:20)
+
+# same module-level caches, same keys as P:17-18 / P:47 / P:62
+yaw_mapping_cache = {}
+pitch_mapping_cache = {}
+
+_DEVICE = int(os.environ.get("P2P_DEVICE", "0"))
+
+
+def set_device(device):
+    """Select the HIP device used by the functions of this module (additive to the reference API)."""
+    global _DEVICE
+    _DEVICE = int(device)
+
+
+def get_version():
+    return VERSION
+
+
+# ----------------------------------------------------------------------------------------------
+# coordinate maps (returned as float32 arrays exactly like the reference's)
+# ----------------------------------------------------------------------------------------------
+def precompute_yaw_mapping(pano_width, pano_height, yaw_angle):
+    """(U, V) float32 (pano_height, pano_width) of P:79-108.  The formula depends on the column
+    only, so the device computes one row (bit-exact dtype flow) and it is broadcast here."""
+    logging.debug(f"[Yaw] Precomputing yaw mapping for yaw_angle: {yaw_angle} degrees")
+    row = _native.build_yaw_row(pano_width, float(np.radians(yaw_angle)), _DEVICE)
+    U = np.broadcast_to(row, (pano_height, pano_width)).copy()
+    V = np.broadcast_to(np.arange(pano_height, dtype=np.float32)[:, None], (pano_height, pano_width)).copy()
+    return U, V
+
+
+def precompute_pitch_mapping(W, H, FOV_rad, pitch_radian, pano_width, pano_height):
+    """(U, V) float32 (H, W) of P:114-175, evaluated by the same device function the fused kernel uses."""
+    return _native.build_pitch_map(W, H, float(FOV_rad), float(pitch_radian), pano_width, pano_height, _DEVICE)
+
+
+def get_yaw_mapping(pano_width, pano_height, yaw_angle):
+    key = (pano_width, pano_height, yaw_angle)
+    if key not in yaw_mapping_cache:
+        yaw_mapping_cache[key] = precompute_yaw_mapping(pano_width, pano_height, yaw_angle)
+    return yaw_mapping_cache[key]
+
+
+def get_pitch_mapping(output_width, output_height, pitch_angle, pano_width, pano_height, fov_deg=90):
+    key = (output_width, output_height, pitch_angle, pano_width, pano_height, fov_deg)
+    if key not in pitch_mapping_cache:
+        pitch_mapping_cache[key] = precompute_pitch_mapping(
+            W=output_width,
+            H=output_height,
+            FOV_rad=np.radians(fov_deg),
+            pitch_radian=np.radians(pitch_angle),
+            pano_width=pano_width,
+            pano_height=pano_height,
+        )
+    return pitch_mapping_cache[key]
+
+
+# ----------------------------------------------------------------------------------------------
+# view synthesis
+# ----------------------------------------------------------------------------------------------
+def _int_angle(value, what):
+    if isinstance(value, (bool, np.bool_)):
+        raise TypeError(f"{what} must be an integer number of degrees")
+    if isinstance(value, (int, np.integer)):
+        return int(value)
+    if isinstance(value, (float, np.floating)) and float(value).is_integer():
+        return int(value)
+    raise TypeError(f"{what} must be an integer number of degrees, got {value!r}")
+
+
+def process_views(pano_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg=90):
+    """All yaws x pitches of one panorama in one kernel launch.
+    Returns uint8 [n_yaw][n_pitch][output_height][output_width][3]."""
+    yaws = [_int_angle(y, "yaw angle") for y in yaw_angles]
+    pitches = [_int_angle(p, "pitch angle") for p in pitch_angles]
+    return _native.remap_views(pano_image, yaws, pitches, _int_angle(fov_deg, "FOV"),
+                               output_width, output_height, _DEVICE)
+
+
+def process_yaw_and_pitchs(pano_image, yaw_angle, pitch_angles, output_width, output_height, fov_deg=90):
+    """Drop-in for P:181-221: one yaw, several pitches -> list of (output_height, output_width, 3) uint8."""
+    logging.debug(f"[Yaw/Pitch] Starting processing for yaw_angle={yaw_angle}")
+    views = process_views(pano_image, [yaw_angle], list(pitch_angles), output_width, output_height, fov_deg)
+    return [views[0, i] for i in range(views.shape[1])]
+
+
+# ----------------------------------------------------------------------------------------------
+# image files (Pillow, presented with cv2.imread / cv2.imwrite conventions)
+# ----------------------------------------------------------------------------------------------
+def _imread_bgr(path):
+    """cv2.imread(path) stand-in: HxWx3 uint8 BGR, or None when the file cannot be decoded (P:244-247)."""
+    try:
+        from PIL import Image, ImageOps
+
+        with Image.open(str(path)) as im:
+            im = ImageOps.exif_transpose(im)
+            if im.mode in ("I;16", "I;16B", "I;16L", "I"):
+                arr = (np.asarray(im, dtype=np.uint32) >> 8).astype(np.uint8)
+                rgb = np.stack([arr, arr, arr], axis=-1)
+            else:
+                rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
+        return np.ascontiguousarray(rgb[:, :, ::-1])
+    except Exception:
+        return None
+
+
+def _imwrite_bgr(path, image):
+    """cv2.imwrite(path, image) stand-in for .png / .jpg / .jpeg (cv2 defaults: JPEG quality 95)."""
+    from PIL import Image
+
+    im = Image.fromarray(np.ascontiguousarray(image[:, :, ::-1]))
+    ext = Path(path).suffix.lower()
+    if ext in (".jpg", ".jpeg"):
+        im.save(str(path), format="JPEG", quality=95)
+    else:
+        im.save(str(path), format="PNG", compress_level=1)
+    return True
+
+
+def process_single_image(
+    input_image_path,
+    output_dir,
+    yaw_angles,
+    pitch_angles,
+    output_width,
+    output_height,
+    num_workers=4,
+    output_format="png",
+    fov_deg=90,
+):
+    """Drop-in for P:227-280.  num_workers is accepted for compatibility: the reference's thread
+    pool over yaws is replaced by one kernel launch covering every yaw and pitch of the image."""
+    from tqdm import tqdm
+
+    logging.info(f"Loading image: {input_image_path}")
+    input_image = _imread_bgr(input_image_path)
+    if input_image is None:
+        logging.error(f"Failed to read image: {input_image_path}")
+        return
+
+    input_image_path = Path(input_image_path)
+    output_dir = Path(output_dir)
+    base_name = input_image_path.stem
+
+    views = None
+    error = None
+    try:
+        views = process_views(input_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg)
+    except Exception as e:  # the reference reports task failures per yaw and carries on (P:279-280)
+        error = e
+
+    for yi, yaw_angle in enumerate(tqdm(list(yaw_angles), desc="Processing yaw angles")):
+        try:
+            if error is not None:
+                raise error
+            for pi, pitch_angle in enumerate(pitch_angles):
+                out_filename = f"{base_name}_{output_width}x{output_height}_yaw_{yaw_angle}_pitch_{pitch_angle}.{output_format}"
+                output_file = output_dir / out_filename
+                _imwrite_bgr(output_file, views[yi, pi])
+                logging.debug(f"Saved {output_file}")
+        except Exception as e:
+            logging.error(f"Error processing yaw_angle {yaw_angle}: {e}")
+
+
+def main(
+    input_path,
+    output_path,
+    yaw_angles,
+    pitch_angles,
+    output_width,
+    output_height,
+    num_workers=None,
+    output_format="png",
+    fov_deg=90,
+    enable_file_logging=False,
+):
+    """Drop-in for P:286-356: one image or every .jpg/.jpeg/.png under a directory (recursive)."""
+    if num_workers is None:
+        cpu_cores = os.cpu_count() or 1
+        num_workers = max(1, int(cpu_cores * 0.9))
+        logging.info(f"No num_workers specified. Using {num_workers} (~90% of CPU cores).")
+    else:
+        logging.info(f"Using {num_workers} worker threads.")
+
+    output_dir = Path(output_path)
+    output_dir.mkdir(parents=True, exist_ok=True)
+    logging.info(f"Output directory set to: {output_dir}")
+
+    input_path_obj = Path(input_path)
+    common = dict(
+        output_dir=output_dir,
+        yaw_angles=yaw_angles,
+        pitch_angles=pitch_angles,
+        output_width=output_width,
+        output_height=output_height,
+        num_workers=num_workers,
+        output_format=output_format,
+        fov_deg=fov_deg,
+    )
+    if input_path_obj.is_dir():
+        valid_exts = {".jpg", ".jpeg", ".png"}
+        all_images = [f for f in input_path_obj.rglob("*") if f.suffix.lower() in valid_exts]
+        if not all_images:
+            logging.warning(f"No images found in directory: {input_path_obj}")
+            return
+        logging.info(f"Found {len(all_images)} images in folder: {input_path_obj}")
+        for image_file in all_images:
+            process_single_image(input_image_path=image_file, **common)
+    else:
+        process_single_image(input_image_path=input_path_obj, **common)
+
+    logging.info("All processing completed.")
+
+
+def check_pitch(value: str) -> int:
+    """Pitch validator of P:362-376 (integer, 1..179)."""
+    try:
+        pitch = int(value)
+    except ValueError:
+        raise argparse.ArgumentTypeError(f"Pitch angle must be an integer, got '{value}'.")
+    if not (1 <= pitch <= 179):
+        raise argparse.ArgumentTypeError(f"Pitch angle must be between 1 and 179 degrees, got {pitch}.")
+    return pitch
+
+
+def build_arg_parser():
+    """The reference's argparse surface (P:383-455), flag for flag, plus --device."""
+    p = argparse.ArgumentParser(
+        description="Process panorama images or an entire folder of images into planar projections."
+    )
+    p.add_argument("--input_path", type=str, required=True,
+                   help="Path to the input panorama image or folder of images")
+    p.add_argument("--output_path", type=str, default="output_images", help="Path to save the output images")
+    p.add_argument("--output_format", type=str, choices=["png", "jpg", "jpeg"], default="png",
+                   help="Output image format (png, jpg, jpeg)")
+    p.add_argument("--FOV", type=int, default=90, help="Field of View in degrees")
+    p.add_argument("--output_width", type=int, default=800, help="Width of the output image in pixels")
+    p.add_argument("--output_height", type=int, default=800, help="Height of the output image in pixels")
+    p.add_argument("--pitch_angles", nargs="+", type=check_pitch, default=[30, 60, 90, 120, 150],
+                   help="List of pitch angles in degrees (1-179). e.g. --pitch_angles 30 60 90")
+    p.add_argument("--yaw_angles", nargs="+", type=int, default=[0, 90, 180, 270],
+                   help="List of yaw angles in degrees (0-360). e.g. --yaw_angles 0 90 180 270")
+    p.add_argument("--num_workers", type=int, default=None,
+                   help="Number of worker threads for parallel yaw processing. If not specified, uses ~90%% of CPU cores.")
+    p.add_argument("--enable_file_logging", action="store_true", help="Enable logging to a file.")
+    p.add_argument("-v", "--version", action="version", version=f"%(prog)s {get_version()}",
+                   help="Show version information")
+    p.add_argument("--device", type=int, default=None, help="HIP device index (default 0 or $P2P_DEVICE)")
+    return p
+
+
+def cli(argv=None):
+    args = build_arg_parser().parse_args(argv)
+    # logging set-up as P:462-475 (the logs/ directory is created even without file logging)
+    log_file_path = Path(__file__).resolve().parent.parent / "logs" / "app.log"
+    log_file_path.parent.mkdir(parents=True, exist_ok=True)
+    handlers = [logging.StreamHandler()]
+    if args.enable_file_logging:
+        handlers.append(logging.FileHandler(log_file_path, mode="a"))
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s [%(levelname)s] %(message)s", handlers=handlers)
+    if args.device is not None:
+        set_device(args.device)
+    main(
+        input_path=args.input_path,
+        output_path=args.output_path,
+        yaw_angles=args.yaw_angles,
+        pitch_angles=args.pitch_angles,
+        output_width=args.output_width,
+        output_height=args.output_height,
+        num_workers=args.num_workers,
+        output_format=args.output_format,
+        fov_deg=args.FOV,
+        enable_file_logging=args.enable_file_logging,
+    )
+
+
+if __name__ == "__main__":
+    cli()

@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X: Mpix/s remapped, 8K equirect -> 1080p x 36 views.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg1|cfg4|cfg5] [--maps fused|caller]
+
+A "step" is one pass of the hot path over one batch of synthetic input: every (yaw, pitch) view of
+the rank's resident panorama(s), i.e. one launch of remap_views_kernel.  Inputs are resident in HBM
+before the timed region; outputs stay in HBM.  With N > 1 (launched by torch.distributed.run, one
+rank per GPU) every rank owns its own panorama(s) and view set -- the (image x yaw x pitch) batch is
+independent work, so there is NO data-path collective; torch.distributed (RCCL) is used only for the
+barrier and the max-over-ranks of the elapsed time.  value = pixels all ranks produced / that time.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     -- algorithmic bytes of one launch / mean launch duration (HIP events around every
+                  launch, on the stream the kernel runs on) against the 8 TB/s HBM peak
+  cpu_baseline -- the CPU restatement of the reference path (oracle/, "port") timed on this box's
+                  host cores on a bounded sample of the same workload (N = 1 only)
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PKG = "360-to-planer-images_amd"
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "cfg2": dict(pw=8192, ph=4096, ow=1920, oh=1080, fov=90, yaws=list(range(0, 360, 30)), pitches=[60, 90, 120],
+                 name="8192x4096 pano -> 1920x1080, FOV 90, 12 yaw x 3 pitch = 36 views"),
+    "cfg1": dict(pw=2048, ph=1024, ow=512, oh=512, fov=90, yaws=[0], pitches=[90],
+                 name="2048x1024 pano -> one 512x512 view, FOV 90 yaw 0 pitch 90"),
+    "cfg4": dict(pw=16384, ph=8192, ow=4096, oh=4096, fov=60, yaws=list(range(0, 360, 5)), pitches=[30, 60, 90, 120, 150],
+                 name="16384x8192 pano -> 4096x4096, FOV 60, 72 yaw x 5 pitch = 360 views"),
+    "cfg5": dict(pw=8192, ph=4096, ow=1920, oh=1080, fov=90, yaws=list(range(360)), pitches=[90],
+                 name="8192x4096 pano -> 1920x1080, FOV 90, 360 yaw x 1 pitch = 360 views"),
+}
+
+
+def algorithmic_bytes(w, n_panos):
+    """every source byte read once, every output byte written once; maps are computed."""
+    views = n_panos * len(w["yaws"]) * len(w["pitches"])
+    return 3 * w["pw"] * w["ph"] * n_panos + 3 * w["ow"] * w["oh"] * views
+
+
+# ------------------------------------------------------------------------------------------------
+# distributed scaffolding (importable: tests/test_distributed_cpu.py drives it with gloo, 2 ranks)
+# ------------------------------------------------------------------------------------------------
+class Dist:
+    def __init__(self, backend=None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.pg = None
+        if self.world > 1:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            if backend is None:
+                import torch
+
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if backend == "nccl":
+                import torch
+
+                torch.cuda.set_device(self.local_rank)
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+            self.pg = dist
+            self.backend = backend
+
+    def barrier(self):
+        if self.pg is not None:
+            self.pg.barrier()
+
+    def max_over_ranks(self, x):
+        if self.pg is None:
+            return float(x)
+        import torch
+
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+        self.pg.all_reduce(t, op=self.pg.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.pg is not None:
+            self.pg.destroy_process_group()
+
+
+def shard_round_robin(n_items, world, rank):
+    """Items (panoramas, or views when there are fewer panoramas than GPUs) dealt round-robin."""
+    return list(range(rank, n_items, world))
+
+
+def run_timed(step, device_sync, dist, steps, warmup):
+    """W untimed steps, then exactly K steps bracketed by barrier + device sync on both sides;
+    returns the MAX over ranks of the elapsed seconds."""
+    for _ in range(warmup):
+        step()
+    device_sync()
+    dist.barrier()
+    device_sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    device_sync()
+    dist.barrier()
+    t1 = time.perf_counter()
+    return dist.max_over_ranks(t1 - t0)
+
+
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(w, budget_s=20.0):
+    """The oracle (CPU restatement of P:181-221 + cv2.remap arithmetic) on a bounded sample:
+    whole yaws of the workload (each = one full-panorama yaw remap + every pitch view), 1 thread."""
+    from oracle import cpu_ref
+
+    synth = importlib.import_module(PKG + ".synth")
+    pano = synth.synth_pano(w["pw"], w["ph"], 1000, "S")
+    cache = {}
+    done, t0 = 0, time.perf_counter()
+    for yaw in w["yaws"]:
+        cpu_ref.process_yaw_and_pitchs(pano, yaw, w["pitches"], w["ow"], w["oh"], w["fov"], _pitch_cache=cache)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    pix = done * len(w["pitches"]) * w["ow"] * w["oh"]
+    return {
+        "value": pix / dt / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
+        "sample": "%d of %d yaws x %d pitches of the same workload (%.1f s, map building included, "
+                  "host has %d cores)" % (done, len(w["yaws"]), len(w["pitches"]), dt, os.cpu_count() or 0),
+    }
+
+
+def load_traffic(workload):
+    """HBM bytes per launch from the PMC passes (profiles/traffic.json, written from rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE runs with the guide's gfx950 corrections), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--panos-per-gpu", type=int, default=1)
+    ap.add_argument("--maps", default="fused", choices=["fused", "caller"],
+                    help="fused: coordinate maps computed in-kernel (default, the product path); "
+                         "caller: float maps handed in (the bit-exact mode)")
+    ap.add_argument("--kind", default="S", choices=["S", "N"], help="synthetic panorama distribution")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    dist = Dist()
+    if dist.world != args.gpus:
+        if dist.rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, dist.world),
+                  file=sys.stderr)
+        sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU fallback for the hot path)"
+    torch.cuda.set_device(dist.local_rank)
+
+    pkg = importlib.import_module(PKG)
+    nat = pkg._native
+    synth = importlib.import_module(PKG + ".synth")
+    w = WORKLOADS[args.workload]
+    npg = args.panos_per_gpu
+    views_per_rank = npg * len(w["yaws"]) * len(w["pitches"])
+
+    ctx = nat.Context(dist.local_rank)
+    job = nat.Job(ctx, w["pw"], w["ph"], npg, w["yaws"], w["pitches"], w["fov"], w["ow"], w["oh"])
+    for i in range(npg):
+        # weak scaling: panorama index = rank * panos_per_gpu + i, seed 1000 + index
+        job.set_pano(i, synth.synth_pano(w["pw"], w["ph"], 1000 + dist.rank * npg + i, args.kind))
+    if args.maps == "caller":
+        import numpy as np  # float maps from the library's own device map builders, handed back in
+
+        rows = np.stack([nat.build_yaw_row(w["pw"], float(np.radians(y)), dist.local_rank) for y in w["yaws"]])
+        UV = [nat.build_pitch_map(w["ow"], w["oh"], float(np.radians(w["fov"])), float(np.radians(p)),
+                                  w["pw"], w["ph"], dist.local_rank) for p in w["pitches"]]
+        job.set_maps(rows, np.stack([u for u, _ in UV]), np.stack([v for _, v in UV]))
+
+    def device_sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    steps = min(args.steps, 256)
+    elapsed = run_timed(job.run, device_sync, dist, steps, args.warmup)
+    kms = job.kernel_ms_last(steps)
+    k_avg_s = float(kms.mean()) / 1e3
+
+    pix_per_step = views_per_rank * w["ow"] * w["oh"] * dist.world
+    value = pix_per_step * steps / elapsed / 1e6
+    b_alg = algorithmic_bytes(w, npg)
+    achieved = b_alg / k_avg_s / 1e9
+    out = {
+        "metric": "Mpix/s remapped, 8K equirect->1080p x36 views" if args.workload == "cfg2"
+                  else "Mpix/s remapped (%s)" % args.workload,
+        "value": value, "unit": "Mpix/s", "n_gpus": dist.world, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": w["name"], "panos_per_gpu": npg, "views_per_gpu": views_per_rank,
+                   "maps": args.maps, "pano_kind": args.kind, "sharding": "independent panoramas per rank, no collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
+                     "kernel": "remap_views_kernel", "kernel_ms_avg": k_avg_s * 1e3,
+                     "kernel_ms_min": float(kms.min()), "algorithmic_bytes_per_launch": b_alg},
+    }
+    if dist.rank == 0 and dist.world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(w)
+    elif dist.rank == 0:
+        out["cpu_baseline"] = None
+    job.close()
+    ctx.close()
+    dist.close()
+    if dist.rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

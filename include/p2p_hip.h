@@ -1,0 +1,161 @@
+/*
+ * p2p_hip.h -- C ABI of libp2p_hip.so, the MI355X (gfx950) implementation of the
+ * equirectangular -> perspective view-synthesis hot path of
+ * Maxiviper117/360-to-planer-images.
+ *
+ * The reference has NO FFI: its boundary for this path is a handful of Python
+ * functions in app/panorama_to_plane-pitch.py ("P") and app/legacy/panorama_to_plane.py
+ * ("L").  Each entry point below names the reference interface it replaces; the
+ * Python mirror that binds them with ctypes lives in
+ * 360-to-planer-images_amd/panorama_to_plane_pitch.py and the stub a reference
+ * maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every host buffer;
+ * the library owns device memory, streams and events; every function returns
+ * P2P_OK (0) or a negative p2p_status and never throws; p2p_last_error() gives a
+ * thread-local message for the last failure on the calling thread.  All entry
+ * points are re-entrant; the one-shot functions keep one device context per
+ * calling thread, so the reference's ThreadPoolExecutor fan-out (P:252-265) can
+ * call them concurrently on one shared panorama.
+ *
+ * There is no CPU fallback in this library: without a usable HIP device every
+ * compute entry point fails with P2P_ERR_NO_DEVICE.
+ */
+#ifndef P2P_HIP_H
+#define P2P_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum p2p_status {
+    P2P_OK = 0,
+    P2P_ERR_INVALID = -1,     /* bad argument (what OpenCV would CV_Assert on, or NULL/size errors) */
+    P2P_ERR_NO_DEVICE = -2,   /* no HIP device / device index out of range */
+    P2P_ERR_HIP = -3,         /* a HIP runtime call failed; see p2p_last_error() */
+    P2P_ERR_OOM = -4,         /* device or host allocation failed */
+    P2P_ERR_STATE = -5        /* call sequence error (e.g. run before a panorama was set) */
+} p2p_status;
+
+/* cv2 border codes accepted by p2p_remap_maps_u8 (OpenCV core/base.hpp numbering). */
+enum { P2P_BORDER_CONSTANT = 0, P2P_BORDER_REPLICATE = 1, P2P_BORDER_REFLECT = 2,
+       P2P_BORDER_WRAP = 3, P2P_BORDER_REFLECT_101 = 4 };
+
+/* p2p_job_desc.flags / p2p_remap_views_u8 flags */
+enum {
+    P2P_FLAG_DEFAULT = 0,
+    P2P_FLAG_KEEP_COORDS = 1   /* keep the quantised pitch-stage coordinates the kernel used
+                                  (readable with p2p_job_get_coords); for parity tests */
+};
+
+const char* p2p_version(void);
+const char* p2p_last_error(void);
+/* Number of usable HIP devices (0 when there is none; never an error). */
+int p2p_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * One-shot host-buffer API (what the Python drop-in functions bind)
+ * ---------------------------------------------------------------------------------------- */
+
+/*
+ * Replaces process_yaw_and_pitchs() (P:181-221) for a whole list of yaws, i.e. the
+ * per-image fan-out of process_single_image() (P:252-265): for every yaw the panorama is
+ * resampled by the yaw map (P:79-108, cv2.remap P:192-199) and every pitch view is gathered
+ * from that resampled panorama (P:114-175, cv2.remap P:212-218), all inside one HIP kernel.
+ *   pano       : uint8 [ph][pw][3], row_stride bytes between rows (channel order untouched)
+ *   out        : uint8 [n_yaw][n_pitch][oh][ow][3], contiguous
+ *   yaw_deg    : any integers (P:431-437 leaves yaw unvalidated; it wraps through '%', P:98)
+ *   pitch_deg  : 1..179 (check_pitch, P:362-376) -- other values are P2P_ERR_INVALID
+ */
+int p2p_remap_views_u8(const uint8_t* pano, int pw, int ph, int64_t row_stride,
+                       const int32_t* yaw_deg, int n_yaw,
+                       const int32_t* pitch_deg, int n_pitch, int fov_deg,
+                       int ow, int oh, uint8_t* out, int device, int flags);
+
+/*
+ * The same two-stage synthesis with caller-supplied float32 maps instead of in-kernel ones:
+ *   yaw_rows : [n_yaw][pw]      = U_yaw[0, :] of precompute_yaw_mapping (P:79-108; V_yaw[y,x] == y)
+ *   U, V     : [n_pitch][oh][ow] = precompute_pitch_mapping outputs (P:114-175)
+ * Given the reference's own maps the result is the reference's result bit for bit.
+ */
+int p2p_remap_views_maps_u8(const uint8_t* pano, int pw, int ph, int64_t row_stride,
+                            const float* yaw_rows, int n_yaw,
+                            const float* U, const float* V, int n_pitch,
+                            int ow, int oh, uint8_t* out, int device);
+
+/*
+ * Replaces panorama_to_plane(pano_array, U, V) (L:182-194) == cv2.remap(src, U, V,
+ * INTER_LINEAR, borderMode) (L:179 uses BORDER_REFLECT; P:192-199/212-218 use BORDER_CONSTANT
+ * with borderValue 0).  src: uint8 [sh][sw][cn], cn in {1,3,4}; U,V: float32 [oh][ow];
+ * out: uint8 [oh][ow][cn].  border_value: cn bytes or NULL (zeros).
+ */
+int p2p_remap_maps_u8(const uint8_t* src, int sw, int sh, int64_t row_stride, int cn,
+                      const float* U, const float* V, int ow, int oh, uint8_t* out,
+                      int border_mode, const uint8_t* border_value, int device);
+
+/*
+ * Replaces precompute_pitch_mapping(W, H, FOV_rad, pitch_radian, pano_width, pano_height)
+ * (P:114-175; get_pitch_mapping P:55-73 passes np.radians() of its degree arguments): float32
+ * U, V [oh][ow] computed on the device with the arithmetic the fused kernel uses.
+ */
+int p2p_build_pitch_map(int ow, int oh, double fov_rad, double pitch_rad, int pw, int ph,
+                        float* U, float* V, int device);
+
+/*
+ * Replaces get_yaw_mapping()/precompute_yaw_mapping() (P:42-52, P:79-108): the float32 row
+ * U_yaw[0, :] of length pw (every row of the reference's U equals it; V_yaw[y, x] == y).
+ * yaw_rad = np.radians(yaw_angle) (P:85).
+ */
+int p2p_build_yaw_row(int pw, double yaw_rad, float* U_row, int device);
+
+/* ------------------------------------------------------------------------------------------
+ * Resident (device-buffer) API: the batch driver and bench.py keep panoramas and views in HBM
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct p2p_ctx p2p_ctx;   /* one device + one HIP stream + events */
+typedef struct p2p_job p2p_job;   /* n_panos panoramas of one size x (yaw x pitch) view set */
+
+typedef struct p2p_job_desc {
+    int32_t pw, ph;               /* panorama size (both < 32767: cv::remap's SHRT_MAX assert) */
+    int32_t n_panos;              /* panoramas resident at once */
+    int32_t n_yaw;
+    const int32_t* yaw_deg;
+    int32_t n_pitch;
+    const int32_t* pitch_deg;
+    int32_t fov_deg, ow, oh;
+    int32_t flags;
+} p2p_job_desc;
+
+int p2p_ctx_create(int device, p2p_ctx** out);
+void p2p_ctx_destroy(p2p_ctx* ctx);
+int p2p_ctx_synchronize(p2p_ctx* ctx);
+
+int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out);
+void p2p_job_destroy(p2p_job* job);
+/* Asynchronous H2D copy of panorama `index` (uint8 [ph][pw][3]). */
+int p2p_job_set_pano(p2p_job* job, int index, const uint8_t* pano, int64_t row_stride);
+/* Optional: use caller float maps instead of in-kernel ones (see p2p_remap_views_maps_u8). */
+int p2p_job_set_maps(p2p_job* job, const float* yaw_rows, const float* U, const float* V);
+/* Enqueue the view-synthesis kernel for all panoramas x yaws x pitches (asynchronous). */
+int p2p_job_run(p2p_job* job);
+/* Wait, then copy all views of panorama `index` to host: uint8 [n_yaw][n_pitch][oh][ow][3]. */
+int p2p_job_get_views(p2p_job* job, int index, uint8_t* out);
+/* Device time of the last p2p_job_run's view kernel(s), from HIP events on the job's stream. */
+int p2p_job_kernel_ms(p2p_job* job, float* ms);
+/* Device times of the last n p2p_job_run launches (n <= 256), oldest first; synchronises once.
+   Each launch is bracketed by its own HIP event pair on the job's stream. */
+int p2p_job_kernel_ms_last(p2p_job* job, float* ms, int n);
+/* Device address / byte size of the output block [n_panos][n_yaw][n_pitch][oh][ow][3]. */
+void* p2p_job_device_out(p2p_job* job, int64_t* bytes);
+/* With P2P_FLAG_KEEP_COORDS: the pitch-stage coordinates in 1/32 px the last run used,
+   int32 [n_pitch][oh][ow][2] = (sx, sy); INT32_MIN marks a NaN coordinate (black pixel). */
+int p2p_job_get_coords(p2p_job* job, int32_t* sxsy);
+/* The packed per-column yaw tables in use, uint32 [n_yaw][pw] = 3*ix | fx << 20. */
+int p2p_job_get_yaw_tables(p2p_job* job, uint32_t* packed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P2P_HIP_H */

@@ -1,0 +1,82 @@
+"""oracle/maps.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+NumPy restatement of the reference's two coordinate-map builders, with the same
+dtype flow (NumPy >= 2 / NEP 50 promotion rules), so that the result is the
+reference's float32 map bit for bit on the same host:
+
+  yaw map   : /root/reference/app/panorama_to_plane-pitch.py:79-108
+  pitch map : /root/reference/app/panorama_to_plane-pitch.py:114-175
+  wrappers  : /root/reference/app/panorama_to_plane-pitch.py:42-73 (radians conversion)
+
+PINNED: tests/golden/maps_*.npz were produced by importing the reference's own
+functions in the build container (tests/golden/make_golden_maps.py) and
+tests/test_oracle_maps.py checks this restatement against them.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product never does.
+"""
+import numpy as np
+
+TWO_PI = 2 * np.pi  # python float, "weak" under NEP 50 (P:95, P:98, P:101, P:164, P:167)
+
+
+def yaw_column_table(pano_width, yaw_angle):
+    """U_yaw[0, :] of P:79-108: one float32 row of length pano_width.
+
+    Every row of the reference's U is this row and V[y, x] == y (P:102), because
+    the formula depends on the column index only.
+    dtype flow: phi float32 (P:95) -> + np.float64 yaw (P:85, P:98) promotes to
+    float64 -> % 2pi, * pw / 2pi in float64 (P:98-101) -> clip -> float32 (P:105).
+    """
+    yaw_radians = np.radians(yaw_angle)  # np.float64 scalar (P:85)
+    u = np.arange(pano_width, dtype=np.float32)
+    phi = (TWO_PI * u / pano_width).astype(np.float32)  # P:95
+    phi_rotated = (phi + yaw_radians) % TWO_PI  # float64, P:98
+    U = (phi_rotated * pano_width) / TWO_PI  # P:101
+    return np.clip(U, 0, pano_width - 1).astype(np.float32)  # P:105
+
+
+def yaw_map(pano_width, pano_height, yaw_angle):
+    """Full (U, V) pair of P:79-108, each (pano_height, pano_width) float32."""
+    row = yaw_column_table(pano_width, yaw_angle)
+    U = np.broadcast_to(row, (pano_height, pano_width)).copy()
+    V = np.broadcast_to(
+        np.arange(pano_height, dtype=np.float32)[:, None], (pano_height, pano_width)
+    ).copy()
+    return U, V
+
+
+def pitch_map(W, H, FOV_rad, pitch_radian, pano_width, pano_height):
+    """(U, V) of P:114-175, each (H, W) float32.  Arguments as P:114."""
+    focal = (0.5 * W) / np.tan(FOV_rad / 2)  # P:119 (float64 scalar)
+    u, v = np.meshgrid(
+        np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing="xy"
+    )  # P:122-126
+    x = u - (W / 2.0)  # P:129
+    y = (H / 2.0) - v  # P:130
+    z = np.full_like(x, focal, dtype=np.float32)  # P:131
+    norm = np.sqrt(x**2 + y**2 + z**2)  # P:134
+    vec = np.stack((x / norm, y / norm, z / norm), axis=0).reshape(3, -1)  # P:137-152
+    c, s = np.cos(pitch_radian), np.sin(pitch_radian)
+    R = np.array([[1, 0, 0], [0, c, -s], [0, s, c]], dtype=np.float32)  # P:142-149
+    x_rot, y_rot, z_rot = (R @ vec).reshape(3, H, W)  # P:155-158 (float32 sgemm)
+    with np.errstate(invalid="ignore"):
+        theta = np.arccos(z_rot).astype(np.float32)  # P:162 (NaN when z_rot rounds above 1)
+    phi = (np.arctan2(y_rot, x_rot) % TWO_PI).astype(np.float32)  # P:164
+    U = (phi * pano_width) / TWO_PI  # P:167
+    V = (theta * pano_height) / np.pi  # P:169
+    U = np.clip(U, 0, pano_width - 1).astype(np.float32)  # P:172
+    V = np.clip(V, 0, pano_height - 1).astype(np.float32)  # P:173 (NaN stays NaN)
+    return U, V
+
+
+def pitch_map_deg(output_width, output_height, pitch_angle, pano_width, pano_height, fov_deg=90):
+    """get_pitch_mapping()'s argument convention (P:55-73): degrees in, np.radians() applied."""
+    return pitch_map(
+        output_width,
+        output_height,
+        np.radians(fov_deg),
+        np.radians(pitch_angle),
+        pano_width,
+        pano_height,
+    )

@@ -1,0 +1,60 @@
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PKG = "360-to-planer-images_amd"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    b = importlib.import_module(PKG + "._build")
+    b.build()
+    return importlib.import_module(PKG)
+
+
+@pytest.fixture(scope="session")
+def nat(pkg):
+    return pkg._native
+
+
+@pytest.fixture(scope="session")
+def gpu(nat):
+    """The native binding, on a box that has a HIP device.  GPU tests fail (not skip) without one."""
+    assert nat.device_count() >= 1, "this test is marked gpu and needs a HIP device"
+    return nat
+
+
+@pytest.fixture(scope="session")
+def synth():
+    return importlib.import_module(PKG + ".synth")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "maps_golden.npz"))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    return z, meta
+
+
+@pytest.fixture(scope="session")
+def same_platform_as_golden(golden):
+    """Bit-level checks of arccos/arctan2/sgemm outputs only make sense on the NumPy build and
+    CPU feature level that produced the fixtures; elsewhere the 1e-5 tolerance is the gate."""
+    _, meta = golden
+    try:
+        avx512 = "avx512f" in open("/proc/cpuinfo").read()
+    except OSError:
+        avx512 = None
+    return meta["numpy"] == np.__version__ and meta["avx512f"] == avx512

@@ -1,0 +1,98 @@
+"""GPU parity, integer path: with the oracle's own float maps handed to the kernel
+(p2p_remap_views_maps_u8 / p2p_job_set_maps) every output byte must equal the CPU restatement of
+the reference's two cv2.remap stages (P:181-221).  Bit-exact, no tolerance."""
+import numpy as np
+import pytest
+
+from _util import oracle_maps, oracle_views
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(gpu, pano, yaws, pitches, ow, oh, fov=90):
+    ph, pw = pano.shape[:2]
+    rows, U, V = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
+    got = gpu.remap_views_maps(pano, rows, U, V)
+    want = oracle_views(pano, yaws, pitches, ow, oh, fov)
+    assert got.shape == want.shape
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, (len(bad), bad[:5], got[tuple(bad[0])], want[tuple(bad[0])])
+
+
+def test_cfg1_noise(gpu, synth):
+    # BASELINE config 1: 2048x1024 -> 512x512, FOV 90, yaw 0, pitch 90
+    _check(gpu, synth.synth_pano(2048, 1024, 1000, "N"), [0], [90], 512, 512)
+
+
+def test_cfg1_bandlimited(gpu, synth):
+    _check(gpu, synth.synth_pano(2048, 1024, 1000, "S"), [0], [90], 512, 512)
+
+
+def test_fractional_yaw_and_pitch(gpu, synth):
+    # yaw 30 (non-integer column shift), pitch 60
+    _check(gpu, synth.synth_pano(2048, 1024, 1001, "N"), [30], [60], 512, 512)
+
+
+def test_many_yaws_pitches_order(gpu, synth):
+    _check(gpu, synth.synth_pano(1024, 512, 1002, "N"), [0, 1, 45, 77, 90, 359, 360, -30, 400],
+           [30, 60, 90, 120, 150], 200, 120)
+
+
+def test_pole_views_use_direct_gather(gpu, synth):
+    # pitch 1 / 179 look at the poles: the footprint spans every column (seam, no wrap) -> global gather path
+    _check(gpu, synth.synth_pano(1024, 512, 1003, "N"), [0, 77], [1, 5, 175, 179], 160, 160)
+
+
+def test_nan_pixel_is_black(gpu, synth):
+    # pitch 5 at 1920x1080 has one NaN coordinate (arccos of 1+eps, P:162) -> borderValue 0
+    pano = synth.synth_pano(2048, 1024, 1004, "N")
+    pano[pano == 0] = 1  # so that a black output pixel can only be the NaN one
+    ph, pw = pano.shape[:2]
+    rows, U, V = oracle_maps([0], [5], 1920, 1080, pw, ph, 90)
+    got = gpu.remap_views_maps(pano, rows, U, V)
+    want = oracle_views(pano, [0], [5], 1920, 1080, 90)
+    assert np.array_equal(got, want)
+    nan_px = np.argwhere(np.isnan(V[0]))
+    for (r, c) in nan_px:
+        assert (got[0, 0, r, c] == 0).all()
+
+
+@pytest.mark.parametrize("ow,oh", [(33, 7), (1, 1), (5, 300), (130, 9), (257, 64)])
+def test_odd_output_sizes_byte_store_path(gpu, synth, ow, oh):
+    _check(gpu, synth.synth_pano(512, 256, 1005, "N"), [0, 123], [45, 90], ow, oh)
+
+
+@pytest.mark.parametrize("pw,ph", [(64, 32), (100, 50), (333, 111), (17, 9)])
+def test_odd_panorama_sizes(gpu, synth, pw, ph):
+    _check(gpu, synth.synth_pano(pw, ph, 1006, "N"), [0, 10, 200], [30, 90, 150], 64, 48, fov=120)
+
+
+def test_wide_fov_and_narrow_fov(gpu, synth):
+    pano = synth.synth_pano(1024, 512, 1007, "N")
+    _check(gpu, pano, [15], [90, 60], 128, 128, fov=150)
+    _check(gpu, pano, [15], [90, 60], 128, 128, fov=20)
+
+
+def test_strided_panorama_rows(gpu, synth):
+    big = synth.synth_pano(600, 200, 1008, "N")
+    view = big[:, 44:556]  # row stride 1800 bytes, width 512
+    assert not view.flags.c_contiguous
+    _check(gpu, view, [0, 50], [90], 96, 64)
+
+
+def test_resident_job_multi_pano(gpu, synth):
+    pw, ph, ow, oh = 512, 256, 96, 64
+    yaws, pitches = [0, 30, 200], [60, 120]
+    ctx = gpu.Context(0)
+    job = gpu.Job(ctx, pw, ph, 3, yaws, pitches, 90, ow, oh)
+    rows, U, V = oracle_maps(yaws, pitches, ow, oh, pw, ph, 90)
+    job.set_maps(rows, U, V)
+    panos = [synth.synth_pano(pw, ph, 1010 + i, "N") for i in range(3)]
+    for i, p in enumerate(panos):
+        job.set_pano(i, p)
+    job.run()
+    for i, p in enumerate(panos):
+        assert np.array_equal(job.get_views(i), oracle_views(p, yaws, pitches, ow, oh, 90))
+    assert job.kernel_ms() > 0
+    job.close()
+    ctx.close()

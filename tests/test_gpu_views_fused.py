@@ -1,0 +1,104 @@
+"""GPU parity, fused path (maps computed in-kernel, p2p_remap_views_u8):
+  * the float maps agree with the reference's within 1e-5 relative (north_star tolerance);
+  * given the coordinates the kernel itself used, the integer gather is bit-exact vs the oracle;
+  * on band-limited panoramas every output channel is within +-1 of the oracle (north_star);
+  * on noise the mismatch fraction is reported and bounded (a 1-ulp map difference flips the
+    1/32-px quantisation of a few pixels)."""
+import numpy as np
+import pytest
+
+from _util import coords_to_maps, diff_stats, oracle_views
+from oracle import cpu_ref, maps
+
+pytestmark = pytest.mark.gpu
+
+
+def _fused_with_coords(gpu, pano, yaws, pitches, ow, oh, fov):
+    ph, pw = pano.shape[:2]
+    ctx = gpu.Context(0)
+    job = gpu.Job(ctx, pw, ph, 1, yaws, pitches, fov, ow, oh, flags=gpu.FLAG_KEEP_COORDS)
+    job.set_pano(0, pano)
+    job.run()
+    views, coords, tabs = job.get_views(0), job.get_coords(), job.get_yaw_tables()
+    job.close()
+    ctx.close()
+    return views, coords, tabs
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(pw=2048, ph=1024, ow=512, oh=512, fov=90, yaws=[0], pitches=[90]),          # BASELINE cfg 1
+    dict(pw=2048, ph=1024, ow=480, oh=270, fov=90, yaws=[0, 30, 77], pitches=[60, 90, 120]),
+    dict(pw=1024, ph=512, ow=256, oh=256, fov=60, yaws=[5], pitches=[30, 150]),
+])
+def test_integer_gather_bit_exact_given_kernel_coords(gpu, synth, cfg):
+    pano = synth.synth_pano(cfg["pw"], cfg["ph"], 1000, "N")
+    views, coords, tabs = _fused_with_coords(gpu, pano, cfg["yaws"], cfg["pitches"], cfg["ow"], cfg["oh"], cfg["fov"])
+    for yi, yaw in enumerate(cfg["yaws"]):
+        # the yaw tables are bit-exact (IEEE-only arithmetic): check, then use the oracle's stage 1
+        row = maps.yaw_column_table(cfg["pw"], yaw)
+        ix, _, fx, _ = cpu_ref.quantise_maps(row[None, :], np.zeros((1, cfg["pw"]), np.float32))
+        assert np.array_equal(tabs[yi], (3 * ix[0].astype(np.uint32)) | (fx[0].astype(np.uint32) << 20))
+        rot = cpu_ref.yaw_stage(pano, yaw)
+        for pi in range(len(cfg["pitches"])):
+            U, V = coords_to_maps(coords[pi])
+            want = cpu_ref.remap(rot, U, V, cpu_ref.BORDER_CONSTANT)
+            assert np.array_equal(views[yi, pi], want)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(pw=2048, ph=1024, ow=512, oh=512, fov=90, yaws=[0], pitches=[90]),
+    dict(pw=2048, ph=1024, ow=480, oh=270, fov=90, yaws=[0, 30, 330], pitches=[60, 90, 120]),
+    dict(pw=4096, ph=2048, ow=800, oh=800, fov=90, yaws=[90], pitches=[30, 150]),   # reference CLI defaults
+])
+def test_within_one_level_on_bandlimited(gpu, pkg, synth, cfg):
+    pano = synth.synth_pano(cfg["pw"], cfg["ph"], 1000, "S")
+    got = pkg.process_views(pano, cfg["yaws"], cfg["pitches"], cfg["ow"], cfg["oh"], cfg["fov"])
+    want = oracle_views(pano, cfg["yaws"], cfg["pitches"], cfg["ow"], cfg["oh"], cfg["fov"])
+    mx, frac_gt1, frac_any = diff_stats(got, want)
+    print("band-limited: max |diff| %d, >1: %.4g, any: %.4g" % (mx, frac_gt1, frac_any))
+    assert mx <= 1  # north_star: +-1 per uint8 channel
+
+
+def test_noise_mismatch_fraction_is_small(gpu, pkg, synth):
+    pano = synth.synth_pano(2048, 1024, 1000, "N")
+    yaws, pitches = [0, 30], [60, 90, 120]
+    got = pkg.process_views(pano, yaws, pitches, 480, 270, 90)
+    want = oracle_views(pano, yaws, pitches, 480, 270, 90)
+    mx, frac_gt1, frac_any = diff_stats(got, want)
+    print("noise: max |diff| %d, >1: %.4g, any: %.4g" % (mx, frac_gt1, frac_any))
+    # each flipped 1/32-px coordinate moves a noise pixel by up to ~8 levels; flips must stay rare
+    assert mx <= 16
+    assert frac_gt1 < 0.02
+
+
+@pytest.mark.parametrize("args", [
+    (64, 48, 90, 256, 128, 90), (64, 48, 1, 256, 128, 60), (64, 48, 179, 256, 128, 120),
+    (512, 512, 90, 2048, 1024, 90), (1920, 1080, 60, 8192, 4096, 90), (800, 800, 30, 4096, 2048, 90),
+])
+def test_pitch_map_matches_reference_1e5(gpu, pkg, args):
+    ow, oh, pitch, pw, ph, fov = args
+    pkg.panorama_to_plane_pitch.pitch_mapping_cache.clear()
+    U, V = pkg.get_pitch_mapping(ow, oh, pitch, pw, ph, fov)
+    Ur, Vr = maps.pitch_map_deg(ow, oh, pitch, pw, ph, fov)
+    assert U.dtype == np.float32 and U.shape == (oh, ow)
+    ok = ~(np.isnan(Vr) | np.isnan(V))
+    assert ok.mean() > 0.9999
+    # U wraps at the seam (phi = 0 / 2pi): compare modulo the panorama width there
+    dU = np.abs(U - Ur)
+    dU = np.minimum(dU, pw - 1 - dU)
+    assert (dU[ok] <= 1e-5 * np.maximum(np.abs(Ur[ok]), 1.0)).all(), dU[ok].max()
+    assert np.allclose(V[ok], Vr[ok], rtol=1e-5, atol=1e-5)
+    sx, sy, _, _ = cpu_ref.quantise_maps(U, V)
+    rx, ry, _, _ = cpu_ref.quantise_maps(Ur, Vr)
+    print("quantised coordinate flips: %.4g" % float(((sx != rx) | (sy != ry))[ok].mean()))
+
+
+@pytest.mark.parametrize("pw", [256, 2048, 8192, 16384, 1000, 4095])
+def test_yaw_rows_bit_exact(gpu, pkg, pw):
+    for yaw in (0, 1, 30, 45, 77, 90, 359, 360, -30, 400, 123456, -7):
+        pkg.panorama_to_plane_pitch.yaw_mapping_cache.clear()
+        row = gpu.build_yaw_row(pw, float(np.radians(yaw)))
+        assert np.array_equal(row, maps.yaw_column_table(pw, yaw)), (pw, yaw)
+    U, V = pkg.get_yaw_mapping(pw, 4, 30)
+    Ur, Vr = maps.yaw_map(pw, 4, 30)
+    assert np.array_equal(U, Ur) and np.array_equal(V, Vr)
