@@ -10,9 +10,19 @@
 namespace p2p {
 
 constexpr int TILE_W = 32;          // output tile of one workgroup
-constexpr int TILE_H = 8;
-constexpr int VIEWS_BLOCK = TILE_W * TILE_H;
-constexpr int LDS_TILE_CAP = 4096;  // dwords of yaw-resampled panorama footprint per LDS buffer
+constexpr int TILE_H = 16;
+constexpr int VIEWS_BLOCK = 256;
+constexpr int VIEWS_PXT = TILE_W * TILE_H / VIEWS_BLOCK;  // output pixels per thread (rows ROWSTEP apart)
+constexpr int VIEWS_SLOTS = 2;      // 16-byte footprint items one thread produces per (panorama, yaw) pair
+constexpr int LDS_ITEMS_CAP = VIEWS_SLOTS * VIEWS_BLOCK;  // items (4 rot pixels each) per LDS buffer
+
+// how the yaw map of one yaw angle acts on columns (see yaw_desc_kernel)
+struct YawDesc {
+    int s;        // rot column c reads source column (c + s) mod pw
+    int mode;     // 0: one two-tap weight f for every column; 1: per-column weights (f4tab); 2: not a shift
+    int f;        // mode 0: the weight, 0..32
+    int c_clamp;  // mode 0: the one column whose weight differs (clipped to pw-1), or -1
+};
 
 // scalars of precompute_pitch_mapping (P:114-175) that NumPy evaluates once, on the host, in
 // float64 and then uses as float32
@@ -32,6 +42,8 @@ struct ViewsParams {
     int src_pitch;           // bytes between rows (>= 3 * pw)
     int pw, ph;
     const uint32_t* ytab;    // [n_yaw][pw] packed yaw-table entries: 3*ix | fx << 20
+    const YawDesc* ydesc;    // [n_yaw]
+    const uint32_t* f4tab;   // [n_yaw][pw] weights of columns c..c+3 (mod pw), one byte each
     int n_yaw, n_pitch, n_panos;
     int pairs_per_block;     // (panorama, yaw) pairs looped over by one workgroup
     const PitchConst* pitch; // [n_pitch]
@@ -57,6 +69,8 @@ struct RemapParams {
 hipError_t launch_yaw_tables(uint32_t* packed, float* rows, int pw, int n_yaw, const double* yaw_rad,
                              hipStream_t st);
 hipError_t launch_yaw_pack(uint32_t* packed, const float* rows, size_t n, hipStream_t st);
+hipError_t launch_yaw_desc(YawDesc* desc, uint32_t* f4tab, const uint32_t* packed, int pw, int n_yaw,
+                           hipStream_t st);
 hipError_t launch_pitch_map(float* U, float* V, int ow, int oh, const MapGeom& g, float c, float s,
                             hipStream_t st);
 hipError_t launch_remap_views(const ViewsParams& P, bool host_maps, hipStream_t st);

@@ -67,6 +67,8 @@ struct p2p_job {
     uint8_t* d_out = nullptr;
     size_t out_bytes = 0;
     uint32_t* d_ytab = nullptr;
+    uint32_t* d_f4tab = nullptr;
+    p2p::YawDesc* d_ydesc = nullptr;
     double* d_yaw_rad = nullptr;
     p2p::PitchConst* d_pitch = nullptr;
     float* d_mapU = nullptr;
@@ -219,6 +221,8 @@ void p2p_job_destroy(p2p_job* j)
     (void)hipFree(j->d_src);
     (void)hipFree(j->d_out);
     (void)hipFree(j->d_ytab);
+    (void)hipFree(j->d_f4tab);
+    (void)hipFree(j->d_ydesc);
     (void)hipFree(j->d_yaw_rad);
     (void)hipFree(j->d_pitch);
     (void)hipFree(j->d_mapU);
@@ -282,6 +286,8 @@ int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out)
     hipError_t e = hipMalloc((void**)&j->d_src, j->pano_stride * d.n_panos);
     if (e == hipSuccess) e = hipMalloc((void**)&j->d_out, j->out_bytes + 16);
     if (e == hipSuccess) e = hipMalloc((void**)&j->d_ytab, (size_t)d.n_yaw * d.pw * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&j->d_f4tab, (size_t)d.n_yaw * d.pw * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&j->d_ydesc, (size_t)d.n_yaw * sizeof(p2p::YawDesc));
     if (e == hipSuccess) e = hipMalloc((void**)&j->d_yaw_rad, (size_t)d.n_yaw * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&j->d_pitch, (size_t)d.n_pitch * sizeof(p2p::PitchConst));
     if (e == hipSuccess && (d.flags & P2P_FLAG_KEEP_COORDS))
@@ -292,6 +298,8 @@ int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out)
         e = hipMemcpyAsync(j->d_pitch, pc.data(), pc.size() * sizeof(p2p::PitchConst), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
         e = p2p::launch_yaw_tables(j->d_ytab, nullptr, d.pw, d.n_yaw, j->d_yaw_rad, ctx->stream);
+    if (e == hipSuccess)
+        e = p2p::launch_yaw_desc(j->d_ydesc, j->d_f4tab, j->d_ytab, d.pw, d.n_yaw, ctx->stream);
     if (e == hipSuccess)
         e = hipStreamSynchronize(ctx->stream);  // yr / pc are stack-lifetime host buffers
     if (e != hipSuccess) {
@@ -340,6 +348,7 @@ int p2p_job_set_maps(p2p_job* j, const float* yaw_rows, const float* U, const fl
         if (!j->d_rows) HIP_TRY(hipMalloc((void**)&j->d_rows, n * sizeof(float)));
         HIP_TRY(hipMemcpyAsync(j->d_rows, yaw_rows, n * sizeof(float), hipMemcpyHostToDevice, j->ctx->stream));
         HIP_TRY(p2p::launch_yaw_pack(j->d_ytab, j->d_rows, n, j->ctx->stream));
+        HIP_TRY(p2p::launch_yaw_desc(j->d_ydesc, j->d_f4tab, j->d_ytab, d.pw, d.n_yaw, j->ctx->stream));
     }
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));
     j->host_maps = true;
@@ -361,6 +370,8 @@ int p2p_job_run(p2p_job* j)
     P.pw = j->d.pw;
     P.ph = j->d.ph;
     P.ytab = j->d_ytab;
+    P.ydesc = j->d_ydesc;
+    P.f4tab = j->d_f4tab;
     P.n_yaw = j->d.n_yaw;
     P.n_pitch = j->d.n_pitch;
     P.n_panos = j->d.n_panos;

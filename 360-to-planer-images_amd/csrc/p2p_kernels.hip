@@ -121,6 +121,102 @@ __global__ void yaw_pack_kernel(uint32_t* __restrict__ packed, const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------
+// Yaw descriptor: the yaw table of P:79-108 is a circular shift.  For rot column c the source
+// column is (c + s) mod pw and the two-tap weight is F[c] in 0..32 (F == 32 encodes "next pixel,
+// fraction 0"; (32-F)*a + F*b + 16 >> 5 then returns b exactly, which is what the table's entry
+// (i+1, 0) gives).  F is one value for the whole yaw except (a) the single column that P:105
+// clips to pw-1 and (b) yaws whose shift fraction sits within float noise of a 1/32-px rounding
+// tie, where F flickers between two neighbours column by column.  mode 0: uniform F (+ optional
+// clamp column); mode 1: per-column F (f4tab); mode 2: not a shift at all (only possible with
+// caller-supplied rows) -> the kernel's direct path uses the packed table.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int yaw_delta(uint32_t te, int c, int s, int pw)
+{
+    int off = (int)(te & 0xFFFFFu), f = (int)(te >> 20);
+    int col = c + s;
+    if (col >= pw)
+        col -= pw;
+    if (off == 3 * col)
+        return f;
+    if (off == 3 * (col + 1) && f == 0 && col + 1 < pw)
+        return 32;
+    return -1;
+}
+
+__global__ __launch_bounds__(256) void yaw_desc_kernel(YawDesc* __restrict__ desc, uint32_t* __restrict__ f4tab,
+                                                       const uint32_t* __restrict__ packed, int pw)
+{
+    __shared__ int bad[2];
+    __shared__ int dmin, dmax;
+    const int yi = blockIdx.x, t = threadIdx.x;
+    const uint32_t* T = packed + (size_t)yi * pw;
+    uint32_t* F4 = f4tab + (size_t)yi * pw;
+    const int i0 = (int)(T[0] & 0xFFFFFu) / 3;
+    if (t < 2)
+        bad[t] = 0;
+    if (t == 0) {
+        dmin = 64;
+        dmax = -1;
+    }
+    __syncthreads();
+    const int s_a = i0, s_b = (i0 + pw - 1) % pw;
+    int nb_a = 0, nb_b = 0;
+    for (int c = t; c < pw; c += 256) {
+        uint32_t te = T[c];
+        nb_a += yaw_delta(te, c, s_a, pw) < 0;
+        nb_b += yaw_delta(te, c, s_b, pw) < 0;
+    }
+    if (nb_a) atomicAdd(&bad[0], nb_a);
+    if (nb_b) atomicAdd(&bad[1], nb_b);
+    __syncthreads();
+    const bool ok_a = bad[0] == 0, ok_b = bad[1] == 0;
+    const int s = ok_a ? s_a : s_b;
+    if (!ok_a && !ok_b) {
+        for (int c = t; c < pw; c += 256)
+            F4[c] = 0u;
+        if (t == 0)
+            desc[yi] = YawDesc{0, 2, 0, -1};
+        return;
+    }
+    const int c_last = (pw - 1 - s + pw) % pw;  // the rot column whose source column is pw-1
+    int lmin = 64, lmax = -1;
+    for (int c = t; c < pw; c += 256) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            int cm = c + m;
+            if (cm >= pw)
+                cm -= pw;
+            int d = yaw_delta(T[cm], cm, s, pw);
+            w |= (uint32_t)d << (8 * m);
+            if (m == 0 && c != c_last) {
+                lmin = min(lmin, d);
+                lmax = max(lmax, d);
+            }
+        }
+        F4[c] = w;
+    }
+    atomicMin(&dmin, lmin);
+    atomicMax(&dmax, lmax);
+    __syncthreads();
+    if (t == 0) {
+        YawDesc d;
+        d.s = s;
+        if (dmin == dmax || pw == 1) {
+            d.mode = 0;
+            d.f = pw == 1 ? 0 : dmin;
+            int dl = yaw_delta(T[c_last], c_last, s, pw);
+            d.c_clamp = (pw > 1 && dl != d.f) ? c_last : -1;
+        } else {
+            d.mode = 1;
+            d.f = 0;
+            d.c_clamp = -1;
+        }
+        desc[yi] = d;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // pitch map as float32 arrays (get_pitch_mapping drop-in, and the 1e-5 map-parity check)
 // ---------------------------------------------------------------------------------------------
 __global__ void pitch_map_kernel(float* __restrict__ U, float* __restrict__ V, int ow, int oh,
@@ -137,23 +233,26 @@ __global__ void pitch_map_kernel(float* __restrict__ U, float* __restrict__ V, i
 }
 
 // ---------------------------------------------------------------------------------------------
-// Stage 1 for one pixel of the yaw-resampled panorama ("rot"), P:192-199:
-//   rot[r][c] = ((32-f)*src[r][i] + f*src[r][i+1] + 16) >> 5  per channel, (i, f) = yaw table[c]
-// (cv::remap with fy == 0: weights 1024*(32-f), 1024*f, rounding 1<<14, shift 15).
-// Returns the pixel as a dword B | G<<8 | R<<16.
+// Stage 1, P:192-199: one pixel of the yaw-resampled panorama ("rot") from two horizontally
+// adjacent source pixels p0, p1 (dwords B | G<<8 | R<<16 | x<<24):
+//   rot = ((32-f)*p0 + f*p1 + 16) >> 5 per channel
+// which is cv::remap with fy == 0 (weights 1024*(32-f), 1024*f, rounding 1<<14, shift 15).
+// Two channels share one 32-bit multiply (16-bit fields hold <= 32*255 + 16).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t rot_pixel(const uint8_t* __restrict__ row, uint32_t te)
+__device__ __forceinline__ uint32_t rot_blend2(uint32_t p0, uint32_t p1, uint32_t f, uint32_t g)
 {
-    uint32_t off = te & 0xFFFFFu;
-    uint32_t f = te >> 20;
-    uint2 q;
-    __builtin_memcpy(&q, row + off, 8);  // unaligned 8-byte load: pixels i and i+1 (6 bytes used)
-    uint32_t p0 = q.x;
-    uint32_t p1 = __builtin_amdgcn_alignbyte(q.y, q.x, 3);
-    uint32_t g = 32u - f;
     uint32_t br = g * (p0 & 0x00FF00FFu) + f * (p1 & 0x00FF00FFu) + 0x00100010u;
     uint32_t gg = g * (p0 & 0x0000FF00u) + f * (p1 & 0x0000FF00u) + 0x00001000u;
     return ((br >> 5) & 0x00FF00FFu) | ((gg >> 5) & 0x0000FF00u);
+}
+
+// direct path: (3*i | f << 20) table entry, unaligned 8-byte load of pixels i and i+1
+__device__ __forceinline__ uint32_t rot_pixel(const uint8_t* __restrict__ row, uint32_t te)
+{
+    uint2 q;
+    __builtin_memcpy(&q, row + (te & 0xFFFFFu), 8);
+    const uint32_t f = te >> 20;
+    return rot_blend2(q.x, __builtin_amdgcn_alignbyte(q.y, q.x, 3), f, 32u - f);
 }
 
 // Stage 2 for one output pixel, P:212-218: bilinear blend of four rot pixels with cv::remap's
@@ -173,139 +272,255 @@ __device__ __forceinline__ uint32_t blend4(uint32_t a, uint32_t b, uint32_t c, u
     return vb | (vg << 8) | (vr << 16);
 }
 
+struct __attribute__((aligned(4))) Q16 { uint32_t d[4]; };
+
 // ---------------------------------------------------------------------------------------------
-// The hot kernel: one workgroup = one TILE_W x TILE_H tile of output pixels of one pitch view;
-// it keeps the pitch-stage coordinates of its pixels in registers and loops over a chunk of
-// (panorama, yaw) pairs.  Per pair it materialises the tile's footprint of the yaw-resampled
-// panorama in LDS (stage 1, exact uint8 intermediate), then gathers the 2x2 taps from LDS
-// (stage 2).  Footprints too large for LDS (views containing a pole) gather straight from
-// global memory with the same arithmetic.
+// The hot kernel.  One workgroup = one TILE_W x TILE_H tile of output pixels of one pitch view,
+// VIEWS_PXT pixels per thread.  Once per tile: every thread evaluates (or loads) the pitch-stage
+// coordinates of its pixels and quantises them as cv::remap does; the workgroup reduces the
+// tile's footprint [c0..c1+1] x [r0..r1+1] in the yaw-resampled panorama ("rot") and cuts it into
+// items of 4 horizontally adjacent rot pixels.  Then, per (panorama, yaw) pair of its chunk:
+//   stage 1  the yaw map is a circular column shift (YawDesc), so a footprint row is one
+//            contiguous run of source bytes: each thread loads one 4-byte-aligned 16-byte piece
+//            (5 1/3 source pixels: fully coalesced, no per-pixel table lookup), blends 4 rot
+//            pixels in registers with the exact uint8 arithmetic and writes them to the LDS tile
+//            (double-buffered) with one ds_write_b128;
+//   stage 2  after one barrier each thread reads the 2x2 taps of its pixels from LDS, blends
+//            with cv::remap's fixed-point weights, and the tile is stored as aligned dwords.
+// Whatever does not fit that scheme takes the direct path (same arithmetic, taps gathered from
+// global memory through the packed yaw table): footprints too large for LDS or touching the
+// panorama border (views containing a pole), panorama widths not divisible by 4, yaw rows that
+// are not a shift.  Blocks map to tiles XCD-aware: each of the 8 XCDs owns a contiguous run of
+// the tile raster, so neighbouring tiles (shared source halo and output lines) meet in one L2.
 // ---------------------------------------------------------------------------------------------
 template <bool HOST_MAPS>
 __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_kernel(ViewsParams P)
 {
-    __shared__ uint32_t tile[2][LDS_TILE_CAP];
+    __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
     __shared__ int bbox[4];
 
     const int t = threadIdx.x;
     const int tiles_x = (P.ow + TILE_W - 1) / TILE_W;
-    const int tile_id = blockIdx.x;
+    const int tiles_y = (P.oh + TILE_H - 1) / TILE_H;
+    const int chunk = gridDim.x >> 3;  // gridDim.x == 8 * ceil(tiles / 8)
+    const int tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (tile_id >= tiles_x * tiles_y)
+        return;
     const int pitch_i = blockIdx.y;
     const int x0 = (tile_id % tiles_x) * TILE_W;
     const int y0 = (tile_id / tiles_x) * TILE_H;
     const int px = x0 + (t % TILE_W);
-    const int py = y0 + (t / TILE_W);
-    const bool inside = px < P.ow && py < P.oh;
+    const int py0 = y0 + (t / TILE_W);
+    constexpr int ROWSTEP = VIEWS_BLOCK / TILE_W;  // rows between a thread's pixels
 
-    // ---- pitch-stage coordinate of this thread's pixel, quantised as cv::remap does ----
-    int sx = INT32_MIN, sy = INT32_MIN;
-    if (inside) {
-        float U, V;
-        if (HOST_MAPS) {
-            size_t k = ((size_t)pitch_i * P.oh + py) * P.ow + px;
-            U = P.mapU[k];
-            V = P.mapV[k];
-        } else {
-            PitchConst pc = P.pitch[pitch_i];
-            pitch_map_eval((float)px, (float)py, P.geom, pc.c, pc.s, U, V);
+    // ---- pitch-stage coordinates of this thread's pixels, quantised as cv::remap does ----
+    int ix[VIEWS_PXT], iy[VIEWS_PXT];
+    uint32_t fx[VIEWS_PXT], fy[VIEWS_PXT];
+    bool inside[VIEWS_PXT], live[VIEWS_PXT];
+#pragma unroll
+    for (int j = 0; j < VIEWS_PXT; ++j) {
+        const int py = py0 + j * ROWSTEP;
+        inside[j] = px < P.ow && py < P.oh;
+        int sx = INT32_MIN, sy = INT32_MIN;
+        if (inside[j]) {
+            float U, V;
+            if (HOST_MAPS) {
+                size_t k = ((size_t)pitch_i * P.oh + py) * P.ow + px;
+                U = P.mapU[k];
+                V = P.mapV[k];
+            } else {
+                PitchConst pc = P.pitch[pitch_i];
+                pitch_map_eval((float)px, (float)py, P.geom, pc.c, pc.s, U, V);
+            }
+            sx = cv_round_f32(U * 32.0f);
+            sy = cv_round_f32(V * 32.0f);
+            if (P.coords && blockIdx.z == 0) {
+                size_t k = (((size_t)pitch_i * P.oh + py) * P.ow + px) * 2;
+                P.coords[k] = sx;
+                P.coords[k + 1] = sy;
+            }
         }
-        sx = cv_round_f32(U * 32.0f);
-        sy = cv_round_f32(V * 32.0f);
-        if (P.coords && blockIdx.z == 0) {
-            size_t k = (((size_t)pitch_i * P.oh + py) * P.ow + px) * 2;
-            P.coords[k] = sx;
-            P.coords[k + 1] = sy;
-        }
+        ix[j] = sat_short(sx >> 5);
+        iy[j] = sat_short(sy >> 5);
+        fx[j] = (uint32_t)sx & 31u;
+        fy[j] = (uint32_t)sy & 31u;
+        // A pixel contributes only if its 2x2 footprint touches the panorama (BORDER_CONSTANT 0:
+        // cv::remap writes borderValue when sx >= w || sx+1 < 0 || sy >= h || sy+1 < 0).  For the
+        // reference's clipped maps that is every pixel except NaN ones (ix = iy = -32768).
+        live[j] = inside[j] && ix[j] >= -1 && iy[j] >= -1 && ix[j] < P.pw && iy[j] < P.ph;
     }
-    int ix = sat_short(sx >> 5), iy = sat_short(sy >> 5);
-    const uint32_t fx = (uint32_t)sx & 31u, fy = (uint32_t)sy & 31u;
-    // A pixel contributes only if its 2x2 footprint touches the panorama (BORDER_CONSTANT 0:
-    // cv::remap writes borderValue when sx >= w || sx+1 < 0 || sy >= h || sy+1 < 0).  For the
-    // reference's clipped maps that is every pixel except NaN ones (ix = iy = -32768).
-    const bool live = inside && ix >= -1 && iy >= -1 && ix < P.pw && iy < P.ph;
 
     // ---- footprint of the tile in rot space ----
     if (t < 4)
         bbox[t] = (t & 1) ? -2 : INT32_MAX;  // [0]=min x, [1]=max x, [2]=min y, [3]=max y
     __syncthreads();
-    if (live) {
-        atomicMin(&bbox[0], ix);
-        atomicMax(&bbox[1], ix);
-        atomicMin(&bbox[2], iy);
-        atomicMax(&bbox[3], iy);
-    }
+#pragma unroll
+    for (int j = 0; j < VIEWS_PXT; ++j)
+        if (live[j]) {
+            atomicMin(&bbox[0], ix[j]);
+            atomicMax(&bbox[1], ix[j]);
+            atomicMin(&bbox[2], iy[j]);
+            atomicMax(&bbox[3], iy[j]);
+        }
     __syncthreads();
     const int c0 = bbox[0], c1 = bbox[1], r0 = bbox[2], r1 = bbox[3];
     const bool any_live = c1 >= -1;
     const int Wt = c1 - c0 + 2, Ht = r1 - r0 + 2;  // +1 for the right / lower taps
-    const int area = Wt * Ht;
-    const bool use_lds = any_live && Wt <= 255 && area <= LDS_TILE_CAP;
-    // idx / Wt by multiply-shift: exact for idx*Wt < 2^20 (idx < 4096, Wt < 256)
-    const uint32_t magic = use_lds ? ((1u << 20) + (uint32_t)Wt - 1u) / (uint32_t)Wt : 0u;
-    const int tap = live ? (iy - r0) * Wt + (ix - c0) : 0;
+    const int G = (Wt + 6) >> 2;                   // 4-pixel items per footprint row (+3: alignment slack)
+    const int rowdw = 4 * G;                       // LDS tile row stride in dwords
+    const int items = Ht * G;
+    // the LDS scheme needs the whole footprint strictly inside the panorama (so that no tap is a
+    // border tap) and a width divisible by 4 (so that 12-byte items never straddle a row end)
+    const bool fast_tile = any_live && (P.pw & 3) == 0 && c0 >= 0 && r0 >= 0 && c1 + 1 < P.pw &&
+                           r1 + 1 < P.ph && G <= 255 && items <= LDS_ITEMS_CAP;
+    const int nslots = fast_tile ? (items + VIEWS_BLOCK - 1) / VIEWS_BLOCK : 0;
+
+    // ---- the items this thread produces (same for every pair) ----
+    uint32_t slot_row[VIEWS_SLOTS];
+    int slot_g[VIEWS_SLOTS];
+    {
+        // item / G by multiply-shift: exact for item * G < 2^20 (item < 512, G < 256)
+        const uint32_t magic = fast_tile ? ((1u << 20) + (uint32_t)G - 1u) / (uint32_t)G : 0u;
+#pragma unroll
+        for (int k = 0; k < VIEWS_SLOTS; ++k) {
+            int item = t + k * VIEWS_BLOCK;
+            if (item >= items)
+                item = 0;  // surplus threads redo item 0 into LDS space nobody reads
+            const int rr = (int)(((uint32_t)item * magic) >> 20);
+            slot_row[k] = (uint32_t)(r0 + rr) * (uint32_t)P.src_pitch;
+            slot_g[k] = item - rr * G;
+        }
+    }
+    int tap[VIEWS_PXT];
+    uint32_t lmask[VIEWS_PXT];
+#pragma unroll
+    for (int j = 0; j < VIEWS_PXT; ++j) {
+        tap[j] = (live[j] && fast_tile) ? (iy[j] - r0) * rowdw + (ix[j] - c0) : 0;
+        lmask[j] = live[j] ? 0xFFFFFFFFu : 0u;
+    }
 
     // output addressing: 4 horizontally adjacent pixels = 12 bytes = 3 aligned dwords
     const int lane4 = t & 3;
     const bool fast_store = (P.ow & 3) == 0;
     const size_t view_bytes = (size_t)P.oh * P.ow * 3;
+    const size_t pix_off = ((size_t)py0 * P.ow + px) * 3;
+    const size_t pix_step = (size_t)ROWSTEP * P.ow * 3;
 
     const int pair0 = blockIdx.z * P.pairs_per_block;
     int pair1 = pair0 + P.pairs_per_block;
     const int n_pairs = P.n_panos * P.n_yaw;
     if (pair1 > n_pairs)
         pair1 = n_pairs;
+    int pano_i = pair0 / P.n_yaw;
+    int yaw_i = pair0 - pano_i * P.n_yaw;
+    const int ngroups = P.pw >> 2;
 
     int buf = 0;
-    for (int pair = pair0; pair < pair1; ++pair, buf ^= 1) {
-        const int pano_i = pair / P.n_yaw;
-        const int yaw_i = pair - pano_i * P.n_yaw;
+    for (int pair = pair0; pair < pair1; ++pair) {
         const uint8_t* __restrict__ S = P.src + (size_t)pano_i * P.pano_stride;
-        const uint32_t* __restrict__ T = P.ytab + (size_t)yaw_i * P.pw;
-        uint32_t pix = 0;
+        const YawDesc yd = P.ydesc[yaw_i];
+        uint32_t pix[VIEWS_PXT];
 
-        if (use_lds) {
-            uint32_t* tl = tile[buf];
-            for (int idx = t; idx < area; idx += VIEWS_BLOCK) {
-                int rr = (int)(((uint32_t)idx * magic) >> 20);
-                int cc = idx - rr * Wt;
-                int r = r0 + rr, c = c0 + cc;
-                uint32_t val = 0;
-                if (r >= 0 && c >= 0 && r < P.ph && c < P.pw)
-                    val = rot_pixel(S + (size_t)r * P.src_pitch, T[c]);
-                tl[idx] = val;
+        if (fast_tile && yd.mode != 2) {
+            int i_first = c0 + yd.s;
+            if (i_first >= P.pw)
+                i_first -= P.pw;
+            const int g0 = i_first >> 2, joff = i_first & 3;
+            // uniform F unless this yaw flickers or the tile holds the column clipped to pw-1
+            const bool per_column = yd.mode == 1 || (yd.c_clamp >= c0 && yd.c_clamp <= c1 + 1);
+            uint4* tl4 = tile4[buf];
+            Q16 q[VIEWS_SLOTS];
+            uint32_t fw[VIEWS_SLOTS];
+#pragma unroll
+            for (int k = 0; k < VIEWS_SLOTS; ++k) {
+                if (k < nslots) {
+                    int gi = g0 + slot_g[k];
+                    if (gi >= ngroups)
+                        gi -= ngroups;
+                    q[k] = *reinterpret_cast<const Q16*>(S + slot_row[k] + 12u * (uint32_t)gi);
+                    if (per_column) {
+                        int cf = 4 * gi - yd.s;
+                        if (cf < 0)
+                            cf += P.pw;
+                        fw[k] = P.f4tab[(size_t)yaw_i * P.pw + cf];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < VIEWS_SLOTS; ++k) {
+                if (k < nslots) {
+                    const uint32_t p0 = q[k].d[0];
+                    const uint32_t p1 = __builtin_amdgcn_alignbyte(q[k].d[1], q[k].d[0], 3);
+                    const uint32_t p2 = __builtin_amdgcn_alignbyte(q[k].d[2], q[k].d[1], 2);
+                    const uint32_t p3 = __builtin_amdgcn_alignbyte(q[k].d[3], q[k].d[2], 1);
+                    const uint32_t p4 = q[k].d[3];
+                    uint4 o;
+                    if (per_column) {
+                        const uint32_t f0 = fw[k] & 0xFFu, f1 = (fw[k] >> 8) & 0xFFu,
+                                       f2 = (fw[k] >> 16) & 0xFFu, f3 = fw[k] >> 24;
+                        o.x = rot_blend2(p0, p1, f0, 32u - f0);
+                        o.y = rot_blend2(p1, p2, f1, 32u - f1);
+                        o.z = rot_blend2(p2, p3, f2, 32u - f2);
+                        o.w = rot_blend2(p3, p4, f3, 32u - f3);
+                    } else {
+                        const uint32_t f = (uint32_t)yd.f, g = 32u - f;
+                        o.x = rot_blend2(p0, p1, f, g);
+                        o.y = rot_blend2(p1, p2, f, g);
+                        o.z = rot_blend2(p2, p3, f, g);
+                        o.w = rot_blend2(p3, p4, f, g);
+                    }
+                    tl4[t + k * VIEWS_BLOCK] = o;
+                }
             }
             __syncthreads();
-            if (live)
-                pix = blend4(tl[tap], tl[tap + 1], tl[tap + Wt], tl[tap + Wt + 1], fx, fy);
-        } else if (live) {
-            // direct gather (pole-containing footprints): same arithmetic, taps from global memory
-            const bool c0in = ix >= 0, c1in = ix + 1 < P.pw, r0in = iy >= 0, r1in = iy + 1 < P.ph;
-            const uint8_t* row0 = S + (ptrdiff_t)iy * P.src_pitch;
-            const uint8_t* row1 = row0 + P.src_pitch;
-            const uint32_t t0 = c0in ? T[ix] : 0u, t1 = c1in ? T[ix + 1] : 0u;
-            uint32_t a = (c0in && r0in) ? rot_pixel(row0, t0) : 0u;
-            uint32_t b = (c1in && r0in) ? rot_pixel(row0, t1) : 0u;
-            uint32_t c = (c0in && r1in) ? rot_pixel(row1, t0) : 0u;
-            uint32_t d = (c1in && r1in) ? rot_pixel(row1, t1) : 0u;
-            pix = blend4(a, b, c, d, fx, fy);
+            const uint32_t* tl = reinterpret_cast<const uint32_t*>(tl4);
+#pragma unroll
+            for (int j = 0; j < VIEWS_PXT; ++j) {
+                const int b = tap[j] + joff;
+                pix[j] = blend4(tl[b], tl[b + 1], tl[b + rowdw], tl[b + rowdw + 1], fx[j], fy[j]) & lmask[j];
+            }
+            buf ^= 1;  // the next pair writes the other buffer; its readers are past this barrier
+        } else {
+            // direct gather: same arithmetic, taps from global memory through the packed yaw table
+            const uint32_t* __restrict__ T = P.ytab + (size_t)yaw_i * P.pw;
+#pragma unroll
+            for (int j = 0; j < VIEWS_PXT; ++j) {
+                pix[j] = 0;
+                if (live[j]) {
+                    const bool c0in = ix[j] >= 0, c1in = ix[j] + 1 < P.pw, r0in = iy[j] >= 0, r1in = iy[j] + 1 < P.ph;
+                    const uint8_t* row0 = S + (ptrdiff_t)iy[j] * P.src_pitch;
+                    const uint8_t* row1 = row0 + P.src_pitch;
+                    const uint32_t t0 = c0in ? T[ix[j]] : 0u, t1 = c1in ? T[ix[j] + 1] : 0u;
+                    uint32_t a = (c0in && r0in) ? rot_pixel(row0, t0) : 0u;
+                    uint32_t b = (c1in && r0in) ? rot_pixel(row0, t1) : 0u;
+                    uint32_t c = (c0in && r1in) ? rot_pixel(row1, t0) : 0u;
+                    uint32_t d = (c1in && r1in) ? rot_pixel(row1, t1) : 0u;
+                    pix[j] = blend4(a, b, c, d, fx[j], fy[j]);
+                }
+            }
         }
 
         // ---- store: [pano][yaw][pitch][oh][ow][3] ----
-        uint8_t* O = P.out + ((size_t)pair * P.n_pitch + pitch_i) * view_bytes;
-        if (fast_store) {
-            // lanes 4k..4k+3 hold pixels P0..P3; lanes with lane4 < 3 emit dword lane4 of the 12 bytes
-            uint32_t nxt = __shfl_down(pix, 1);
-            uint32_t dw = __builtin_amdgcn_alignbit(nxt, pix << 8, 8u * (uint32_t)(lane4 + 1));
-            if (inside && lane4 < 3)
-                *reinterpret_cast<uint32_t*>(O + ((size_t)py * P.ow + px) * 3 + lane4) = dw;
-        } else if (inside) {
-            uint8_t* o = O + ((size_t)py * P.ow + px) * 3;
-            o[0] = (uint8_t)pix;
-            o[1] = (uint8_t)(pix >> 8);
-            o[2] = (uint8_t)(pix >> 16);
+        uint8_t* O = P.out + ((size_t)pair * P.n_pitch + pitch_i) * view_bytes + pix_off;
+#pragma unroll
+        for (int j = 0; j < VIEWS_PXT; ++j) {
+            if (fast_store) {
+                // lanes 4k..4k+3 hold pixels P0..P3; lanes with lane4 < 3 emit dword lane4 of the 12 bytes
+                uint32_t nxt = __shfl_down(pix[j], 1);
+                uint32_t dw = __builtin_amdgcn_alignbit(nxt, pix[j] << 8, 8u * (uint32_t)(lane4 + 1));
+                if (inside[j] && lane4 < 3)
+                    *reinterpret_cast<uint32_t*>(O + j * pix_step + lane4) = dw;
+            } else if (inside[j]) {
+                uint8_t* o = O + j * pix_step;
+                o[0] = (uint8_t)pix[j];
+                o[1] = (uint8_t)(pix[j] >> 8);
+                o[2] = (uint8_t)(pix[j] >> 16);
+            }
         }
-        // the other LDS buffer is written next iteration; its readers finished before the
-        // barrier above, so one barrier per pair suffices
+        if (++yaw_i == P.n_yaw) {
+            yaw_i = 0;
+            ++pano_i;
+        }
     }
 }
 
@@ -407,6 +622,13 @@ hipError_t launch_yaw_pack(uint32_t* packed, const float* rows, size_t n, hipStr
     return hipGetLastError();
 }
 
+hipError_t launch_yaw_desc(YawDesc* desc, uint32_t* f4tab, const uint32_t* packed, int pw, int n_yaw,
+                           hipStream_t st)
+{
+    hipLaunchKernelGGL(yaw_desc_kernel, dim3(n_yaw), dim3(256), 0, st, desc, f4tab, packed, pw);
+    return hipGetLastError();
+}
+
 hipError_t launch_pitch_map(float* U, float* V, int ow, int oh, const MapGeom& g, float c, float s,
                             hipStream_t st)
 {
@@ -420,7 +642,7 @@ hipError_t launch_remap_views(const ViewsParams& P, bool host_maps, hipStream_t 
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
     const int n_pairs = P.n_panos * P.n_yaw;
     const int zblocks = (n_pairs + P.pairs_per_block - 1) / P.pairs_per_block;
-    dim3 grid(tiles, P.n_pitch, zblocks);
+    dim3 grid(8 * ((tiles + 7) / 8), P.n_pitch, zblocks);  // 8 XCDs, each a contiguous run of tiles
     if (host_maps)
         hipLaunchKernelGGL(remap_views_kernel<true>, grid, dim3(VIEWS_BLOCK), 0, st, P);
     else
