@@ -10,7 +10,10 @@ SOURCES = [os.path.join(CSRC, "p2p_kernels.hip"), os.path.join(CSRC, "p2p_host.c
 DEPS = SOURCES + [os.path.join(CSRC, "p2p_device.h"), os.path.join(HERE, "..", "include", "p2p_hip.h")]
 # -ffp-contract=off: the coordinate maths must round exactly where NumPy rounds (no fused a*b+c
 # unless written as fmaf).  IEEE divide / sqrt are hipcc's default for fp32.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-Wall"]
+# -amdgpu-atomic-optimizer-strategy=DPP: the default (iterative) strategy turns every LDS atomicMin/Max
+# of the footprint reduction into a 64-iteration scalar loop; DPP makes it a 6-step wave reduction.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-Wall",
+         "-mllvm", "-amdgpu-atomic-optimizer-strategy=DPP"]
 
 
 def build(force=False, verbose=False):

@@ -294,7 +294,11 @@ struct __attribute__((aligned(4))) Q16 { uint32_t d[4]; };
 // the tile raster, so neighbouring tiles (shared source halo and output lines) meet in one L2.
 // ---------------------------------------------------------------------------------------------
 template <bool HOST_MAPS>
-__global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_kernel(ViewsParams P)
+__global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_kernel(
+    ViewsParams P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab,
+    const YawDesc* __restrict__ ydesc, const uint32_t* __restrict__ f4tab,
+    const PitchConst* __restrict__ pitch, const float* __restrict__ mapU,
+    const float* __restrict__ mapV, uint8_t* __restrict__ out, int32_t* __restrict__ coords)
 {
     __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
     __shared__ int bbox[4];
@@ -326,18 +330,18 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_kernel(ViewsParams P)
             float U, V;
             if (HOST_MAPS) {
                 size_t k = ((size_t)pitch_i * P.oh + py) * P.ow + px;
-                U = P.mapU[k];
-                V = P.mapV[k];
+                U = mapU[k];
+                V = mapV[k];
             } else {
-                PitchConst pc = P.pitch[pitch_i];
+                PitchConst pc = pitch[pitch_i];
                 pitch_map_eval((float)px, (float)py, P.geom, pc.c, pc.s, U, V);
             }
             sx = cv_round_f32(U * 32.0f);
             sy = cv_round_f32(V * 32.0f);
-            if (P.coords && blockIdx.z == 0) {
+            if (coords && blockIdx.z == 0) {
                 size_t k = (((size_t)pitch_i * P.oh + py) * P.ow + px) * 2;
-                P.coords[k] = sx;
-                P.coords[k + 1] = sy;
+                coords[k] = sx;
+                coords[k + 1] = sy;
             }
         }
         ix[j] = sat_short(sx >> 5);
@@ -417,8 +421,8 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_kernel(ViewsParams P)
 
     int buf = 0;
     for (int pair = pair0; pair < pair1; ++pair) {
-        const uint8_t* __restrict__ S = P.src + (size_t)pano_i * P.pano_stride;
-        const YawDesc yd = P.ydesc[yaw_i];
+        const uint8_t* __restrict__ S = src + (size_t)pano_i * P.pano_stride;
+        const YawDesc yd = ydesc[yaw_i];
         uint32_t pix[VIEWS_PXT];
 
         if (fast_tile && yd.mode != 2) {
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_kernel(ViewsParams P)
                         int cf = 4 * gi - yd.s;
                         if (cf < 0)
                             cf += P.pw;
-                        fw[k] = P.f4tab[(size_t)yaw_i * P.pw + cf];
+                        fw[k] = f4tab[(size_t)yaw_i * P.pw + cf];
                     }
                 }
             }
@@ -482,7 +486,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_kernel(ViewsParams P)
             buf ^= 1;  // the next pair writes the other buffer; its readers are past this barrier
         } else {
             // direct gather: same arithmetic, taps from global memory through the packed yaw table
-            const uint32_t* __restrict__ T = P.ytab + (size_t)yaw_i * P.pw;
+            const uint32_t* __restrict__ T = ytab + (size_t)yaw_i * P.pw;
 #pragma unroll
             for (int j = 0; j < VIEWS_PXT; ++j) {
                 pix[j] = 0;
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_kernel(ViewsParams P)
         }
 
         // ---- store: [pano][yaw][pitch][oh][ow][3] ----
-        uint8_t* O = P.out + ((size_t)pair * P.n_pitch + pitch_i) * view_bytes + pix_off;
+        uint8_t* O = out + ((size_t)pair * P.n_pitch + pitch_i) * view_bytes + pix_off;
 #pragma unroll
         for (int j = 0; j < VIEWS_PXT; ++j) {
             if (fast_store) {
@@ -644,9 +648,11 @@ hipError_t launch_remap_views(const ViewsParams& P, bool host_maps, hipStream_t 
     const int zblocks = (n_pairs + P.pairs_per_block - 1) / P.pairs_per_block;
     dim3 grid(8 * ((tiles + 7) / 8), P.n_pitch, zblocks);  // 8 XCDs, each a contiguous run of tiles
     if (host_maps)
-        hipLaunchKernelGGL(remap_views_kernel<true>, grid, dim3(VIEWS_BLOCK), 0, st, P);
+        hipLaunchKernelGGL(remap_views_kernel<true>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc,
+                           P.f4tab, P.pitch, P.mapU, P.mapV, P.out, P.coords);
     else
-        hipLaunchKernelGGL(remap_views_kernel<false>, grid, dim3(VIEWS_BLOCK), 0, st, P);
+        hipLaunchKernelGGL(remap_views_kernel<false>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc,
+                           P.f4tab, P.pitch, P.mapU, P.mapV, P.out, P.coords);
     return hipGetLastError();
 }
 

@@ -96,3 +96,48 @@ def test_resident_job_multi_pano(gpu, synth):
     assert job.kernel_ms() > 0
     job.close()
     ctx.close()
+
+
+def test_flickering_yaw_fraction_per_column_weights(gpu, synth):
+    # yaw 14 on an 8192-wide panorama: 32 * 14 * 8192 / 360 sits within float32 noise of a rounding
+    # tie, so the 1/32-px fraction differs from column to column (YawDesc mode 1)
+    from oracle import cpu_ref, maps
+    row = maps.yaw_column_table(8192, 14)
+    _, _, fxq, _ = cpu_ref.quantise_maps(row[None], np.zeros((1, 8192), np.float32))
+    assert len(np.unique(fxq)) >= 2
+    _check(gpu, synth.synth_pano(8192, 512, 1011, "N"), [14, 59, 0], [80, 100], 256, 144)
+
+
+def test_caller_yaw_rows_that_are_not_a_shift(gpu, synth):
+    # p2p_remap_views_maps_u8 accepts any in-range yaw row; a mirrored / stretched row is not a circular
+    # shift (YawDesc mode 2) and must still equal two chained cv2.remap calls
+    from oracle import cpu_ref, maps
+    pw, ph, ow, oh = 512, 256, 96, 64
+    pano = synth.synth_pano(pw, ph, 1012, "N")
+    x = np.arange(pw, dtype=np.float32)
+    rows = np.stack([pw - 1 - x, np.clip(x * 0.731 + 3.3, 0, pw - 1), maps.yaw_column_table(pw, 40)]).astype(np.float32)
+    U, V = maps.pitch_map_deg(ow, oh, 75, pw, ph, 90)
+    got = gpu.remap_views_maps(pano, rows, U[None], V[None])
+    Vy = np.broadcast_to(np.arange(ph, dtype=np.float32)[:, None], (ph, pw))
+    for k in range(3):
+        rot = cpu_ref.remap(pano, np.broadcast_to(rows[k], (ph, pw)), Vy, cpu_ref.BORDER_CONSTANT)
+        want = cpu_ref.remap(rot, U, V, cpu_ref.BORDER_CONSTANT)
+        assert np.array_equal(got[k, 0], want), k
+
+
+def test_general_caller_pitch_maps_with_border_taps(gpu, synth):
+    # maps that leave the panorama (not produced by the reference, but legal cv2.remap input):
+    # BORDER_CONSTANT 0 taps, partially and fully outside pixels
+    from oracle import cpu_ref, maps
+    pw, ph, ow, oh = 256, 128, 80, 48
+    pano = synth.synth_pano(pw, ph, 1013, "N")
+    rng = np.random.default_rng(5)
+    U = rng.uniform(-3, pw + 2, size=(1, oh, ow)).astype(np.float32)
+    V = rng.uniform(-3, ph + 2, size=(1, oh, ow)).astype(np.float32)
+    U[0, :4, :8] = [[-1.0, -0.5, pw - 1, pw - 0.5, pw, 0, 0.25, -1.03125]] * 4
+    V[0, :4, :8] = np.array([[-1.0], [ph - 1], [ph - 0.5], [0.0]], np.float32)
+    rows = maps.yaw_column_table(pw, 77)[None]
+    got = gpu.remap_views_maps(pano, rows, U, V)
+    rot = cpu_ref.yaw_stage(pano, 77)
+    want = cpu_ref.remap(rot, U[0], V[0], cpu_ref.BORDER_CONSTANT)
+    assert np.array_equal(got[0, 0], want)
