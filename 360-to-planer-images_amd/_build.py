@@ -21,7 +21,8 @@ def build(force=False, verbose=False):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tmp = OUT + ".tmp.%d" % os.getpid()
-    cmd = [hipcc] + FLAGS + ["-o", tmp] + SOURCES
+    extra = os.environ.get("P2P_EXTRA_FLAGS", "").split()  # e.g. -DP2P_STAMPS for the diagnostic build
+    cmd = [hipcc] + FLAGS + extra + ["-o", tmp] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -26,7 +26,7 @@ ABI_SYMBOLS = (
     "p2p_ctx_create", "p2p_ctx_destroy", "p2p_ctx_synchronize",
     "p2p_job_create", "p2p_job_destroy", "p2p_job_set_pano", "p2p_job_set_maps", "p2p_job_run",
     "p2p_job_get_views", "p2p_job_kernel_ms", "p2p_job_kernel_ms_last", "p2p_job_device_out", "p2p_job_get_coords",
-    "p2p_job_get_yaw_tables",
+    "p2p_job_get_yaw_tables", "p2p_debug_stamps",
 )
 
 
@@ -108,6 +108,8 @@ def lib():
     L.p2p_job_get_coords.argtypes = [c_vp, c_vp]
     L.p2p_job_get_yaw_tables.restype = c_int
     L.p2p_job_get_yaw_tables.argtypes = [c_vp, c_vp]
+    L.p2p_debug_stamps.restype = c_int
+    L.p2p_debug_stamps.argtypes = [c_vp, c_int]
     _lib = L
     return L
 
@@ -203,6 +205,12 @@ def remap_maps(src, U, V, border=BORDER_CONSTANT, border_value=None, device=0):
                                   ow, oh, out.ctypes.data, int(border),
                                   None if bv is None else bv.ctypes.data, int(device)))
     return out[:, :, 0] if squeeze else out
+
+
+def debug_stamps(reset=True):
+    out = np.zeros(16, dtype=np.uint64)
+    check(lib().p2p_debug_stamps(out.ctypes.data, int(bool(reset))))
+    return out
 
 
 def build_pitch_map(ow, oh, fov_rad, pitch_rad, pw, ph, device=0):

@@ -476,6 +476,15 @@ int p2p_job_get_yaw_tables(p2p_job* j, uint32_t* packed)
     return P2P_OK;
 }
 
+int p2p_debug_stamps(uint64_t* out16, int reset)
+{
+    if (!out16)
+        return fail(P2P_ERR_INVALID, "NULL pointer");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(p2p::read_stamps(reinterpret_cast<unsigned long long*>(out16), reset != 0));
+    return P2P_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // one-shot entry points
 // ------------------------------------------------------------------------------------------

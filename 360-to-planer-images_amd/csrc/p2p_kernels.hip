@@ -274,6 +274,53 @@ __device__ __forceinline__ uint32_t blend4(uint32_t a, uint32_t b, uint32_t c, u
 
 struct __attribute__((aligned(4))) Q16 { uint32_t d[4]; };
 
+// ---- diagnostic build only: in-kernel phase stamps (never compiled into the shipped library) ----
+__device__ unsigned long long g_stamps[16];
+#ifdef P2P_STAMPS
+#define STAMP(var)                                                                              \
+    do {                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");            \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#endif
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+
+// per-pixel stage-2 weights, constant across (panorama, yaw) pairs
+struct TapWeights {
+    uint32_t gx2, fx2;  // [32-fx, 32-fx], [fx, fx] as two u16
+    uint32_t wy;        // [32-fy, fy] as two u16
+};
+
+// Stage 2 with packed 16-bit maths: per channel, the two rows ride in the two halves of a dword:
+//   H = [a.c, c.c] * [gx, gx] + [b.c, d.c] * [fx, fx]   (v_pk_mul_lo_u16, v_pk_mad_u16; <= 8160)
+//   V = H.lo * gy + H.hi * fy + 512                      (v_dot2_u32_u16)
+// identical in value to blend4().
+__device__ __forceinline__ uint32_t blend4_packed(uint32_t a, uint32_t b, uint32_t c, uint32_t d,
+                                                  const TapWeights& w)
+{
+    const u16x2 gx = as_u16x2(w.gx2), fx = as_u16x2(w.fx2), wy = as_u16x2(w.wy);
+    // v_perm_b32(S0, S1, sel): selector bytes 0-3 pick S1's bytes, 4-7 pick S0's, 0x0c is zero
+    const u16x2 b_ac = as_u16x2(__builtin_amdgcn_perm(c, a, 0x0C040C00u));
+    const u16x2 b_bd = as_u16x2(__builtin_amdgcn_perm(d, b, 0x0C040C00u));
+    const u16x2 g_ac = as_u16x2(__builtin_amdgcn_perm(c, a, 0x0C050C01u));
+    const u16x2 g_bd = as_u16x2(__builtin_amdgcn_perm(d, b, 0x0C050C01u));
+    const u16x2 r_ac = as_u16x2(__builtin_amdgcn_perm(c, a, 0x0C060C02u));
+    const u16x2 r_bd = as_u16x2(__builtin_amdgcn_perm(d, b, 0x0C060C02u));
+    const u16x2 hb = b_ac * gx + b_bd * fx;
+    const u16x2 hg = g_ac * gx + g_bd * fx;
+    const u16x2 hr = r_ac * gx + r_bd * fx;
+    const uint32_t vb = __builtin_amdgcn_udot2(hb, wy, 512u, false);
+    const uint32_t vg = __builtin_amdgcn_udot2(hg, wy, 512u, false);
+    const uint32_t vr = __builtin_amdgcn_udot2(hr, wy, 512u, false);
+    return (vb >> 10) | ((vg >> 2) & 0x0000FF00u) | ((vr << 6) & 0x00FF0000u);
+}
+
 // ---------------------------------------------------------------------------------------------
 // The hot kernel.  One workgroup = one TILE_W x TILE_H tile of output pixels of one pitch view,
 // VIEWS_PXT pixels per thread.  Once per tile: every thread evaluates (or loads) the pitch-stage
@@ -284,7 +331,8 @@ struct __attribute__((aligned(4))) Q16 { uint32_t d[4]; };
 //            contiguous run of source bytes: each thread loads one 4-byte-aligned 16-byte piece
 //            (5 1/3 source pixels: fully coalesced, no per-pixel table lookup), blends 4 rot
 //            pixels in registers with the exact uint8 arithmetic and writes them to the LDS tile
-//            (double-buffered) with one ds_write_b128;
+//            (double-buffered) with one ds_write_b128; the loads of the NEXT pair are issued
+//            before stage 2 so that their latency hides behind it;
 //   stage 2  after one barrier each thread reads the 2x2 taps of its pixels from LDS, blends
 //            with cv::remap's fixed-point weights, and the tile is stored as aligned dwords.
 // Whatever does not fit that scheme takes the direct path (same arithmetic, taps gathered from
@@ -293,6 +341,16 @@ struct __attribute__((aligned(4))) Q16 { uint32_t d[4]; };
 // are not a shift.  Blocks map to tiles XCD-aware: each of the 8 XCDs owns a contiguous run of
 // the tile raster, so neighbouring tiles (shared source halo and output lines) meet in one L2.
 // ---------------------------------------------------------------------------------------------
+struct PairCtx {      // uniform per (tile, pair)
+    bool fast;        // LDS scheme applies
+    bool per_column;  // per-column weights (f4tab) instead of one f
+    int joff;         // tile column of rot column c0
+    uint32_t goff;    // byte offset of the first item of a footprint row within a source row
+    uint32_t wrap_g;  // items with g >= wrap_g wrap to the start of the row
+    uint32_t f;       // uniform weight
+    int cf0;          // rot column of source column 4 * g0
+};
+
 template <bool HOST_MAPS>
 __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_kernel(
     ViewsParams P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab,
@@ -377,38 +435,14 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_kernel(
     // border tap) and a width divisible by 4 (so that 12-byte items never straddle a row end)
     const bool fast_tile = any_live && (P.pw & 3) == 0 && c0 >= 0 && r0 >= 0 && c1 + 1 < P.pw &&
                            r1 + 1 < P.ph && G <= 255 && items <= LDS_ITEMS_CAP;
-    const int nslots = fast_tile ? (items + VIEWS_BLOCK - 1) / VIEWS_BLOCK : 0;
-
-    // ---- the items this thread produces (same for every pair) ----
-    uint32_t slot_row[VIEWS_SLOTS];
-    int slot_g[VIEWS_SLOTS];
-    {
-        // item / G by multiply-shift: exact for item * G < 2^20 (item < 512, G < 256)
-        const uint32_t magic = fast_tile ? ((1u << 20) + (uint32_t)G - 1u) / (uint32_t)G : 0u;
-#pragma unroll
-        for (int k = 0; k < VIEWS_SLOTS; ++k) {
-            int item = t + k * VIEWS_BLOCK;
-            if (item >= items)
-                item = 0;  // surplus threads redo item 0 into LDS space nobody reads
-            const int rr = (int)(((uint32_t)item * magic) >> 20);
-            slot_row[k] = (uint32_t)(r0 + rr) * (uint32_t)P.src_pitch;
-            slot_g[k] = item - rr * G;
-        }
-    }
-    int tap[VIEWS_PXT];
-    uint32_t lmask[VIEWS_PXT];
-#pragma unroll
-    for (int j = 0; j < VIEWS_PXT; ++j) {
-        tap[j] = (live[j] && fast_tile) ? (iy[j] - r0) * rowdw + (ix[j] - c0) : 0;
-        lmask[j] = live[j] ? 0xFFFFFFFFu : 0u;
-    }
 
     // output addressing: 4 horizontally adjacent pixels = 12 bytes = 3 aligned dwords
     const int lane4 = t & 3;
     const bool fast_store = (P.ow & 3) == 0;
     const size_t view_bytes = (size_t)P.oh * P.ow * 3;
-    const size_t pix_off = ((size_t)py0 * P.ow + px) * 3;
-    const size_t pix_step = (size_t)ROWSTEP * P.ow * 3;
+    const uint32_t pix_off = (uint32_t)(((size_t)py0 * P.ow + px) * 3);  // < 3 * 32766^2 < 2^32
+    const uint32_t pix_step = (uint32_t)ROWSTEP * (uint32_t)P.ow * 3u;
+    const uint32_t sh8 = 8u * (uint32_t)(lane4 + 1);
 
     const int pair0 = blockIdx.z * P.pairs_per_block;
     int pair1 = pair0 + P.pairs_per_block;
@@ -417,49 +451,168 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_kernel(
         pair1 = n_pairs;
     int pano_i = pair0 / P.n_yaw;
     int yaw_i = pair0 - pano_i * P.n_yaw;
+
+    auto store_pixels = [&](int pair, const uint32_t (&pix)[VIEWS_PXT]) {
+        // [pano][yaw][pitch][oh][ow][3]
+        uint8_t* O = out + ((size_t)pair * P.n_pitch + pitch_i) * view_bytes;
+#pragma unroll
+        for (int j = 0; j < VIEWS_PXT; ++j) {
+            const uint32_t off = pix_off + (uint32_t)j * pix_step;
+            if (fast_store) {
+                // lanes 4k..4k+3 hold pixels P0..P3; lanes with lane4 < 3 emit dword lane4 of the 12 bytes
+                // neighbour lane's pixel: row_shl:1 DPP (lane4 groups never straddle a 16-lane row)
+                uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pix[j], 0x101, 0xF, 0xF, false);
+                uint32_t dw = __builtin_amdgcn_alignbit(nxt, pix[j] << 8, sh8);
+                if (inside[j] && lane4 < 3)
+                    *reinterpret_cast<uint32_t*>(O + off + lane4) = dw;
+            } else if (inside[j]) {
+                uint8_t* o = O + off;
+                o[0] = (uint8_t)pix[j];
+                o[1] = (uint8_t)(pix[j] >> 8);
+                o[2] = (uint8_t)(pix[j] >> 16);
+            }
+        }
+    };
+
+    auto direct_pixels = [&](const uint8_t* __restrict__ S, int yi, uint32_t (&pix)[VIEWS_PXT]) {
+        // same arithmetic, taps gathered from global memory through the packed yaw table
+        const uint32_t* __restrict__ T = ytab + (size_t)yi * P.pw;
+#pragma unroll
+        for (int j = 0; j < VIEWS_PXT; ++j) {
+            pix[j] = 0;
+            if (live[j]) {
+                const bool c0in = ix[j] >= 0, c1in = ix[j] + 1 < P.pw, r0in = iy[j] >= 0, r1in = iy[j] + 1 < P.ph;
+                const uint8_t* row0 = S + (ptrdiff_t)iy[j] * P.src_pitch;
+                const uint8_t* row1 = row0 + P.src_pitch;
+                const uint32_t t0 = c0in ? T[ix[j]] : 0u, t1 = c1in ? T[ix[j] + 1] : 0u;
+                uint32_t a = (c0in && r0in) ? rot_pixel(row0, t0) : 0u;
+                uint32_t b = (c1in && r0in) ? rot_pixel(row0, t1) : 0u;
+                uint32_t c = (c0in && r1in) ? rot_pixel(row1, t0) : 0u;
+                uint32_t d = (c1in && r1in) ? rot_pixel(row1, t1) : 0u;
+                pix[j] = blend4(a, b, c, d, fx[j], fy[j]);
+            }
+        }
+    };
+
+    if (!fast_tile) {
+        for (int pair = pair0; pair < pair1; ++pair) {
+            uint32_t pix[VIEWS_PXT];
+            direct_pixels(src + (size_t)pano_i * P.pano_stride, yaw_i, pix);
+            store_pixels(pair, pix);
+            if (++yaw_i == P.n_yaw) {
+                yaw_i = 0;
+                ++pano_i;
+            }
+        }
+        return;
+    }
+
+    // ---- LDS scheme: the items this thread produces (same for every pair) ----
+    // A wave runs slot k only if its first lane has an item there (wave-uniform test).
+    const int wave_base = __builtin_amdgcn_readfirstlane(t & ~63);
+    uint32_t slot_off[VIEWS_SLOTS];  // (r0 + rr) * src_pitch + 12 * g
+    uint32_t slot_g[VIEWS_SLOTS];
+    {
+        // item / G by multiply-shift: exact for item * G < 2^20 (item < 512, G < 256)
+        const uint32_t magic = ((1u << 20) + (uint32_t)G - 1u) / (uint32_t)G;
+#pragma unroll
+        for (int k = 0; k < VIEWS_SLOTS; ++k) {
+            int item = t + k * VIEWS_BLOCK;
+            if (item >= items)
+                item = 0;  // surplus lanes redo item 0 into LDS space nobody reads
+            const uint32_t rr = ((uint32_t)item * magic) >> 20;
+            slot_g[k] = (uint32_t)item - rr * (uint32_t)G;
+            slot_off[k] = (uint32_t)(r0 + (int)rr) * (uint32_t)P.src_pitch + 12u * slot_g[k];
+        }
+    }
+    int tap[VIEWS_PXT];
+    TapWeights tw[VIEWS_PXT];
+    uint32_t lmask[VIEWS_PXT];
+#pragma unroll
+    for (int j = 0; j < VIEWS_PXT; ++j) {
+        tap[j] = live[j] ? (iy[j] - r0) * rowdw + (ix[j] - c0) : 0;
+        lmask[j] = live[j] ? 0xFFFFFFFFu : 0u;
+        const uint32_t gx = 32u - fx[j], gy = 32u - fy[j];
+        tw[j].gx2 = gx | (gx << 16);
+        tw[j].fx2 = fx[j] | (fx[j] << 16);
+        tw[j].wy = gy | (fy[j] << 16);
+    }
+    const uint32_t row_bytes = 3u * (uint32_t)P.pw;
     const int ngroups = P.pw >> 2;
 
-    int buf = 0;
-    for (int pair = pair0; pair < pair1; ++pair) {
-        const uint8_t* __restrict__ S = src + (size_t)pano_i * P.pano_stride;
-        const YawDesc yd = ydesc[yaw_i];
-        uint32_t pix[VIEWS_PXT];
+    auto pair_ctx = [&](int yi) {
+        const YawDesc yd = ydesc[yi];
+        PairCtx c;
+        c.fast = yd.mode != 2;
+        int i_first = c0 + yd.s;
+        if (i_first >= P.pw)
+            i_first -= P.pw;
+        const int g0 = i_first >> 2;
+        c.joff = i_first & 3;
+        c.goff = 12u * (uint32_t)g0;
+        c.wrap_g = (uint32_t)(ngroups - g0);
+        // uniform weight unless this yaw flickers or the tile holds the column clipped to pw-1
+        c.per_column = yd.mode == 1 || (yd.c_clamp >= c0 && yd.c_clamp <= c1 + 1);
+        c.f = (uint32_t)yd.f;
+        c.cf0 = 4 * g0 - yd.s;
+        return c;
+    };
 
-        if (fast_tile && yd.mode != 2) {
-            int i_first = c0 + yd.s;
-            if (i_first >= P.pw)
-                i_first -= P.pw;
-            const int g0 = i_first >> 2, joff = i_first & 3;
-            // uniform F unless this yaw flickers or the tile holds the column clipped to pw-1
-            const bool per_column = yd.mode == 1 || (yd.c_clamp >= c0 && yd.c_clamp <= c1 + 1);
-            uint4* tl4 = tile4[buf];
-            Q16 q[VIEWS_SLOTS];
-            uint32_t fw[VIEWS_SLOTS];
+    auto issue_loads = [&](const PairCtx& pc, const uint8_t* __restrict__ S, int yi, Q16 (&q)[VIEWS_SLOTS],
+                           uint32_t (&fw)[VIEWS_SLOTS]) {
 #pragma unroll
-            for (int k = 0; k < VIEWS_SLOTS; ++k) {
-                if (k < nslots) {
-                    int gi = g0 + slot_g[k];
-                    if (gi >= ngroups)
-                        gi -= ngroups;
-                    q[k] = *reinterpret_cast<const Q16*>(S + slot_row[k] + 12u * (uint32_t)gi);
-                    if (per_column) {
-                        int cf = 4 * gi - yd.s;
-                        if (cf < 0)
-                            cf += P.pw;
-                        fw[k] = f4tab[(size_t)yaw_i * P.pw + cf];
-                    }
+        for (int k = 0; k < VIEWS_SLOTS; ++k) {
+            if (wave_base + k * VIEWS_BLOCK < items) {
+                uint32_t off = slot_off[k] + pc.goff;
+                if (slot_g[k] >= pc.wrap_g)
+                    off -= row_bytes;
+                q[k] = *reinterpret_cast<const Q16*>(S + off);
+                if (pc.per_column) {
+                    // rot column of the item's first pixel: its source column - s (mod pw)
+                    int cf = 4 * (int)slot_g[k] + pc.cf0;
+                    if (slot_g[k] >= pc.wrap_g)
+                        cf -= P.pw;
+                    if (cf < 0)
+                        cf += P.pw;
+                    fw[k] = f4tab[(size_t)yi * P.pw + cf];
                 }
             }
+        }
+    };
+
+    PairCtx pc = pair_ctx(yaw_i);
+    Q16 q[VIEWS_SLOTS];
+    uint32_t fw[VIEWS_SLOTS];
+    if (pc.fast)
+        issue_loads(pc, src + (size_t)pano_i * P.pano_stride, yaw_i, q, fw);
+
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0;
+    unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+    (void)st0; (void)st1; (void)st2; (void)st3; (void)st4; (void)st5; (void)st6; (void)acc;
+    int buf = 0;
+    for (int pair = pair0; pair < pair1; ++pair) {
+        STAMP(st0);
+        const uint8_t* __restrict__ S = src + (size_t)pano_i * P.pano_stride;
+        const int cur_yaw = yaw_i;
+        if (++yaw_i == P.n_yaw) {
+            yaw_i = 0;
+            ++pano_i;
+        }
+        const bool has_next = pair + 1 < pair1;
+        uint32_t pix[VIEWS_PXT];
+
+        if (pc.fast) {
+            uint4* tl4 = tile4[buf];
 #pragma unroll
             for (int k = 0; k < VIEWS_SLOTS; ++k) {
-                if (k < nslots) {
+                if (wave_base + k * VIEWS_BLOCK < items) {
                     const uint32_t p0 = q[k].d[0];
                     const uint32_t p1 = __builtin_amdgcn_alignbyte(q[k].d[1], q[k].d[0], 3);
                     const uint32_t p2 = __builtin_amdgcn_alignbyte(q[k].d[2], q[k].d[1], 2);
                     const uint32_t p3 = __builtin_amdgcn_alignbyte(q[k].d[3], q[k].d[2], 1);
                     const uint32_t p4 = q[k].d[3];
                     uint4 o;
-                    if (per_column) {
+                    if (pc.per_column) {
                         const uint32_t f0 = fw[k] & 0xFFu, f1 = (fw[k] >> 8) & 0xFFu,
                                        f2 = (fw[k] >> 16) & 0xFFu, f3 = fw[k] >> 24;
                         o.x = rot_blend2(p0, p1, f0, 32u - f0);
@@ -467,7 +620,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_kernel(
                         o.z = rot_blend2(p2, p3, f2, 32u - f2);
                         o.w = rot_blend2(p3, p4, f3, 32u - f3);
                     } else {
-                        const uint32_t f = (uint32_t)yd.f, g = 32u - f;
+                        const uint32_t f = pc.f, g = 32u - f;
                         o.x = rot_blend2(p0, p1, f, g);
                         o.y = rot_blend2(p1, p2, f, g);
                         o.z = rot_blend2(p2, p3, f, g);
@@ -476,56 +629,63 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_kernel(
                     tl4[t + k * VIEWS_BLOCK] = o;
                 }
             }
+            const int joff = pc.joff;
+            STAMP(st1);
             __syncthreads();
+            STAMP(st2);
+            // the next pair's source loads go out now; their latency hides behind stage 2
+            if (has_next) {
+                pc = pair_ctx(yaw_i);
+                if (pc.fast)
+                    issue_loads(pc, src + (size_t)pano_i * P.pano_stride, yaw_i, q, fw);
+            }
+            STAMP(st3);
             const uint32_t* tl = reinterpret_cast<const uint32_t*>(tl4);
+            uint32_t ta[VIEWS_PXT][4];
 #pragma unroll
             for (int j = 0; j < VIEWS_PXT; ++j) {
                 const int b = tap[j] + joff;
-                pix[j] = blend4(tl[b], tl[b + 1], tl[b + rowdw], tl[b + rowdw + 1], fx[j], fy[j]) & lmask[j];
+                ta[j][0] = tl[b];
+                ta[j][1] = tl[b + 1];
+                ta[j][2] = tl[b + rowdw];
+                ta[j][3] = tl[b + rowdw + 1];
             }
+#ifdef P2P_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            STAMP(st4);
+#pragma unroll
+            for (int j = 0; j < VIEWS_PXT; ++j)
+                pix[j] = blend4_packed(ta[j][0], ta[j][1], ta[j][2], ta[j][3], tw[j]) & lmask[j];
+            STAMP(st5);
             buf ^= 1;  // the next pair writes the other buffer; its readers are past this barrier
         } else {
-            // direct gather: same arithmetic, taps from global memory through the packed yaw table
-            const uint32_t* __restrict__ T = ytab + (size_t)yaw_i * P.pw;
-#pragma unroll
-            for (int j = 0; j < VIEWS_PXT; ++j) {
-                pix[j] = 0;
-                if (live[j]) {
-                    const bool c0in = ix[j] >= 0, c1in = ix[j] + 1 < P.pw, r0in = iy[j] >= 0, r1in = iy[j] + 1 < P.ph;
-                    const uint8_t* row0 = S + (ptrdiff_t)iy[j] * P.src_pitch;
-                    const uint8_t* row1 = row0 + P.src_pitch;
-                    const uint32_t t0 = c0in ? T[ix[j]] : 0u, t1 = c1in ? T[ix[j] + 1] : 0u;
-                    uint32_t a = (c0in && r0in) ? rot_pixel(row0, t0) : 0u;
-                    uint32_t b = (c1in && r0in) ? rot_pixel(row0, t1) : 0u;
-                    uint32_t c = (c0in && r1in) ? rot_pixel(row1, t0) : 0u;
-                    uint32_t d = (c1in && r1in) ? rot_pixel(row1, t1) : 0u;
-                    pix[j] = blend4(a, b, c, d, fx[j], fy[j]);
-                }
+            direct_pixels(S, cur_yaw, pix);
+            if (has_next) {
+                pc = pair_ctx(yaw_i);
+                if (pc.fast)
+                    issue_loads(pc, src + (size_t)pano_i * P.pano_stride, yaw_i, q, fw);
             }
         }
-
-        // ---- store: [pano][yaw][pitch][oh][ow][3] ----
-        uint8_t* O = out + ((size_t)pair * P.n_pitch + pitch_i) * view_bytes + pix_off;
-#pragma unroll
-        for (int j = 0; j < VIEWS_PXT; ++j) {
-            if (fast_store) {
-                // lanes 4k..4k+3 hold pixels P0..P3; lanes with lane4 < 3 emit dword lane4 of the 12 bytes
-                uint32_t nxt = __shfl_down(pix[j], 1);
-                uint32_t dw = __builtin_amdgcn_alignbit(nxt, pix[j] << 8, 8u * (uint32_t)(lane4 + 1));
-                if (inside[j] && lane4 < 3)
-                    *reinterpret_cast<uint32_t*>(O + j * pix_step + lane4) = dw;
-            } else if (inside[j]) {
-                uint8_t* o = O + j * pix_step;
-                o[0] = (uint8_t)pix[j];
-                o[1] = (uint8_t)(pix[j] >> 8);
-                o[2] = (uint8_t)(pix[j] >> 16);
-            }
-        }
-        if (++yaw_i == P.n_yaw) {
-            yaw_i = 0;
-            ++pano_i;
-        }
+        store_pixels(pair, pix);
+#ifdef P2P_STAMPS
+        STAMP(st6);
+        acc[0] += st1 - st0;
+        acc[1] += st2 - st1;
+        acc[2] += st3 - st2;
+        acc[3] += st4 - st3;
+        acc[4] += st5 - st4;
+        acc[5] += st6 - st5;
+#endif
     }
+#ifdef P2P_STAMPS
+    if ((t & 63) == 0) {
+        for (int i = 0; i < 6; ++i)
+            atomicAdd(&g_stamps[i], acc[i]);
+        atomicAdd(&g_stamps[6], 1ull);
+        atomicAdd(&g_stamps[7], (unsigned long long)(pair1 - pair0));
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -667,6 +827,16 @@ hipError_t launch_remap_maps(const RemapParams& P, int cn, hipStream_t st)
     else
         hipLaunchKernelGGL(remap_maps_kernel<4>, grid, block, 0, st, P);
     return hipGetLastError();
+}
+
+hipError_t read_stamps(unsigned long long* out16, bool reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), 16 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
+    }
+    return e;
 }
 
 }  // namespace p2p

@@ -155,6 +155,11 @@ int p2p_job_get_coords(p2p_job* job, int32_t* sxsy);
 /* The packed per-column yaw tables in use, uint32 [n_yaw][pw] = 3*ix | fx << 20. */
 int p2p_job_get_yaw_tables(p2p_job* job, uint32_t* packed);
 
+/* Diagnostic: with a -DP2P_STAMPS build of the library, the summed s_memtime ticks the view
+   kernel's waves spent per phase of the pair loop ([0..5] phases, [6] waves, [7] pair iterations);
+   all zeros in the shipped build. */
+int p2p_debug_stamps(uint64_t* out16, int reset);
+
 #ifdef __cplusplus
 }
 #endif
