@@ -13,7 +13,7 @@ constexpr int TILE_W = 32;          // output tile of one workgroup
 constexpr int TILE_H = 16;
 constexpr int VIEWS_BLOCK = 256;
 constexpr int VIEWS_PXT = TILE_W * TILE_H / VIEWS_BLOCK;  // output pixels per thread (rows ROWSTEP apart)
-constexpr int VIEWS_SLOTS = 3;      // 16-byte footprint items one thread produces per (panorama, yaw) pair
+constexpr int VIEWS_SLOTS = 2;      // 16-byte footprint items one thread produces per (panorama, yaw) pair
 constexpr int LDS_ITEMS_CAP = VIEWS_SLOTS * VIEWS_BLOCK;  // items (4 rot pixels each) per LDS buffer
 
 // how the yaw map of one yaw angle acts on columns (see yaw_desc_kernel)

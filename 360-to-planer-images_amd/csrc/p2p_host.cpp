@@ -136,6 +136,8 @@ int choose_pairs_per_block(const p2p_job_desc& d)
     const long long base = (long long)tiles * d.n_pitch;
     const int n_pairs = d.n_panos * d.n_yaw;
     int forced = env_int("P2P_PAIRS_PER_BLOCK", 0);
+    if (forced > 64)
+        forced = 64;  // the kernel keeps one pair context per lane of a wave
     if (forced > 0)
         return forced > n_pairs ? n_pairs : forced;
     // keep >= ~8 workgroups per CU in flight, otherwise amortise the map maths over many pairs
@@ -144,7 +146,8 @@ int choose_pairs_per_block(const p2p_job_desc& d)
     if (z < 1) z = 1;
     if (z > n_pairs) z = n_pairs;
     int ppb = (int)((n_pairs + z - 1) / z);
-    const int cap = env_int("P2P_MAX_PAIRS_PER_BLOCK", 16);
+    int cap = env_int("P2P_MAX_PAIRS_PER_BLOCK", 16);
+    if (cap > 64) cap = 64;
     if (ppb > cap) ppb = cap;
     return ppb < 1 ? 1 : ppb;
 }

@@ -275,7 +275,7 @@ __device__ __forceinline__ uint32_t blend4(uint32_t a, uint32_t b, uint32_t c, u
 struct __attribute__((aligned(4))) Q16 { uint32_t d[4]; };
 
 // ---- diagnostic build only: in-kernel phase stamps (never compiled into the shipped library) ----
-__device__ unsigned long long g_stamps[16];
+__device__ unsigned long long g_stamps[8 * 4096];  // [counter][slot]: spread, same-address atomics crawl
 #ifdef P2P_STAMPS
 #define STAMP(var)                                                                              \
     do {                                                                                        \
@@ -341,18 +341,19 @@ __device__ __forceinline__ uint32_t blend4_packed(uint32_t a, uint32_t b, uint32
 // are not a shift.  Blocks map to tiles XCD-aware: each of the 8 XCDs owns a contiguous run of
 // the tile raster, so neighbouring tiles (shared source halo and output lines) meet in one L2.
 // ---------------------------------------------------------------------------------------------
-struct PairCtx {      // uniform per (tile, pair)
-    bool fast;        // LDS scheme applies
+struct PairCtx {      // uniform per (tile, pair); precomputed per lane at tile set-up, read back with v_readlane
+    bool fast;        // LDS scheme applies (the yaw row is a circular shift)
     bool per_column;  // per-column weights (f4tab) instead of one f
     int joff;         // tile column of rot column c0
     uint32_t goff;    // byte offset of the first item of a footprint row within a source row
     uint32_t wrap_g;  // items with g >= wrap_g wrap to the start of the row
     uint32_t f;       // uniform weight
     int cf0;          // rot column of source column 4 * g0
+    int yaw_i;
 };
 
 template <bool HOST_MAPS>
-__global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_kernel(
+__global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
     ViewsParams P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab,
     const YawDesc* __restrict__ ydesc, const uint32_t* __restrict__ f4tab,
     const PitchConst* __restrict__ pitch, const float* __restrict__ mapU,
@@ -527,38 +528,56 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_kernel(
     }
     int tap[VIEWS_PXT];
     TapWeights tw[VIEWS_PXT];
-    uint32_t lmask[VIEWS_PXT];
 #pragma unroll
     for (int j = 0; j < VIEWS_PXT; ++j) {
         tap[j] = live[j] ? (iy[j] - r0) * rowdw + (ix[j] - c0) : 0;
-        lmask[j] = live[j] ? 0xFFFFFFFFu : 0u;
         const uint32_t gx = 32u - fx[j], gy = 32u - fy[j];
         tw[j].gx2 = gx | (gx << 16);
         tw[j].fx2 = fx[j] | (fx[j] << 16);
-        tw[j].wy = gy | (fy[j] << 16);
+        // a pixel with no footprint in the panorama (NaN coordinate) gets weight 0 everywhere:
+        // (0 + 512) >> 10 == 0, the BORDER_CONSTANT value
+        tw[j].wy = live[j] ? (gy | (fy[j] << 16)) : 0u;
     }
     const uint32_t row_bytes = 3u * (uint32_t)P.pw;
     const int ngroups = P.pw >> 2;
 
-    auto pair_ctx = [&](int yi) {
-        const YawDesc yd = ydesc[yi];
+    // ---- per-pair contexts: lane k of every wave works out pair0 + k once; the loop reads them
+    // back with v_readlane, so no descriptor load sits on the per-pair critical path ----
+    uint32_t cw0 = 0, cw1 = 0;
+    int cw2 = 0;
+    {
+        const int k = t & 63;
+        if (k < pair1 - pair0) {
+            const int yi = (pair0 + k) % P.n_yaw;
+            const YawDesc yd = ydesc[yi];
+            int i_first = c0 + yd.s;
+            if (i_first >= P.pw)
+                i_first -= P.pw;
+            const int g0 = i_first >> 2;
+            // uniform weight unless this yaw flickers or the tile holds the column clipped to pw-1
+            const bool per_column = yd.mode == 1 || (yd.c_clamp >= c0 && yd.c_clamp <= c1 + 1);
+            cw0 = 12u * (uint32_t)g0 | (uint32_t)(i_first & 3) << 20 | (uint32_t)(yd.mode != 2) << 22 |
+                  (uint32_t)per_column << 23 | (uint32_t)yd.f << 24;
+            cw1 = (uint32_t)(ngroups - g0) | (uint32_t)yi << 16;
+            cw2 = 4 * g0 - yd.s;
+        }
+    }
+    auto pair_ctx = [&](int k) {
+        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)cw0, k);
+        const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)cw1, k);
         PairCtx c;
-        c.fast = yd.mode != 2;
-        int i_first = c0 + yd.s;
-        if (i_first >= P.pw)
-            i_first -= P.pw;
-        const int g0 = i_first >> 2;
-        c.joff = i_first & 3;
-        c.goff = 12u * (uint32_t)g0;
-        c.wrap_g = (uint32_t)(ngroups - g0);
-        // uniform weight unless this yaw flickers or the tile holds the column clipped to pw-1
-        c.per_column = yd.mode == 1 || (yd.c_clamp >= c0 && yd.c_clamp <= c1 + 1);
-        c.f = (uint32_t)yd.f;
-        c.cf0 = 4 * g0 - yd.s;
+        c.goff = w0 & 0xFFFFFu;
+        c.joff = (int)((w0 >> 20) & 3u);
+        c.fast = (w0 >> 22) & 1u;
+        c.per_column = (w0 >> 23) & 1u;
+        c.f = w0 >> 24;
+        c.wrap_g = w1 & 0xFFFFu;
+        c.yaw_i = (int)(w1 >> 16);
+        c.cf0 = __builtin_amdgcn_readlane(cw2, k);
         return c;
     };
 
-    auto issue_loads = [&](const PairCtx& pc, const uint8_t* __restrict__ S, int yi, Q16 (&q)[VIEWS_SLOTS],
+    auto issue_loads = [&](const PairCtx& pc, const uint8_t* __restrict__ S, Q16 (&q)[VIEWS_SLOTS],
                            uint32_t (&fw)[VIEWS_SLOTS]) {
 #pragma unroll
         for (int k = 0; k < VIEWS_SLOTS; ++k) {
@@ -574,17 +593,17 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_kernel(
                         cf -= P.pw;
                     if (cf < 0)
                         cf += P.pw;
-                    fw[k] = f4tab[(size_t)yi * P.pw + cf];
+                    fw[k] = f4tab[(size_t)pc.yaw_i * P.pw + cf];
                 }
             }
         }
     };
 
-    PairCtx pc = pair_ctx(yaw_i);
+    PairCtx pc = pair_ctx(0);
     Q16 q[VIEWS_SLOTS];
     uint32_t fw[VIEWS_SLOTS];
     if (pc.fast)
-        issue_loads(pc, src + (size_t)pano_i * P.pano_stride, yaw_i, q, fw);
+        issue_loads(pc, src + (size_t)pano_i * P.pano_stride, q, fw);
 
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0;
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
@@ -633,13 +652,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_kernel(
             STAMP(st1);
             __syncthreads();
             STAMP(st2);
-            // the next pair's source loads go out now; their latency hides behind stage 2
-            if (has_next) {
-                pc = pair_ctx(yaw_i);
-                if (pc.fast)
-                    issue_loads(pc, src + (size_t)pano_i * P.pano_stride, yaw_i, q, fw);
-            }
-            STAMP(st3);
+            // the 2x2 taps of this thread's pixels
             const uint32_t* tl = reinterpret_cast<const uint32_t*>(tl4);
             uint32_t ta[VIEWS_PXT][4];
 #pragma unroll
@@ -650,21 +663,28 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_kernel(
                 ta[j][2] = tl[b + rowdw];
                 ta[j][3] = tl[b + rowdw + 1];
             }
+            STAMP(st3);
+            // the next pair's source loads go out now; their latency hides behind stage 2
+            if (has_next) {
+                pc = pair_ctx(pair + 1 - pair0);
+                if (pc.fast)
+                    issue_loads(pc, src + (size_t)pano_i * P.pano_stride, q, fw);
+            }
 #ifdef P2P_STAMPS
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
             STAMP(st4);
 #pragma unroll
             for (int j = 0; j < VIEWS_PXT; ++j)
-                pix[j] = blend4_packed(ta[j][0], ta[j][1], ta[j][2], ta[j][3], tw[j]) & lmask[j];
+                pix[j] = blend4_packed(ta[j][0], ta[j][1], ta[j][2], ta[j][3], tw[j]);
             STAMP(st5);
             buf ^= 1;  // the next pair writes the other buffer; its readers are past this barrier
         } else {
             direct_pixels(S, cur_yaw, pix);
             if (has_next) {
-                pc = pair_ctx(yaw_i);
+                pc = pair_ctx(pair + 1 - pair0);
                 if (pc.fast)
-                    issue_loads(pc, src + (size_t)pano_i * P.pano_stride, yaw_i, q, fw);
+                    issue_loads(pc, src + (size_t)pano_i * P.pano_stride, q, fw);
             }
         }
         store_pixels(pair, pix);
@@ -680,10 +700,11 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_kernel(
     }
 #ifdef P2P_STAMPS
     if ((t & 63) == 0) {
+        const int slot = (int)((blockIdx.x * 7u + blockIdx.y * 131u + blockIdx.z * 977u + (t >> 6) * 1031u) & 4095u);
         for (int i = 0; i < 6; ++i)
-            atomicAdd(&g_stamps[i], acc[i]);
-        atomicAdd(&g_stamps[6], 1ull);
-        atomicAdd(&g_stamps[7], (unsigned long long)(pair1 - pair0));
+            atomicAdd(&g_stamps[i * 4096 + slot], acc[i]);
+        atomicAdd(&g_stamps[6 * 4096 + slot], 1ull);
+        atomicAdd(&g_stamps[7 * 4096 + slot], (unsigned long long)(pair1 - pair0));
     }
 #endif
 }
@@ -831,10 +852,17 @@ hipError_t launch_remap_maps(const RemapParams& P, int cn, hipStream_t st)
 
 hipError_t read_stamps(unsigned long long* out16, bool reset)
 {
-    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), 16 * sizeof(unsigned long long));
+    static unsigned long long host[8 * 4096];
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(host));
+    for (int i = 0; i < 16; ++i)
+        out16[i] = 0;
+    for (int i = 0; i < 8; ++i)
+        for (int k = 0; k < 4096; ++k)
+            out16[i] += host[i * 4096 + k];
     if (e == hipSuccess && reset) {
-        unsigned long long z[16] = {0};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
+        for (auto& v : host)
+            v = 0;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), host, sizeof(host));
     }
     return e;
 }
