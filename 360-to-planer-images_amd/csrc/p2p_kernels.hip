@@ -638,6 +638,13 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
                         o.y = rot_blend2(p1, p2, f1, 32u - f1);
                         o.z = rot_blend2(p2, p3, f2, 32u - f2);
                         o.w = rot_blend2(p3, p4, f3, 32u - f3);
+                    } else if (pc.f == 0) {
+                        // whole-column yaw shift (e.g. multiples of 45 degrees on 8192 columns):
+                        // stage 1 is a copy, ((32*a + 0*b + 16) >> 5) == a
+                        o.x = p0 & 0x00FFFFFFu;
+                        o.y = p1 & 0x00FFFFFFu;
+                        o.z = p2 & 0x00FFFFFFu;
+                        o.w = p3 & 0x00FFFFFFu;
                     } else {
                         const uint32_t f = pc.f, g = 32u - f;
                         o.x = rot_blend2(p0, p1, f, g);
