@@ -1,0 +1,98 @@
+"""GPU: the drop-in Python surface end to end (shapes, ordering, thread-pool re-entrancy, error codes, files)."""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from _util import diff_stats, oracle_views
+
+pytestmark = pytest.mark.gpu
+
+
+def test_process_yaw_and_pitchs_contract(gpu, pkg, synth):
+    pano = synth.synth_pano(1024, 512, 3000, "S")
+    out = pkg.process_yaw_and_pitchs(pano, 30, [60, 90, 120], 160, 120, 90)
+    assert isinstance(out, list) and len(out) == 3
+    for o in out:
+        assert o.shape == (120, 160, 3) and o.dtype == np.uint8
+    want = oracle_views(pano, [30], [60, 90, 120], 160, 120, 90)
+    assert diff_stats(np.stack(out)[None], want)[0] <= 1
+    # default FOV 90, numpy integer angles, float angles that are whole numbers
+    a = pkg.process_yaw_and_pitchs(pano, np.int64(30), [np.int32(90)], 160, 120)
+    b = pkg.process_yaw_and_pitchs(pano, 30.0, [90], 160, 120, fov_deg=90)
+    assert np.array_equal(a[0], out[1]) and np.array_equal(b[0], out[1])
+    with pytest.raises(TypeError):
+        pkg.process_yaw_and_pitchs(pano, 30.5, [90], 160, 120)
+
+
+def test_thread_pool_fan_out_like_the_reference(gpu, pkg, synth):
+    # P:252-265: one task per yaw on a shared panorama, up to int(0.9 * cores) threads
+    pano = synth.synth_pano(1024, 512, 3001, "N")
+    yaws, pitches = list(range(0, 360, 30)), [60, 120]
+    serial = [pkg.process_yaw_and_pitchs(pano, y, pitches, 96, 64) for y in yaws]
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        futs = [ex.submit(pkg.process_yaw_and_pitchs, pano, y, pitches, 96, 64) for y in yaws]
+        par = [f.result() for f in futs]
+    for s, p in zip(serial, par):
+        for a, b in zip(s, p):
+            assert np.array_equal(a, b)
+    batched = pkg.process_views(pano, yaws, pitches, 96, 64)
+    for yi in range(len(yaws)):
+        for pi in range(len(pitches)):
+            assert np.array_equal(batched[yi, pi], serial[yi][pi])
+
+
+def test_error_codes(gpu, pkg, synth):
+    pano = synth.synth_pano(64, 32, 3002, "N")
+    for bad in (0, 180, -5):
+        with pytest.raises(gpu.P2PError) as e:
+            pkg.process_yaw_and_pitchs(pano, 0, [bad], 16, 16)
+        assert e.value.code == gpu.P2P_ERR_INVALID and "between 1 and 179" in str(e.value)
+    with pytest.raises(gpu.P2PError) as e:
+        gpu.remap_views(pano, [0], [90], 90, 40000, 16)
+    assert e.value.code == gpu.P2P_ERR_INVALID
+    with pytest.raises(gpu.P2PError) as e:
+        gpu.remap_views(pano, [0], [90], 90, 16, 16, device=99)
+    assert e.value.code == gpu.P2P_ERR_NO_DEVICE
+    with pytest.raises(gpu.P2PError) as e:
+        gpu.remap_views_maps(pano, np.full((1, 64), 64.0, np.float32), np.zeros((1, 4, 4), np.float32),
+                             np.zeros((1, 4, 4), np.float32))
+    assert e.value.code == gpu.P2P_ERR_INVALID  # yaw row outside [0, pw-1]
+    ctx = gpu.Context(0)
+    job = gpu.Job(ctx, 64, 32, 2, [0], [90], 90, 16, 16)
+    job.set_pano(0, pano)
+    with pytest.raises(gpu.P2PError) as e:
+        job.run()  # panorama 1 was never set
+    assert e.value.code == gpu.P2P_ERR_STATE
+    assert pkg.process_views(pano, [], [90], 16, 16).shape == (0, 1, 16, 16, 3)
+    job.close()
+    ctx.close()
+
+
+def test_cli_end_to_end_files(gpu, pkg, synth, tmp_path):
+    from PIL import Image
+
+    m = pkg.panorama_to_plane_pitch
+    pano = synth.synth_pano(512, 256, 3003, "S")  # BGR in memory
+    (tmp_path / "in").mkdir()
+    Image.fromarray(pano[:, :, ::-1]).save(tmp_path / "in" / "room.png")
+    m.cli(["--input_path", str(tmp_path / "in"), "--output_path", str(tmp_path / "out"), "--output_width", "64",
+           "--output_height", "48", "--yaw_angles", "0", "77", "--pitch_angles", "60", "120", "--FOV", "100"])
+    want = oracle_views(pano, [0, 77], [60, 120], 64, 48, 100)
+    for yi, y in enumerate((0, 77)):
+        for pi, p in enumerate((60, 120)):
+            f = tmp_path / "out" / f"room_64x48_yaw_{y}_pitch_{p}.png"
+            assert f.exists(), f
+            got = np.asarray(Image.open(f).convert("RGB"))[:, :, ::-1]
+            assert diff_stats(got, want[yi, pi])[0] <= 1
+
+
+def test_maps_cache_keys_and_shapes(gpu, pkg):
+    m = pkg.panorama_to_plane_pitch
+    m.pitch_mapping_cache.clear()
+    m.yaw_mapping_cache.clear()
+    U, V = m.get_pitch_mapping(64, 48, 60, 512, 256, 90)
+    assert (64, 48, 60, 512, 256, 90) in m.pitch_mapping_cache and U.shape == (48, 64)
+    assert m.get_pitch_mapping(64, 48, 60, 512, 256)[0] is U
+    Uy, Vy = m.get_yaw_mapping(512, 16, 30)
+    assert (512, 16, 30) in m.yaw_mapping_cache and Uy.shape == (16, 512) and Vy[5, 7] == 5.0

@@ -1,0 +1,177 @@
+"""Host-side logic that needs no GPU: the C ABI surface, the Python mirror of the reference's
+interface (names, defaults, validators, file naming, error swallowing) and loud failure without a device."""
+import argparse
+import inspect
+import logging
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_exactly_what_the_header_declares(nat):
+    header = open(os.path.join(ROOT, "include", "p2p_hip.h")).read()
+    declared = set(re.findall(r"\b(p2p_[a-z0-9_]+)\s*\(", header))
+    declared -= {"p2p_status"}
+    assert declared == set(nat.ABI_SYMBOLS), declared ^ set(nat.ABI_SYMBOLS)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", nat.LIB_PATH], text=True)
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("p2p_")}
+    assert exported == declared, exported ^ declared
+    L = nat.lib()
+    for sym in nat.ABI_SYMBOLS:
+        assert hasattr(L, sym)
+    assert nat.version().endswith("gfx950")
+
+
+def test_header_cites_the_reference_interfaces():
+    header = open(os.path.join(ROOT, "include", "p2p_hip.h")).read()
+    for cite in ("P:181-221", "P:252-265", "P:79-108", "P:114-175", "L:182-194", "P:362-376", "P:55-73"):
+        assert cite in header, cite
+
+
+def test_no_cpu_fallback_without_a_device(nat, pkg):
+    if nat.device_count() > 0:
+        pytest.skip("a HIP device is present; the no-device behaviour is exercised in the CPU container")
+    pano = np.zeros((8, 16, 3), np.uint8)
+    with pytest.raises(nat.P2PError) as e:
+        pkg.process_yaw_and_pitchs(pano, 0, [90], 8, 8)
+    assert e.value.code == nat.P2P_ERR_NO_DEVICE
+    with pytest.raises(nat.P2PError):
+        pkg.panorama_to_plane(pano, np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32))
+    with pytest.raises(nat.P2PError):
+        pkg.get_pitch_mapping(8, 8, 90, 16, 8)
+    with pytest.raises(nat.P2PError):
+        nat.Context(0)
+
+
+def test_product_never_imports_the_oracle():
+    pkg_dir = os.path.join(ROOT, "360-to-planer-images_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"(from|import)\s+\.*oracle|libp2p_oracle|oracle[./](cpu_ref|maps|cv_remap)", text), \
+                    os.path.join(dirpath, f)
+
+
+def test_signatures_match_the_reference(pkg):
+    m = pkg.panorama_to_plane_pitch
+    def params(f):
+        return [(p.name, p.default) for p in inspect.signature(f).parameters.values()]
+    E = inspect.Parameter.empty
+    assert params(m.process_yaw_and_pitchs) == [("pano_image", E), ("yaw_angle", E), ("pitch_angles", E),
+                                                ("output_width", E), ("output_height", E), ("fov_deg", 90)]
+    assert params(m.get_yaw_mapping) == [("pano_width", E), ("pano_height", E), ("yaw_angle", E)]
+    assert params(m.get_pitch_mapping) == [("output_width", E), ("output_height", E), ("pitch_angle", E),
+                                           ("pano_width", E), ("pano_height", E), ("fov_deg", 90)]
+    assert params(m.precompute_yaw_mapping) == [("pano_width", E), ("pano_height", E), ("yaw_angle", E)]
+    assert params(m.precompute_pitch_mapping) == [("W", E), ("H", E), ("FOV_rad", E), ("pitch_radian", E),
+                                                  ("pano_width", E), ("pano_height", E)]
+    assert params(m.process_single_image) == [("input_image_path", E), ("output_dir", E), ("yaw_angles", E),
+                                              ("pitch_angles", E), ("output_width", E), ("output_height", E),
+                                              ("num_workers", 4), ("output_format", "png"), ("fov_deg", 90)]
+    assert params(m.main) == [("input_path", E), ("output_path", E), ("yaw_angles", E), ("pitch_angles", E),
+                              ("output_width", E), ("output_height", E), ("num_workers", None),
+                              ("output_format", "png"), ("fov_deg", 90), ("enable_file_logging", False)]
+    assert params(pkg.panorama_to_plane) == [("pano_array", E), ("U", E), ("V", E)]
+    assert m.get_version() == "0.3.2"
+    assert isinstance(m.yaw_mapping_cache, dict) and isinstance(m.pitch_mapping_cache, dict)
+
+
+def test_check_pitch_matches_reference_vectors(pkg, golden):
+    _, meta = golden
+    for s, want in meta["check_pitch"].items():
+        if isinstance(want, int):
+            assert pkg.check_pitch(s) == want
+        else:
+            with pytest.raises(argparse.ArgumentTypeError):
+                pkg.check_pitch(s)
+    with pytest.raises(argparse.ArgumentTypeError, match="between 1 and 179"):
+        pkg.check_pitch("180")
+    with pytest.raises(argparse.ArgumentTypeError, match="must be an integer"):
+        pkg.check_pitch("x")
+
+
+def test_cli_surface_and_defaults(pkg):
+    p = pkg.panorama_to_plane_pitch.build_arg_parser()
+    a = p.parse_args(["--input_path", "x"])
+    assert (a.output_path, a.output_format, a.FOV, a.output_width, a.output_height) == ("output_images", "png", 90, 800, 800)
+    assert a.pitch_angles == [30, 60, 90, 120, 150] and a.yaw_angles == [0, 90, 180, 270]
+    assert a.num_workers is None and a.enable_file_logging is False
+    a = p.parse_args("--input_path x --yaw_angles -30 400 --pitch_angles 1 179 --output_format jpeg --FOV 60".split())
+    assert a.yaw_angles == [-30, 400] and a.pitch_angles == [1, 179]
+    with pytest.raises(SystemExit):
+        p.parse_args("--input_path x --pitch_angles 0".split())
+    with pytest.raises(SystemExit):
+        p.parse_args("--input_path x --output_format bmp".split())
+    with pytest.raises(SystemExit):
+        p.parse_args([])  # --input_path is required
+
+
+def test_file_naming_and_error_swallowing(pkg, tmp_path, monkeypatch, caplog):
+    from PIL import Image
+
+    m = pkg.panorama_to_plane_pitch
+    src = tmp_path / "in" / "sub"
+    src.mkdir(parents=True)
+    Image.fromarray(np.full((16, 32, 3), (10, 20, 30), np.uint8)).save(src / "Pano One.PNG")
+    (src / "broken.jpg").write_bytes(b"not a jpeg")
+    (src / "notes.txt").write_text("ignored")
+    calls = []
+
+    def fake_views(pano, yaws, pitches, ow, oh, fov=90):
+        calls.append((pano.shape, tuple(yaws), tuple(pitches), ow, oh, fov))
+        assert pano[0, 0].tolist() == [30, 20, 10]  # BGR at the API boundary, like cv2.imread
+        return np.zeros((len(yaws), len(pitches), oh, ow, 3), np.uint8)
+
+    monkeypatch.setattr(m, "process_views", fake_views)
+    out = tmp_path / "out"
+    with caplog.at_level(logging.INFO):
+        m.main(str(tmp_path / "in"), str(out), [0, 90], [60, 120], 8, 6, num_workers=2, output_format="jpg", fov_deg=75)
+    names = sorted(f.name for f in out.iterdir())
+    assert names == sorted(f"Pano One_8x6_yaw_{y}_pitch_{p}.jpg" for y in (0, 90) for p in (60, 120))
+    assert calls == [((16, 32, 3), (0, 90), (60, 120), 8, 6, 75)]
+    assert any("Failed to read image" in r.message for r in caplog.records)   # P:245-247: log + skip
+    assert any("Found 2 images" in r.message for r in caplog.records)
+    assert any("All processing completed." in r.message for r in caplog.records)
+
+    # an exception inside the view synthesis is logged per yaw and does not propagate (P:279-280)
+    def boom(*a, **k):
+        raise RuntimeError("device fell over")
+
+    monkeypatch.setattr(m, "process_views", boom)
+    caplog.clear()
+    with caplog.at_level(logging.ERROR):
+        m.main(str(src / "Pano One.PNG"), str(tmp_path / "out2"), [0, 90], [60], 8, 6, num_workers=1)
+    errs = [r.message for r in caplog.records if "Error processing yaw_angle" in r.message]
+    assert len(errs) == 2 and "device fell over" in errs[0]
+    assert list((tmp_path / "out2").iterdir()) == []
+
+
+def test_empty_directory_warns_and_returns(pkg, tmp_path, caplog):
+    (tmp_path / "empty").mkdir()
+    with caplog.at_level(logging.WARNING):
+        pkg.main(str(tmp_path / "empty"), str(tmp_path / "o"), [0], [90], 8, 8, num_workers=1)
+    assert any("No images found in directory" in r.message for r in caplog.records)
+
+
+def test_argument_validation_in_the_binding(nat):
+    with pytest.raises(TypeError):
+        nat.as_image(np.zeros((4, 4, 3), np.float32))
+    with pytest.raises(ValueError):
+        nat.as_image(np.zeros((4, 4), np.uint8))
+    with pytest.raises(ValueError):
+        nat._i32([[1, 2]])
+
+
+def test_synthetic_panoramas_are_seeded_and_smooth(synth):
+    a, b = synth.synth_pano(256, 128, 1000, "S"), synth.synth_pano(256, 128, 1000, "S")
+    assert np.array_equal(a, b) and not np.array_equal(a, synth.synth_pano(256, 128, 1001, "S"))
+    assert np.abs(np.diff(a.astype(np.int16), axis=1)).max() <= 12
+    n = synth.synth_pano(256, 128, 1000, "N")
+    assert n.dtype == np.uint8 and 100 < n.mean() < 155
