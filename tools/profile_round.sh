@@ -1,0 +1,38 @@
+#!/bin/bash
+# One-shot profile collection for a round: bash tools/profile_round.sh r01   (on the GPU box, repo root)
+TAG=$1
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/profile_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/trace.log
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 120 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$c.log
+  timeout 120 rocprofv3 --pmc $c --output-format csv -d $OUT/calib_$c -- $ROOT/tools/ubench/fetch_calib > /dev/null 2> $OUT/calib_$c.log
+done
+timeout 120 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $OUT/pmc_ea -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/pmc_ea.log
+timeout 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum --output-format csv -d $OUT/pmc_tcc -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/pmc_tcc.log
+cd $ROOT
+python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+python3 - <<PY
+import csv, glob, json, os
+out = "$OUT"
+def counters(d, key):
+    vals = {}
+    for f in glob.glob(os.path.join(out, d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if key in row["Kernel_Name"]:
+                vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in vals.items()}
+res = {"views": {}, "calib": {}}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    res["views"].update(counters("pmc_" + c, "remap_views_kernel"))
+    res["calib"]["pieces_" + c] = counters("calib_" + c, "pieces").get(c)
+    res["calib"]["stream16_" + c] = counters("calib_" + c, "stream16").get(c)
+res["views"].update(counters("pmc_ea", "remap_views_kernel"))
+res["views"].update(counters("pmc_tcc", "remap_views_kernel"))
+json.dump(res, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY
+cat $(find $OUT/trace -name "*kernel_stats.csv" | head -1)
+cat $OUT/bench.json
