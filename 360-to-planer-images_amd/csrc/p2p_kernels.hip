@@ -246,6 +246,24 @@ __device__ __forceinline__ uint32_t rot_blend2(uint32_t p0, uint32_t p1, uint32_
     return ((br >> 5) & 0x00FF00FFu) | ((gg >> 5) & 0x0000FF00u);
 }
 
+// The same value with the weights pre-multiplied by 8 (f8 = 8f, g8 = 8g): every 16-bit field then holds
+// 8*(g*a + f*b + 16) <= 65408, so the wanted byte (sum >> 5) is simply the field's HIGH byte and one
+// v_perm_b32 assembles B | G<<8 | R<<16 -- no shifts, no masks on the way out.
+//   m0 = p & 0x00FF00FF (B, R fields), m1 = p & 0x0000FF00 (G field) of the left / right source pixel.
+__device__ __forceinline__ uint32_t umad24(uint32_t a, uint32_t b, uint32_t c)
+{
+    return (uint32_t)__umul24(a, b) + c;  // v_mad_u32_u24: both factors fit 24 bits
+}
+
+__device__ __forceinline__ uint32_t rot_blend8(uint32_t a_br, uint32_t a_g, uint32_t b_br, uint32_t b_g,
+                                               uint32_t f8, uint32_t g8)
+{
+    const uint32_t br = umad24(f8, b_br, umad24(g8, a_br, 0x00800080u));  // bytes 1 and 3
+    const uint32_t gg = umad24(f8, b_g, umad24(g8, a_g, 0x00008000u));    // byte 2
+    // v_perm_b32(S0, S1, sel): selector bytes 0-3 pick S1's bytes, 4-7 pick S0's, 0x0c is zero
+    return __builtin_amdgcn_perm(br, gg, 0x0C070205u);
+}
+
 // direct path: (3*i | f << 20) table entry, unaligned 8-byte load of pixels i and i+1
 __device__ __forceinline__ uint32_t rot_pixel(const uint8_t* __restrict__ row, uint32_t te)
 {
@@ -294,7 +312,7 @@ __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cas
 // per-pixel stage-2 weights, constant across (panorama, yaw) pairs
 struct TapWeights {
     uint32_t gx2, fx2;  // [32-fx, 32-fx], [fx, fx] as two u16
-    uint32_t wy;        // [32-fy, fy] as two u16
+    uint32_t wy;        // 64 * [32-fy, fy] as two u16 (0 for a pixel with no footprint)
 };
 
 // Stage 2 with packed 16-bit maths: per channel, the two rows ride in the two halves of a dword:
@@ -315,10 +333,12 @@ __device__ __forceinline__ uint32_t blend4_packed(uint32_t a, uint32_t b, uint32
     const u16x2 hb = b_ac * gx + b_bd * fx;
     const u16x2 hg = g_ac * gx + g_bd * fx;
     const u16x2 hr = r_ac * gx + r_bd * fx;
-    const uint32_t vb = __builtin_amdgcn_udot2(hb, wy, 512u, false);
-    const uint32_t vg = __builtin_amdgcn_udot2(hg, wy, 512u, false);
-    const uint32_t vr = __builtin_amdgcn_udot2(hr, wy, 512u, false);
-    return (vb >> 10) | ((vg >> 2) & 0x0000FF00u) | ((vr << 6) & 0x00FF0000u);
+    // wy holds 64*[32-fy, fy]: the sums come out scaled by 64, so (sum + 512) >> 10 is byte 2 of each
+    const uint32_t vb = __builtin_amdgcn_udot2(hb, wy, 32768u, false);
+    const uint32_t vg = __builtin_amdgcn_udot2(hg, wy, 32768u, false);
+    const uint32_t vr = __builtin_amdgcn_udot2(hr, wy, 32768u, false);
+    const uint32_t bg = __builtin_amdgcn_perm(vg, vb, 0x0C0C0602u);  // B | G << 8
+    return __builtin_amdgcn_perm(vr, bg, 0x0C060100u);               // | R << 16
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -536,7 +556,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
         tw[j].fx2 = fx[j] | (fx[j] << 16);
         // a pixel with no footprint in the panorama (NaN coordinate) gets weight 0 everywhere:
         // (0 + 512) >> 10 == 0, the BORDER_CONSTANT value
-        tw[j].wy = live[j] ? (gy | (fy[j] << 16)) : 0u;
+        tw[j].wy = live[j] ? 64u * (gy | (fy[j] << 16)) : 0u;
     }
     const uint32_t row_bytes = 3u * (uint32_t)P.pw;
     const int ngroups = P.pw >> 2;
@@ -638,19 +658,24 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
                         o.y = rot_blend2(p1, p2, f1, 32u - f1);
                         o.z = rot_blend2(p2, p3, f2, 32u - f2);
                         o.w = rot_blend2(p3, p4, f3, 32u - f3);
-                    } else if (pc.f == 0) {
+                    } else if (pc.f != 0) {
+                        const uint32_t f8 = 8u * pc.f, g8 = 256u - f8;
+                        const uint32_t m0 = p0 & 0x00FF00FFu, n0 = p0 & 0x0000FF00u;
+                        const uint32_t m1 = p1 & 0x00FF00FFu, n1 = p1 & 0x0000FF00u;
+                        const uint32_t m2 = p2 & 0x00FF00FFu, n2 = p2 & 0x0000FF00u;
+                        const uint32_t m3 = p3 & 0x00FF00FFu, n3 = p3 & 0x0000FF00u;
+                        const uint32_t m4 = p4 & 0x00FF00FFu, n4 = p4 & 0x0000FF00u;
+                        o.x = rot_blend8(m0, n0, m1, n1, f8, g8);
+                        o.y = rot_blend8(m1, n1, m2, n2, f8, g8);
+                        o.z = rot_blend8(m2, n2, m3, n3, f8, g8);
+                        o.w = rot_blend8(m3, n3, m4, n4, f8, g8);
+                    } else {
                         // whole-column yaw shift (e.g. multiples of 45 degrees on 8192 columns):
                         // stage 1 is a copy, ((32*a + 0*b + 16) >> 5) == a
                         o.x = p0 & 0x00FFFFFFu;
                         o.y = p1 & 0x00FFFFFFu;
                         o.z = p2 & 0x00FFFFFFu;
                         o.w = p3 & 0x00FFFFFFu;
-                    } else {
-                        const uint32_t f = pc.f, g = 32u - f;
-                        o.x = rot_blend2(p0, p1, f, g);
-                        o.y = rot_blend2(p1, p2, f, g);
-                        o.z = rot_blend2(p2, p3, f, g);
-                        o.w = rot_blend2(p3, p4, f, g);
                     }
                     tl4[t + k * VIEWS_BLOCK] = o;
                 }
