@@ -361,6 +361,36 @@ __device__ __forceinline__ uint32_t blend4_packed(uint32_t a, uint32_t b, uint32
 // are not a shift.  Blocks map to tiles XCD-aware: each of the 8 XCDs owns a contiguous run of
 // the tile raster, so neighbouring tiles (shared source halo and output lines) meet in one L2.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(as_u16x2(a), as_u16x2(b)));
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(as_u16x2(a), as_u16x2(b)));
+}
+
+// Wave-wide packed-u16 min / max; the result is valid in lane 63.  gfx9 DPP: two quad permutes, the
+// two row mirrors, then row_bcast15 / row_bcast31 carry the row results up to the last row.
+template <bool MIN>
+__device__ __forceinline__ uint32_t wave_reduce_pk(uint32_t v)
+{
+    const int ident = MIN ? -1 : 0;
+#define P2P_STEP(ctrl, rmask)                                                                        \
+    {                                                                                               \
+        uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(ident, (int)v, ctrl, rmask, 0xF, false); \
+        v = MIN ? pk_min(v, o) : pk_max(v, o);                                                      \
+    }
+    P2P_STEP(0xB1, 0xF)   // quad_perm [1,0,3,2]
+    P2P_STEP(0x4E, 0xF)   // quad_perm [2,3,0,1]
+    P2P_STEP(0x141, 0xF)  // row_half_mirror
+    P2P_STEP(0x140, 0xF)  // row_mirror
+    P2P_STEP(0x142, 0xA)  // row_bcast15 -> rows 1 and 3
+    P2P_STEP(0x143, 0xC)  // row_bcast31 -> rows 2 and 3
+#undef P2P_STEP
+    return v;
+}
+
 struct PairCtx {      // uniform per (tile, pair); precomputed per lane at tile set-up, read back with v_readlane
     bool fast;        // LDS scheme applies (the yaw row is a circular shift)
     bool per_column;  // per-column weights (f4tab) instead of one f
@@ -380,7 +410,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
     const float* __restrict__ mapV, uint8_t* __restrict__ out, int32_t* __restrict__ coords)
 {
     __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
-    __shared__ int bbox[4];
+    __shared__ int bbox[2 * VIEWS_BLOCK / 64];
 
     const int t = threadIdx.x;
     const int tiles_x = (P.ow + TILE_W - 1) / TILE_W;
@@ -433,20 +463,30 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
         live[j] = inside[j] && ix[j] >= -1 && iy[j] >= -1 && ix[j] < P.pw && iy[j] < P.ph;
     }
 
-    // ---- footprint of the tile in rot space ----
-    if (t < 4)
-        bbox[t] = (t & 1) ? -2 : INT32_MAX;  // [0]=min x, [1]=max x, [2]=min y, [3]=max y
-    __syncthreads();
+    // ---- footprint of the tile in rot space: packed (ix+1, iy+1) u16 pairs, one min and one max
+    // reduction per wave with DPP (v_pk_min_u16 / v_pk_max_u16), then across the 4 waves through LDS ----
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
     for (int j = 0; j < VIEWS_PXT; ++j)
         if (live[j]) {
-            atomicMin(&bbox[0], ix[j]);
-            atomicMax(&bbox[1], ix[j]);
-            atomicMin(&bbox[2], iy[j]);
-            atomicMax(&bbox[3], iy[j]);
+            const uint32_t key = (uint32_t)(ix[j] + 1) | (uint32_t)(iy[j] + 1) << 16;  // both in 0..32767
+            kmin = pk_min(kmin, key);
+            kmax = pk_max(kmax, key);
         }
+    kmin = wave_reduce_pk<true>(kmin);
+    kmax = wave_reduce_pk<false>(kmax);
+    if ((t & 63) == 63) {
+        bbox[(t >> 6) * 2] = (int)kmin;
+        bbox[(t >> 6) * 2 + 1] = (int)kmax;
+    }
     __syncthreads();
-    const int c0 = bbox[0], c1 = bbox[1], r0 = bbox[2], r1 = bbox[3];
+#pragma unroll
+    for (int w = 0; w < VIEWS_BLOCK / 64; ++w) {
+        kmin = w == 0 ? (uint32_t)bbox[0] : pk_min(kmin, (uint32_t)bbox[2 * w]);
+        kmax = w == 0 ? (uint32_t)bbox[1] : pk_max(kmax, (uint32_t)bbox[2 * w + 1]);
+    }
+    const int c0 = (int)(kmin & 0xFFFFu) - 1, r0 = (int)(kmin >> 16) - 1;
+    const int c1 = kmax ? (int)(kmax & 0xFFFFu) - 1 : -2, r1 = kmax ? (int)(kmax >> 16) - 1 : -2;
     const bool any_live = c1 >= -1;
     const int Wt = c1 - c0 + 2, Ht = r1 - r0 + 2;  // +1 for the right / lower taps
     const int G = (Wt + 6) >> 2;                   // 4-pixel items per footprint row (+3: alignment slack)
@@ -485,7 +525,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
                 uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pix[j], 0x101, 0xF, 0xF, false);
                 uint32_t dw = __builtin_amdgcn_alignbit(nxt, pix[j] << 8, sh8);
                 if (inside[j] && lane4 < 3)
-                    *reinterpret_cast<uint32_t*>(O + off + lane4) = dw;
+                    *reinterpret_cast<uint32_t*>(O + (off + (uint32_t)lane4)) = dw;
             } else if (inside[j]) {
                 uint8_t* o = O + off;
                 o[0] = (uint8_t)pix[j];
