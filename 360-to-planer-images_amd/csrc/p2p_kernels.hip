@@ -51,7 +51,14 @@ __device__ __forceinline__ void pitch_map_eval(float u, float v, const MapGeom& 
     float y = g.half_h - v;  // P:130
     float z = g.focal;       // P:131
     float n = __fsqrt_rn(x * x + y * y + z * z);  // P:134
-    float xn = __fdiv_rn(x, n), yn = __fdiv_rn(y, n), zn = __fdiv_rn(z, n);  // P:137-139
+    // P:137-139: x/n, y/n, z/n.  One IEEE reciprocal, then q = a*r corrected by its exact FMA
+    // residual: RN(q + (a - q*n)*r) is the correctly rounded quotient (Markstein) -- the same bits as
+    // three IEEE divisions at half their cost.
+    const float r = __fdiv_rn(1.0f, n);
+    float xn = x * r, yn = y * r, zn = z * r;
+    xn = __builtin_fmaf(__builtin_fmaf(-xn, n, x), r, xn);
+    yn = __builtin_fmaf(__builtin_fmaf(-yn, n, y), r, yn);
+    zn = __builtin_fmaf(__builtin_fmaf(-zn, n, z), r, zn);
     float yr = __builtin_fmaf(-s, zn, c * yn);  // P:155 row 1: [0, cos, -sin]
     float zr = __builtin_fmaf(c, zn, s * yn);   // P:155 row 2: [0, sin,  cos]
     float theta = acosf(zr);                    // P:162 (NaN if zr rounds above 1)
@@ -60,8 +67,13 @@ __device__ __forceinline__ void pitch_map_eval(float u, float v, const MapGeom& 
         phi += TWO_PI_F;  // floored '%': |phi| <= pi so fmod is the identity; -0.0 -> +0.0 either way
     else if (phi == 0.0f)
         phi = 0.0f;
-    U = __fdiv_rn(phi * g.pw_f, TWO_PI_F);  // P:167
-    V = __fdiv_rn(theta * g.ph_f, PI_F);    // P:169
+    // P:167 / P:169: division by the constants float32(2 pi) / float32(pi), same correction scheme
+    const float R_TWO_PI = 0.15915494f, R_PI = 0.31830987f;  // RN(1 / 6.2831855f), RN(1 / 3.1415927f)
+    const float tu = phi * g.pw_f, tv = theta * g.ph_f;
+    U = tu * R_TWO_PI;
+    V = tv * R_PI;
+    U = __builtin_fmaf(__builtin_fmaf(-U, TWO_PI_F, tu), R_TWO_PI, U);
+    V = __builtin_fmaf(__builtin_fmaf(-V, PI_F, tv), R_PI, V);
     U = clip_keep_nan(U, 0.0f, g.pw_f - 1.0f);  // P:172
     V = clip_keep_nan(V, 0.0f, g.ph_f - 1.0f);  // P:173
 }
