@@ -17,6 +17,7 @@ P2P_OK = 0
 P2P_ERR_INVALID, P2P_ERR_NO_DEVICE, P2P_ERR_HIP, P2P_ERR_OOM, P2P_ERR_STATE = -1, -2, -3, -4, -5
 BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_101 = 0, 1, 2, 3, 4
 FLAG_KEEP_COORDS = 1
+FLAG_CACHE_COORDS = 2
 
 # every symbol include/p2p_hip.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (

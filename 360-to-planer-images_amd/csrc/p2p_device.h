@@ -73,7 +73,7 @@ hipError_t launch_yaw_desc(YawDesc* desc, uint32_t* f4tab, const uint32_t* packe
                            hipStream_t st);
 hipError_t launch_pitch_map(float* U, float* V, int ow, int oh, const MapGeom& g, float c, float s,
                             hipStream_t st);
-hipError_t launch_remap_views(const ViewsParams& P, bool host_maps, hipStream_t st);
+hipError_t launch_remap_views(const ViewsParams& P, int mapsrc, hipStream_t st);
 hipError_t launch_remap_maps(const RemapParams& P, int cn, hipStream_t st);
 // diagnostic build only (-DP2P_STAMPS): per-phase s_memtime sums of remap_views_kernel's pair loop
 hipError_t read_stamps(unsigned long long* out16, bool reset);

@@ -77,6 +77,7 @@ struct p2p_job {
     int32_t* d_coords = nullptr;
     p2p::MapGeom geom{};
     bool host_maps = false;
+    bool coords_valid = false;  // d_coords holds what the last in-kernel evaluation produced
     bool ran = false;
     std::vector<char> pano_set;
     // ring of event pairs: one per p2p_job_run, so a caller can time K back-to-back launches
@@ -293,7 +294,7 @@ int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out)
     if (e == hipSuccess) e = hipMalloc((void**)&j->d_ydesc, (size_t)d.n_yaw * sizeof(p2p::YawDesc));
     if (e == hipSuccess) e = hipMalloc((void**)&j->d_yaw_rad, (size_t)d.n_yaw * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&j->d_pitch, (size_t)d.n_pitch * sizeof(p2p::PitchConst));
-    if (e == hipSuccess && (d.flags & P2P_FLAG_KEEP_COORDS))
+    if (e == hipSuccess && (d.flags & (P2P_FLAG_KEEP_COORDS | P2P_FLAG_CACHE_COORDS)))
         e = hipMalloc((void**)&j->d_coords, (size_t)d.n_pitch * d.oh * d.ow * 2 * sizeof(int32_t));
     if (e == hipSuccess)
         e = hipMemcpyAsync(j->d_yaw_rad, yr.data(), yr.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
@@ -355,6 +356,7 @@ int p2p_job_set_maps(p2p_job* j, const float* yaw_rows, const float* U, const fl
     }
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));
     j->host_maps = true;
+    j->coords_valid = false;
     return P2P_OK;
 }
 
@@ -394,7 +396,13 @@ int p2p_job_run(p2p_job* j)
     }
     const int slot = (int)(j->runs % kEvRing);
     HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
-    HIP_TRY(p2p::launch_remap_views(P, j->host_maps, j->ctx->stream));
+    // coordinate cache (opt-in): the first launch evaluates the maps in-kernel and stores the quantised
+    // coordinates, later launches of the job load them -- the reference's pitch_mapping_cache (P:62-73)
+    const bool use_cache = (j->d.flags & P2P_FLAG_CACHE_COORDS) && j->coords_valid && !j->host_maps;
+    const int mapsrc = j->host_maps ? 1 : (use_cache ? 2 : 0);
+    HIP_TRY(p2p::launch_remap_views(P, mapsrc, j->ctx->stream));
+    if (!j->host_maps && j->d_coords)
+        j->coords_valid = true;
     HIP_TRY(hipEventRecord(j->ev_ring[2 * slot + 1], j->ctx->stream));
     j->runs++;
     j->ran = true;
@@ -540,7 +548,7 @@ int p2p_remap_views_u8(const uint8_t* pano, int pw, int ph, int64_t row_stride,
     if (n_yaw < 0 || n_pitch < 0 || (n_yaw > 0 && !yaw_deg) || (n_pitch > 0 && !pitch_deg))
         return fail(P2P_ERR_INVALID, "bad yaw/pitch list");
     return views_oneshot(pano, pw, ph, row_stride, yaw_deg, n_yaw, pitch_deg, n_pitch, fov_deg, ow, oh,
-                         out, device, flags & ~P2P_FLAG_KEEP_COORDS, nullptr, nullptr, nullptr);
+                         out, device, flags & ~(P2P_FLAG_KEEP_COORDS | P2P_FLAG_CACHE_COORDS), nullptr, nullptr, nullptr);
 }
 
 int p2p_remap_views_maps_u8(const uint8_t* pano, int pw, int ph, int64_t row_stride,

@@ -414,7 +414,9 @@ struct PairCtx {      // uniform per (tile, pair); precomputed per lane at tile 
     int yaw_i;
 };
 
-template <bool HOST_MAPS>
+// MAPSRC: 0 = coordinates computed in-kernel (pitch_map_eval), 1 = caller float maps, 2 = the job's
+// coordinate cache (what an earlier MAPSRC 0 launch stored; the reference's pitch_mapping_cache, P:62-73)
+template <int MAPSRC>
 __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
     ViewsParams P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab,
     const YawDesc* __restrict__ ydesc, const uint32_t* __restrict__ f4tab,
@@ -448,21 +450,24 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
         inside[j] = px < P.ow && py < P.oh;
         int sx = INT32_MIN, sy = INT32_MIN;
         if (inside[j]) {
-            float U, V;
-            if (HOST_MAPS) {
-                size_t k = ((size_t)pitch_i * P.oh + py) * P.ow + px;
-                U = mapU[k];
-                V = mapV[k];
+            const size_t k = ((size_t)pitch_i * P.oh + py) * P.ow + px;
+            if (MAPSRC == 2) {
+                const int2 sc = reinterpret_cast<const int2*>(coords)[k];
+                sx = sc.x;
+                sy = sc.y;
             } else {
-                PitchConst pc = pitch[pitch_i];
-                pitch_map_eval((float)px, (float)py, P.geom, pc.c, pc.s, U, V);
-            }
-            sx = cv_round_f32(U * 32.0f);
-            sy = cv_round_f32(V * 32.0f);
-            if (coords && blockIdx.z == 0) {
-                size_t k = (((size_t)pitch_i * P.oh + py) * P.ow + px) * 2;
-                coords[k] = sx;
-                coords[k + 1] = sy;
+                float U, V;
+                if (MAPSRC == 1) {
+                    U = mapU[k];
+                    V = mapV[k];
+                } else {
+                    PitchConst pc = pitch[pitch_i];
+                    pitch_map_eval((float)px, (float)py, P.geom, pc.c, pc.s, U, V);
+                }
+                sx = cv_round_f32(U * 32.0f);
+                sy = cv_round_f32(V * 32.0f);
+                if (coords && blockIdx.z == 0)
+                    reinterpret_cast<int2*>(coords)[k] = make_int2(sx, sy);
             }
         }
         ix[j] = sat_short(sx >> 5);
@@ -906,17 +911,20 @@ hipError_t launch_pitch_map(float* U, float* V, int ow, int oh, const MapGeom& g
     return hipGetLastError();
 }
 
-hipError_t launch_remap_views(const ViewsParams& P, bool host_maps, hipStream_t st)
+hipError_t launch_remap_views(const ViewsParams& P, int mapsrc, hipStream_t st)
 {
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
     const int n_pairs = P.n_panos * P.n_yaw;
     const int zblocks = (n_pairs + P.pairs_per_block - 1) / P.pairs_per_block;
     dim3 grid(8 * ((tiles + 7) / 8), P.n_pitch, zblocks);  // 8 XCDs, each a contiguous run of tiles
-    if (host_maps)
-        hipLaunchKernelGGL(remap_views_kernel<true>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc,
+    if (mapsrc == 1)
+        hipLaunchKernelGGL(remap_views_kernel<1>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc,
+                           P.f4tab, P.pitch, P.mapU, P.mapV, P.out, P.coords);
+    else if (mapsrc == 2)
+        hipLaunchKernelGGL(remap_views_kernel<2>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc,
                            P.f4tab, P.pitch, P.mapU, P.mapV, P.out, P.coords);
     else
-        hipLaunchKernelGGL(remap_views_kernel<false>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc,
+        hipLaunchKernelGGL(remap_views_kernel<0>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc,
                            P.f4tab, P.pitch, P.mapU, P.mapV, P.out, P.coords);
     return hipGetLastError();
 }

@@ -162,6 +162,10 @@ def main():
                     help="fused: coordinate maps computed in-kernel (default, the product path); "
                          "caller: float maps handed in (the bit-exact mode)")
     ap.add_argument("--kind", default="S", choices=["S", "N"], help="synthetic panorama distribution")
+    ap.add_argument("--cache-coords", action="store_true",
+                    help="opt-in coordinate cache (P2P_FLAG_CACHE_COORDS): the first launch evaluates the pitch "
+                         "maps, later launches load the stored coordinates, as the reference's "
+                         "pitch_mapping_cache does across yaws and images; default off = maps evaluated in every launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -184,7 +188,8 @@ def main():
     views_per_rank = npg * len(w["yaws"]) * len(w["pitches"])
 
     ctx = nat.Context(dist.local_rank)
-    job = nat.Job(ctx, w["pw"], w["ph"], npg, w["yaws"], w["pitches"], w["fov"], w["ow"], w["oh"])
+    job = nat.Job(ctx, w["pw"], w["ph"], npg, w["yaws"], w["pitches"], w["fov"], w["ow"], w["oh"],
+                  flags=nat.FLAG_CACHE_COORDS if args.cache_coords else 0)
     for i in range(npg):
         # weak scaling: panorama index = rank * panos_per_gpu + i, seed 1000 + index
         job.set_pano(i, synth.synth_pano(w["pw"], w["ph"], 1000 + dist.rank * npg + i, args.kind))
@@ -216,7 +221,7 @@ def main():
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": w["name"], "panos_per_gpu": npg, "views_per_gpu": views_per_rank,
-                   "maps": args.maps, "pano_kind": args.kind, "sharding": "independent panoramas per rank, no collective"},
+                   "maps": args.maps + ("+coordinate cache" if args.cache_coords else ""), "pano_kind": args.kind, "sharding": "independent panoramas per rank, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
                      "kernel": "remap_views_kernel", "kernel_ms_avg": k_avg_s * 1e3,

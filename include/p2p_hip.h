@@ -46,8 +46,12 @@ enum { P2P_BORDER_CONSTANT = 0, P2P_BORDER_REPLICATE = 1, P2P_BORDER_REFLECT = 2
 /* p2p_job_desc.flags / p2p_remap_views_u8 flags */
 enum {
     P2P_FLAG_DEFAULT = 0,
-    P2P_FLAG_KEEP_COORDS = 1   /* keep the quantised pitch-stage coordinates the kernel used
+    P2P_FLAG_KEEP_COORDS = 1,  /* keep the quantised pitch-stage coordinates the kernel used
                                   (readable with p2p_job_get_coords); for parity tests */
+    P2P_FLAG_CACHE_COORDS = 2  /* jobs only: the first p2p_job_run evaluates the pitch maps in-kernel and
+                                  stores the quantised coordinates; later runs of the job load them
+                                  instead of re-evaluating -- the reference's pitch_mapping_cache (P:17-18,
+                                  P:62-73), which it keeps across yaws AND images.  Off by default. */
 };
 
 const char* p2p_version(void);

@@ -121,3 +121,23 @@ def test_yaw_rows_bit_exact(gpu, pkg, pw):
     U, V = pkg.get_yaw_mapping(pw, 4, 30)
     Ur, Vr = maps.yaw_map(pw, 4, 30)
     assert np.array_equal(U, Ur) and np.array_equal(V, Vr)
+
+
+def test_coordinate_cache_reproduces_in_kernel_maps(gpu, synth):
+    # P2P_FLAG_CACHE_COORDS (the reference's pitch_mapping_cache, P:62-73): the first run evaluates the maps
+    # and stores the quantised coordinates, later runs -- also with a different panorama -- load them
+    pw, ph, ow, oh = 1024, 512, 200, 144
+    yaws, pitches = [0, 30, 77], [45, 90]
+    a, b = synth.synth_pano(pw, ph, 1100, "N"), synth.synth_pano(pw, ph, 1101, "N")
+    ctx = gpu.Context(0)
+    plain = gpu.Job(ctx, pw, ph, 1, yaws, pitches, 90, ow, oh)
+    cached = gpu.Job(ctx, pw, ph, 1, yaws, pitches, 90, ow, oh, flags=gpu.FLAG_CACHE_COORDS)
+    for pano in (a, b, a):
+        plain.set_pano(0, pano)
+        cached.set_pano(0, pano)
+        plain.run()
+        cached.run()
+        assert np.array_equal(plain.get_views(0), cached.get_views(0))
+    plain.close()
+    cached.close()
+    ctx.close()
