@@ -155,6 +155,15 @@ def _imwrite_bgr(path, image):
     return True
 
 
+def _write_yaw(views_y, yaw_angle, pitch_angles, base_name, output_width, output_height, output_format, output_dir):
+    """Encode and write every pitch view of one yaw (one task of the writer pool)."""
+    for pi, pitch_angle in enumerate(pitch_angles):
+        out_filename = f"{base_name}_{output_width}x{output_height}_yaw_{yaw_angle}_pitch_{pitch_angle}.{output_format}"
+        output_file = output_dir / out_filename
+        _imwrite_bgr(output_file, views_y[pi])
+        logging.debug(f"Saved {output_file}")
+
+
 def process_single_image(
     input_image_path,
     output_dir,
@@ -166,19 +175,29 @@ def process_single_image(
     output_format="png",
     fov_deg=90,
 ):
-    """Drop-in for P:227-280.  num_workers is accepted for compatibility: the reference's thread
-    pool over yaws is replaced by one kernel launch covering every yaw and pitch of the image."""
-    from tqdm import tqdm
-
+    """Drop-in for P:227-280.  The reference fans one task per yaw out to `num_workers` threads that
+    each resample on the CPU and the caller writes the files; here every yaw and pitch of the image
+    comes from ONE kernel launch and the `num_workers` threads encode / write the files, one task
+    per yaw (the codecs release the GIL), which is where the time goes once the resampling is on the GPU."""
     logging.info(f"Loading image: {input_image_path}")
     input_image = _imread_bgr(input_image_path)
     if input_image is None:
         logging.error(f"Failed to read image: {input_image_path}")
         return
+    _process_decoded_image(input_image, input_image_path, output_dir, yaw_angles, pitch_angles, output_width,
+                           output_height, num_workers, output_format, fov_deg)
+
+
+def _process_decoded_image(input_image, input_image_path, output_dir, yaw_angles, pitch_angles, output_width,
+                           output_height, num_workers, output_format, fov_deg):
+    from concurrent.futures import ThreadPoolExecutor
+
+    from tqdm import tqdm
 
     input_image_path = Path(input_image_path)
     output_dir = Path(output_dir)
     base_name = input_image_path.stem
+    yaw_angles = list(yaw_angles)
 
     views = None
     error = None
@@ -187,17 +206,21 @@ def process_single_image(
     except Exception as e:  # the reference reports task failures per yaw and carries on (P:279-280)
         error = e
 
-    for yi, yaw_angle in enumerate(tqdm(list(yaw_angles), desc="Processing yaw angles")):
-        try:
-            if error is not None:
-                raise error
-            for pi, pitch_angle in enumerate(pitch_angles):
-                out_filename = f"{base_name}_{output_width}x{output_height}_yaw_{yaw_angle}_pitch_{pitch_angle}.{output_format}"
-                output_file = output_dir / out_filename
-                _imwrite_bgr(output_file, views[yi, pi])
-                logging.debug(f"Saved {output_file}")
-        except Exception as e:
-            logging.error(f"Error processing yaw_angle {yaw_angle}: {e}")
+    with ThreadPoolExecutor(max_workers=max(1, int(num_workers or 1))) as executor:
+        tasks = []
+        for yi, yaw_angle in enumerate(yaw_angles):
+            if error is None:
+                tasks.append(executor.submit(_write_yaw, views[yi], yaw_angle, pitch_angles, base_name,
+                                             output_width, output_height, output_format, output_dir))
+            else:
+                tasks.append(None)
+        for future, yaw_angle in zip(tqdm(tasks, desc="Processing yaw angles"), yaw_angles):
+            try:
+                if future is None:
+                    raise error
+                future.result()
+            except Exception as e:
+                logging.error(f"Error processing yaw_angle {yaw_angle}: {e}")
 
 
 def main(
@@ -242,8 +265,22 @@ def main(
             logging.warning(f"No images found in directory: {input_path_obj}")
             return
         logging.info(f"Found {len(all_images)} images in folder: {input_path_obj}")
-        for image_file in all_images:
-            process_single_image(input_image_path=image_file, **common)
+        # images are processed serially, as in P:330-341, but the next file is decoded on a helper thread
+        # while the current one is resampled and written
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=1) as decoder:
+            pending = decoder.submit(_imread_bgr, all_images[0])
+            for k, image_file in enumerate(all_images):
+                decoded = pending.result()
+                if k + 1 < len(all_images):
+                    pending = decoder.submit(_imread_bgr, all_images[k + 1])
+                logging.info(f"Loading image: {image_file}")
+                if decoded is None:
+                    logging.error(f"Failed to read image: {image_file}")
+                    continue
+                _process_decoded_image(decoded, image_file, output_dir, yaw_angles, pitch_angles, output_width,
+                                       output_height, num_workers, output_format, fov_deg)
     else:
         process_single_image(input_image_path=input_path_obj, **common)
 
