@@ -141,3 +141,31 @@ def test_general_caller_pitch_maps_with_border_taps(gpu, synth):
     rot = cpu_ref.yaw_stage(pano, 77)
     want = cpu_ref.remap(rot, U[0], V[0], cpu_ref.BORDER_CONSTANT)
     assert np.array_equal(got[0, 0], want)
+
+
+def test_pair_chunking_across_workgroups(gpu, synth, monkeypatch):
+    # P2P_PAIRS_PER_BLOCK forces the (panorama, yaw) pairs of a tile to be split over several workgroups
+    # (grid.z chunks, as happens by itself for small outputs and long yaw sweeps); results must not depend on it
+    pw, ph, ow, oh = 512, 256, 96, 64
+    yaws, pitches = list(range(0, 360, 24)), [70, 110]  # 15 yaws
+    panos = [synth.synth_pano(pw, ph, 1020 + i, "N") for i in range(2)]
+    rows, U, V = oracle_maps(yaws, pitches, ow, oh, pw, ph, 90)
+    want = [oracle_views(p, yaws, pitches, ow, oh, 90) for p in panos]
+    for ppb in ("1", "4", "7", "64"):
+        monkeypatch.setenv("P2P_PAIRS_PER_BLOCK", ppb)
+        ctx = gpu.Context(0)
+        job = gpu.Job(ctx, pw, ph, 2, yaws, pitches, 90, ow, oh)
+        job.set_maps(rows, U, V)
+        for i, p in enumerate(panos):
+            job.set_pano(i, p)
+        job.run()
+        for i in range(2):
+            assert np.array_equal(job.get_views(i), want[i]), (ppb, i)
+        job.close()
+        ctx.close()
+
+
+def test_long_yaw_sweep_config5_style(gpu, synth):
+    # config 5 geometry at reduced size: a 1-degree yaw sweep (whole-column, fractional and flickering shifts mixed)
+    pano = synth.synth_pano(2048, 1024, 1030, "N")
+    _check(gpu, pano, list(range(0, 360, 7)) + [359, 360, 361], [90], 240, 136)
