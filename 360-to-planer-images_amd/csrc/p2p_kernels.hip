@@ -621,11 +621,13 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
     // ---- per-pair contexts: lane k of every wave works out pair0 + k once; the loop reads them
     // back with v_readlane, so no descriptor load sits on the per-pair critical path ----
     uint32_t cw0 = 0, cw1 = 0;
-    int cw2 = 0;
+    int cw2 = 0, cw3 = 0;
+    bool ctx_plain = true;  // this lane's pair: circular-shift yaw with one weight for the whole tile
     {
         const int k = t & 63;
         if (k < pair1 - pair0) {
             const int yi = (pair0 + k) % P.n_yaw;
+            cw3 = (pair0 + k) / P.n_yaw;
             const YawDesc yd = ydesc[yi];
             int i_first = c0 + yd.s;
             if (i_first >= P.pw)
@@ -637,8 +639,11 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
                   (uint32_t)per_column << 23 | (uint32_t)yd.f << 24;
             cw1 = (uint32_t)(ngroups - g0) | (uint32_t)yi << 16;
             cw2 = 4 * g0 - yd.s;
+            ctx_plain = yd.mode != 2 && !per_column;
         }
     }
+    // every pair of this chunk plain -> the tight loop below; otherwise the general loop
+    const bool all_plain = __ballot(!ctx_plain) == 0ull;
     auto pair_ctx = [&](int k) {
         const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)cw0, k);
         const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)cw1, k);
@@ -675,6 +680,88 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
             }
         }
     };
+
+    if (all_plain) {
+        // ---- tight loop: no per-pair mode branches, source pieces ping-pong between two register
+        // sets (pair loop unrolled by two), so nothing is copied and nothing is re-decided per pair ----
+        const int npairs = pair1 - pair0;
+        auto load_pieces = [&](int k, Q16 (&qq)[VIEWS_SLOTS]) {
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)cw0, k);
+            const uint32_t wrap_g = (uint32_t)__builtin_amdgcn_readlane((int)cw1, k) & 0xFFFFu;
+            const uint8_t* __restrict__ S = src + (size_t)__builtin_amdgcn_readlane(cw3, k) * P.pano_stride;
+            const uint32_t goff = w0 & 0xFFFFFu;
+#pragma unroll
+            for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
+                if (wave_base + sl * VIEWS_BLOCK < items) {
+                    uint32_t off = slot_off[sl] + goff;
+                    if (slot_g[sl] >= wrap_g)
+                        off -= row_bytes;
+                    qq[sl] = *reinterpret_cast<const Q16*>(S + off);
+                }
+        };
+        auto stage1 = [&](int k, const Q16 (&qq)[VIEWS_SLOTS], uint4* tl4) {
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)cw0, k) >> 24;
+#pragma unroll
+            for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
+                if (wave_base + sl * VIEWS_BLOCK < items) {
+                    const uint32_t p0 = qq[sl].d[0];
+                    const uint32_t p1 = __builtin_amdgcn_alignbyte(qq[sl].d[1], qq[sl].d[0], 3);
+                    const uint32_t p2 = __builtin_amdgcn_alignbyte(qq[sl].d[2], qq[sl].d[1], 2);
+                    const uint32_t p3 = __builtin_amdgcn_alignbyte(qq[sl].d[3], qq[sl].d[2], 1);
+                    const uint32_t p4 = qq[sl].d[3];
+                    uint4 o;
+                    if (f != 0) {
+                        const uint32_t f8 = 8u * f, g8 = 256u - f8;
+                        const uint32_t m0 = p0 & 0x00FF00FFu, n0 = p0 & 0x0000FF00u;
+                        const uint32_t m1 = p1 & 0x00FF00FFu, n1 = p1 & 0x0000FF00u;
+                        const uint32_t m2 = p2 & 0x00FF00FFu, n2 = p2 & 0x0000FF00u;
+                        const uint32_t m3 = p3 & 0x00FF00FFu, n3 = p3 & 0x0000FF00u;
+                        const uint32_t m4 = p4 & 0x00FF00FFu, n4 = p4 & 0x0000FF00u;
+                        o.x = rot_blend8(m0, n0, m1, n1, f8, g8);
+                        o.y = rot_blend8(m1, n1, m2, n2, f8, g8);
+                        o.z = rot_blend8(m2, n2, m3, n3, f8, g8);
+                        o.w = rot_blend8(m3, n3, m4, n4, f8, g8);
+                    } else {
+                        o.x = p0 & 0x00FFFFFFu;
+                        o.y = p1 & 0x00FFFFFFu;
+                        o.z = p2 & 0x00FFFFFFu;
+                        o.w = p3 & 0x00FFFFFFu;
+                    }
+                    tl4[t + sl * VIEWS_BLOCK] = o;
+                }
+        };
+        auto half = [&](int k, const Q16 (&qcur)[VIEWS_SLOTS], Q16 (&qnext)[VIEWS_SLOTS], uint4* tl4) {
+            stage1(k, qcur, tl4);
+            const int joff = (int)(((uint32_t)__builtin_amdgcn_readlane((int)cw0, k) >> 20) & 3u);
+            __syncthreads();
+            const uint32_t* tl = reinterpret_cast<const uint32_t*>(tl4);
+            uint32_t ta[VIEWS_PXT][4];
+#pragma unroll
+            for (int j = 0; j < VIEWS_PXT; ++j) {
+                const int b = tap[j] + joff;
+                ta[j][0] = tl[b];
+                ta[j][1] = tl[b + 1];
+                ta[j][2] = tl[b + rowdw];
+                ta[j][3] = tl[b + rowdw + 1];
+            }
+            if (k + 1 < npairs)
+                load_pieces(k + 1, qnext);
+            uint32_t pix[VIEWS_PXT];
+#pragma unroll
+            for (int j = 0; j < VIEWS_PXT; ++j)
+                pix[j] = blend4_packed(ta[j][0], ta[j][1], ta[j][2], ta[j][3], tw[j]);
+            store_pixels(pair0 + k, pix);
+        };
+        Q16 qa[VIEWS_SLOTS], qb[VIEWS_SLOTS];
+        load_pieces(0, qa);
+        for (int k = 0; k < npairs; k += 2) {
+            half(k, qa, qb, tile4[0]);
+            if (k + 1 >= npairs)
+                break;
+            half(k + 1, qb, qa, tile4[1]);
+        }
+        return;
+    }
 
     PairCtx pc = pair_ctx(0);
     Q16 q[VIEWS_SLOTS];
