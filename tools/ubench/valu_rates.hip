@@ -14,6 +14,8 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed, int iters
     uint32_t a[8];
     for (int i = 0; i < 8; ++i) a[i] = seed * (threadIdx.x + 1) + i * 0x9E3779B9u;
     uint32_t b = seed | 1u, c = seed ^ 0x55AA55AAu;
+    unsigned long long mask64 = 0x5555555555555555ull * (seed & 3u);
+    asm volatile("s_mov_b64 vcc, %0" :: "s"(mask64) : "vcc");
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 p[8]; for (int i = 0; i < 8; ++i) { p[i].x = (float)a[i]; p[i].y = 1.0f; }
     f2 pb = {1.0001f, 0.9999f}, pc = {0.5f, 0.25f};
@@ -39,7 +41,11 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed, int iters
                 if (OP == 14) asm volatile("v_mul_u32_u24_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "+v"(a[i]) : "v"(b));
                 if (OP == 15) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
                 if (OP == 16) asm volatile("v_mov_b32_dpp %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
-                if (OP == 17) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b));
+                if (OP == 17) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+                if (OP == 48) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "s"(mask64));
+                if (OP == 49) asm volatile("v_cmp_gt_u32_e32 vcc, %1, %0\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+                if (OP == 50) asm volatile("v_cmp_gt_u32_e64 %2, %1, %0" : "+v"(a[i]) : "v"(b), "s"(mask64));
+                if (OP == 51) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
                 if (OP == 18) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
                 if (OP == 19) asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(a[i]));
                 if (OP == 20) asm volatile("v_pk_lshrrev_b16 %0, 5, %0" : "+v"(a[i]));
@@ -151,6 +157,10 @@ int main()
         run<45>("v_pk_add_u16", d_out, w);
         run<46>("v_add_f32", d_out, w);
         run<47>("v_mad_mix_f32", d_out, w);
+        run<48>("v_cndmask_e64 sgpr mask", d_out, w);
+        run<49>("v_cmp+v_cndmask pair", d_out, w);
+        run<50>("v_cmp_e64 (-> sgpr)", d_out, w);
+        run<51>("v_min_u32", d_out, w);
     }
     return 0;
 }
