@@ -42,12 +42,21 @@ yaw_mapping_cache = {}
 pitch_mapping_cache = {}
 
 _DEVICE = int(os.environ.get("P2P_DEVICE", "0"))
+_DEVICES = None  # devices the directory walk of main() deals images to (None: just _DEVICE)
 
 
 def set_device(device):
     """Select the HIP device used by the functions of this module (additive to the reference API)."""
     global _DEVICE
     _DEVICE = int(device)
+
+
+def set_devices(devices):
+    """Devices main() spreads a folder of images over, round-robin, one host thread and one HIP stream
+    per device, no collective (every image / yaw / pitch view is independent work).
+    None or an empty list restores single-device operation."""
+    global _DEVICES
+    _DEVICES = [int(d) for d in devices] if devices else None
 
 
 def get_version():
@@ -106,13 +115,13 @@ def _int_angle(value, what):
     raise TypeError(f"{what} must be an integer number of degrees, got {value!r}")
 
 
-def process_views(pano_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg=90):
+def process_views(pano_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg=90, device=None):
     """All yaws x pitches of one panorama in one kernel launch.
     Returns uint8 [n_yaw][n_pitch][output_height][output_width][3]."""
     yaws = [_int_angle(y, "yaw angle") for y in yaw_angles]
     pitches = [_int_angle(p, "pitch angle") for p in pitch_angles]
     return _native.remap_views(pano_image, yaws, pitches, _int_angle(fov_deg, "FOV"),
-                               output_width, output_height, _DEVICE)
+                               output_width, output_height, _DEVICE if device is None else device)
 
 
 def process_yaw_and_pitchs(pano_image, yaw_angle, pitch_angles, output_width, output_height, fov_deg=90):
@@ -189,7 +198,7 @@ def process_single_image(
 
 
 def _process_decoded_image(input_image, input_image_path, output_dir, yaw_angles, pitch_angles, output_width,
-                           output_height, num_workers, output_format, fov_deg):
+                           output_height, num_workers, output_format, fov_deg, device=None):
     from concurrent.futures import ThreadPoolExecutor
 
     from tqdm import tqdm
@@ -202,7 +211,11 @@ def _process_decoded_image(input_image, input_image_path, output_dir, yaw_angles
     views = None
     error = None
     try:
-        views = process_views(input_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg)
+        if device is None:
+            views = process_views(input_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg)
+        else:
+            views = process_views(input_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg,
+                                  device=device)
     except Exception as e:  # the reference reports task failures per yaw and carries on (P:279-280)
         error = e
 
@@ -265,22 +278,34 @@ def main(
             logging.warning(f"No images found in directory: {input_path_obj}")
             return
         logging.info(f"Found {len(all_images)} images in folder: {input_path_obj}")
-        # images are processed serially, as in P:330-341, but the next file is decoded on a helper thread
-        # while the current one is resampled and written
         from concurrent.futures import ThreadPoolExecutor
 
-        with ThreadPoolExecutor(max_workers=1) as decoder:
-            pending = decoder.submit(_imread_bgr, all_images[0])
-            for k, image_file in enumerate(all_images):
-                decoded = pending.result()
-                if k + 1 < len(all_images):
-                    pending = decoder.submit(_imread_bgr, all_images[k + 1])
-                logging.info(f"Loading image: {image_file}")
-                if decoded is None:
-                    logging.error(f"Failed to read image: {image_file}")
-                    continue
-                _process_decoded_image(decoded, image_file, output_dir, yaw_angles, pitch_angles, output_width,
-                                       output_height, num_workers, output_format, fov_deg)
+        def run_share(image_files, device):
+            # images are processed serially, as in P:330-341, but the next file is decoded on a helper
+            # thread while the current one is resampled and written
+            with ThreadPoolExecutor(max_workers=1) as decoder:
+                pending = decoder.submit(_imread_bgr, image_files[0])
+                for k, image_file in enumerate(image_files):
+                    decoded = pending.result()
+                    if k + 1 < len(image_files):
+                        pending = decoder.submit(_imread_bgr, image_files[k + 1])
+                    logging.info(f"Loading image: {image_file}")
+                    if decoded is None:
+                        logging.error(f"Failed to read image: {image_file}")
+                        continue
+                    _process_decoded_image(decoded, image_file, output_dir, yaw_angles, pitch_angles, output_width,
+                                           output_height, num_workers, output_format, fov_deg, device)
+
+        if _DEVICES and len(_DEVICES) > 1:
+            # one host thread per GPU, images dealt round-robin, nothing exchanged between devices
+            shares = [(all_images[i::len(_DEVICES)], d) for i, d in enumerate(_DEVICES)]
+            shares = [(files, d) for files, d in shares if files]
+            logging.info(f"Dealing {len(all_images)} images round-robin to devices {[d for _, d in shares]}")
+            with ThreadPoolExecutor(max_workers=len(shares)) as per_device:
+                for f in [per_device.submit(run_share, files, d) for files, d in shares]:
+                    f.result()
+        else:
+            run_share(all_images, _DEVICES[0] if _DEVICES else None)
     else:
         process_single_image(input_image_path=input_path_obj, **common)
 
@@ -321,6 +346,8 @@ def build_arg_parser():
     p.add_argument("-v", "--version", action="version", version=f"%(prog)s {get_version()}",
                    help="Show version information")
     p.add_argument("--device", type=int, default=None, help="HIP device index (default 0 or $P2P_DEVICE)")
+    p.add_argument("--devices", type=int, nargs="+", default=None,
+                   help="HIP devices a folder of images is dealt to round-robin (one host thread per device)")
     return p
 
 
@@ -335,6 +362,7 @@ def cli(argv=None):
     logging.basicConfig(level=logging.INFO, format="%(asctime)s [%(levelname)s] %(message)s", handlers=handlers)
     if args.device is not None:
         set_device(args.device)
+    set_devices(args.devices)
     main(
         input_path=args.input_path,
         output_path=args.output_path,

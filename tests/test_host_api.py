@@ -175,3 +175,37 @@ def test_synthetic_panoramas_are_seeded_and_smooth(synth):
     assert np.abs(np.diff(a.astype(np.int16), axis=1)).max() <= 12
     n = synth.synth_pano(256, 128, 1000, "N")
     assert n.dtype == np.uint8 and 100 < n.mean() < 155
+
+
+def test_multi_device_round_robin_of_a_folder(pkg, tmp_path, monkeypatch):
+    """SURVEY 8(e) in the batch driver: images of a folder are dealt round-robin to the configured devices,
+    one host thread per device, every image exactly once, no exchange between devices."""
+    import threading
+
+    from PIL import Image
+
+    m = pkg.panorama_to_plane_pitch
+    (tmp_path / "in").mkdir()
+    for i in range(7):
+        Image.fromarray(np.full((8, 16, 3), i, np.uint8)).save(tmp_path / "in" / f"p{i}.png")
+    seen, lock = [], threading.Lock()
+
+    def fake_views(pano, yaws, pitches, ow, oh, fov=90, device=None):
+        with lock:
+            seen.append((int(pano[0, 0, 0]), device, threading.get_ident()))
+        return np.zeros((len(yaws), len(pitches), oh, ow, 3), np.uint8)
+
+    monkeypatch.setattr(m, "process_views", fake_views)
+    m.set_devices([0, 1, 2])
+    try:
+        m.main(str(tmp_path / "in"), str(tmp_path / "out"), [0], [90], 8, 8, num_workers=2)
+    finally:
+        m.set_devices(None)
+    assert sorted(i for i, _, _ in seen) == list(range(7))
+    by_dev = {}
+    for i, d, tid in seen:
+        by_dev.setdefault(d, []).append((i, tid))
+    assert set(by_dev) == {0, 1, 2} and sorted(len(v) for v in by_dev.values()) == [2, 2, 3]
+    for d, lst in by_dev.items():
+        assert len({tid for _, tid in lst}) == 1  # one host thread per device
+    assert len(list((tmp_path / "out").iterdir())) == 7
