@@ -520,7 +520,8 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
     const size_t view_bytes = (size_t)P.oh * P.ow * 3;
     const uint32_t pix_off = (uint32_t)(((size_t)py0 * P.ow + px) * 3);  // < 3 * 32766^2 < 2^32
     const uint32_t pix_step = (uint32_t)ROWSTEP * (uint32_t)P.ow * 3u;
-    const uint32_t sh8 = 8u * (uint32_t)(lane4 + 1);
+    // dword lane4 of the 12 bytes P0 P1 P2 P3: bytes of the own pixel (0-2) and of the next lane's (4-6)
+    const uint32_t store_sel = lane4 == 0 ? 0x04020100u : (lane4 == 1 ? 0x05040201u : 0x06050402u);
 
     const int pair0 = blockIdx.z * P.pairs_per_block;
     int pair1 = pair0 + P.pairs_per_block;
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
                 // lanes 4k..4k+3 hold pixels P0..P3; lanes with lane4 < 3 emit dword lane4 of the 12 bytes
                 // neighbour lane's pixel: row_shl:1 DPP (lane4 groups never straddle a 16-lane row)
                 uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pix[j], 0x101, 0xF, 0xF, false);
-                uint32_t dw = __builtin_amdgcn_alignbit(nxt, pix[j] << 8, sh8);
+                uint32_t dw = __builtin_amdgcn_perm(nxt, pix[j], store_sel);
                 if (inside[j] && lane4 < 3)
                     *reinterpret_cast<uint32_t*>(O + (off + (uint32_t)lane4)) = dw;
             } else if (inside[j]) {
@@ -704,28 +705,30 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
 #pragma unroll
             for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
                 if (wave_base + sl * VIEWS_BLOCK < items) {
-                    const uint32_t p0 = qq[sl].d[0];
-                    const uint32_t p1 = __builtin_amdgcn_alignbyte(qq[sl].d[1], qq[sl].d[0], 3);
-                    const uint32_t p2 = __builtin_amdgcn_alignbyte(qq[sl].d[2], qq[sl].d[1], 2);
-                    const uint32_t p3 = __builtin_amdgcn_alignbyte(qq[sl].d[3], qq[sl].d[2], 1);
-                    const uint32_t p4 = qq[sl].d[3];
+                    // the piece holds source pixels 0..4 at byte offsets 0, 3, 6, 9, 12; one v_perm_b32
+                    // both fetches a pixel across the dword seam and masks it
+                    // (selector bytes 0-3 pick the second operand's bytes, 4-7 the first's, 0x0c is zero)
+                    const uint32_t d0 = qq[sl].d[0], d1 = qq[sl].d[1], d2 = qq[sl].d[2], d3 = qq[sl].d[3];
                     uint4 o;
                     if (f != 0) {
                         const uint32_t f8 = 8u * f, g8 = 256u - f8;
-                        const uint32_t m0 = p0 & 0x00FF00FFu, n0 = p0 & 0x0000FF00u;
-                        const uint32_t m1 = p1 & 0x00FF00FFu, n1 = p1 & 0x0000FF00u;
-                        const uint32_t m2 = p2 & 0x00FF00FFu, n2 = p2 & 0x0000FF00u;
-                        const uint32_t m3 = p3 & 0x00FF00FFu, n3 = p3 & 0x0000FF00u;
-                        const uint32_t m4 = p4 & 0x00FF00FFu, n4 = p4 & 0x0000FF00u;
+                        const uint32_t m0 = d0 & 0x00FF00FFu, n0 = d0 & 0x0000FF00u;                    // bytes 0,1,2
+                        const uint32_t m1 = __builtin_amdgcn_perm(d1, d0, 0x0C050C03u);                  // 3,(4),5
+                        const uint32_t n1 = __builtin_amdgcn_perm(d1, d0, 0x0C0C040Cu);
+                        const uint32_t m2 = __builtin_amdgcn_perm(d2, d1, 0x0C040C02u);                  // 6,(7),8
+                        const uint32_t n2 = __builtin_amdgcn_perm(d2, d1, 0x0C0C030Cu);
+                        const uint32_t m3 = __builtin_amdgcn_perm(d3, d2, 0x0C030C01u);                  // 9,(10),11
+                        const uint32_t n3 = __builtin_amdgcn_perm(d3, d2, 0x0C0C020Cu);
+                        const uint32_t m4 = d3 & 0x00FF00FFu, n4 = d3 & 0x0000FF00u;                    // 12,13,14
                         o.x = rot_blend8(m0, n0, m1, n1, f8, g8);
                         o.y = rot_blend8(m1, n1, m2, n2, f8, g8);
                         o.z = rot_blend8(m2, n2, m3, n3, f8, g8);
                         o.w = rot_blend8(m3, n3, m4, n4, f8, g8);
                     } else {
-                        o.x = p0 & 0x00FFFFFFu;
-                        o.y = p1 & 0x00FFFFFFu;
-                        o.z = p2 & 0x00FFFFFFu;
-                        o.w = p3 & 0x00FFFFFFu;
+                        o.x = d0 & 0x00FFFFFFu;
+                        o.y = __builtin_amdgcn_perm(d1, d0, 0x0C050403u);
+                        o.z = __builtin_amdgcn_perm(d2, d1, 0x0C040302u);
+                        o.w = __builtin_amdgcn_perm(d3, d2, 0x0C030201u);
                     }
                     tl4[t + sl * VIEWS_BLOCK] = o;
                 }
