@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -250,6 +251,8 @@ int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out)
         return fail(P2P_ERR_INVALID, "output %dx%d: both sides must be in 1..32766", d.ow, d.oh);
     if (d.n_panos < 1 || d.n_yaw < 1 || d.n_pitch < 1 || !d.yaw_deg || !d.pitch_deg)
         return fail(P2P_ERR_INVALID, "need at least one panorama, yaw and pitch");
+    if (d.n_pitch > 64 || d.n_yaw > 65535)
+        return fail(P2P_ERR_INVALID, "at most 64 pitch angles and 65535 yaw angles per job (got %d, %d)", d.n_pitch, d.n_yaw);
     for (int i = 0; i < d.n_pitch; ++i)
         if (d.pitch_deg[i] < 1 || d.pitch_deg[i] > 179)
             return fail(P2P_ERR_INVALID, "Pitch angle must be between 1 and 179 degrees, got %d.", d.pitch_deg[i]);
@@ -395,6 +398,17 @@ int p2p_job_run(p2p_job* j)
             HIP_TRY(hipEventCreate(&e));
     }
     const int slot = (int)(j->runs % kEvRing);
+    // views looking further from the horizon have larger source footprints: launch them first
+    {
+        std::vector<int> ord(j->d.n_pitch);
+        for (int i = 0; i < j->d.n_pitch; ++i)
+            ord[i] = i;
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+            return std::abs(j->pitch[a] - 90) > std::abs(j->pitch[b] - 90);
+        });
+        for (int i = 0; i < j->d.n_pitch; ++i)
+            P.pitch_order[i] = (uint8_t)ord[i];
+    }
     HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
     // coordinate cache (opt-in): the first launch evaluates the maps in-kernel and stores the quantised
     // coordinates, later launches of the job load them -- the reference's pitch_mapping_cache (P:62-73)

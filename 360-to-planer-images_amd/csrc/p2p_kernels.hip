@@ -433,7 +433,8 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
     const int tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     if (tile_id >= tiles_x * tiles_y)
         return;
-    const int pitch_i = blockIdx.y;
+    // heaviest views first (the host orders pitch_order by |pitch - 90| descending): a smoother tail
+    const int pitch_i = P.pitch_order[blockIdx.y];
     const int x0 = (tile_id % tiles_x) * TILE_W;
     const int y0 = (tile_id / tiles_x) * TILE_H;
     const int px = x0 + (t % TILE_W);
