@@ -253,6 +253,8 @@ int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out)
         return fail(P2P_ERR_INVALID, "need at least one panorama, yaw and pitch");
     if (d.n_pitch > 64 || d.n_yaw > 65535)
         return fail(P2P_ERR_INVALID, "at most 64 pitch angles and 65535 yaw angles per job (got %d, %d)", d.n_pitch, d.n_yaw);
+    if ((unsigned long long)d.n_panos * d.n_yaw * d.n_yaw >= (1ull << 32))
+        return fail(P2P_ERR_INVALID, "n_panos * n_yaw^2 must stay below 2^32 (got %d panoramas, %d yaws)", d.n_panos, d.n_yaw);
     for (int i = 0; i < d.n_pitch; ++i)
         if (d.pitch_deg[i] < 1 || d.pitch_deg[i] > 179)
             return fail(P2P_ERR_INVALID, "Pitch angle must be between 1 and 179 degrees, got %d.", d.pitch_deg[i]);
@@ -384,6 +386,7 @@ int p2p_job_run(p2p_job* j)
     P.n_pitch = j->d.n_pitch;
     P.n_panos = j->d.n_panos;
     P.pairs_per_block = choose_pairs_per_block(j->d);
+    P.n_yaw_magic = (uint32_t)(((1ull << 32) + (uint64_t)j->d.n_yaw - 1) / (uint64_t)j->d.n_yaw);
     P.pitch = j->d_pitch;
     P.mapU = j->d_mapU;
     P.mapV = j->d_mapV;

@@ -529,7 +529,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
     const int n_pairs = P.n_panos * P.n_yaw;
     if (pair1 > n_pairs)
         pair1 = n_pairs;
-    int pano_i = pair0 / P.n_yaw;
+    int pano_i = (int)__umulhi((uint32_t)pair0, P.n_yaw_magic);
     int yaw_i = pair0 - pano_i * P.n_yaw;
 
     auto store_pixels = [&](int pair, const uint32_t (&pix)[VIEWS_PXT]) {
@@ -628,8 +628,9 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
     {
         const int k = t & 63;
         if (k < pair1 - pair0) {
-            const int yi = (pair0 + k) % P.n_yaw;
-            cw3 = (pair0 + k) / P.n_yaw;
+            // pair -> (panorama, yaw) by the host's multiply-high constant (exact for the job's sizes)
+            cw3 = (int)__umulhi((uint32_t)(pair0 + k), P.n_yaw_magic);
+            const int yi = pair0 + k - cw3 * P.n_yaw;
             const YawDesc yd = ydesc[yi];
             int i_first = c0 + yd.s;
             if (i_first >= P.pw)
