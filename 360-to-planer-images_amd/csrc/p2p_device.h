@@ -54,6 +54,7 @@ struct ViewsParams {
     int ow, oh;
     uint8_t* out;            // [n_panos][n_yaw][n_pitch][oh][ow][3]
     int32_t* coords;         // optional [n_pitch][oh][ow][2] dump of (sx, sy)
+    int border;              // stage-2 border mode (0 = BORDER_CONSTANT 0, the reference's current tool)
     uint8_t pitch_order[64]; // blockIdx.y -> pitch index, heaviest view first (n_pitch <= 64 per job)
 };
 

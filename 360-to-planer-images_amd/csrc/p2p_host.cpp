@@ -78,6 +78,7 @@ struct p2p_job {
     int32_t* d_coords = nullptr;
     p2p::MapGeom geom{};
     bool host_maps = false;
+    int border = 0;             // stage-2 border mode; non-zero only for the legacy single-remap entry point
     bool coords_valid = false;  // d_coords holds what the last in-kernel evaluation produced
     bool ran = false;
     std::vector<char> pano_set;
@@ -395,6 +396,7 @@ int p2p_job_run(p2p_job* j)
     P.oh = j->d.oh;
     P.out = j->d_out;
     P.coords = j->d_coords;
+    P.border = j->border;
     if (j->ev_ring.empty()) {
         j->ev_ring.resize(2 * kEvRing, nullptr);
         for (auto& e : j->ev_ring)
@@ -519,7 +521,7 @@ int p2p_debug_stamps(uint64_t* out16, int reset)
 static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride,
                          const int32_t* yaw_deg, int n_yaw, const int32_t* pitch_deg, int n_pitch,
                          int fov_deg, int ow, int oh, uint8_t* out, int device, int flags,
-                         const float* yaw_rows, const float* U, const float* V)
+                         const float* yaw_rows, const float* U, const float* V, int border = 0)
 {
     if (!pano || !out)
         return fail(P2P_ERR_INVALID, "NULL image pointer");
@@ -547,6 +549,7 @@ static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride
     rc = p2p_job_create(ctx, &d, &j);
     if (rc != P2P_OK)
         return rc;
+    j->border = border;
     rc = p2p_job_set_pano(j, 0, pano, row_stride);
     if (rc == P2P_OK && U)
         rc = p2p_job_set_maps(j, yaw_rows, U, V);
@@ -592,6 +595,17 @@ int p2p_remap_maps_u8(const uint8_t* src, int sw, int sh, int64_t row_stride, in
         return fail(P2P_ERR_INVALID, "unsupported border mode %d", border_mode);
     if (row_stride < (int64_t)sw * cn)
         return fail(P2P_ERR_INVALID, "row_stride too small");
+    bool zero_border = true;
+    for (int k = 0; k < cn; ++k)
+        zero_border = zero_border && (!border_value || border_value[k] == 0);
+    if (cn == 3 && (border_mode != P2P_BORDER_CONSTANT || zero_border)) {
+        // three interleaved channels: the view kernel with an identity yaw stage (yaw 0 quantises to
+        // "column x, fraction 0", so stage 1 is a copy) and the caller's maps as its pitch stage --
+        // LDS-staged taps instead of per-pixel byte gathers
+        const int32_t yaw0 = 0;
+        return views_oneshot(src, sw, sh, row_stride, &yaw0, 1, nullptr, 1, 90, ow, oh, out, device, 0,
+                             nullptr, U, V, border_mode);
+    }
     p2p_ctx* ctx = nullptr;
     int rc = thread_ctx(device, &ctx);
     if (rc != P2P_OK)

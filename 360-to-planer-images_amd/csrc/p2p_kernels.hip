@@ -302,6 +302,35 @@ __device__ __forceinline__ uint32_t blend4(uint32_t a, uint32_t b, uint32_t c, u
     return vb | (vg << 8) | (vr << 16);
 }
 
+// cv::borderInterpolate (core/src/copy.cpp) for the border codes of include/p2p_hip.h
+__device__ __forceinline__ int border_interpolate(int p, int len, int border)
+{
+    if ((unsigned)p < (unsigned)len)
+        return p;
+    if (border == 1)  // REPLICATE
+        return p < 0 ? 0 : len - 1;
+    if (border == 2 || border == 4) {  // REFLECT / REFLECT_101
+        int delta = border == 4;
+        if (len == 1)
+            return 0;
+        do {
+            if (p < 0)
+                p = -p - 1 + delta;
+            else
+                p = len - 1 - (p - len) - delta;
+        } while ((unsigned)p >= (unsigned)len);
+        return p;
+    }
+    if (border == 3) {  // WRAP
+        if (p < 0)
+            p -= ((p - len + 1) / len) * len;
+        if (p >= len)
+            p %= len;
+        return p;
+    }
+    return -1;  // CONSTANT
+}
+
 struct __attribute__((aligned(4))) Q16 { uint32_t d[4]; };
 
 // ---- diagnostic build only: in-kernel phase stamps (never compiled into the shipped library) ----
@@ -444,7 +473,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
     // ---- pitch-stage coordinates of this thread's pixels, quantised as cv::remap does ----
     int ix[VIEWS_PXT], iy[VIEWS_PXT];
     uint32_t fx[VIEWS_PXT], fy[VIEWS_PXT];
-    bool inside[VIEWS_PXT], live[VIEWS_PXT];
+    bool inside[VIEWS_PXT], live[VIEWS_PXT], inrange[VIEWS_PXT];
 #pragma unroll
     for (int j = 0; j < VIEWS_PXT; ++j) {
         const int py = py0 + j * ROWSTEP;
@@ -478,7 +507,9 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
         // A pixel contributes only if its 2x2 footprint touches the panorama (BORDER_CONSTANT 0:
         // cv::remap writes borderValue when sx >= w || sx+1 < 0 || sy >= h || sy+1 < 0).  For the
         // reference's clipped maps that is every pixel except NaN ones (ix = iy = -32768).
-        live[j] = inside[j] && ix[j] >= -1 && iy[j] >= -1 && ix[j] < P.pw && iy[j] < P.ph;
+        inrange[j] = inside[j] && ix[j] >= -1 && iy[j] >= -1 && ix[j] < P.pw && iy[j] < P.ph;
+        // other border modes (legacy entry point, L:179) resolve every tap to some pixel
+        live[j] = P.border == 0 ? inrange[j] : inside[j];
     }
 
     // ---- footprint of the tile in rot space: packed (ix+1, iy+1) u16 pairs, one min and one max
@@ -486,7 +517,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
     for (int j = 0; j < VIEWS_PXT; ++j)
-        if (live[j]) {
+        if (inrange[j]) {
             const uint32_t key = (uint32_t)(ix[j] + 1) | (uint32_t)(iy[j] + 1) << 16;  // both in 0..32767
             kmin = pk_min(kmin, key);
             kmax = pk_max(kmax, key);
@@ -512,7 +543,17 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
     const int items = Ht * G;
     // the LDS scheme needs the whole footprint strictly inside the panorama (so that no tap is a
     // border tap) and a width divisible by 4 (so that 12-byte items never straddle a row end)
-    const bool fast_tile = any_live && (P.pw & 3) == 0 && c0 >= 0 && r0 >= 0 && c1 + 1 < P.pw &&
+    // with a non-constant border a pixel outside the panorama still reads pixels (reflected, wrapped ...):
+    // such tiles go the direct way, where the taps are resolved by cv::borderInterpolate
+    bool stray = false;
+    if (P.border != 0) {
+        bool mine = false;
+#pragma unroll
+        for (int j = 0; j < VIEWS_PXT; ++j)
+            mine |= inside[j] && !inrange[j];
+        stray = __syncthreads_or(mine) != 0;
+    }
+    const bool fast_tile = any_live && !stray && (P.pw & 3) == 0 && c0 >= 0 && r0 >= 0 && c1 + 1 < P.pw &&
                            r1 + 1 < P.ph && G <= 255 && items <= LDS_ITEMS_CAP;
 
     // output addressing: 4 horizontally adjacent pixels = 12 bytes = 3 aligned dwords
@@ -560,7 +601,15 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
 #pragma unroll
         for (int j = 0; j < VIEWS_PXT; ++j) {
             pix[j] = 0;
-            if (live[j]) {
+            if (live[j] && P.border != 0) {
+                const int xa = border_interpolate(ix[j], P.pw, P.border), xb = border_interpolate(ix[j] + 1, P.pw, P.border);
+                const int ya = border_interpolate(iy[j], P.ph, P.border), yb = border_interpolate(iy[j] + 1, P.ph, P.border);
+                const uint8_t* row0 = S + (size_t)ya * P.src_pitch;
+                const uint8_t* row1 = S + (size_t)yb * P.src_pitch;
+                const uint32_t t0 = T[xa], t1 = T[xb];
+                pix[j] = blend4(rot_pixel(row0, t0), rot_pixel(row0, t1), rot_pixel(row1, t0), rot_pixel(row1, t1),
+                                fx[j], fy[j]);
+            } else if (live[j]) {
                 const bool c0in = ix[j] >= 0, c1in = ix[j] + 1 < P.pw, r0in = iy[j] >= 0, r1in = iy[j] + 1 < P.ph;
                 const uint8_t* row0 = S + (ptrdiff_t)iy[j] * P.src_pitch;
                 const uint8_t* row1 = row0 + P.src_pitch;
@@ -894,34 +943,6 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
 // Generic cv2.remap(src, U, V, INTER_LINEAR, border) for uint8, cn in {1,3,4}
 // (panorama_to_plane, L:159-194).  One thread per destination pixel.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int border_interpolate(int p, int len, int border)
-{
-    if ((unsigned)p < (unsigned)len)
-        return p;
-    if (border == 1)  // REPLICATE
-        return p < 0 ? 0 : len - 1;
-    if (border == 2 || border == 4) {  // REFLECT / REFLECT_101
-        int delta = border == 4;
-        if (len == 1)
-            return 0;
-        do {
-            if (p < 0)
-                p = -p - 1 + delta;
-            else
-                p = len - 1 - (p - len) - delta;
-        } while ((unsigned)p >= (unsigned)len);
-        return p;
-    }
-    if (border == 3) {  // WRAP
-        if (p < 0)
-            p -= ((p - len + 1) / len) * len;
-        if (p >= len)
-            p %= len;
-        return p;
-    }
-    return -1;  // CONSTANT
-}
-
 template <int CN>
 __global__ void remap_maps_kernel(RemapParams P)
 {

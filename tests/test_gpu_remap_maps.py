@@ -56,3 +56,19 @@ def test_grayscale_2d_and_errors(gpu):
     assert e.value.code == gpu.P2P_ERR_INVALID
     with pytest.raises(gpu.P2PError):
         gpu.remap_maps(img, U, V, border=7)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_three_channel_maps_through_the_view_kernel(gpu, mode):
+    # cn == 3 with a zero border value (or any non-constant border) is served by the fused view kernel with an
+    # identity yaw stage: random maps incl. far out-of-range, NaN, exact edges; plus a smooth in-range map
+    rng = np.random.default_rng(200 + mode)
+    img = rng.integers(0, 256, size=(64, 96, 3), dtype=np.uint8)   # width divisible by 4: LDS path eligible
+    U = rng.uniform(-40, 140, size=(70, 90)).astype(np.float32)
+    V = rng.uniform(-30, 95, size=(70, 90)).astype(np.float32)
+    U[0, :6] = [np.nan, 0.0, 95.0, 95.5, -1.0, 1e9]
+    V[0, :6] = [3.0, np.nan, 63.0, 63.5, -0.5, -1e9]
+    assert np.array_equal(gpu.remap_maps(img, U, V, border=mode), cpu_ref.remap(img, U, V, mode))
+    yy, xx = np.mgrid[0:70, 0:90].astype(np.float32)
+    Us, Vs = (3.0 + xx * 0.97 + yy * 0.05).astype(np.float32), (2.0 + yy * 0.8 + xx * 0.03).astype(np.float32)
+    assert np.array_equal(gpu.remap_maps(img, Us, Vs, border=mode), cpu_ref.remap(img, Us, Vs, mode))
