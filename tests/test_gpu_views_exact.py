@@ -169,3 +169,21 @@ def test_long_yaw_sweep_config5_style(gpu, synth):
     # config 5 geometry at reduced size: a 1-degree yaw sweep (whole-column, fractional and flickering shifts mixed)
     pano = synth.synth_pano(2048, 1024, 1030, "N")
     _check(gpu, pano, list(range(0, 360, 7)) + [359, 360, 361], [90], 240, 136)
+
+
+def test_randomised_configurations(gpu, synth):
+    # seeded sweep over panorama / view sizes, FOVs, yaw and pitch lists: every byte equals the oracle
+    rng = np.random.default_rng(4242)
+    for case in range(24):
+        pw = int(rng.choice([64, 128, 200, 256, 372, 512, 1000, 1024]))
+        ph = int(rng.choice([32, 64, 100, 128, 256, 500]))
+        ow, oh = int(rng.integers(1, 160)), int(rng.integers(1, 100))
+        fov = int(rng.integers(10, 170))
+        yaws = [int(v) for v in rng.integers(-400, 800, size=int(rng.integers(1, 5)))]
+        pitches = [int(v) for v in rng.integers(1, 180, size=int(rng.integers(1, 4)))]
+        pano = synth.synth_pano(pw, ph, 5000 + case, "N")
+        ph_, pw_ = pano.shape[:2]
+        rows, U, V = oracle_maps(yaws, pitches, ow, oh, pw_, ph_, fov)
+        got = gpu.remap_views_maps(pano, rows, U, V)
+        want = oracle_views(pano, yaws, pitches, ow, oh, fov)
+        assert np.array_equal(got, want), dict(case=case, pw=pw, ph=ph, ow=ow, oh=oh, fov=fov, yaws=yaws, pitches=pitches)
