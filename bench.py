@@ -66,7 +66,8 @@ class Dist:
             if backend is None:
                 import torch
 
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                # P2P_BENCH_BACKEND=gloo: dry run of the N > 1 path where the ranks share one GPU (RCCL refuses that)
+                backend = os.environ.get("P2P_BENCH_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
                 import torch
 
@@ -178,6 +179,8 @@ def main():
                   file=sys.stderr)
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU fallback for the hot path)"
+    if os.environ.get("P2P_BENCH_SHARE_GPU") == "1":  # dry run only: several ranks on one device
+        dist.local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(dist.local_rank)
 
     pkg = importlib.import_module(PKG)
