@@ -138,9 +138,11 @@ int p2p_ctx_synchronize(p2p_ctx* ctx);
 
 int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out);
 void p2p_job_destroy(p2p_job* job);
-/* Asynchronous H2D copy of panorama `index` (uint8 [ph][pw][3]). */
+/* H2D copy of panorama `index` (uint8 [ph][pw][3]) on the job's stream; returns once the host buffer may
+   be reused or freed. */
 int p2p_job_set_pano(p2p_job* job, int index, const uint8_t* pano, int64_t row_stride);
-/* Optional: use caller float maps instead of in-kernel ones (see p2p_remap_views_maps_u8). */
+/* Optional: use caller float maps instead of in-kernel ones (see p2p_remap_views_maps_u8).  yaw_rows may be
+   NULL to keep the yaw tables built from yaw_deg. */
 int p2p_job_set_maps(p2p_job* job, const float* yaw_rows, const float* U, const float* V);
 /* Enqueue the view-synthesis kernel for all panoramas x yaws x pitches (asynchronous). */
 int p2p_job_run(p2p_job* job);
