@@ -24,7 +24,8 @@ ABI_SYMBOLS = (
     "p2p_version", "p2p_last_error", "p2p_device_count",
     "p2p_remap_views_u8", "p2p_remap_views_maps_u8", "p2p_remap_maps_u8",
     "p2p_build_pitch_map", "p2p_build_yaw_row",
-    "p2p_ctx_create", "p2p_ctx_destroy", "p2p_ctx_synchronize",
+    "p2p_ctx_create", "p2p_ctx_destroy", "p2p_ctx_synchronize", "p2p_ctx_mark", "p2p_ctx_marked_ms",
+    "p2p_job_time_launches",
     "p2p_job_create", "p2p_job_destroy", "p2p_job_set_pano", "p2p_job_set_maps", "p2p_job_run",
     "p2p_job_get_views", "p2p_job_kernel_ms", "p2p_job_kernel_ms_last", "p2p_job_device_out", "p2p_job_get_coords",
     "p2p_job_get_yaw_tables", "p2p_debug_stamps",
@@ -87,6 +88,12 @@ def lib():
     L.p2p_ctx_destroy.argtypes = [c_vp]
     L.p2p_ctx_synchronize.restype = c_int
     L.p2p_ctx_synchronize.argtypes = [c_vp]
+    L.p2p_ctx_mark.restype = c_int
+    L.p2p_ctx_mark.argtypes = [c_vp, c_int]
+    L.p2p_ctx_marked_ms.restype = c_int
+    L.p2p_ctx_marked_ms.argtypes = [c_vp, ctypes.POINTER(ctypes.c_float)]
+    L.p2p_job_time_launches.restype = c_int
+    L.p2p_job_time_launches.argtypes = [c_vp, c_int]
     L.p2p_job_create.restype = c_int
     L.p2p_job_create.argtypes = [c_vp, ctypes.POINTER(JobDesc), ctypes.POINTER(c_vp)]
     L.p2p_job_destroy.restype = None
@@ -239,6 +246,14 @@ class Context:
     def synchronize(self):
         check(lib().p2p_ctx_synchronize(self._h))
 
+    def mark(self, which):
+        check(lib().p2p_ctx_mark(self._h, int(which)))
+
+    def marked_ms(self):
+        ms = ctypes.c_float()
+        check(lib().p2p_ctx_marked_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
     def close(self):
         if self._h:
             lib().p2p_ctx_destroy(self._h)
@@ -287,6 +302,9 @@ class Job:
 
     def run(self):
         check(lib().p2p_job_run(self._h))
+
+    def time_launches(self, on):
+        check(lib().p2p_job_time_launches(self._h, int(bool(on))))
 
     def kernel_ms(self):
         ms = ctypes.c_float()

@@ -78,6 +78,7 @@ struct p2p_job {
     int32_t* d_coords = nullptr;
     p2p::MapGeom geom{};
     bool host_maps = false;
+    bool time_launches = true;  // bracket every launch with its own event pair (p2p_job_kernel_ms*)
     int border = 0;             // stage-2 border mode; non-zero only for the legacy single-remap entry point
     bool coords_valid = false;  // d_coords holds what the last in-kernel evaluation produced
     bool ran = false;
@@ -414,7 +415,9 @@ int p2p_job_run(p2p_job* j)
         for (int i = 0; i < j->d.n_pitch; ++i)
             P.pitch_order[i] = (uint8_t)ord[i];
     }
-    HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
+    const bool timed = j->time_launches;
+    if (timed)
+        HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
     // coordinate cache (opt-in): the first launch evaluates the maps in-kernel and stores the quantised
     // coordinates, later launches of the job load them -- the reference's pitch_mapping_cache (P:62-73)
     const bool use_cache = (j->d.flags & P2P_FLAG_CACHE_COORDS) && j->coords_valid && !j->host_maps;
@@ -422,9 +425,38 @@ int p2p_job_run(p2p_job* j)
     HIP_TRY(p2p::launch_remap_views(P, mapsrc, j->ctx->stream));
     if (!j->host_maps && j->d_coords)
         j->coords_valid = true;
-    HIP_TRY(hipEventRecord(j->ev_ring[2 * slot + 1], j->ctx->stream));
+    if (timed)
+        HIP_TRY(hipEventRecord(j->ev_ring[2 * slot + 1], j->ctx->stream));
     j->runs++;
     j->ran = true;
+    return P2P_OK;
+}
+
+int p2p_job_time_launches(p2p_job* j, int on)
+{
+    if (!j)
+        return fail(P2P_ERR_INVALID, "job is NULL");
+    j->time_launches = on != 0;
+    j->runs = 0;  // the ring only describes launches made in the current mode
+    return P2P_OK;
+}
+
+int p2p_ctx_mark(p2p_ctx* c, int which)
+{
+    if (!c || (which != 0 && which != 1))
+        return fail(P2P_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(which ? c->ev1 : c->ev0, c->stream));
+    return P2P_OK;
+}
+
+int p2p_ctx_marked_ms(p2p_ctx* c, float* ms)
+{
+    if (!c || !ms)
+        return fail(P2P_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
     return P2P_OK;
 }
 
@@ -432,8 +464,8 @@ int p2p_job_kernel_ms(p2p_job* j, float* ms)
 {
     if (!j || !ms)
         return fail(P2P_ERR_INVALID, "NULL argument");
-    if (!j->ran)
-        return fail(P2P_ERR_STATE, "p2p_job_run has not been called");
+    if (!j->ran || !j->time_launches || j->runs < 1)
+        return fail(P2P_ERR_STATE, "no timed p2p_job_run has been made");
     HIP_TRY(hipSetDevice(j->ctx->device));
     const int slot = (int)((j->runs - 1) % kEvRing);
     HIP_TRY(hipEventSynchronize(j->ev_ring[2 * slot + 1]));
@@ -445,8 +477,8 @@ int p2p_job_kernel_ms_last(p2p_job* j, float* ms, int n)
 {
     if (!j || !ms || n < 1)
         return fail(P2P_ERR_INVALID, "bad argument");
-    if (j->runs < n || n > kEvRing)
-        return fail(P2P_ERR_STATE, "only %lld runs recorded (ring holds %d)", j->runs, kEvRing);
+    if (!j->time_launches || j->runs < n || n > kEvRing)
+        return fail(P2P_ERR_STATE, "only %lld timed runs recorded (ring holds %d)", j->time_launches ? j->runs : 0LL, kEvRing);
     HIP_TRY(hipSetDevice(j->ctx->device));
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));
     for (int k = 0; k < n; ++k) {

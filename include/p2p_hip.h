@@ -135,6 +135,10 @@ typedef struct p2p_job_desc {
 int p2p_ctx_create(int device, p2p_ctx** out);
 void p2p_ctx_destroy(p2p_ctx* ctx);
 int p2p_ctx_synchronize(p2p_ctx* ctx);
+/* Two HIP event marks on the context's stream (which = 0 / 1) and the device time between them: brackets a
+   whole region of launches without synchronising inside it. */
+int p2p_ctx_mark(p2p_ctx* ctx, int which);
+int p2p_ctx_marked_ms(p2p_ctx* ctx, float* ms);
 
 int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out);
 void p2p_job_destroy(p2p_job* job);
@@ -148,6 +152,9 @@ int p2p_job_set_maps(p2p_job* job, const float* yaw_rows, const float* U, const 
 int p2p_job_run(p2p_job* job);
 /* Wait, then copy all views of panorama `index` to host: uint8 [n_yaw][n_pitch][oh][ow][3]. */
 int p2p_job_get_views(p2p_job* job, int index, uint8_t* out);
+/* By default every p2p_job_run brackets its kernel with its own HIP event pair (p2p_job_kernel_ms*); on = 0
+   turns that off (two event records less per launch), on = 1 back on.  Either call restarts the history. */
+int p2p_job_time_launches(p2p_job* job, int on);
 /* Device time of the last p2p_job_run's view kernel(s), from HIP events on the job's stream. */
 int p2p_job_kernel_ms(p2p_job* job, float* ms);
 /* Device times of the last n p2p_job_run launches (n <= 256), oldest first; synchronises once.
