@@ -28,7 +28,8 @@ ABI_SYMBOLS = (
     "p2p_job_time_launches",
     "p2p_job_create", "p2p_job_destroy", "p2p_job_set_pano", "p2p_job_set_maps", "p2p_job_run",
     "p2p_job_get_views", "p2p_job_kernel_ms", "p2p_job_kernel_ms_last", "p2p_job_device_out", "p2p_job_get_coords",
-    "p2p_job_get_yaw_tables", "p2p_debug_stamps",
+    "p2p_job_get_yaw_tables", "p2p_job_set_yaws", "p2p_host_alloc", "p2p_host_free", "p2p_release_cache",
+    "p2p_debug_stamps",
 )
 
 
@@ -118,6 +119,14 @@ def lib():
     L.p2p_job_get_yaw_tables.argtypes = [c_vp, c_vp]
     L.p2p_debug_stamps.restype = c_int
     L.p2p_debug_stamps.argtypes = [c_vp, c_int]
+    L.p2p_job_set_yaws.restype = c_int
+    L.p2p_job_set_yaws.argtypes = [c_vp, c_vp]
+    L.p2p_host_alloc.restype = c_int
+    L.p2p_host_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(c_vp)]
+    L.p2p_host_free.restype = c_int
+    L.p2p_host_free.argtypes = [c_vp]
+    L.p2p_release_cache.restype = c_int
+    L.p2p_release_cache.argtypes = []
     _lib = L
     return L
 
@@ -155,12 +164,90 @@ def as_image(a, what="image"):
     return a
 
 
-def remap_views(pano, yaw_deg, pitch_deg, fov_deg, ow, oh, device=0):
-    """p2p_remap_views_u8 -> uint8 [n_yaw][n_pitch][oh][ow][3]."""
+class _PinnedPool:
+    """Free page-locked blocks kept for reuse (hipHostMalloc costs far more than the copy it speeds up):
+    exact-size buckets, bounded by P2P_PINNED_POOL_MB (default 2048) of idle memory."""
+
+    def __init__(self):
+        import threading
+
+        self.lock = threading.Lock()
+        self.free = {}
+        self.idle_bytes = 0
+        self.cap = int(os.environ.get("P2P_PINNED_POOL_MB", "2048")) << 20
+
+    def take(self, nbytes):
+        with self.lock:
+            lst = self.free.get(nbytes)
+            if lst:
+                self.idle_bytes -= nbytes
+                return lst.pop()
+        ptr = ctypes.c_void_p()
+        check(lib().p2p_host_alloc(int(nbytes), ctypes.byref(ptr)))
+        return ptr.value
+
+    def give(self, ptr, nbytes):
+        with self.lock:
+            if self.idle_bytes + nbytes <= self.cap:
+                self.free.setdefault(nbytes, []).append(ptr)
+                self.idle_bytes += nbytes
+                return
+        lib().p2p_host_free(ctypes.c_void_p(ptr))
+
+    def trim(self):
+        with self.lock:
+            blocks = [p for lst in self.free.values() for p in lst]
+            self.free.clear()
+            self.idle_bytes = 0
+        for p in blocks:
+            lib().p2p_host_free(ctypes.c_void_p(p))
+
+
+_pool = _PinnedPool()
+
+
+class _PinnedBlock:
+    """Owner of one page-locked block; it returns to the pool when the last array over it is collected."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.ptr = _pool.take(self.nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _pool.give(self.ptr, self.nbytes)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """np.empty in page-locked host memory (p2p_host_alloc): uploads from it and downloads into it run as
+    DMA at PCIe rate.  The memory is released when the array and every view of it are gone."""
+    dtype = np.dtype(dtype)
+    shape = tuple(int(x) for x in (shape if np.iterable(shape) else (shape,)))
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    block = _PinnedBlock(max(nbytes, 1))
+    buf = (ctypes.c_ubyte * max(nbytes, 1)).from_address(block.ptr)
+    buf._p2p_owner = block  # arr.base -> buf -> block
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+
+
+def release_cache():
+    """Free the device buffers the one-shot calls of THIS thread keep between calls, and the idle
+    page-locked blocks of the host pool."""
+    check(lib().p2p_release_cache())
+    _pool.trim()
+
+
+def remap_views(pano, yaw_deg, pitch_deg, fov_deg, ow, oh, device=0, pinned=False):
+    """p2p_remap_views_u8 -> uint8 [n_yaw][n_pitch][oh][ow][3] (in page-locked memory if pinned)."""
     pano = as_image(pano, "pano_image")
     yaw, pitch = _i32(yaw_deg), _i32(pitch_deg)
     ph, pw = pano.shape[:2]
-    out = np.empty((yaw.size, pitch.size, int(oh), int(ow), 3), dtype=np.uint8)
+    shape = (yaw.size, pitch.size, int(oh), int(ow), 3)
+    out = pinned_empty(shape) if pinned and yaw.size and pitch.size else np.empty(shape, dtype=np.uint8)
     check(lib().p2p_remap_views_u8(pano.ctypes.data, pw, ph, pano.strides[0],
                                    yaw.ctypes.data, yaw.size, pitch.ctypes.data, pitch.size,
                                    int(fov_deg), int(ow), int(oh), out.ctypes.data, int(device), 0))
@@ -287,6 +374,13 @@ class Job:
             raise ValueError("panorama is %s, job expects (%d, %d)" % (pano.shape[:2], self.ph, self.pw))
         check(lib().p2p_job_set_pano(self._h, int(index), pano.ctypes.data, pano.strides[0]))
 
+    def set_yaws(self, yaw_deg):
+        yaw = _i32(yaw_deg)
+        if yaw.size != self.n_yaw:
+            raise ValueError("the job was created with %d yaws, got %d" % (self.n_yaw, yaw.size))
+        check(lib().p2p_job_set_yaws(self._h, yaw.ctypes.data))
+        self._yaw = yaw
+
     def set_maps(self, yaw_rows, U, V):
         U = np.ascontiguousarray(U, dtype=np.float32)
         V = np.ascontiguousarray(V, dtype=np.float32)
@@ -316,8 +410,9 @@ class Job:
         check(lib().p2p_job_kernel_ms_last(self._h, out.ctypes.data, int(n)))
         return out
 
-    def get_views(self, index=0):
-        out = np.empty((self.n_yaw, self.n_pitch, self.oh, self.ow, 3), dtype=np.uint8)
+    def get_views(self, index=0, pinned=False):
+        shape = (self.n_yaw, self.n_pitch, self.oh, self.ow, 3)
+        out = pinned_empty(shape) if pinned else np.empty(shape, dtype=np.uint8)
         check(lib().p2p_job_get_views(self._h, int(index), out.ctypes.data))
         return out
 

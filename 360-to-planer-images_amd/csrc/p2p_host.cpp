@@ -78,6 +78,7 @@ struct p2p_job {
     int32_t* d_coords = nullptr;
     p2p::MapGeom geom{};
     bool host_maps = false;
+    bool rows_from_host = false;  // yaw tables were packed from caller float rows, not built from yaw_deg
     bool time_launches = true;  // bracket every launch with its own event pair (p2p_job_kernel_ms*)
     int border = 0;             // stage-2 border mode; non-zero only for the legacy single-remap entry point
     bool coords_valid = false;  // d_coords holds what the last in-kernel evaluation produced
@@ -106,11 +107,20 @@ int use_device(int device)
 
 bool dims_ok(int w, int h) { return w >= 1 && h >= 1 && w < 32767 && h < 32767; }
 
-// one context per (thread, device) for the one-shot entry points
+// one context per (thread, device) for the one-shot entry points, plus the job of the last one-shot
+// call on that device (the reference keeps its maps for the life of the process, P:17-18)
 struct ThreadCtxs {
     std::map<int, p2p_ctx*> m;
+    std::map<int, p2p_job*> cached;
+    void drop_cached()
+    {
+        for (auto& kv : cached)
+            p2p_job_destroy(kv.second);
+        cached.clear();
+    }
     ~ThreadCtxs()
     {
+        drop_cached();
         for (auto& kv : m)
             p2p_ctx_destroy(kv.second);
     }
@@ -339,6 +349,24 @@ int p2p_job_set_pano(p2p_job* j, int index, const uint8_t* pano, int64_t row_str
     return P2P_OK;
 }
 
+int p2p_job_set_yaws(p2p_job* j, const int32_t* yaw_deg)
+{
+    if (!j || !yaw_deg)
+        return fail(P2P_ERR_INVALID, "p2p_job_set_yaws: NULL argument");
+    const p2p_job_desc& d = j->d;
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    j->yaw.assign(yaw_deg, yaw_deg + d.n_yaw);
+    j->d.yaw_deg = j->yaw.data();
+    std::vector<double> yr(d.n_yaw);
+    for (int i = 0; i < d.n_yaw; ++i)
+        yr[i] = deg2rad((double)j->yaw[i]);  // P:85
+    HIP_TRY(hipMemcpyAsync(j->d_yaw_rad, yr.data(), yr.size() * sizeof(double), hipMemcpyHostToDevice, j->ctx->stream));
+    HIP_TRY(p2p::launch_yaw_tables(j->d_ytab, nullptr, d.pw, d.n_yaw, j->d_yaw_rad, j->ctx->stream));
+    HIP_TRY(p2p::launch_yaw_desc(j->d_ydesc, j->d_f4tab, j->d_ytab, d.pw, d.n_yaw, j->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream));  // yr is a stack-lifetime host buffer
+    return P2P_OK;
+}
+
 int p2p_job_set_maps(p2p_job* j, const float* yaw_rows, const float* U, const float* V)
 {
     if (!j || !U || !V)
@@ -359,6 +387,7 @@ int p2p_job_set_maps(p2p_job* j, const float* yaw_rows, const float* U, const fl
         if (!j->d_rows) HIP_TRY(hipMalloc((void**)&j->d_rows, n * sizeof(float)));
         HIP_TRY(hipMemcpyAsync(j->d_rows, yaw_rows, n * sizeof(float), hipMemcpyHostToDevice, j->ctx->stream));
         HIP_TRY(p2p::launch_yaw_pack(j->d_ytab, j->d_rows, n, j->ctx->stream));
+        j->rows_from_host = true;
         HIP_TRY(p2p::launch_yaw_desc(j->d_ydesc, j->d_f4tab, j->d_ytab, d.pw, d.n_yaw, j->ctx->stream));
     }
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));
@@ -538,6 +567,36 @@ int p2p_job_get_yaw_tables(p2p_job* j, uint32_t* packed)
     return P2P_OK;
 }
 
+int p2p_host_alloc(size_t bytes, void** out)
+{
+    if (!out)
+        return fail(P2P_ERR_INVALID, "p2p_host_alloc: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(P2P_ERR_NO_DEVICE, "no HIP device is available (hipGetDeviceCount found none)");
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable);
+    if (e != hipSuccess) {
+        *out = nullptr;
+        return fail(e == hipErrorOutOfMemory ? P2P_ERR_OOM : P2P_ERR_HIP, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    }
+    return P2P_OK;
+}
+
+int p2p_host_free(void* ptr)
+{
+    if (!ptr)
+        return P2P_OK;
+    HIP_TRY(hipHostFree(ptr));
+    return P2P_OK;
+}
+
+int p2p_release_cache(void)
+{
+    g_tctx.drop_cached();
+    return P2P_OK;
+}
+
 int p2p_debug_stamps(uint64_t* out16, int reset)
 {
     if (!out16)
@@ -577,19 +636,56 @@ static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride
     d.n_yaw = n_yaw; d.yaw_deg = yaw_deg;
     d.n_pitch = n_pitch; d.pitch_deg = pitch_deg;
     d.fov_deg = fov_deg; d.ow = ow; d.oh = oh; d.flags = flags;
+
+    // the job of the previous one-shot call on this thread and device, if its geometry matches
     p2p_job* j = nullptr;
-    rc = p2p_job_create(ctx, &d, &j);
-    if (rc != P2P_OK)
-        return rc;
-    j->border = border;
-    rc = p2p_job_set_pano(j, 0, pano, row_stride);
+    auto it = g_tctx.cached.find(device);
+    if (it != g_tctx.cached.end()) {
+        p2p_job* c = it->second;
+        const p2p_job_desc& k = c->d;
+        const bool same = k.pw == pw && k.ph == ph && k.n_yaw == n_yaw && k.n_pitch == n_pitch &&
+                          k.fov_deg == fov_deg && k.ow == ow && k.oh == oh && k.flags == flags &&
+                          c->border == border && c->host_maps == (U != nullptr) &&
+                          std::equal(c->pitch.begin(), c->pitch.end(), pitch_deg);
+        if (same) {
+            j = c;
+            // caller rows replace the tables below; otherwise rebuild them only when the yaws changed
+            if (!yaw_rows && (c->rows_from_host || !std::equal(c->yaw.begin(), c->yaw.end(), yaw_deg))) {
+                rc = p2p_job_set_yaws(c, yaw_deg);
+                c->rows_from_host = false;
+            }
+        } else {
+            p2p_job_destroy(c);
+            g_tctx.cached.erase(it);
+        }
+    }
+    const bool fresh = (j == nullptr);
+    if (fresh) {
+        rc = p2p_job_create(ctx, &d, &j);
+        if (rc != P2P_OK)
+            return rc;
+        j->border = border;
+    }
+    if (rc == P2P_OK)
+        rc = p2p_job_set_pano(j, 0, pano, row_stride);
     if (rc == P2P_OK && U)
         rc = p2p_job_set_maps(j, yaw_rows, U, V);
     if (rc == P2P_OK)
         rc = p2p_job_run(j);
     if (rc == P2P_OK)
         rc = p2p_job_get_views(j, 0, out);
-    p2p_job_destroy(j);
+
+    const size_t held = j->pano_stride + j->out_bytes + (size_t)n_yaw * pw * 8 +
+                        (U ? (size_t)n_pitch * ow * oh * 8 : 0);
+    const bool keep = rc == P2P_OK && env_int("P2P_ONESHOT_CACHE", 1) != 0 &&
+                      held <= (size_t)env_int("P2P_ONESHOT_CACHE_MAX_MB", 4096) * 1048576ull;
+    if (keep) {
+        g_tctx.cached[device] = j;
+    } else {
+        if (!fresh)
+            g_tctx.cached.erase(device);
+        p2p_job_destroy(j);
+    }
     return rc;
 }
 

@@ -115,13 +115,18 @@ def _int_angle(value, what):
     raise TypeError(f"{what} must be an integer number of degrees, got {value!r}")
 
 
+_PINNED = os.environ.get("P2P_PINNED", "1") != "0"
+
+
 def process_views(pano_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg=90, device=None):
     """All yaws x pitches of one panorama in one kernel launch.
-    Returns uint8 [n_yaw][n_pitch][output_height][output_width][3]."""
+    Returns uint8 [n_yaw][n_pitch][output_height][output_width][3]; the array lives in page-locked host
+    memory (pooled; P2P_PINNED=0 for ordinary memory) so that the copy back from the GPU is one DMA."""
     yaws = [_int_angle(y, "yaw angle") for y in yaw_angles]
     pitches = [_int_angle(p, "pitch angle") for p in pitch_angles]
     return _native.remap_views(pano_image, yaws, pitches, _int_angle(fov_deg, "FOV"),
-                               output_width, output_height, _DEVICE if device is None else device)
+                               output_width, output_height, _DEVICE if device is None else device,
+                               pinned=_PINNED)
 
 
 def process_yaw_and_pitchs(pano_image, yaw_angle, pitch_angles, output_width, output_height, fov_deg=90):
@@ -146,9 +151,22 @@ def _imread_bgr(path):
                 rgb = np.stack([arr, arr, arr], axis=-1)
             else:
                 rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
-        return np.ascontiguousarray(rgb[:, :, ::-1])
+        return _to_bgr(rgb)
     except Exception:
         return None
+
+
+def _to_bgr(rgb):
+    """RGB -> BGR copy (the one copy decoding needs anyway) straight into page-locked memory, from which
+    the upload is one DMA; ordinary memory when no device / P2P_PINNED=0 (the compute call reports that)."""
+    if _PINNED:
+        try:
+            dst = _native.pinned_empty(rgb.shape)
+            dst[...] = rgb[:, :, ::-1]
+            return dst
+        except (_native.P2PError, OSError):
+            pass
+    return np.ascontiguousarray(rgb[:, :, ::-1])
 
 
 def _imwrite_bgr(path, image):

@@ -58,7 +58,9 @@ class Dist:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.pg = None
-        if self.world > 1:
+        # P2P_BENCH_FORCE_PG=1: create the process group at world size 1 too (exercises RCCL init, barrier
+        # and the max-reduction on a single-GPU box)
+        if self.world > 1 or os.environ.get("P2P_BENCH_FORCE_PG") == "1":
             import torch.distributed as dist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -24,6 +24,7 @@
 #ifndef P2P_HIP_H
 #define P2P_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -145,6 +146,10 @@ void p2p_job_destroy(p2p_job* job);
 /* H2D copy of panorama `index` (uint8 [ph][pw][3]) on the job's stream; returns once the host buffer may
    be reused or freed. */
 int p2p_job_set_pano(p2p_job* job, int index, const uint8_t* pano, int64_t row_stride);
+/* Replace the job's yaw list (same count as at creation) and rebuild its column tables -- the key change
+   the reference's yaw_mapping_cache sees between two process_yaw_and_pitchs calls on one image size
+   (P:42-52: key (pano_width, pano_height, yaw_angle)); panoramas and pitch constants stay resident. */
+int p2p_job_set_yaws(p2p_job* job, const int32_t* yaw_deg);
 /* Optional: use caller float maps instead of in-kernel ones (see p2p_remap_views_maps_u8).  yaw_rows may be
    NULL to keep the yaw tables built from yaw_deg. */
 int p2p_job_set_maps(p2p_job* job, const float* yaw_rows, const float* U, const float* V);
@@ -167,6 +172,25 @@ void* p2p_job_device_out(p2p_job* job, int64_t* bytes);
 int p2p_job_get_coords(p2p_job* job, int32_t* sxsy);
 /* The packed per-column yaw tables in use, uint32 [n_yaw][pw] = 3*ix | fx << 20. */
 int p2p_job_get_yaw_tables(p2p_job* job, uint32_t* packed);
+
+/* ------------------------------------------------------------------------------------------
+ * Host memory and the one-shot cache
+ *
+ * The reference keeps its maps for the life of the process (yaw_mapping_cache / pitch_mapping_cache,
+ * P:17-18) and lets NumPy / cv2.imread allocate pageable arrays (P:244, the slices cv2.remap returns at
+ * P:212-218).  Here the one-shot entry points keep, per calling thread and device, the device buffers and
+ * tables of the last call's geometry (panorama size, yaw count, pitch list, FOV, output size): a second
+ * call with the same geometry re-uploads only the panorama (and rebuilds the yaw tables if the yaw values
+ * changed).  P2P_ONESHOT_CACHE=0 in the environment turns this off; P2P_ONESHOT_CACHE_MAX_MB (default 4096)
+ * bounds what is kept.  p2p_release_cache frees what the calling thread holds.
+ *
+ * p2p_host_alloc returns page-locked host memory: panoramas decoded into it and views copied back into it
+ * move by DMA at PCIe rate instead of through the runtime's pageable staging.
+ * Any host pointer is accepted everywhere; page-locked ones are merely faster.
+ * ------------------------------------------------------------------------------------------ */
+int p2p_host_alloc(size_t bytes, void** out);
+int p2p_host_free(void* ptr);
+int p2p_release_cache(void);
 
 /* Diagnostic: with a -DP2P_STAMPS build of the library, the summed s_memtime ticks the view
    kernel's waves spent per phase of the pair loop ([0..5] phases, [6] waves, [7] pair iterations);

@@ -96,3 +96,83 @@ def test_maps_cache_keys_and_shapes(gpu, pkg):
     assert m.get_pitch_mapping(64, 48, 60, 512, 256)[0] is U
     Uy, Vy = m.get_yaw_mapping(512, 16, 30)
     assert (512, 16, 30) in m.yaw_mapping_cache and Uy.shape == (16, 512) and Vy[5, 7] == 5.0
+
+
+def test_oneshot_cache_reuses_buffers_without_changing_results(gpu, pkg, synth, monkeypatch):
+    """The one-shot calls keep the last geometry's device buffers per thread (the reference's map caches,
+    P:17-18); every sequence of calls must give what a cold library gives."""
+    from _util import oracle_maps
+
+    pa = synth.synth_pano(512, 256, 3100, "N")
+    pb = synth.synth_pano(512, 256, 3101, "N")
+    pitches = [60, 90]
+
+    def cold(pano, yaws, pit=pitches, ow=96, oh=64):
+        monkeypatch.setenv("P2P_ONESHOT_CACHE", "0")
+        gpu.release_cache()
+        try:
+            return gpu.remap_views(pano, yaws, pit, 90, ow, oh)
+        finally:
+            monkeypatch.setenv("P2P_ONESHOT_CACHE", "1")
+
+    ref_a = cold(pa, [0, 77])
+    ref_b = cold(pb, [13, 200])
+    ref_small = cold(pa, [0, 77], ow=48, oh=32)
+    gpu.release_cache()
+    assert np.array_equal(gpu.remap_views(pa, [0, 77], pitches, 90, 96, 64), ref_a)           # miss
+    assert np.array_equal(gpu.remap_views(pa, [0, 77], pitches, 90, 96, 64), ref_a)           # hit, same yaws
+    assert np.array_equal(gpu.remap_views(pb, [13, 200], pitches, 90, 96, 64), ref_b)         # hit, new yaws + pano
+    assert np.array_equal(gpu.remap_views(pa, [0, 77], pitches, 90, 48, 32), ref_small)       # other geometry
+    assert np.array_equal(gpu.remap_views(pa, [0, 77], pitches, 90, 96, 64, pinned=True), ref_a)
+    # caller maps <-> in-kernel maps alternate on one geometry; caller rows must not leak into the next call
+    rows, U, V = oracle_maps([5, 300], pitches, 96, 64, 512, 256)
+    m1 = gpu.remap_views_maps(pa, rows, U, V)
+    assert np.array_equal(gpu.remap_views(pa, [0, 77], pitches, 90, 96, 64), ref_a)
+    m2 = gpu.remap_views_maps(pa, rows, U, V)
+    m3 = gpu.remap_views_maps(pb, rows[::-1].copy(), U, V)
+    assert np.array_equal(m1, m2)
+    assert np.array_equal(m3[::-1], gpu.remap_views_maps(pb, rows, U, V))
+    # different pitch list of the same length is a different geometry
+    assert np.array_equal(gpu.remap_views(pa, [0, 77], [61, 90], 90, 96, 64), cold(pa, [0, 77], pit=[61, 90]))
+    gpu.release_cache()
+
+
+def test_job_set_yaws(gpu, synth):
+    pano = synth.synth_pano(1024, 512, 3102, "N")
+    ctx = gpu.Context(0)
+    job = gpu.Job(ctx, 1024, 512, 1, [0, 30, 45], [70, 110], 90, 128, 96)
+    job.set_pano(0, pano)
+    job.run()
+    first = job.get_views()
+    job.set_yaws([181, 30, 359])
+    job.run()
+    second = job.get_views(pinned=True)
+    fresh = gpu.remap_views(pano, [181, 30, 359], [70, 110], 90, 128, 96)
+    assert np.array_equal(second, fresh)
+    assert np.array_equal(second[1], first[1])
+    with pytest.raises(ValueError):
+        job.set_yaws([1, 2])
+    job.close()
+    ctx.close()
+
+
+def test_pinned_arrays_behave_like_numpy_arrays(gpu, pkg, synth):
+    a = gpu.pinned_empty((5, 7, 3))
+    assert a.shape == (5, 7, 3) and a.dtype == np.uint8 and a.flags.c_contiguous and a.flags.writeable
+    a[...] = 7
+    b = a[1:3]
+    del a                       # the block must stay alive while a view of it is
+    assert int(b.sum()) == 7 * 2 * 7 * 3
+    f = gpu.pinned_empty((4,), np.float32)
+    f[:] = 1.5
+    assert f.sum() == 6.0
+    # the drop-in API hands out page-locked views by default; results equal the pageable path
+    pano = synth.synth_pano(512, 256, 3103, "N")
+    pin = gpu.pinned_empty(pano.shape)
+    pin[...] = pano
+    v1 = pkg.process_views(pin, [10, 20], [80], 64, 48)
+    v2 = gpu.remap_views(pano, [10, 20], [80], 90, 64, 48, pinned=False)
+    assert np.array_equal(v1, v2)
+    lst = pkg.process_yaw_and_pitchs(pano, 10, [80], 64, 48)
+    del v1
+    assert np.array_equal(lst[0], v2[0, 0])

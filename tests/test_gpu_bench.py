@@ -1,0 +1,49 @@
+"""GPU: bench.py's contract line, and its process-group path (RCCL init, barrier, max over ranks) at the
+one world size a single-GPU box allows."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _last_json(text):
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_line_small_workload(gpu):
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "cfg1", "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _last_json(r.stdout)
+    assert KEYS <= set(line)
+    assert line["n_gpus"] == 1 and line["steps"] == 5 and line["dtype"] == "u8" and line["value"] > 0
+    rf = line["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+
+
+def test_bench_under_torchrun_with_rccl_group(gpu):
+    env = dict(os.environ, P2P_BENCH_FORCE_PG="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           "bench.py", "--gpus", "1", "--workload", "cfg1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak"
