@@ -582,10 +582,14 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
             if (fast_store) {
                 // lanes 4k..4k+3 hold pixels P0..P3; lanes with lane4 < 3 emit dword lane4 of the 12 bytes
                 // neighbour lane's pixel: row_shl:1 DPP (lane4 groups never straddle a 16-lane row)
-                uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pix[j], 0x101, 0xF, 0xF, false);
+                uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pix[j], 0x101, 0xF, 0xF, true);
                 uint32_t dw = __builtin_amdgcn_perm(nxt, pix[j], store_sel);
+                // the byte offset stays a 32-bit VGPR next to the scalar view base (saddr store form): the
+                // empty asm keeps the compiler from hoisting a 64-bit copy of it out of the pair loop
+                uint32_t voff = off + (uint32_t)lane4;
+                asm volatile("" : "+v"(voff));
                 if (inside[j] && lane4 < 3)
-                    *reinterpret_cast<uint32_t*>(O + (off + (uint32_t)lane4)) = dw;
+                    *reinterpret_cast<uint32_t*>(O + voff) = dw;
             } else if (inside[j]) {
                 uint8_t* o = O + off;
                 o[0] = (uint8_t)pix[j];
@@ -784,19 +788,29 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
                     tl4[t + sl * VIEWS_BLOCK] = o;
                 }
         };
-        auto half = [&](int k, const Q16 (&qcur)[VIEWS_SLOTS], Q16 (&qnext)[VIEWS_SLOTS], uint4* tl4) {
+        // byte offsets of this thread's upper / lower tap pairs inside one LDS buffer; per pair only the
+        // scalar (buffer base + 4 * joff) is added
+        uint32_t tap_up[VIEWS_PXT], tap_lo[VIEWS_PXT];
+#pragma unroll
+        for (int j = 0; j < VIEWS_PXT; ++j) {
+            tap_up[j] = 4u * (uint32_t)tap[j];
+            tap_lo[j] = 4u * (uint32_t)(tap[j] + rowdw);
+        }
+        auto half = [&](int k, const Q16 (&qcur)[VIEWS_SLOTS], Q16 (&qnext)[VIEWS_SLOTS], uint4* tl4, uint32_t buf_bytes) {
             stage1(k, qcur, tl4);
-            const int joff = (int)(((uint32_t)__builtin_amdgcn_readlane((int)cw0, k) >> 20) & 3u);
+            uint32_t soff = buf_bytes + 4u * (((uint32_t)__builtin_amdgcn_readlane((int)cw0, k) >> 20) & 3u);
+            asm volatile("" : "+s"(soff));  // one scalar: keeps the buffer base out of four separate vector adds
             __syncthreads();
-            const uint32_t* tl = reinterpret_cast<const uint32_t*>(tl4);
+            const unsigned char* tl = reinterpret_cast<const unsigned char*>(&tile4[0][0]);
             uint32_t ta[VIEWS_PXT][4];
 #pragma unroll
             for (int j = 0; j < VIEWS_PXT; ++j) {
-                const int b = tap[j] + joff;
-                ta[j][0] = tl[b];
-                ta[j][1] = tl[b + 1];
-                ta[j][2] = tl[b + rowdw];
-                ta[j][3] = tl[b + rowdw + 1];
+                const uint32_t* up = reinterpret_cast<const uint32_t*>(tl + (tap_up[j] + soff));
+                const uint32_t* lo = reinterpret_cast<const uint32_t*>(tl + (tap_lo[j] + soff));
+                ta[j][0] = up[0];
+                ta[j][1] = up[1];
+                ta[j][2] = lo[0];
+                ta[j][3] = lo[1];
             }
             if (k + 1 < npairs)
                 load_pieces(k + 1, qnext);
@@ -809,10 +823,10 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
         Q16 qa[VIEWS_SLOTS], qb[VIEWS_SLOTS];
         load_pieces(0, qa);
         for (int k = 0; k < npairs; k += 2) {
-            half(k, qa, qb, tile4[0]);
+            half(k, qa, qb, tile4[0], 0u);
             if (k + 1 >= npairs)
                 break;
-            half(k + 1, qb, qa, tile4[1]);
+            half(k + 1, qb, qa, tile4[1], (uint32_t)sizeof(tile4[0]));
         }
         return;
     }
