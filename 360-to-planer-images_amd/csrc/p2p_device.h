@@ -56,6 +56,13 @@ struct ViewsParams {
     int32_t* coords;         // optional [n_pitch][oh][ow][2] dump of (sx, sy)
     int border;              // stage-2 border mode (0 = BORDER_CONSTANT 0, the reference's current tool)
     uint8_t pitch_order[64]; // blockIdx.y -> pitch index, heaviest view first (n_pitch <= 64 per job)
+    uint2* plan;             // sub-tiles of the tiles whose footprint outgrows the LDS buffers: x0 | y0 << 15 |
+                             // (16 wide) << 30, pitch index; written by the plan pass, read by the sub-tile pass
+    uint32_t* plan_count;
+    uint8_t* plan_flag;      // [n_pitch][tiles]: 1 = the tile is in the plan (the main pass skips it)
+    int plan_n;              // entries in plan (host copy)
+    int plan_gx;             // sub-tile workgroups per view row of the grid: 8 * ceil(plan_n / n_pitch / 8)
+    int use_plan;            // the main pass leaves the listed tiles to the sub-tile pass
 };
 
 struct RemapParams {
@@ -76,7 +83,7 @@ hipError_t launch_yaw_desc(YawDesc* desc, uint32_t* f4tab, const uint32_t* packe
                            hipStream_t st);
 hipError_t launch_pitch_map(float* U, float* V, int ow, int oh, const MapGeom& g, float c, float s,
                             hipStream_t st);
-hipError_t launch_remap_views(const ViewsParams& P, int mapsrc, hipStream_t st);
+hipError_t launch_remap_views(const ViewsParams& P, int mapsrc, int mode, hipStream_t st);
 hipError_t launch_remap_maps(const RemapParams& P, int cn, hipStream_t st);
 // diagnostic build only (-DP2P_STAMPS): per-phase s_memtime sums of remap_views_kernel's pair loop
 hipError_t read_stamps(unsigned long long* out16, bool reset);

@@ -76,6 +76,11 @@ struct p2p_job {
     float* d_mapV = nullptr;
     float* d_rows = nullptr;
     int32_t* d_coords = nullptr;
+    uint2* d_plan = nullptr;          // sub-tiles of tiles whose footprint outgrows the LDS buffers
+    uint32_t* d_plan_count = nullptr;
+    uint8_t* d_plan_flag = nullptr;
+    size_t plan_flag_bytes = 0;
+    int plan_n = -1;                  // -1: not built yet for the current maps
     p2p::MapGeom geom{};
     bool host_maps = false;
     bool rows_from_host = false;  // yaw tables were packed from caller float rows, not built from yaw_deg
@@ -246,6 +251,9 @@ void p2p_job_destroy(p2p_job* j)
     (void)hipFree(j->d_mapV);
     (void)hipFree(j->d_rows);
     (void)hipFree(j->d_coords);
+    (void)hipFree(j->d_plan);
+    (void)hipFree(j->d_plan_count);
+    (void)hipFree(j->d_plan_flag);
     for (hipEvent_t e : j->ev_ring)
         (void)hipEventDestroy(e);
     delete j;
@@ -313,6 +321,13 @@ int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out)
     if (e == hipSuccess) e = hipMalloc((void**)&j->d_pitch, (size_t)d.n_pitch * sizeof(p2p::PitchConst));
     if (e == hipSuccess && (d.flags & (P2P_FLAG_KEEP_COORDS | P2P_FLAG_CACHE_COORDS)))
         e = hipMalloc((void**)&j->d_coords, (size_t)d.n_pitch * d.oh * d.ow * 2 * sizeof(int32_t));
+    {
+        const size_t tiles = (size_t)((d.ow + p2p::TILE_W - 1) / p2p::TILE_W) * ((d.oh + p2p::TILE_H - 1) / p2p::TILE_H);
+        if (e == hipSuccess) e = hipMalloc((void**)&j->d_plan, tiles * d.n_pitch * 4 * sizeof(uint2));
+        if (e == hipSuccess) e = hipMalloc((void**)&j->d_plan_count, sizeof(uint32_t));
+        j->plan_flag_bytes = tiles * d.n_pitch;
+        if (e == hipSuccess) e = hipMalloc((void**)&j->d_plan_flag, j->plan_flag_bytes);
+    }
     if (e == hipSuccess)
         e = hipMemcpyAsync(j->d_yaw_rad, yr.data(), yr.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
@@ -393,6 +408,7 @@ int p2p_job_set_maps(p2p_job* j, const float* yaw_rows, const float* U, const fl
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));
     j->host_maps = true;
     j->coords_valid = false;
+    j->plan_n = -1;
     return P2P_OK;
 }
 
@@ -445,13 +461,33 @@ int p2p_job_run(p2p_job* j)
             P.pitch_order[i] = (uint8_t)ord[i];
     }
     const bool timed = j->time_launches;
-    if (timed)
-        HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
     // coordinate cache (opt-in): the first launch evaluates the maps in-kernel and stores the quantised
     // coordinates, later launches of the job load them -- the reference's pitch_mapping_cache (P:62-73)
     const bool use_cache = (j->d.flags & P2P_FLAG_CACHE_COORDS) && j->coords_valid && !j->host_maps;
     const int mapsrc = j->host_maps ? 1 : (use_cache ? 2 : 0);
-    HIP_TRY(p2p::launch_remap_views(P, mapsrc, j->ctx->stream));
+    P.plan = j->d_plan;
+    P.plan_count = j->d_plan_count;
+    P.plan_flag = j->d_plan_flag;
+    if (j->plan_n < 0 && env_int("P2P_NO_PLAN", 0) == 0) {
+        // once per job geometry (like the yaw tables): which tiles outgrow the LDS buffers, as a list of
+        // sub-tiles for the second pass.  It depends on the maps only, never on pixel data.
+        uint32_t n = 0;
+        HIP_TRY(hipMemsetAsync(j->d_plan_count, 0, sizeof(uint32_t), j->ctx->stream));
+        HIP_TRY(hipMemsetAsync(j->d_plan_flag, 0, j->plan_flag_bytes, j->ctx->stream));
+        P.plan_n = 0;
+        P.plan_gx = 0;
+        P.use_plan = 0;
+        HIP_TRY(p2p::launch_remap_views(P, j->host_maps ? 1 : 0, 1, j->ctx->stream));
+        HIP_TRY(hipMemcpyAsync(&n, j->d_plan_count, sizeof(uint32_t), hipMemcpyDeviceToHost, j->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+        j->plan_n = (int)n;
+    }
+    P.plan_n = j->plan_n > 0 ? j->plan_n : 0;
+    P.plan_gx = 8 * ((((P.plan_n + j->d.n_pitch - 1) / j->d.n_pitch) + 7) / 8);
+    P.use_plan = j->plan_n >= 0;
+    if (timed)
+        HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
+    HIP_TRY(p2p::launch_remap_views(P, mapsrc, 0, j->ctx->stream));
     if (!j->host_maps && j->d_coords)
         j->coords_valid = true;
     if (timed)

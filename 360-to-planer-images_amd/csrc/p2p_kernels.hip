@@ -445,39 +445,60 @@ struct PairCtx {      // uniform per (tile, pair); precomputed per lane at tile 
 
 // MAPSRC: 0 = coordinates computed in-kernel (pitch_map_eval), 1 = caller float maps, 2 = the job's
 // coordinate cache (what an earlier MAPSRC 0 launch stored; the reference's pitch_mapping_cache, P:62-73)
-template <int MAPSRC>
-__global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
-    ViewsParams P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab,
+// MODE: 0 = the view kernel proper (32x16 tiles, 2 pixels per thread); 1 = plan: classify the tiles whose
+// footprint outgrows the LDS buffers and list their sub-tiles (once per job geometry, nothing is drawn);
+// 2 = sub-tile pass: one listed 32x8 or 16x8 sub-tile per workgroup, 1 pixel per thread
+template <int MAPSRC, int MODE>
+__device__ __forceinline__ void views_body(
+    const ViewsParams& P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab,
     const YawDesc* __restrict__ ydesc, const uint32_t* __restrict__ f4tab,
     const PitchConst* __restrict__ pitch, const float* __restrict__ mapU,
-    const float* __restrict__ mapV, uint8_t* __restrict__ out, int32_t* __restrict__ coords)
+    const float* __restrict__ mapV, uint8_t* __restrict__ out, int32_t* __restrict__ coords,
+    uint4 (*tile4)[LDS_ITEMS_CAP], int* bbox, uint32_t (*half_box)[4], const int bx, const int gx)
 {
-    __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
-    __shared__ int bbox[2 * VIEWS_BLOCK / 64];
-
+    constexpr int PXT = MODE == 2 ? 1 : VIEWS_PXT;
     const int t = threadIdx.x;
-    const int tiles_x = (P.ow + TILE_W - 1) / TILE_W;
-    const int tiles_y = (P.oh + TILE_H - 1) / TILE_H;
-    const int chunk = gridDim.x >> 3;  // gridDim.x == 8 * ceil(tiles / 8)
-    const int tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if (tile_id >= tiles_x * tiles_y)
-        return;
-    // heaviest views first (the host orders pitch_order by |pitch - 90| descending): a smoother tail
-    const int pitch_i = P.pitch_order[blockIdx.y];
-    const int x0 = (tile_id % tiles_x) * TILE_W;
-    const int y0 = (tile_id / tiles_x) * TILE_H;
-    const int px = x0 + (t % TILE_W);
-    const int py0 = y0 + (t / TILE_W);
+    int pitch_i, x0, y0, sub_w = TILE_W, plan_slot = 0;
+    if (MODE == 2) {
+        // the sub-tile workgroups of view row y: entries y * gx .. y * gx + gx - 1 of the plan
+        const int ei = (int)blockIdx.y * gx + bx;
+        if (ei >= P.plan_n)
+            return;
+        const uint2 e = P.plan[ei];  // x0 | y0 << 15 | (16-wide) << 30, pitch index
+        x0 = (int)(e.x & 0x7FFFu);
+        y0 = (int)((e.x >> 15) & 0x7FFFu);
+        sub_w = (e.x >> 30) ? TILE_W / 2 : TILE_W;
+        pitch_i = (int)e.y;
+    } else {
+        const int tiles_x = (P.ow + TILE_W - 1) / TILE_W;
+        const int tiles_y = (P.oh + TILE_H - 1) / TILE_H;
+        const int chunk = gx >> 3;  // gx == 8 * ceil(tiles / 8)
+        const int tile_id = (bx & 7) * chunk + (bx >> 3);
+        if (tile_id >= tiles_x * tiles_y)
+            return;
+        // heaviest views first (the host orders pitch_order by |pitch - 90| descending): a smoother tail
+        pitch_i = P.pitch_order[blockIdx.y];
+        x0 = (tile_id % tiles_x) * TILE_W;
+        y0 = (tile_id / tiles_x) * TILE_H;
+        plan_slot = pitch_i * tiles_x * tiles_y + tile_id;
+        // a tile the plan lists is drawn by the sub-tile workgroups: each pixel's map is evaluated by exactly
+        // one compiled instance of pitch_map_eval (two inlined copies can differ in the last bit)
+        if (MODE == 0 && P.use_plan && P.plan_flag[plan_slot])
+            return;
+    }
+    const int px = x0 + (MODE == 2 ? t % sub_w : t % TILE_W);
+    const int py0 = y0 + (MODE == 2 ? t / sub_w : t / TILE_W);
     constexpr int ROWSTEP = VIEWS_BLOCK / TILE_W;  // rows between a thread's pixels
+    constexpr int SUB_H = TILE_H / 2;              // sub-tiles are 32x8 or 16x8
 
     // ---- pitch-stage coordinates of this thread's pixels, quantised as cv::remap does ----
-    int ix[VIEWS_PXT], iy[VIEWS_PXT];
-    uint32_t fx[VIEWS_PXT], fy[VIEWS_PXT];
-    bool inside[VIEWS_PXT], live[VIEWS_PXT], inrange[VIEWS_PXT];
+    int ix[PXT], iy[PXT];
+    uint32_t fx[PXT], fy[PXT];
+    bool inside[PXT], live[PXT], inrange[PXT];
 #pragma unroll
-    for (int j = 0; j < VIEWS_PXT; ++j) {
+    for (int j = 0; j < PXT; ++j) {
         const int py = py0 + j * ROWSTEP;
-        inside[j] = px < P.ow && py < P.oh;
+        inside[j] = px < P.ow && py < P.oh && (MODE != 2 || py < y0 + SUB_H);
         int sx = INT32_MIN, sy = INT32_MIN;
         if (inside[j]) {
             const size_t k = ((size_t)pitch_i * P.oh + py) * P.ow + px;
@@ -516,7 +537,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
     // reduction per wave with DPP (v_pk_min_u16 / v_pk_max_u16), then across the 4 waves through LDS ----
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
-    for (int j = 0; j < VIEWS_PXT; ++j)
+    for (int j = 0; j < PXT; ++j)
         if (inrange[j]) {
             const uint32_t key = (uint32_t)(ix[j] + 1) | (uint32_t)(iy[j] + 1) << 16;  // both in 0..32767
             kmin = pk_min(kmin, key);
@@ -537,10 +558,14 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
     const int c0 = (int)(kmin & 0xFFFFu) - 1, r0 = (int)(kmin >> 16) - 1;
     const int c1 = kmax ? (int)(kmax & 0xFFFFu) - 1 : -2, r1 = kmax ? (int)(kmax >> 16) - 1 : -2;
     const bool any_live = c1 >= -1;
-    const int Wt = c1 - c0 + 2, Ht = r1 - r0 + 2;  // +1 for the right / lower taps
-    const int G = (Wt + 6) >> 2;                   // 4-pixel items per footprint row (+3: alignment slack)
-    const int rowdw = 4 * G;                       // LDS tile row stride in dwords
-    const int items = Ht * G;
+    // footprint -> 4-pixel items per row (+3: alignment slack; +1 column and row for the right / lower taps)
+    auto items_of = [](int a0, int a1, int b0, int b1, int& g) {
+        g = (a1 - a0 + 2 + 6) >> 2;
+        return (b1 - b0 + 2) * g;
+    };
+    int G;
+    const int items = items_of(c0, c1, r0, r1, G);
+    const int rowdw = 4 * G;  // LDS tile row stride in dwords
     // the LDS scheme needs the whole footprint strictly inside the panorama (so that no tap is a
     // border tap) and a width divisible by 4 (so that 12-byte items never straddle a row end)
     // with a non-constant border a pixel outside the panorama still reads pixels (reflected, wrapped ...):
@@ -549,13 +574,58 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
     if (P.border != 0) {
         bool mine = false;
 #pragma unroll
-        for (int j = 0; j < VIEWS_PXT; ++j)
+        for (int j = 0; j < PXT; ++j)
             mine |= inside[j] && !inrange[j];
         stray = __syncthreads_or(mine) != 0;
     }
-    const bool fast_tile = any_live && !stray && (P.pw & 3) == 0 && c0 >= 0 && r0 >= 0 && c1 + 1 < P.pw &&
-                           r1 + 1 < P.ph && G <= 255 && items <= LDS_ITEMS_CAP;
+    const bool lds_ok = any_live && !stray && (P.pw & 3) == 0 && c0 >= 0 && r0 >= 0 && c1 + 1 < P.pw &&
+                        r1 + 1 < P.ph;
+    const bool fast_tile = lds_ok && G <= 255 && items <= LDS_ITEMS_CAP;
 
+    // A tile that is fine except that its footprint outgrows the LDS buffers (views towards a pole: the rows
+    // stretch by 1 / sin(theta)) is drawn by the sub-tile pass instead: as two 32x8 halves if both fit, else
+    // as four 16x8 quarters (each of which decides again between the LDS scheme and direct gathers).
+    if (MODE == 1) {
+        if (lds_ok && !fast_tile) {
+            // half_box: per half (pixel j): min / max of ix + 1, min / max of iy + 1
+            if (t < 2) {
+                half_box[t][0] = 0xFFFFu; half_box[t][1] = 0u; half_box[t][2] = 0xFFFFu; half_box[t][3] = 0u;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < PXT; ++j)
+                if (inrange[j]) {
+                    atomicMin(&half_box[j][0], (uint32_t)(ix[j] + 1));
+                    atomicMax(&half_box[j][1], (uint32_t)(ix[j] + 1));
+                    atomicMin(&half_box[j][2], (uint32_t)(iy[j] + 1));
+                    atomicMax(&half_box[j][3], (uint32_t)(iy[j] + 1));
+                }
+            __syncthreads();
+            if (t == 0) {
+                bool halves = true;
+                for (int h = 0; h < 2; ++h)
+                    if (half_box[h][1] != 0u) {
+                        int g;
+                        const int n = items_of((int)half_box[h][0] - 1, (int)half_box[h][1] - 1,
+                                               (int)half_box[h][2] - 1, (int)half_box[h][3] - 1, g);
+                        halves = halves && g <= 255 && n <= LDS_ITEMS_CAP;
+                    }
+                uint2 e[4];
+                int n = 0;
+                for (int sy = 0; sy < 2; ++sy)
+                    for (int sx = 0; sx < (halves ? 1 : 2); ++sx) {
+                        const int ex = x0 + sx * (TILE_W / 2), ey = y0 + sy * SUB_H;
+                        if (ex < P.ow && ey < P.oh)
+                            e[n++] = make_uint2((uint32_t)ex | (uint32_t)ey << 15 | (halves ? 0u : 1u << 30), (uint32_t)pitch_i);
+                    }
+                const uint32_t base = atomicAdd(P.plan_count, (uint32_t)n);
+                for (int i = 0; i < n; ++i)
+                    P.plan[base + i] = e[i];
+                P.plan_flag[plan_slot] = 1;
+            }
+        }
+        return;
+    }
     // output addressing: 4 horizontally adjacent pixels = 12 bytes = 3 aligned dwords
     const int lane4 = t & 3;
     const bool fast_store = (P.ow & 3) == 0;
@@ -573,11 +643,11 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
     int pano_i = (int)__umulhi((uint32_t)pair0, P.n_yaw_magic);
     int yaw_i = pair0 - pano_i * P.n_yaw;
 
-    auto store_pixels = [&](int pair, const uint32_t (&pix)[VIEWS_PXT]) {
+    auto store_pixels = [&](int pair, const uint32_t (&pix)[PXT]) {
         // [pano][yaw][pitch][oh][ow][3]
         uint8_t* O = out + ((size_t)pair * P.n_pitch + pitch_i) * view_bytes;
 #pragma unroll
-        for (int j = 0; j < VIEWS_PXT; ++j) {
+        for (int j = 0; j < PXT; ++j) {
             const uint32_t off = pix_off + (uint32_t)j * pix_step;
             if (fast_store) {
                 // lanes 4k..4k+3 hold pixels P0..P3; lanes with lane4 < 3 emit dword lane4 of the 12 bytes
@@ -599,11 +669,11 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
         }
     };
 
-    auto direct_pixels = [&](const uint8_t* __restrict__ S, int yi, uint32_t (&pix)[VIEWS_PXT]) {
+    auto direct_pixels = [&](const uint8_t* __restrict__ S, int yi, uint32_t (&pix)[PXT]) {
         // same arithmetic, taps gathered from global memory through the packed yaw table
         const uint32_t* __restrict__ T = ytab + (size_t)yi * P.pw;
 #pragma unroll
-        for (int j = 0; j < VIEWS_PXT; ++j) {
+        for (int j = 0; j < PXT; ++j) {
             pix[j] = 0;
             if (live[j] && P.border != 0) {
                 const int xa = border_interpolate(ix[j], P.pw, P.border), xb = border_interpolate(ix[j] + 1, P.pw, P.border);
@@ -629,7 +699,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
 
     if (!fast_tile) {
         for (int pair = pair0; pair < pair1; ++pair) {
-            uint32_t pix[VIEWS_PXT];
+            uint32_t pix[PXT];
             direct_pixels(src + (size_t)pano_i * P.pano_stride, yaw_i, pix);
             store_pixels(pair, pix);
             if (++yaw_i == P.n_yaw) {
@@ -658,10 +728,10 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
             slot_off[k] = (uint32_t)(r0 + (int)rr) * (uint32_t)P.src_pitch + 12u * slot_g[k];
         }
     }
-    int tap[VIEWS_PXT];
-    TapWeights tw[VIEWS_PXT];
+    int tap[PXT];
+    TapWeights tw[PXT];
 #pragma unroll
-    for (int j = 0; j < VIEWS_PXT; ++j) {
+    for (int j = 0; j < PXT; ++j) {
         tap[j] = live[j] ? (iy[j] - r0) * rowdw + (ix[j] - c0) : 0;
         const uint32_t gx = 32u - fx[j], gy = 32u - fy[j];
         tw[j].gx2 = gx | (gx << 16);
@@ -790,9 +860,9 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
         };
         // byte offsets of this thread's upper / lower tap pairs inside one LDS buffer; per pair only the
         // scalar (buffer base + 4 * joff) is added
-        uint32_t tap_up[VIEWS_PXT], tap_lo[VIEWS_PXT];
+        uint32_t tap_up[PXT], tap_lo[PXT];
 #pragma unroll
-        for (int j = 0; j < VIEWS_PXT; ++j) {
+        for (int j = 0; j < PXT; ++j) {
             tap_up[j] = 4u * (uint32_t)tap[j];
             tap_lo[j] = 4u * (uint32_t)(tap[j] + rowdw);
         }
@@ -802,9 +872,9 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
             asm volatile("" : "+s"(soff));  // one scalar: keeps the buffer base out of four separate vector adds
             __syncthreads();
             const unsigned char* tl = reinterpret_cast<const unsigned char*>(&tile4[0][0]);
-            uint32_t ta[VIEWS_PXT][4];
+            uint32_t ta[PXT][4];
 #pragma unroll
-            for (int j = 0; j < VIEWS_PXT; ++j) {
+            for (int j = 0; j < PXT; ++j) {
                 const uint32_t* up = reinterpret_cast<const uint32_t*>(tl + (tap_up[j] + soff));
                 const uint32_t* lo = reinterpret_cast<const uint32_t*>(tl + (tap_lo[j] + soff));
                 ta[j][0] = up[0];
@@ -814,9 +884,9 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
             }
             if (k + 1 < npairs)
                 load_pieces(k + 1, qnext);
-            uint32_t pix[VIEWS_PXT];
+            uint32_t pix[PXT];
 #pragma unroll
-            for (int j = 0; j < VIEWS_PXT; ++j)
+            for (int j = 0; j < PXT; ++j)
                 pix[j] = blend4_packed(ta[j][0], ta[j][1], ta[j][2], ta[j][3], tw[j]);
             store_pixels(pair0 + k, pix);
         };
@@ -850,7 +920,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
             ++pano_i;
         }
         const bool has_next = pair + 1 < pair1;
-        uint32_t pix[VIEWS_PXT];
+        uint32_t pix[PXT];
 
         if (pc.fast) {
             uint4* tl4 = tile4[buf];
@@ -898,9 +968,9 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
             STAMP(st2);
             // the 2x2 taps of this thread's pixels
             const uint32_t* tl = reinterpret_cast<const uint32_t*>(tl4);
-            uint32_t ta[VIEWS_PXT][4];
+            uint32_t ta[PXT][4];
 #pragma unroll
-            for (int j = 0; j < VIEWS_PXT; ++j) {
+            for (int j = 0; j < PXT; ++j) {
                 const int b = tap[j] + joff;
                 ta[j][0] = tl[b];
                 ta[j][1] = tl[b + 1];
@@ -919,7 +989,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
 #endif
             STAMP(st4);
 #pragma unroll
-            for (int j = 0; j < VIEWS_PXT; ++j)
+            for (int j = 0; j < PXT; ++j)
                 pix[j] = blend4_packed(ta[j][0], ta[j][1], ta[j][2], ta[j][3], tw[j]);
             STAMP(st5);
             buf ^= 1;  // the next pair writes the other buffer; its readers are past this barrier
@@ -944,13 +1014,34 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
     }
 #ifdef P2P_STAMPS
     if ((t & 63) == 0) {
-        const int slot = (int)((blockIdx.x * 7u + blockIdx.y * 131u + blockIdx.z * 977u + (t >> 6) * 1031u) & 4095u);
+        const int slot = (int)(((uint32_t)bx * 7u + blockIdx.y * 131u + blockIdx.z * 977u + (t >> 6) * 1031u) & 4095u);
         for (int i = 0; i < 6; ++i)
             atomicAdd(&g_stamps[i * 4096 + slot], acc[i]);
         atomicAdd(&g_stamps[6 * 4096 + slot], 1ull);
         atomicAdd(&g_stamps[7 * 4096 + slot], (unsigned long long)(pair1 - pair0));
     }
 #endif
+}
+
+// MODE 0 launches carry the sub-tile workgroups in front of the tile workgroups (blockIdx.x < P.plan_gx):
+// one launch, so the few long-running sub-tile passes overlap with the bulk instead of trailing it.
+template <int MAPSRC, int MODE>
+__global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
+    ViewsParams P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab,
+    const YawDesc* __restrict__ ydesc, const uint32_t* __restrict__ f4tab,
+    const PitchConst* __restrict__ pitch, const float* __restrict__ mapU,
+    const float* __restrict__ mapV, uint8_t* __restrict__ out, int32_t* __restrict__ coords)
+{
+    __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
+    __shared__ int bbox[2 * VIEWS_BLOCK / 64];
+    __shared__ uint32_t half_box[2][4];
+    if (MODE == 0 && (int)blockIdx.x < P.plan_gx) {
+        views_body<MAPSRC, 2>(P, src, ytab, ydesc, f4tab, pitch, mapU, mapV, out, coords, tile4, bbox, half_box,
+                              (int)blockIdx.x, P.plan_gx);
+        return;
+    }
+    views_body<MAPSRC, MODE>(P, src, ytab, ydesc, f4tab, pitch, mapU, mapV, out, coords, tile4, bbox, half_box,
+                             (int)blockIdx.x - (MODE == 0 ? P.plan_gx : 0), (int)gridDim.x - (MODE == 0 ? P.plan_gx : 0));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1038,21 +1129,31 @@ hipError_t launch_pitch_map(float* U, float* V, int ow, int oh, const MapGeom& g
     return hipGetLastError();
 }
 
-hipError_t launch_remap_views(const ViewsParams& P, int mapsrc, hipStream_t st)
+template <int MODE>
+static void launch_views_mode(const ViewsParams& P, int mapsrc, dim3 grid, hipStream_t st)
+{
+    if (mapsrc == 1)
+        hipLaunchKernelGGL((remap_views_kernel<1, MODE>), grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc,
+                           P.f4tab, P.pitch, P.mapU, P.mapV, P.out, P.coords);
+    else if (mapsrc == 2)
+        hipLaunchKernelGGL((remap_views_kernel<2, MODE>), grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc,
+                           P.f4tab, P.pitch, P.mapU, P.mapV, P.out, P.coords);
+    else
+        hipLaunchKernelGGL((remap_views_kernel<0, MODE>), grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc,
+                           P.f4tab, P.pitch, P.mapU, P.mapV, P.out, P.coords);
+}
+
+// mode 0: every tile of every view, preceded by the P.plan_n listed sub-tiles; mode 1: the plan pass (one
+// workgroup per tile and pitch, nothing drawn)
+hipError_t launch_remap_views(const ViewsParams& P, int mapsrc, int mode, hipStream_t st)
 {
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
     const int n_pairs = P.n_panos * P.n_yaw;
     const int zblocks = (n_pairs + P.pairs_per_block - 1) / P.pairs_per_block;
-    dim3 grid(8 * ((tiles + 7) / 8), P.n_pitch, zblocks);  // 8 XCDs, each a contiguous run of tiles
-    if (mapsrc == 1)
-        hipLaunchKernelGGL(remap_views_kernel<1>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc,
-                           P.f4tab, P.pitch, P.mapU, P.mapV, P.out, P.coords);
-    else if (mapsrc == 2)
-        hipLaunchKernelGGL(remap_views_kernel<2>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc,
-                           P.f4tab, P.pitch, P.mapU, P.mapV, P.out, P.coords);
-    else
-        hipLaunchKernelGGL(remap_views_kernel<0>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc,
-                           P.f4tab, P.pitch, P.mapU, P.mapV, P.out, P.coords);
+    if (mode == 1)
+        launch_views_mode<1>(P, mapsrc, dim3(8 * ((tiles + 7) / 8), P.n_pitch, 1), st);
+    else  // 8 XCDs, each a contiguous run of tiles; P.plan_gx is a multiple of 8 too
+        launch_views_mode<0>(P, mapsrc, dim3(P.plan_gx + 8 * ((tiles + 7) / 8), P.n_pitch, zblocks), st);
     return hipGetLastError();
 }
 

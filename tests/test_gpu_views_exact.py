@@ -187,3 +187,20 @@ def test_randomised_configurations(gpu, synth):
         got = gpu.remap_views_maps(pano, rows, U, V)
         want = oracle_views(pano, yaws, pitches, ow, oh, fov)
         assert np.array_equal(got, want), dict(case=case, pw=pw, ph=ph, ow=ow, oh=oh, fov=fov, yaws=yaws, pitches=pitches)
+
+
+@pytest.mark.parametrize("pitch", [12, 30, 45, 56, 135, 150, 168])
+def test_large_footprints_split_into_sub_blocks(gpu, synth, pitch):
+    """Towards a pole a 32x16 tile's footprint outgrows the LDS buffers; the kernel then walks the tile as
+    2..16 sub-blocks with their own footprints (and gathers directly only where a pole sits inside the
+    sub-block).  4096x2048 -> 960x540 has all of those cases for these pitches; several yaw kinds per launch."""
+    pano = synth.synth_pano(4096, 2048, 1200 + pitch, "N")
+    _check(gpu, pano, [0, 45, 77, 200], [pitch], 960, 540)
+
+
+def test_sub_blocks_mixed_with_plain_tiles_in_one_launch(gpu, synth):
+    # the reference's default pitch list (P:428) on one panorama, odd output size (byte store path too)
+    pano = synth.synth_pano(2048, 1024, 1300, "N")
+    _check(gpu, pano, [0, 13, 90], [30, 60, 90, 120, 150], 640, 480)
+    _check(gpu, pano, [13], [30, 150], 333, 250)
+    _check(gpu, pano, [5, 359], [25], 640, 480, fov=120)
