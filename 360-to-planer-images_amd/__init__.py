@@ -8,10 +8,10 @@ or run the CLI file directly: python 360-to-planer-images_amd/panorama_to_plane_
 
 Contents: csrc/ (HIP kernels + C ABI, built into libp2p_hip.so), _native.py (ctypes binding),
 panorama_to_plane_pitch.py (mirror of the reference's current tool), panorama_to_plane.py
-(legacy entry point name).
+(mirror of its legacy tool: combined-rotation maps, one remap, its own CLI).
 """
 from . import _native
-from .panorama_to_plane import interpolate_color, panorama_to_plane
+from .panorama_to_plane import get_rotation_matrix, interpolate_color, panorama_to_plane, precompute_mapping
 from .panorama_to_plane_pitch import (
     check_pitch,
     get_pitch_mapping,
@@ -31,4 +31,5 @@ __all__ = [
     "check_pitch", "get_pitch_mapping", "get_version", "get_yaw_mapping", "main",
     "precompute_pitch_mapping", "precompute_yaw_mapping", "process_single_image", "process_views",
     "process_yaw_and_pitchs", "set_device", "set_devices", "panorama_to_plane", "interpolate_color",
+    "get_rotation_matrix", "precompute_mapping",
 ]

@@ -16,14 +16,15 @@ LIB_PATH = os.path.join(_HERE, "libp2p_hip.so")
 P2P_OK = 0
 P2P_ERR_INVALID, P2P_ERR_NO_DEVICE, P2P_ERR_HIP, P2P_ERR_OOM, P2P_ERR_STATE = -1, -2, -3, -4, -5
 BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_101 = 0, 1, 2, 3, 4
+INTER_NEAREST, INTER_LINEAR, INTER_CUBIC = 0, 1, 2
 FLAG_KEEP_COORDS = 1
 FLAG_CACHE_COORDS = 2
 
 # every symbol include/p2p_hip.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (
     "p2p_version", "p2p_last_error", "p2p_device_count",
-    "p2p_remap_views_u8", "p2p_remap_views_maps_u8", "p2p_remap_maps_u8",
-    "p2p_build_pitch_map", "p2p_build_yaw_row",
+    "p2p_remap_views_u8", "p2p_remap_views_maps_u8", "p2p_remap_maps_u8", "p2p_remap_maps_interp_u8",
+    "p2p_build_pitch_map", "p2p_build_yaw_row", "p2p_build_rot_map",
     "p2p_ctx_create", "p2p_ctx_destroy", "p2p_ctx_synchronize", "p2p_ctx_mark", "p2p_ctx_marked_ms",
     "p2p_job_time_launches",
     "p2p_job_create", "p2p_job_destroy", "p2p_job_set_pano", "p2p_job_set_maps", "p2p_job_run",
@@ -79,8 +80,13 @@ def lib():
     L.p2p_remap_maps_u8.restype = c_int
     L.p2p_remap_maps_u8.argtypes = [c_vp, c_int, c_int, c_i64, c_int, c_vp, c_vp, c_int, c_int, c_vp,
                                     c_int, c_vp, c_int]
+    L.p2p_remap_maps_interp_u8.restype = c_int
+    L.p2p_remap_maps_interp_u8.argtypes = [c_vp, c_int, c_int, c_i64, c_int, c_vp, c_vp, c_int, c_int, c_vp,
+                                           c_int, c_int, c_vp, c_int]
     L.p2p_build_pitch_map.restype = c_int
     L.p2p_build_pitch_map.argtypes = [c_int, c_int, c_dbl, c_dbl, c_int, c_int, c_vp, c_vp, c_int]
+    L.p2p_build_rot_map.restype = c_int
+    L.p2p_build_rot_map.argtypes = [c_int, c_int, c_dbl, c_vp, c_int, c_int, c_vp, c_vp, c_int]
     L.p2p_build_yaw_row.restype = c_int
     L.p2p_build_yaw_row.argtypes = [c_int, c_dbl, c_vp, c_int]
     L.p2p_ctx_create.restype = c_int
@@ -274,8 +280,8 @@ def remap_views_maps(pano, yaw_rows, U, V, device=0):
     return out
 
 
-def remap_maps(src, U, V, border=BORDER_CONSTANT, border_value=None, device=0):
-    """p2p_remap_maps_u8 == cv2.remap(src, U, V, INTER_LINEAR, borderMode=border)."""
+def remap_maps(src, U, V, border=BORDER_CONSTANT, border_value=None, device=0, interpolation=INTER_LINEAR):
+    """p2p_remap_maps_interp_u8 == cv2.remap(src, U, V, interpolation, borderMode=border)."""
     src = np.asarray(src)
     if src.dtype != np.uint8:
         raise TypeError("src must be uint8")
@@ -296,9 +302,9 @@ def remap_maps(src, U, V, border=BORDER_CONSTANT, border_value=None, device=0):
     if border_value is not None:
         bv = np.zeros(4, dtype=np.uint8)
         bv[:cn] = np.asarray(border_value, dtype=np.uint8).ravel()[:cn]
-    check(lib().p2p_remap_maps_u8(src.ctypes.data, sw, sh, src.strides[0], cn, U.ctypes.data, V.ctypes.data,
-                                  ow, oh, out.ctypes.data, int(border),
-                                  None if bv is None else bv.ctypes.data, int(device)))
+    check(lib().p2p_remap_maps_interp_u8(src.ctypes.data, sw, sh, src.strides[0], cn, U.ctypes.data, V.ctypes.data,
+                                         ow, oh, out.ctypes.data, int(interpolation), int(border),
+                                         None if bv is None else bv.ctypes.data, int(device)))
     return out[:, :, 0] if squeeze else out
 
 
@@ -313,6 +319,18 @@ def build_pitch_map(ow, oh, fov_rad, pitch_rad, pw, ph, device=0):
     V = np.empty_like(U)
     check(lib().p2p_build_pitch_map(int(ow), int(oh), float(fov_rad), float(pitch_rad), int(pw), int(ph),
                                     U.ctypes.data, V.ctypes.data, int(device)))
+    return U, V
+
+
+def build_rot_map(ow, oh, fov_rad, R, pw, ph, device=0):
+    """p2p_build_rot_map: the legacy tool's combined-rotation map for a float32 3x3 matrix R."""
+    R = np.ascontiguousarray(R, dtype=np.float32)
+    if R.shape != (3, 3):
+        raise ValueError("R must be 3x3")
+    U = np.empty((int(oh), int(ow)), dtype=np.float32)
+    V = np.empty_like(U)
+    check(lib().p2p_build_rot_map(int(ow), int(oh), float(fov_rad), R.ctypes.data, int(pw), int(ph),
+                                  U.ctypes.data, V.ctypes.data, int(device)))
     return U, V
 
 

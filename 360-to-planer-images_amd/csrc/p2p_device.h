@@ -74,6 +74,7 @@ struct RemapParams {
     int ow, oh;
     int border;
     uint8_t cval[4];
+    const short* ctab;  // INTER_CUBIC only: [32 * 32][4][4] fixed-point weights (cubic_tab_kernel)
 };
 
 hipError_t launch_yaw_tables(uint32_t* packed, float* rows, int pw, int n_yaw, const double* yaw_rad,
@@ -81,10 +82,12 @@ hipError_t launch_yaw_tables(uint32_t* packed, float* rows, int pw, int n_yaw, c
 hipError_t launch_yaw_pack(uint32_t* packed, const float* rows, size_t n, hipStream_t st);
 hipError_t launch_yaw_desc(YawDesc* desc, uint32_t* f4tab, const uint32_t* packed, int pw, int n_yaw,
                            hipStream_t st);
+hipError_t launch_rot_map(float* U, float* V, int ow, int oh, const MapGeom& g, const float* R9, hipStream_t st);
 hipError_t launch_pitch_map(float* U, float* V, int ow, int oh, const MapGeom& g, float c, float s,
                             hipStream_t st);
 hipError_t launch_remap_views(const ViewsParams& P, int mapsrc, int mode, hipStream_t st);
-hipError_t launch_remap_maps(const RemapParams& P, int cn, hipStream_t st);
+hipError_t launch_remap_maps(const RemapParams& P, int cn, int interpolation, hipStream_t st);
+hipError_t launch_cubic_tab(short* tab, hipStream_t st);
 // diagnostic build only (-DP2P_STAMPS): per-phase s_memtime sums of remap_views_kernel's pair loop
 hipError_t read_stamps(unsigned long long* out16, bool reset);
 

@@ -56,6 +56,7 @@ struct p2p_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    short* d_ctab = nullptr;  // INTER_CUBIC weight table, built on first use
 };
 
 struct p2p_job {
@@ -218,6 +219,7 @@ void p2p_ctx_destroy(p2p_ctx* c)
         (void)hipStreamSynchronize(c->stream);
         (void)hipStreamDestroy(c->stream);
     }
+    (void)hipFree(c->d_ctab);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -749,6 +751,16 @@ int p2p_remap_maps_u8(const uint8_t* src, int sw, int sh, int64_t row_stride, in
                       const float* U, const float* V, int ow, int oh, uint8_t* out,
                       int border_mode, const uint8_t* border_value, int device)
 {
+    return p2p_remap_maps_interp_u8(src, sw, sh, row_stride, cn, U, V, ow, oh, out, P2P_INTER_LINEAR,
+                                    border_mode, border_value, device);
+}
+
+int p2p_remap_maps_interp_u8(const uint8_t* src, int sw, int sh, int64_t row_stride, int cn,
+                             const float* U, const float* V, int ow, int oh, uint8_t* out,
+                             int interpolation, int border_mode, const uint8_t* border_value, int device)
+{
+    if (interpolation != P2P_INTER_NEAREST && interpolation != P2P_INTER_LINEAR && interpolation != P2P_INTER_CUBIC)
+        return fail(P2P_ERR_INVALID, "unsupported interpolation %d", interpolation);
     if (!src || !U || !V || !out)
         return fail(P2P_ERR_INVALID, "NULL pointer");
     if (cn != 1 && cn != 3 && cn != 4)
@@ -762,7 +774,7 @@ int p2p_remap_maps_u8(const uint8_t* src, int sw, int sh, int64_t row_stride, in
     bool zero_border = true;
     for (int k = 0; k < cn; ++k)
         zero_border = zero_border && (!border_value || border_value[k] == 0);
-    if (cn == 3 && (border_mode != P2P_BORDER_CONSTANT || zero_border)) {
+    if (interpolation == P2P_INTER_LINEAR && cn == 3 && (border_mode != P2P_BORDER_CONSTANT || zero_border)) {
         // three interleaved channels: the view kernel with an identity yaw stage (yaw 0 quantises to
         // "column x, fraction 0", so stage 1 is a copy) and the caller's maps as its pitch stage --
         // LDS-staged taps instead of per-pixel byte gathers
@@ -781,7 +793,12 @@ int p2p_remap_maps_u8(const uint8_t* src, int sw, int sh, int64_t row_stride, in
     auto cleanup = [&]() {
         (void)hipFree(d_src); (void)hipFree(d_dst); (void)hipFree(d_U); (void)hipFree(d_V);
     };
-    hipError_t e = hipMalloc((void**)&d_src, (size_t)pitch * sh + kSlack);
+    hipError_t e = hipSuccess;
+    if (interpolation == P2P_INTER_CUBIC && !ctx->d_ctab) {
+        e = hipMalloc((void**)&ctx->d_ctab, 1024 * 16 * sizeof(short));
+        if (e == hipSuccess) e = p2p::launch_cubic_tab(ctx->d_ctab, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMalloc((void**)&d_src, (size_t)pitch * sh + kSlack);
     if (e == hipSuccess) e = hipMalloc((void**)&d_dst, n_map * cn);
     if (e == hipSuccess) e = hipMalloc((void**)&d_U, n_map * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&d_V, n_map * sizeof(float));
@@ -795,7 +812,8 @@ int p2p_remap_maps_u8(const uint8_t* src, int sw, int sh, int64_t row_stride, in
         P.U = d_U; P.V = d_V; P.dst = d_dst; P.ow = ow; P.oh = oh; P.border = border_mode;
         for (int k = 0; k < 4; ++k)
             P.cval[k] = (border_value && k < cn) ? border_value[k] : 0;
-        e = p2p::launch_remap_maps(P, cn, ctx->stream);
+        P.ctab = ctx->d_ctab;
+        e = p2p::launch_remap_maps(P, cn, interpolation, ctx->stream);
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_dst, n_map * cn, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -835,6 +853,38 @@ int p2p_build_pitch_map(int ow, int oh, double fov_rad, double pitch_rad, int pw
     (void)hipFree(dV);
     if (e != hipSuccess)
         return fail(e == hipErrorOutOfMemory ? P2P_ERR_OOM : P2P_ERR_HIP, "p2p_build_pitch_map: %s", hipGetErrorString(e));
+    return P2P_OK;
+}
+
+int p2p_build_rot_map(int ow, int oh, double fov_rad, const float* R9, int pw, int ph,
+                      float* U, float* V, int device)
+{
+    if (!U || !V || !R9)
+        return fail(P2P_ERR_INVALID, "NULL pointer");
+    if (!dims_ok(ow, oh) || pw < 1 || ph < 1)
+        return fail(P2P_ERR_INVALID, "bad sizes");
+    p2p_ctx* ctx = nullptr;
+    int rc = thread_ctx(device, &ctx);
+    if (rc != P2P_OK)
+        return rc;
+    p2p::MapGeom g{};
+    g.half_w = (float)(ow / 2.0);
+    g.half_h = (float)(oh / 2.0);
+    g.focal = (float)((0.5 * ow) / std::tan(fov_rad / 2));  // L:95, cast to float32 at L:109
+    g.pw_f = (float)pw;
+    g.ph_f = (float)ph;
+    const size_t n = (size_t)ow * oh;
+    float *dU = nullptr, *dV = nullptr;
+    hipError_t e = hipMalloc((void**)&dU, n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&dV, n * sizeof(float));
+    if (e == hipSuccess) e = p2p::launch_rot_map(dU, dV, ow, oh, g, R9, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(U, dU, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(V, dV, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dU);
+    (void)hipFree(dV);
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? P2P_ERR_OOM : P2P_ERR_HIP, "p2p_build_rot_map: %s", hipGetErrorString(e));
     return P2P_OK;
 }
 

@@ -245,6 +245,45 @@ __global__ void pitch_map_kernel(float* __restrict__ U, float* __restrict__ V, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// legacy tool: one combined rotation R = R_pitch @ R_yaw (L:21-45) applied to the normalised pinhole
+// ray, then the same spherical mapping (precompute_mapping, L:47-157).  float32 throughout; the 3x3 by
+// 3xN sgemm as OpenBLAS accumulates it: acc = R[i][0]*v0; acc = fma(R[i][1], v1, acc); fma(R[i][2], v2, acc)
+// (bit-equal to the reference's output for the golden cases).
+// ---------------------------------------------------------------------------------------------
+struct Rot3 {
+    float m[9];
+};
+
+__global__ void rot_map_kernel(float* __restrict__ U, float* __restrict__ V, int ow, int oh, MapGeom g, Rot3 R)
+{
+    const int px = blockIdx.x * blockDim.x + threadIdx.x;
+    const int py = blockIdx.y;
+    if (px >= ow || py >= oh)
+        return;
+    const float TWO_PI_F = 6.283185307179586f, PI_F = 3.141592653589793f;
+    const float x = (float)px - g.half_w;  // L:107
+    const float y = g.half_h - (float)py;  // L:108
+    const float z = g.focal;               // L:109
+    const float n = __fsqrt_rn(x * x + y * y + z * z);  // L:113
+    const float xn = __fdiv_rn(x, n), yn = __fdiv_rn(y, n), zn = __fdiv_rn(z, n);  // L:114-116
+    const float xr = __builtin_fmaf(R.m[2], zn, __builtin_fmaf(R.m[1], yn, R.m[0] * xn));  // L:123
+    const float yr = __builtin_fmaf(R.m[5], zn, __builtin_fmaf(R.m[4], yn, R.m[3] * xn));
+    const float zr = __builtin_fmaf(R.m[8], zn, __builtin_fmaf(R.m[7], yn, R.m[6] * xn));
+    const float theta = acosf(zr);  // L:130
+    float phi = atan2f(yr, xr);     // L:145, floored '%' of a value in [-pi, pi]
+    if (phi < 0.0f)
+        phi += TWO_PI_F;
+    else if (phi == 0.0f)
+        phi = 0.0f;
+    float uu = __fdiv_rn(phi * g.pw_f, TWO_PI_F);  // L:157
+    float vv = __fdiv_rn(theta * g.ph_f, PI_F);    // L:158
+    uu = clip_keep_nan(uu, 0.0f, g.pw_f - 1.0f);   // L:161
+    vv = clip_keep_nan(vv, 0.0f, g.ph_f - 1.0f);   // L:162
+    U[(size_t)py * ow + px] = uu;
+    V[(size_t)py * ow + px] = vv;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stage 1, P:192-199: one pixel of the yaw-resampled panorama ("rot") from two horizontally
 // adjacent source pixels p0, p1 (dwords B | G<<8 | R<<16 | x<<24):
 //   rot = ((32-f)*p0 + f*p1 + 16) >> 5 per channel
@@ -1098,6 +1137,126 @@ __global__ void remap_maps_kernel(RemapParams P)
 }
 
 // ---------------------------------------------------------------------------------------------
+// The other two rows of the legacy tool's method table (L:172-176): INTER_NEAREST and INTER_CUBIC, as
+// OpenCV 4.10 evaluates them for uint8 (remapNearest; remapBicubic with the 15-bit fixed-point table).
+// ---------------------------------------------------------------------------------------------
+template <int CN>
+__global__ void remap_maps_nearest_kernel(RemapParams P)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= P.ow || y >= P.oh)
+        return;
+    const size_t k = (size_t)y * P.ow + x;
+    // saturate_cast<short>(float): cvRound (half-even), then saturation
+    int sx = sat_short(cv_round_f32(P.U[k])), sy = sat_short(cv_round_f32(P.V[k]));
+    uint8_t* D = P.dst + k * CN;
+    const uint8_t* S = nullptr;
+    if ((unsigned)sx < (unsigned)P.sw && (unsigned)sy < (unsigned)P.sh) {
+        S = P.src + (size_t)sy * P.src_pitch + (size_t)sx * CN;
+    } else if (P.border != 0) {
+        sx = border_interpolate(sx, P.sw, P.border);
+        sy = border_interpolate(sy, P.sh, P.border);
+        S = P.src + (size_t)sy * P.src_pitch + (size_t)sx * CN;
+    }
+#pragma unroll
+    for (int ch = 0; ch < CN; ++ch)
+        D[ch] = S ? S[ch] : P.cval[ch];
+}
+
+// initInterTab2D(INTER_CUBIC, fixpt): thread (fy, fx) builds its 4x4 cell of shorts.  interpolateCubic with
+// A = -0.75 in float32, products scaled by 32768 and rounded half-even, then the cell sum forced to 32768 by
+// adjusting the largest (or smallest) of the four entries [2..3][2..3] -- the window OpenCV scans.
+__device__ __forceinline__ void cubic_coeffs(float x, float* c)
+{
+    const float A = -0.75f;
+    c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+__global__ void cubic_tab_kernel(short* __restrict__ tab)
+{
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= 1024)
+        return;
+    const float scale = 1.f / 32;
+    float cy[4], cx[4];
+    cubic_coeffs((cell >> 5) * scale, cy);
+    cubic_coeffs((cell & 31) * scale, cx);
+    short w[16];
+    int isum = 0;
+    for (int k1 = 0; k1 < 4; ++k1)
+        for (int k2 = 0; k2 < 4; ++k2) {
+            const float v = cy[k1] * cx[k2];
+            w[k1 * 4 + k2] = (short)sat_short(cv_round_f32(v * 32768.0f));
+            isum += w[k1 * 4 + k2];
+        }
+    if (isum != 32768) {
+        const int diff = isum - 32768;
+        int M = 2 * 4 + 2, m = 2 * 4 + 2;
+        for (int k1 = 2; k1 < 4; ++k1)
+            for (int k2 = 2; k2 < 4; ++k2) {
+                const int i = k1 * 4 + k2;
+                if (w[i] < w[m])
+                    m = i;
+                else if (w[i] > w[M])
+                    M = i;
+            }
+        if (diff < 0)
+            w[M] = (short)(w[M] - diff);
+        else
+            w[m] = (short)(w[m] - diff);
+    }
+    for (int i = 0; i < 16; ++i)
+        tab[cell * 16 + i] = w[i];
+}
+
+template <int CN>
+__global__ void remap_maps_cubic_kernel(RemapParams P)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= P.ow || y >= P.oh)
+        return;
+    const size_t k = (size_t)y * P.ow + x;
+    const int qx = cv_round_f32(P.U[k] * 32.0f), qy = cv_round_f32(P.V[k] * 32.0f);
+    const int sx = sat_short(qx >> 5) - 1, sy = sat_short(qy >> 5) - 1;
+    const short* __restrict__ w = P.ctab + ((qy & 31) * 32 + (qx & 31)) * 16;
+    uint8_t* D = P.dst + k * CN;
+    if (P.border == 0 && (sx >= P.sw || sx + 4 <= 0 || sy >= P.sh || sy + 4 <= 0)) {
+#pragma unroll
+        for (int ch = 0; ch < CN; ++ch)
+            D[ch] = P.cval[ch];
+        return;
+    }
+    int xs[4], ys[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        xs[i] = border_interpolate(sx + i, P.sw, P.border);
+        ys[i] = border_interpolate(sy + i, P.sh, P.border);
+    }
+#pragma unroll
+    for (int ch = 0; ch < CN; ++ch) {
+        // sum = cval * 32768 + sum (p - cval) * w over the taps that exist == sum p * w with cval at the missing
+        // taps, because the 16 weights add up to 32768
+        const int cv = P.cval[ch];
+        int sum = cv << 15;
+        for (int r = 0; r < 4; ++r) {
+            if (ys[r] < 0)
+                continue;
+            const uint8_t* S = P.src + (size_t)ys[r] * P.src_pitch;
+            for (int c = 0; c < 4; ++c)
+                if (xs[c] >= 0)
+                    sum += ((int)S[xs[c] * CN + ch] - cv) * (int)w[r * 4 + c];
+        }
+        sum = (sum + 16384) >> 15;
+        D[ch] = (uint8_t)(sum < 0 ? 0 : (sum > 255 ? 255 : sum));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers (called from p2p_host.cpp through p2p_device.h)
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_yaw_tables(uint32_t* packed, float* rows, int pw, int n_yaw, const double* yaw_rad,
@@ -1129,6 +1288,16 @@ hipError_t launch_pitch_map(float* U, float* V, int ow, int oh, const MapGeom& g
     return hipGetLastError();
 }
 
+hipError_t launch_rot_map(float* U, float* V, int ow, int oh, const MapGeom& g, const float* R9, hipStream_t st)
+{
+    Rot3 R;
+    for (int i = 0; i < 9; ++i)
+        R.m[i] = R9[i];
+    dim3 grid((ow + 255) / 256, oh);
+    hipLaunchKernelGGL(rot_map_kernel, grid, dim3(256), 0, st, U, V, ow, oh, g, R);
+    return hipGetLastError();
+}
+
 template <int MODE>
 static void launch_views_mode(const ViewsParams& P, int mapsrc, dim3 grid, hipStream_t st)
 {
@@ -1157,10 +1326,35 @@ hipError_t launch_remap_views(const ViewsParams& P, int mapsrc, int mode, hipStr
     return hipGetLastError();
 }
 
-hipError_t launch_remap_maps(const RemapParams& P, int cn, hipStream_t st)
+hipError_t launch_cubic_tab(short* tab, hipStream_t st)
+{
+    hipLaunchKernelGGL(cubic_tab_kernel, dim3(4), dim3(256), 0, st, tab);
+    return hipGetLastError();
+}
+
+// interpolation: cv2's codes, 0 = INTER_NEAREST, 1 = INTER_LINEAR, 2 = INTER_CUBIC
+hipError_t launch_remap_maps(const RemapParams& P, int cn, int interpolation, hipStream_t st)
 {
     dim3 block(64, 4);
     dim3 grid((P.ow + 63) / 64, (P.oh + 3) / 4);
+    if (interpolation == 0) {
+        if (cn == 1)
+            hipLaunchKernelGGL(remap_maps_nearest_kernel<1>, grid, block, 0, st, P);
+        else if (cn == 3)
+            hipLaunchKernelGGL(remap_maps_nearest_kernel<3>, grid, block, 0, st, P);
+        else
+            hipLaunchKernelGGL(remap_maps_nearest_kernel<4>, grid, block, 0, st, P);
+        return hipGetLastError();
+    }
+    if (interpolation == 2) {
+        if (cn == 1)
+            hipLaunchKernelGGL(remap_maps_cubic_kernel<1>, grid, block, 0, st, P);
+        else if (cn == 3)
+            hipLaunchKernelGGL(remap_maps_cubic_kernel<3>, grid, block, 0, st, P);
+        else
+            hipLaunchKernelGGL(remap_maps_cubic_kernel<4>, grid, block, 0, st, P);
+        return hipGetLastError();
+    }
     if (cn == 1)
         hipLaunchKernelGGL(remap_maps_kernel<1>, grid, block, 0, st, P);
     else if (cn == 3)

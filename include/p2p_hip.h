@@ -44,6 +44,9 @@ typedef enum p2p_status {
 enum { P2P_BORDER_CONSTANT = 0, P2P_BORDER_REPLICATE = 1, P2P_BORDER_REFLECT = 2,
        P2P_BORDER_WRAP = 3, P2P_BORDER_REFLECT_101 = 4 };
 
+/* interpolation codes = cv2.INTER_NEAREST / INTER_LINEAR / INTER_CUBIC (the legacy tool's method table, L:172-176) */
+enum { P2P_INTER_NEAREST = 0, P2P_INTER_LINEAR = 1, P2P_INTER_CUBIC = 2 };
+
 /* p2p_job_desc.flags / p2p_remap_views_u8 flags */
 enum {
     P2P_FLAG_DEFAULT = 0,
@@ -100,6 +103,13 @@ int p2p_remap_maps_u8(const uint8_t* src, int sw, int sh, int64_t row_stride, in
                       const float* U, const float* V, int ow, int oh, uint8_t* out,
                       int border_mode, const uint8_t* border_value, int device);
 
+/* interpolate_color(U, V, img, method) of the legacy tool, L:159-180: the same call with the method chosen,
+   cv2.remap(img, U, V, interpolation, borderMode).  INTER_NEAREST rounds the coordinates half-even and copies;
+   INTER_CUBIC uses OpenCV's 4x4 fixed-point kernel (A = -0.75, 1/32-pixel phases, 15-bit weights). */
+int p2p_remap_maps_interp_u8(const uint8_t* src, int sw, int sh, int64_t row_stride, int cn,
+                             const float* U, const float* V, int ow, int oh, uint8_t* out,
+                             int interpolation, int border_mode, const uint8_t* border_value, int device);
+
 /*
  * Replaces precompute_pitch_mapping(W, H, FOV_rad, pitch_radian, pano_width, pano_height)
  * (P:114-175; get_pitch_mapping P:55-73 passes np.radians() of its degree arguments): float32
@@ -107,6 +117,13 @@ int p2p_remap_maps_u8(const uint8_t* src, int sw, int sh, int64_t row_stride, in
  */
 int p2p_build_pitch_map(int ow, int oh, double fov_rad, double pitch_rad, int pw, int ph,
                         float* U, float* V, int device);
+
+/* The legacy tool's combined map (app/legacy/panorama_to_plane.py precompute_mapping, L:47-157): the
+   normalised pinhole ray of every output pixel is rotated by the float32 3x3 matrix R9 (row-major; the
+   caller builds it as get_rotation_matrix does, L:21-45: R_pitch @ R_yaw) and mapped to panorama
+   coordinates, clipped to [0, pw-1] x [0, ph-1].  U, V: float32 [oh][ow] host buffers. */
+int p2p_build_rot_map(int ow, int oh, double fov_rad, const float* R9, int pw, int ph,
+                      float* U, float* V, int device);
 
 /*
  * Replaces get_yaw_mapping()/precompute_yaw_mapping() (P:42-52, P:79-108): the float32 row

@@ -55,6 +55,11 @@ def lib():
                                         ctypes.c_void_p, ctypes.c_void_p]
         L.orc_get_wtab.restype = None
         L.orc_get_wtab.argtypes = [ctypes.c_void_p]
+        for fn in (L.orc_remap_nearest_u8, L.orc_remap_cubic_u8):
+            fn.restype = ctypes.c_int
+            fn.argtypes = L.orc_remap_u8.argtypes
+        L.orc_get_cubic_wtab.restype = None
+        L.orc_get_cubic_wtab.argtypes = [ctypes.c_void_p]
         _lib = L
     return _lib
 
@@ -75,8 +80,17 @@ def quantise_maps(U, V):
     return ixy[..., 0], ixy[..., 1], (fxy & 31).astype(np.int32), (fxy >> 5).astype(np.int32)
 
 
-def remap(src, U, V, border=BORDER_CONSTANT, border_value=None):
-    """cv2.remap(src, U, V, INTER_LINEAR, borderMode=border, borderValue=border_value) for uint8."""
+INTER_NEAREST, INTER_LINEAR, INTER_CUBIC = 0, 1, 2  # cv2's codes
+
+
+def cubic_weight_table():
+    out = np.zeros((1024, 16), dtype=np.int16)
+    lib().orc_get_cubic_wtab(out.ctypes.data)
+    return out
+
+
+def remap(src, U, V, border=BORDER_CONSTANT, border_value=None, interpolation=INTER_LINEAR):
+    """cv2.remap(src, U, V, interpolation, borderMode=border, borderValue=border_value) for uint8."""
     src = np.asarray(src)
     if src.dtype != np.uint8:
         raise TypeError("oracle remap handles uint8 only")
@@ -96,7 +110,9 @@ def remap(src, U, V, border=BORDER_CONSTANT, border_value=None):
     if border_value is not None:
         bv = np.zeros(4, dtype=np.uint8)
         bv[:cn] = np.asarray(border_value, dtype=np.uint8).ravel()[:cn]
-    rc = lib().orc_remap_u8(
+    fn = {INTER_NEAREST: lib().orc_remap_nearest_u8, INTER_LINEAR: lib().orc_remap_u8,
+          INTER_CUBIC: lib().orc_remap_cubic_u8}[interpolation]
+    rc = fn(
         src.ctypes.data, sw, sh, src.strides[0], cn,
         U.ctypes.data, V.ctypes.data, dw,
         dst.ctypes.data, dw, dh, dst.strides[0],

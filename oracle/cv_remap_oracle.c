@@ -255,3 +255,177 @@ int orc_remap_u8(const uint8_t* src, int sw, int sh, int64_t sstride, int cn,
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * INTER_NEAREST and INTER_CUBIC: the other two entries of the legacy tool's method table
+ * (app/legacy/panorama_to_plane.py:172-176; only 'bilinear' is reachable from its own callers, L:194).
+ * Same status as above: restated from OpenCV 4.10 imgwarp.cpp (remapNearest, remapBicubic,
+ * initInterTab1D/2D with interpolateCubic), PARITY UNPINNED.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* RemapInvoker, nearest branch with two CV_32FC1 maps: XY = saturate_cast<short>(map) (cvRound, then
+ * saturation); remapNearest copies the pixel or resolves the border. */
+int orc_remap_nearest_u8(const uint8_t* src, int sw, int sh, int64_t sstride, int cn,
+                         const float* mapx, const float* mapy, int64_t mstride,
+                         uint8_t* dst, int dw, int dh, int64_t dstride,
+                         int border, const uint8_t* border_value)
+{
+    uint8_t cval[4] = {0, 0, 0, 0};
+    if (!src || !mapx || !mapy || !dst || cn < 1 || cn > 4)
+        return -1;
+    if (!(dw < SHRT_MAX && dh < SHRT_MAX && sw < SHRT_MAX && sh < SHRT_MAX) || sw <= 0 || sh <= 0)
+        return -2;
+    if (border < ORC_BORDER_CONSTANT || border > ORC_BORDER_REFLECT_101)
+        return -3;
+    if (border_value)
+        memcpy(cval, border_value, (size_t)cn);
+    for (int dy = 0; dy < dh; dy++) {
+        const float* mx = mapx + (int64_t)dy * mstride;
+        const float* my = mapy + (int64_t)dy * mstride;
+        uint8_t* D = dst + (int64_t)dy * dstride;
+        for (int dx = 0; dx < dw; dx++, D += cn) {
+            int sx = orc_sat_short_f(mx[dx]), sy = orc_sat_short_f(my[dx]);
+            const uint8_t* S;
+            if ((unsigned)sx < (unsigned)sw && (unsigned)sy < (unsigned)sh) {
+                S = src + (int64_t)sy * sstride + (int64_t)sx * cn;
+            } else if (border == ORC_BORDER_REPLICATE) {
+                sx = sx < 0 ? 0 : (sx > sw - 1 ? sw - 1 : sx);
+                sy = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
+                S = src + (int64_t)sy * sstride + (int64_t)sx * cn;
+            } else if (border == ORC_BORDER_CONSTANT) {
+                S = cval;
+            } else {
+                sx = orc_border_interpolate(sx, sw, border);
+                sy = orc_border_interpolate(sy, sh, border);
+                S = src + (int64_t)sy * sstride + (int64_t)sx * cn;
+            }
+            for (int k = 0; k < cn; k++)
+                D[k] = S[k];
+        }
+    }
+    return 0;
+}
+
+static short g_ctab[ORC_INTER_TAB_SIZE * ORC_INTER_TAB_SIZE][16];
+static int g_ctab_ready = 0;
+
+/* interpolateCubic (A = -0.75) in float, initInterTab1D / initInterTab2D(INTER_CUBIC, fixpt) */
+static void orc_init_ctab(void)
+{
+    float tab1d[ORC_INTER_TAB_SIZE * 4];
+    const float scale = 1.f / ORC_INTER_TAB_SIZE;
+    const int ksize = 4;
+    int i, j, k1, k2;
+    for (i = 0; i < ORC_INTER_TAB_SIZE; i++) {
+        const float A = -0.75f;
+        float x = i * scale;
+        float* c = tab1d + i * 4;
+        c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+        c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+        c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+        c[3] = 1.f - c[0] - c[1] - c[2];
+    }
+    for (i = 0; i < ORC_INTER_TAB_SIZE; i++)
+        for (j = 0; j < ORC_INTER_TAB_SIZE; j++) {
+            short* itab = g_ctab[i * ORC_INTER_TAB_SIZE + j];
+            int isum = 0;
+            for (k1 = 0; k1 < ksize; k1++) {
+                float vy = tab1d[i * ksize + k1];
+                for (k2 = 0; k2 < ksize; k2++) {
+                    float v = vy * tab1d[j * ksize + k2];
+                    itab[k1 * ksize + k2] = orc_sat_short_f(v * ORC_COEF_SCALE);
+                    isum += itab[k1 * ksize + k2];
+                }
+            }
+            if (isum != ORC_COEF_SCALE) {
+                int diff = isum - ORC_COEF_SCALE;
+                int ksize2 = ksize / 2, Mk1 = ksize2, Mk2 = ksize2, mk1 = ksize2, mk2 = ksize2;
+                for (k1 = ksize2; k1 < ksize2 + 2; k1++)
+                    for (k2 = ksize2; k2 < ksize2 + 2; k2++) {
+                        if (itab[k1 * ksize + k2] < itab[mk1 * ksize + mk2])
+                            mk1 = k1, mk2 = k2;
+                        else if (itab[k1 * ksize + k2] > itab[Mk1 * ksize + Mk2])
+                            Mk1 = k1, Mk2 = k2;
+                    }
+                if (diff < 0)
+                    itab[Mk1 * ksize + Mk2] = (short)(itab[Mk1 * ksize + Mk2] - diff);
+                else
+                    itab[mk1 * ksize + mk2] = (short)(itab[mk1 * ksize + mk2] - diff);
+            }
+        }
+    g_ctab_ready = 1;
+}
+
+void orc_get_cubic_wtab(short* out /* [1024][16] */)
+{
+    if (!g_ctab_ready)
+        orc_init_ctab();
+    memcpy(out, g_ctab, sizeof(g_ctab));
+}
+
+/* remapBicubic<FixedPtCast<int,uchar,15>, short, INTER_REMAP_COEF_SCALE> */
+int orc_remap_cubic_u8(const uint8_t* src, int sw, int sh, int64_t sstride, int cn,
+                       const float* mapx, const float* mapy, int64_t mstride,
+                       uint8_t* dst, int dw, int dh, int64_t dstride,
+                       int border, const uint8_t* border_value)
+{
+    uint8_t cval[4] = {0, 0, 0, 0};
+    if (!src || !mapx || !mapy || !dst || cn < 1 || cn > 4)
+        return -1;
+    if (!(dw < SHRT_MAX && dh < SHRT_MAX && sw < SHRT_MAX && sh < SHRT_MAX) || sw <= 0 || sh <= 0)
+        return -2;
+    if (border < ORC_BORDER_CONSTANT || border > ORC_BORDER_REFLECT_101)
+        return -3;
+    if (border_value)
+        memcpy(cval, border_value, (size_t)cn);
+    if (!g_ctab_ready)
+        orc_init_ctab();
+    const unsigned width1 = (unsigned)(sw - 3 > 0 ? sw - 3 : 0);
+    const unsigned height1 = (unsigned)(sh - 3 > 0 ? sh - 3 : 0);
+    for (int dy = 0; dy < dh; dy++) {
+        const float* mx = mapx + (int64_t)dy * mstride;
+        const float* my = mapy + (int64_t)dy * mstride;
+        uint8_t* D = dst + (int64_t)dy * dstride;
+        for (int dx = 0; dx < dw; dx++, D += cn) {
+            int qx = orc_cvround_f32(mx[dx] * (float)ORC_INTER_TAB_SIZE);
+            int qy = orc_cvround_f32(my[dx] * (float)ORC_INTER_TAB_SIZE);
+            int sx = orc_sat_short(qx >> ORC_INTER_BITS) - 1;
+            int sy = orc_sat_short(qy >> ORC_INTER_BITS) - 1;
+            const short* w = g_ctab[(qy & 31) * ORC_INTER_TAB_SIZE + (qx & 31)];
+            if ((unsigned)sx < width1 && (unsigned)sy < height1) {
+                const uint8_t* S = src + (int64_t)sy * sstride + (int64_t)sx * cn;
+                for (int k = 0; k < cn; k++) {
+                    int sum = 0;
+                    for (int r = 0; r < 4; r++)
+                        for (int c = 0; c < 4; c++)
+                            sum += S[(int64_t)r * sstride + c * cn + k] * w[r * 4 + c];
+                    D[k] = orc_fixedpt_cast_u8(sum);
+                }
+                continue;
+            }
+            if (border == ORC_BORDER_CONSTANT && (sx >= sw || sx + 4 <= 0 || sy >= sh || sy + 4 <= 0)) {
+                for (int k = 0; k < cn; k++)
+                    D[k] = cval[k];
+                continue;
+            }
+            int x[4], y[4];
+            for (int i = 0; i < 4; i++) {
+                x[i] = orc_border_interpolate(sx + i, sw, border);
+                y[i] = orc_border_interpolate(sy + i, sh, border);
+            }
+            for (int k = 0; k < cn; k++) {
+                int cv = cval[k], sum = cv * ORC_COEF_SCALE;
+                for (int r = 0; r < 4; r++) {
+                    if (y[r] < 0)
+                        continue;
+                    const uint8_t* S = src + (int64_t)y[r] * sstride;
+                    for (int c = 0; c < 4; c++)
+                        if (x[c] >= 0)
+                            sum += (S[x[c] * cn + k] - cv) * w[r * 4 + c];
+                }
+                D[k] = orc_fixedpt_cast_u8(sum);
+            }
+        }
+    }
+    return 0;
+}

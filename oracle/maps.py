@@ -80,3 +80,41 @@ def pitch_map_deg(output_width, output_height, pitch_angle, pano_width, pano_hei
         pano_width,
         pano_height,
     )
+
+
+# ------------------------------------------------------------------------------------------------
+# legacy tool: one combined yaw + pitch rotation, one remap
+#   /root/reference/app/legacy/panorama_to_plane.py ("L"): get_rotation_matrix L:21-45,
+#   precompute_mapping L:47-157.  Pinned by tests/golden/legacy_maps_golden.npz
+#   (tests/golden/make_golden_legacy.py imports the reference's functions).
+# ------------------------------------------------------------------------------------------------
+def legacy_rotation_matrix(yaw_radian, pitch_radian):
+    """L:21-45: float32 R_pitch @ R_yaw (np.dot of two float32 3x3 arrays)."""
+    cy, sy = np.cos(yaw_radian), np.sin(yaw_radian)
+    cp, sp = np.cos(pitch_radian), np.sin(pitch_radian)
+    R_yaw = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], dtype=np.float32)  # L:32-36
+    R_pitch = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]], dtype=np.float32)  # L:38-42
+    return np.dot(R_pitch, R_yaw)  # L:45
+
+
+def legacy_map(W, H, FOV_rad, yaw_radian, pitch_radian, pano_width, pano_height):
+    """(U, V) of L:47-157, each (H, W) float32.  Arguments as L:48."""
+    focal = (0.5 * W) / np.tan(FOV_rad / 2)  # L:95
+    u, v = np.meshgrid(np.arange(W), np.arange(H), indexing="xy")  # L:98
+    u = u.astype(np.float32)  # L:101-102
+    v = v.astype(np.float32)
+    x = u - (W / 2.0)  # L:107
+    y = (H / 2.0) - v  # L:108
+    z = np.full_like(x, focal, dtype=np.float32)  # L:109
+    norm = np.sqrt(x**2 + y**2 + z**2)  # L:113
+    vec = np.stack((x / norm, y / norm, z / norm), axis=0)  # L:114-116, L:122
+    R = legacy_rotation_matrix(yaw_radian, pitch_radian)  # L:121
+    x_rot, y_rot, z_rot = (R @ vec.reshape(3, -1)).reshape(3, H, W)  # L:123-125
+    with np.errstate(invalid="ignore"):
+        theta = np.arccos(z_rot).astype(np.float32)  # L:130
+    phi = (np.arctan2(y_rot, x_rot) % TWO_PI).astype(np.float32)  # L:145
+    U = (phi * pano_width) / TWO_PI  # L:157-158
+    V = (theta * pano_height) / np.pi
+    U = np.clip(U, 0, pano_width - 1).astype(np.float32)  # L:161-162
+    V = np.clip(V, 0, pano_height - 1).astype(np.float32)
+    return U, V

@@ -33,8 +33,8 @@ def test_legacy_panorama_to_plane_entry_point(gpu, pkg, synth):
     assert got.shape == (200, 320, 3) and got.dtype == np.uint8
     assert np.array_equal(got, cpu_ref.panorama_to_plane(pano, U, V))
     assert np.array_equal(pkg.interpolate_color(U, V, pano, "bilinear"), got)
-    with pytest.raises(NotImplementedError):
-        pkg.interpolate_color(U, V, pano, "bicubic")
+    # an unknown method name falls back to bilinear, as the reference's dict.get(method, INTER_LINEAR) does (L:177)
+    assert np.array_equal(pkg.interpolate_color(U, V, pano, "no such method"), got)
 
 
 def test_legacy_path_equals_single_stage_of_current_path(gpu, pkg, synth):
