@@ -19,6 +19,8 @@ BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_1
 INTER_NEAREST, INTER_LINEAR, INTER_CUBIC = 0, 1, 2
 FLAG_KEEP_COORDS = 1
 FLAG_CACHE_COORDS = 2
+FLAG_PIXELS_F32 = 4   # opt-in float pixel path (beyond the reference): one float32 resample per view
+FLAG_PIXELS_F16 = 8   # the same with the 2x2 blend in packed float16
 
 # every symbol include/p2p_hip.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (
@@ -247,7 +249,7 @@ def release_cache():
     _pool.trim()
 
 
-def remap_views(pano, yaw_deg, pitch_deg, fov_deg, ow, oh, device=0, pinned=False):
+def remap_views(pano, yaw_deg, pitch_deg, fov_deg, ow, oh, device=0, pinned=False, flags=0):
     """p2p_remap_views_u8 -> uint8 [n_yaw][n_pitch][oh][ow][3] (in page-locked memory if pinned)."""
     pano = as_image(pano, "pano_image")
     yaw, pitch = _i32(yaw_deg), _i32(pitch_deg)
@@ -256,7 +258,7 @@ def remap_views(pano, yaw_deg, pitch_deg, fov_deg, ow, oh, device=0, pinned=Fals
     out = pinned_empty(shape) if pinned and yaw.size and pitch.size else np.empty(shape, dtype=np.uint8)
     check(lib().p2p_remap_views_u8(pano.ctypes.data, pw, ph, pano.strides[0],
                                    yaw.ctypes.data, yaw.size, pitch.ctypes.data, pitch.size,
-                                   int(fov_deg), int(ow), int(oh), out.ctypes.data, int(device), 0))
+                                   int(fov_deg), int(ow), int(oh), out.ctypes.data, int(device), int(flags)))
     return out
 
 

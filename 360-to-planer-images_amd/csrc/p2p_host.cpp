@@ -467,6 +467,19 @@ int p2p_job_run(p2p_job* j)
     // coordinates, later launches of the job load them -- the reference's pitch_mapping_cache (P:62-73)
     const bool use_cache = (j->d.flags & P2P_FLAG_CACHE_COORDS) && j->coords_valid && !j->host_maps;
     const int mapsrc = j->host_maps ? 1 : (use_cache ? 2 : 0);
+    if (j->d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)) {
+        // opt-in float pixel path (beyond the reference): one float resample per view, see float_views_kernel
+        if (j->host_maps)
+            return fail(P2P_ERR_STATE, "the float pixel path evaluates its own maps; caller maps are not supported");
+        if (timed)
+            HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
+        HIP_TRY(p2p::launch_float_views(P, j->d_yaw_rad, (j->d.flags & P2P_FLAG_PIXELS_F16) != 0, j->ctx->stream));
+        if (timed)
+            HIP_TRY(hipEventRecord(j->ev_ring[2 * slot + 1], j->ctx->stream));
+        j->runs++;
+        j->ran = true;
+        return P2P_OK;
+    }
     P.plan = j->d_plan;
     P.plan_count = j->d_plan_count;
     P.plan_flag = j->d_plan_flag;

@@ -118,15 +118,21 @@ def _int_angle(value, what):
 _PINNED = os.environ.get("P2P_PINNED", "1") != "0"
 
 
-def process_views(pano_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg=90, device=None):
+_PIXEL_PATHS = {"u8": 0, "f32": _native.FLAG_PIXELS_F32, "f16": _native.FLAG_PIXELS_F16}
+
+
+def process_views(pano_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg=90, device=None,
+                  pixel_path="u8"):
     """All yaws x pitches of one panorama in one kernel launch.
     Returns uint8 [n_yaw][n_pitch][output_height][output_width][3]; the array lives in page-locked host
-    memory (pooled; P2P_PINNED=0 for ordinary memory) so that the copy back from the GPU is one DMA."""
+    memory (pooled; P2P_PINNED=0 for ordinary memory) so that the copy back from the GPU is one DMA.
+    pixel_path: "u8" = the reference's arithmetic (two fixed-point cv2.remap stages, the default and the only
+    parity mode); "f32" / "f16" = the opt-in single float resample with wrap-around (not in the reference)."""
     yaws = [_int_angle(y, "yaw angle") for y in yaw_angles]
     pitches = [_int_angle(p, "pitch angle") for p in pitch_angles]
     return _native.remap_views(pano_image, yaws, pitches, _int_angle(fov_deg, "FOV"),
                                output_width, output_height, _DEVICE if device is None else device,
-                               pinned=_PINNED)
+                               pinned=_PINNED, flags=_PIXEL_PATHS[pixel_path])
 
 
 def process_yaw_and_pitchs(pano_image, yaw_angle, pitch_angles, output_width, output_height, fov_deg=90):

@@ -169,6 +169,9 @@ def main():
                     help="opt-in coordinate cache (P2P_FLAG_CACHE_COORDS): the first launch evaluates the pitch "
                          "maps, later launches load the stored coordinates, as the reference's "
                          "pitch_mapping_cache does across yaws and images; default off = maps evaluated in every launch")
+    ap.add_argument("--pixel-path", default="u8", choices=["u8", "f32", "f16"],
+                    help="u8: the reference's two fixed-point remap stages (default; the parity path). "
+                         "f32 / f16: the opt-in single float resample, which the reference does not have")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -194,7 +197,8 @@ def main():
 
     ctx = nat.Context(dist.local_rank)
     job = nat.Job(ctx, w["pw"], w["ph"], npg, w["yaws"], w["pitches"], w["fov"], w["ow"], w["oh"],
-                  flags=nat.FLAG_CACHE_COORDS if args.cache_coords else 0)
+                  flags=(nat.FLAG_CACHE_COORDS if args.cache_coords else 0) |
+                        {"u8": 0, "f32": nat.FLAG_PIXELS_F32, "f16": nat.FLAG_PIXELS_F16}[args.pixel_path])
     for i in range(npg):
         # weak scaling: panorama index = rank * panos_per_gpu + i, seed 1000 + index
         job.set_pano(i, synth.synth_pano(w["pw"], w["ph"], 1000 + dist.rank * npg + i, args.kind))
@@ -243,12 +247,12 @@ def main():
                   else "Mpix/s remapped (%s)" % args.workload,
         "value": value, "unit": "Mpix/s", "n_gpus": dist.world, "steps": steps, "warmup": args.warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "vs_baseline": None, "dtype": args.pixel_path, "data": "synthetic",
         "config": {"workload": w["name"], "panos_per_gpu": npg, "views_per_gpu": views_per_rank,
                    "maps": args.maps + ("+coordinate cache" if args.cache_coords else ""), "pano_kind": args.kind, "sharding": "independent panoramas per rank, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
-                     "kernel": "remap_views_kernel", "kernel_ms_avg": k_avg_s * 1e3,
+                     "kernel": "remap_views_kernel" if args.pixel_path == "u8" else "float_views_kernel", "kernel_ms_avg": k_avg_s * 1e3,
                      "kernel_ms_sample": {"n": int(sample), "mean": float(kms.mean()), "min": float(kms.min()),
                                           "max": float(kms.max()), "how": "own HIP event pair per launch, after the timed region"},
                      "algorithmic_bytes_per_launch": b_alg},

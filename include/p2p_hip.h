@@ -52,10 +52,17 @@ enum {
     P2P_FLAG_DEFAULT = 0,
     P2P_FLAG_KEEP_COORDS = 1,  /* keep the quantised pitch-stage coordinates the kernel used
                                   (readable with p2p_job_get_coords); for parity tests */
-    P2P_FLAG_CACHE_COORDS = 2  /* jobs only: the first p2p_job_run evaluates the pitch maps in-kernel and
+    P2P_FLAG_CACHE_COORDS = 2, /* jobs only: the first p2p_job_run evaluates the pitch maps in-kernel and
                                   stores the quantised coordinates; later runs of the job load them
                                   instead of re-evaluating -- the reference's pitch_mapping_cache (P:17-18,
                                   P:62-73), which it keeps across yaws AND images.  Off by default. */
+    /* Float pixel path, opt-in and BEYOND the reference (BASELINE config 5's "fp16 pixel path"):
+       one float resample per view instead of two fixed-point ones -- the pitch map's coordinate shifted by
+       yaw * pw / 360 with true wrap-around at the seam, no 1/32-pixel quantisation, no uint8 intermediate;
+       the 2x2 blend in float32 or packed float16, rounded to uint8 once.  Not comparable bit for bit with
+       cv2.remap; within 1-2 levels of the exact path on band-limited panoramas. */
+    P2P_FLAG_PIXELS_F32 = 4,
+    P2P_FLAG_PIXELS_F16 = 8
 };
 
 const char* p2p_version(void);
