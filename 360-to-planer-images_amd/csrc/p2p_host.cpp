@@ -166,9 +166,15 @@ int choose_pairs_per_block(const p2p_job_desc& d)
     if (z < 1) z = 1;
     if (z > n_pairs) z = n_pairs;
     int ppb = (int)((n_pairs + z - 1) / z);
-    int cap = env_int("P2P_MAX_PAIRS_PER_BLOCK", 16);
+    // measured: 16 pairs per workgroup is the sweet spot (longer loops do not run faster per pair), except
+    // for very large view sets (config 4: 164 k tile-views), where halving the chunk count still pays
+    int cap = env_int("P2P_MAX_PAIRS_PER_BLOCK", base >= 16 * target ? 40 : 16);
     if (cap > 64) cap = 64;
-    if (ppb > cap) ppb = cap;
+    if (cap < 1) cap = 1;
+    if (ppb > cap) {
+        const int chunks = (n_pairs + cap - 1) / cap;  // even chunks instead of full ones plus a remainder
+        ppb = (n_pairs + chunks - 1) / chunks;
+    }
     return ppb < 1 ? 1 : ppb;
 }
 
@@ -275,6 +281,8 @@ int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out)
         return fail(P2P_ERR_INVALID, "need at least one panorama, yaw and pitch");
     if (d.n_pitch > 64 || d.n_yaw > 65535)
         return fail(P2P_ERR_INVALID, "at most 64 pitch angles and 65535 yaw angles per job (got %d, %d)", d.n_pitch, d.n_yaw);
+    if (d.n_panos >= (1 << 26))
+        return fail(P2P_ERR_INVALID, "at most 2^26 - 1 panoramas per job");
     if ((unsigned long long)d.n_panos * d.n_yaw * d.n_yaw >= (1ull << 32))
         return fail(P2P_ERR_INVALID, "n_panos * n_yaw^2 must stay below 2^32 (got %d panoramas, %d yaws)", d.n_panos, d.n_yaw);
     for (int i = 0; i < d.n_pitch; ++i)

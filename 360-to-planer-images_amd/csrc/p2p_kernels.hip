@@ -481,6 +481,8 @@ struct PairCtx {      // uniform per (tile, pair); precomputed per lane at tile 
     uint32_t f;       // uniform weight
     int cf0;          // rot column of source column 4 * g0
     int yaw_i;
+    int pano;         // panorama index
+    int korig;        // pair index inside the chunk (its output slot is pair0 + korig)
 };
 
 // MAPSRC: 0 = coordinates computed in-kernel (pitch_map_eval), 1 = caller float maps, 2 = the job's
@@ -805,11 +807,30 @@ __device__ __forceinline__ void views_body(
                   (uint32_t)per_column << 23 | (uint32_t)yd.f << 24;
             cw1 = (uint32_t)(ngroups - g0) | (uint32_t)yi << 16;
             cw2 = 4 * g0 - yd.s;
+            cw3 |= k << 26;  // n_panos < 2^26 (host check): the chunk-local pair index rides along
             ctx_plain = yd.mode != 2 && !per_column;
         }
     }
-    // every pair of this chunk plain -> the tight loop below; otherwise the general loop
-    const bool all_plain = __ballot(!ctx_plain) == 0ull;
+    // Plain pairs (the common case) run in the tight loop below, the others in the general loop after it:
+    // the contexts are sorted plain-first across the lanes, so that one odd yaw in a chunk (6 of the 360
+    // one-degree yaws on 8192 columns have per-column weights) does not slow its whole chunk down.
+    const int npairs = pair1 - pair0;
+    int nplain;
+    {
+        const int k = t & 63;
+        const bool valid = k < npairs;
+        const unsigned long long plain_mask = __ballot(valid && ctx_plain);
+        const unsigned long long other_mask = __ballot(valid && !ctx_plain);
+        nplain = __popcll(plain_mask);
+        if (other_mask != 0ull) {
+            const unsigned long long below = (1ull << k) - 1ull;
+            const int r = !valid ? k : (ctx_plain ? __popcll(plain_mask & below) : nplain + __popcll(other_mask & below));
+            cw0 = (uint32_t)__builtin_amdgcn_ds_permute(4 * r, (int)cw0);
+            cw1 = (uint32_t)__builtin_amdgcn_ds_permute(4 * r, (int)cw1);
+            cw2 = __builtin_amdgcn_ds_permute(4 * r, cw2);
+            cw3 = __builtin_amdgcn_ds_permute(4 * r, cw3);
+        }
+    }
     auto pair_ctx = [&](int k) {
         const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)cw0, k);
         const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)cw1, k);
@@ -822,6 +843,9 @@ __device__ __forceinline__ void views_body(
         c.wrap_g = w1 & 0xFFFFu;
         c.yaw_i = (int)(w1 >> 16);
         c.cf0 = __builtin_amdgcn_readlane(cw2, k);
+        const int w3 = __builtin_amdgcn_readlane(cw3, k);
+        c.pano = w3 & 0x3FFFFFF;
+        c.korig = (int)((uint32_t)w3 >> 26);
         return c;
     };
 
@@ -847,14 +871,13 @@ __device__ __forceinline__ void views_body(
         }
     };
 
-    if (all_plain) {
+    if (nplain > 0) {
         // ---- tight loop: no per-pair mode branches, source pieces ping-pong between two register
         // sets (pair loop unrolled by two), so nothing is copied and nothing is re-decided per pair ----
-        const int npairs = pair1 - pair0;
         auto load_pieces = [&](int k, Q16 (&qq)[VIEWS_SLOTS]) {
             const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)cw0, k);
             const uint32_t wrap_g = (uint32_t)__builtin_amdgcn_readlane((int)cw1, k) & 0xFFFFu;
-            const uint8_t* __restrict__ S = src + (size_t)__builtin_amdgcn_readlane(cw3, k) * P.pano_stride;
+            const uint8_t* __restrict__ S = src + (size_t)(__builtin_amdgcn_readlane(cw3, k) & 0x3FFFFFF) * P.pano_stride;
             const uint32_t goff = w0 & 0xFFFFFu;
 #pragma unroll
             for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
@@ -922,44 +945,43 @@ __device__ __forceinline__ void views_body(
                 ta[j][2] = lo[0];
                 ta[j][3] = lo[1];
             }
-            if (k + 1 < npairs)
+            if (k + 1 < nplain)
                 load_pieces(k + 1, qnext);
             uint32_t pix[PXT];
 #pragma unroll
             for (int j = 0; j < PXT; ++j)
                 pix[j] = blend4_packed(ta[j][0], ta[j][1], ta[j][2], ta[j][3], tw[j]);
-            store_pixels(pair0 + k, pix);
+            store_pixels(pair0 + (int)((uint32_t)__builtin_amdgcn_readlane(cw3, k) >> 26), pix);
         };
         Q16 qa[VIEWS_SLOTS], qb[VIEWS_SLOTS];
         load_pieces(0, qa);
-        for (int k = 0; k < npairs; k += 2) {
+        for (int k = 0; k < nplain; k += 2) {
             half(k, qa, qb, tile4[0], 0u);
-            if (k + 1 >= npairs)
+            if (k + 1 >= nplain)
                 break;
             half(k + 1, qb, qa, tile4[1], (uint32_t)sizeof(tile4[0]));
         }
-        return;
+        if (nplain == npairs)
+            return;
+        __syncthreads();  // the last plain pair's taps are read before the general loop writes the buffers
     }
 
-    PairCtx pc = pair_ctx(0);
+    PairCtx pc = pair_ctx(nplain);
     Q16 q[VIEWS_SLOTS];
     uint32_t fw[VIEWS_SLOTS];
     if (pc.fast)
-        issue_loads(pc, src + (size_t)pano_i * P.pano_stride, q, fw);
+        issue_loads(pc, src + (size_t)pc.pano * P.pano_stride, q, fw);
 
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0;
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     (void)st0; (void)st1; (void)st2; (void)st3; (void)st4; (void)st5; (void)st6; (void)acc;
     int buf = 0;
-    for (int pair = pair0; pair < pair1; ++pair) {
+    for (int ki = nplain; ki < npairs; ++ki) {
         STAMP(st0);
-        const uint8_t* __restrict__ S = src + (size_t)pano_i * P.pano_stride;
-        const int cur_yaw = yaw_i;
-        if (++yaw_i == P.n_yaw) {
-            yaw_i = 0;
-            ++pano_i;
-        }
-        const bool has_next = pair + 1 < pair1;
+        const uint8_t* __restrict__ S = src + (size_t)pc.pano * P.pano_stride;
+        const int cur_yaw = pc.yaw_i;
+        const int pair = pair0 + pc.korig;
+        const bool has_next = ki + 1 < npairs;
         uint32_t pix[PXT];
 
         if (pc.fast) {
@@ -1020,9 +1042,9 @@ __device__ __forceinline__ void views_body(
             STAMP(st3);
             // the next pair's source loads go out now; their latency hides behind stage 2
             if (has_next) {
-                pc = pair_ctx(pair + 1 - pair0);
+                pc = pair_ctx(ki + 1);
                 if (pc.fast)
-                    issue_loads(pc, src + (size_t)pano_i * P.pano_stride, q, fw);
+                    issue_loads(pc, src + (size_t)pc.pano * P.pano_stride, q, fw);
             }
 #ifdef P2P_STAMPS
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1036,9 +1058,9 @@ __device__ __forceinline__ void views_body(
         } else {
             direct_pixels(S, cur_yaw, pix);
             if (has_next) {
-                pc = pair_ctx(pair + 1 - pair0);
+                pc = pair_ctx(ki + 1);
                 if (pc.fast)
-                    issue_loads(pc, src + (size_t)pano_i * P.pano_stride, q, fw);
+                    issue_loads(pc, src + (size_t)pc.pano * P.pano_stride, q, fw);
             }
         }
         store_pixels(pair, pix);
