@@ -157,8 +157,9 @@ def load_traffic(workload):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=2000,
+                    help="timed launches (default 2000 = 0.3 s of GPU time on config 2: long enough for the clock to settle)")
+    ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--panos-per-gpu", type=int, default=1)
     ap.add_argument("--maps", default="fused", choices=["fused", "caller"],

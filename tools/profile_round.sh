@@ -15,13 +15,15 @@ timeout 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum --
 cd $ROOT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 - <<PY
-import csv, glob, json, os
+import csv, glob, json, os, re
 out = "$OUT"
 def counters(d, key):
+    # key "remap_views_kernel" = the drawing instance <MAPSRC 0, MODE 0> only (the plan pass <0, 1> runs once per job)
+    pat = re.compile(r"remap_views_kernel<0,\s*0>") if key == "remap_views_kernel" else re.compile(re.escape(key))
     vals = {}
     for f in glob.glob(os.path.join(out, d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if key in row["Kernel_Name"]:
+            if pat.search(row["Kernel_Name"]):
                 vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in vals.items()}
 res = {"views": {}, "calib": {}}
