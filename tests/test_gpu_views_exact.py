@@ -189,11 +189,41 @@ def test_randomised_configurations(gpu, synth):
         assert np.array_equal(got, want), dict(case=case, pw=pw, ph=ph, ow=ow, oh=oh, fov=fov, yaws=yaws, pitches=pitches)
 
 
+def test_randomised_large_panoramas_mixed_chunks_and_sub_tiles(gpu, synth):
+    # larger sources (footprints that outgrow LDS at low pitch), many yaws per workgroup incl. the odd ones that
+    # leave the tight loop, several panoramas per job
+    rng = np.random.default_rng(777)
+    for case in range(6):
+        pw = int(rng.choice([2048, 4096, 8192]))
+        ph = pw // 2
+        ow, oh = int(rng.integers(200, 700)), int(rng.integers(100, 400))
+        fov = int(rng.choice([60, 90, 110]))
+        yaws = sorted({int(v) for v in rng.integers(0, 360, size=int(rng.integers(13, 40)))} | {14, 59})
+        pitches = [int(v) for v in rng.integers(15, 166, size=2)]
+        n_panos = int(rng.integers(1, 3))
+        panos = [synth.synth_pano(pw, ph, 6000 + 10 * case + i, "N") for i in range(n_panos)]
+        rows, U, V = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
+        ctx = gpu.Context(0)
+        job = gpu.Job(ctx, pw, ph, n_panos, yaws, pitches, fov, ow, oh)
+        for i, p in enumerate(panos):
+            job.set_pano(i, p)
+        job.set_maps(rows, U, V)
+        job.run()
+        for i, p in enumerate(panos):
+            got = job.get_views(i)
+            # the oracle is slow at these sizes: check three of the yaws
+            for yi in (0, len(yaws) // 2, len(yaws) - 1):
+                want = oracle_views(p, [yaws[yi]], pitches, ow, oh, fov)
+                assert np.array_equal(got[yi], want[0]), dict(case=case, pw=pw, ow=ow, oh=oh, fov=fov, yaw=yaws[yi], pitches=pitches)
+        job.close()
+        ctx.close()
+
+
 @pytest.mark.parametrize("pitch", [12, 30, 45, 56, 135, 150, 168])
 def test_large_footprints_split_into_sub_blocks(gpu, synth, pitch):
-    """Towards a pole a 32x16 tile's footprint outgrows the LDS buffers; the kernel then walks the tile as
-    2..16 sub-blocks with their own footprints (and gathers directly only where a pole sits inside the
-    sub-block).  4096x2048 -> 960x540 has all of those cases for these pitches; several yaw kinds per launch."""
+    """Towards a pole a 32x16 tile's footprint outgrows the LDS buffers; the kernel then draws the tile as
+    32x8 or 16x8 sub-tiles with their own footprints (and gathers directly only where a pole sits inside a
+    sub-tile).  4096x2048 -> 960x540 has all of those cases for these pitches; several yaw kinds per launch."""
     pano = synth.synth_pano(4096, 2048, 1200 + pitch, "N")
     _check(gpu, pano, [0, 45, 77, 200], [pitch], 960, 540)
 
