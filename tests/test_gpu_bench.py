@@ -47,3 +47,20 @@ def test_bench_under_torchrun_with_rccl_group(gpu):
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     line = _last_json(r.stdout)
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak"
+
+
+def test_two_ranks_on_one_gpu_dry_run(gpu):
+    """The N > 1 path with real kernels: two ranks share the one GPU of the box (gloo for the barrier and the max
+    over ranks, because RCCL refuses two ranks on one device).  Whole-job value = both ranks' pixels over the
+    slower rank's time."""
+    env = dict(os.environ, P2P_BENCH_BACKEND="gloo", P2P_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           "bench.py", "--gpus", "2", "--workload", "cfg1", "--steps", "20", "--warmup", "5"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["cpu_baseline"] is None
+    assert line["config"]["views_per_gpu"] == 1 and line["value"] > 0
