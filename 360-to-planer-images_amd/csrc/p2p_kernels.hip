@@ -643,15 +643,47 @@ __device__ __forceinline__ void views_body(
                     atomicMax(&half_box[j][3], (uint32_t)(iy[j] + 1));
                 }
             __syncthreads();
-            if (t == 0) {
-                bool halves = true;
-                for (int h = 0; h < 2; ++h)
-                    if (half_box[h][1] != 0u) {
-                        int g;
-                        const int n = items_of((int)half_box[h][0] - 1, (int)half_box[h][1] - 1,
-                                               (int)half_box[h][2] - 1, (int)half_box[h][3] - 1, g);
-                        halves = halves && g <= 255 && n <= LDS_ITEMS_CAP;
+            // a half is fine if its footprint rectangle fits, or if the items its taps can touch do (the
+            // sub-tile pass then keeps a compacted item list, see there); count those with the same bitmap
+            bool halves = true;
+            for (int h = 0; h < 2; ++h) {
+                if (half_box[h][1] == 0u)
+                    continue;  // no live pixel
+                const int hc0 = (int)half_box[h][0] - 1, hr0 = (int)half_box[h][2] - 1;
+                int g;
+                const int n = items_of(hc0, (int)half_box[h][1] - 1, hr0, (int)half_box[h][3] - 1, g);
+                if (g <= 255 && n <= LDS_ITEMS_CAP)
+                    continue;
+                if (n > 65536 || g >= 65536) {
+                    halves = false;
+                    continue;
+                }
+                uint32_t* bm = reinterpret_cast<uint32_t*>(&tile4[0][0]);
+                __syncthreads();
+                for (int i = 0; i < 8; ++i)
+                    bm[t * 8 + i] = 0u;
+                if (t == 0)
+                    half_box[h][1] = 0u;  // reused as the counter below (its value is already in n, g)
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < PXT; ++j)
+                    if (j == h && inrange[j]) {
+                        const uint32_t b0 = (uint32_t)((iy[j] - hr0) * g + ((ix[j] - hc0) >> 2));
+                        for (int dr = 0; dr < 2; ++dr)
+                            for (int dg = 0; dg < 2; ++dg) {
+                                const uint32_t b = b0 + (uint32_t)(dr * g + dg);
+                                atomicOr(&bm[b >> 5], 1u << (b & 31u));
+                            }
                     }
+                __syncthreads();
+                uint32_t cnt = 0u;
+                for (int i = 0; i < 8; ++i)
+                    cnt += (uint32_t)__popc(bm[t * 8 + i]);
+                atomicAdd(&half_box[h][1], cnt);
+                __syncthreads();
+                halves = halves && half_box[h][1] <= (uint32_t)LDS_ITEMS_CAP;
+            }
+            if (t == 0) {
                 uint2 e[4];
                 int n = 0;
                 for (int sy = 0; sy < 2; ++sy)
@@ -739,7 +771,103 @@ __device__ __forceinline__ void views_body(
         }
     };
 
-    if (!fast_tile) {
+    // ---- sub-tile pass only: a footprint RECTANGLE too large for the LDS buffers is usually sparse (towards a
+    // pole the rows stretch, neighbouring pixels hit items far apart).  Mark the items the taps can touch in a
+    // bitmap (each pixel: items g0, g0 + 1 of rows rr, rr + 1 -- every alignment joff = 0..3 stays inside them),
+    // rank them, and keep only those in LDS: slot k of the buffer holds the k-th needed item, and a pixel's two
+    // consecutive items are consecutive slots, so the tap reads stay "two dwords at base + 4 * joff".
+    // The tile buffers themselves serve as scratch: bitmap 8 KB | per-word ranks 4 KB | item list 2 KB | scan 1 KB.
+    bool list_tile = false;
+    int n_need = 0;
+    uint32_t list_item[VIEWS_SLOTS] = {0u, 0u};
+    uint32_t list_tap_up[PXT], list_tap_lo[PXT];
+#pragma unroll
+    for (int j = 0; j < PXT; ++j)
+        list_tap_up[j] = list_tap_lo[j] = 0u;
+    if (MODE == 2) {
+        constexpr int MAX_BITS = 65536, WPT = MAX_BITS / 32 / VIEWS_BLOCK;  // 8 bitmap words per thread
+        const int Ht = r1 - r0 + 2;
+        // (only when the rectangle does not fit: for rectangles that fit, building the list costs more than the
+        // empty items it saves at 12 yaws per workgroup -- measured)
+        if (lds_ok && !fast_tile && Ht * G <= MAX_BITS && G < 65536) {
+            uint32_t* bm = reinterpret_cast<uint32_t*>(&tile4[0][0]);
+            unsigned short* wpre = reinterpret_cast<unsigned short*>(bm + MAX_BITS / 32);
+            uint32_t* lst = bm + MAX_BITS / 32 + MAX_BITS / 64;
+            uint32_t* scan = lst + LDS_ITEMS_CAP;
+            const int nw = (Ht * G + 31) >> 5;
+#pragma unroll
+            for (int i = 0; i < WPT; ++i)
+                bm[t * WPT + i] = 0u;
+            __syncthreads();
+            uint32_t bit0[PXT];
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) {
+                bit0[j] = 0u;
+                if (live[j]) {
+                    bit0[j] = (uint32_t)((iy[j] - r0) * G + ((ix[j] - c0) >> 2));
+                    for (int dr = 0; dr < 2; ++dr)
+                        for (int dg = 0; dg < 2; ++dg) {
+                            const uint32_t b = bit0[j] + (uint32_t)(dr * G + dg);
+                            atomicOr(&bm[b >> 5], 1u << (b & 31u));
+                        }
+                }
+            }
+            __syncthreads();
+            // ranks: per-thread popcount of its 8 words, block-wide exclusive scan, then per word
+            uint32_t wv[WPT];
+            uint32_t mine = 0u;
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                wv[i] = t * WPT + i < nw ? bm[t * WPT + i] : 0u;
+                mine += (uint32_t)__popc(wv[i]);
+            }
+            uint32_t incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+                if ((t & 63) >= d)
+                    incl += up;
+            }
+            if ((t & 63) == 63)
+                scan[t >> 6] = incl;
+            __syncthreads();
+            uint32_t base = incl - mine;
+            for (int w = 0; w < (t >> 6); ++w)
+                base += scan[w];
+            n_need = (int)(scan[0] + scan[1] + scan[2] + scan[3]);
+            if (n_need <= LDS_ITEMS_CAP) {
+#pragma unroll
+                for (int i = 0; i < WPT; ++i) {
+                    if (t * WPT + i < nw)
+                        wpre[t * WPT + i] = (unsigned short)base;
+                    uint32_t v = wv[i];
+                    while (v) {
+                        const int b = __ffs((int)v) - 1;
+                        v &= v - 1u;
+                        lst[base++] = (uint32_t)((t * WPT + i) * 32 + b);
+                    }
+                }
+                __syncthreads();
+                auto rank_of = [&](uint32_t b) {
+                    return (uint32_t)wpre[b >> 5] + (uint32_t)__popc(bm[b >> 5] & ((1u << (b & 31u)) - 1u));
+                };
+#pragma unroll
+                for (int j = 0; j < PXT; ++j)
+                    if (live[j]) {
+                        const uint32_t within = 4u * (uint32_t)((ix[j] - c0) & 3);
+                        list_tap_up[j] = 16u * rank_of(bit0[j]) + within;
+                        list_tap_lo[j] = 16u * rank_of(bit0[j] + (uint32_t)G) + within;
+                    }
+#pragma unroll
+                for (int k = 0; k < VIEWS_SLOTS; ++k)
+                    list_item[k] = t + k * VIEWS_BLOCK < n_need ? lst[t + k * VIEWS_BLOCK] : lst[0];
+                list_tile = true;
+            }
+            __syncthreads();  // the scratch becomes tile storage again
+        }
+    }
+
+    if (!fast_tile && !list_tile) {
         for (int pair = pair0; pair < pair1; ++pair) {
             uint32_t pix[PXT];
             direct_pixels(src + (size_t)pano_i * P.pano_stride, yaw_i, pix);
@@ -757,7 +885,15 @@ __device__ __forceinline__ void views_body(
     const int wave_base = __builtin_amdgcn_readfirstlane(t & ~63);
     uint32_t slot_off[VIEWS_SLOTS];  // (r0 + rr) * src_pitch + 12 * g
     uint32_t slot_g[VIEWS_SLOTS];
-    {
+    const int n_items = (MODE == 2 && list_tile) ? n_need : items;  // LDS slots in use
+    if (MODE == 2 && list_tile) {
+#pragma unroll
+        for (int k = 0; k < VIEWS_SLOTS; ++k) {  // the k-th needed item: rectangle index rr * G + g
+            const uint32_t rr = list_item[k] / (uint32_t)G;
+            slot_g[k] = list_item[k] - rr * (uint32_t)G;
+            slot_off[k] = (uint32_t)(r0 + (int)rr) * (uint32_t)P.src_pitch + 12u * slot_g[k];
+        }
+    } else {
         // item / G by multiply-shift: exact for item * G < 2^20 (item < 512, G < 256)
         const uint32_t magic = ((1u << 20) + (uint32_t)G - 1u) / (uint32_t)G;
 #pragma unroll
@@ -853,7 +989,7 @@ __device__ __forceinline__ void views_body(
                            uint32_t (&fw)[VIEWS_SLOTS]) {
 #pragma unroll
         for (int k = 0; k < VIEWS_SLOTS; ++k) {
-            if (wave_base + k * VIEWS_BLOCK < items) {
+            if (wave_base + k * VIEWS_BLOCK < n_items) {
                 uint32_t off = slot_off[k] + pc.goff;
                 if (slot_g[k] >= pc.wrap_g)
                     off -= row_bytes;
@@ -881,7 +1017,7 @@ __device__ __forceinline__ void views_body(
             const uint32_t goff = w0 & 0xFFFFFu;
 #pragma unroll
             for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
-                if (wave_base + sl * VIEWS_BLOCK < items) {
+                if (wave_base + sl * VIEWS_BLOCK < n_items) {
                     uint32_t off = slot_off[sl] + goff;
                     if (slot_g[sl] >= wrap_g)
                         off -= row_bytes;
@@ -892,7 +1028,7 @@ __device__ __forceinline__ void views_body(
             const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)cw0, k) >> 24;
 #pragma unroll
             for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
-                if (wave_base + sl * VIEWS_BLOCK < items) {
+                if (wave_base + sl * VIEWS_BLOCK < n_items) {
                     // the piece holds source pixels 0..4 at byte offsets 0, 3, 6, 9, 12; one v_perm_b32
                     // both fetches a pixel across the dword seam and masks it
                     // (selector bytes 0-3 pick the second operand's bytes, 4-7 the first's, 0x0c is zero)
@@ -926,8 +1062,8 @@ __device__ __forceinline__ void views_body(
         uint32_t tap_up[PXT], tap_lo[PXT];
 #pragma unroll
         for (int j = 0; j < PXT; ++j) {
-            tap_up[j] = 4u * (uint32_t)tap[j];
-            tap_lo[j] = 4u * (uint32_t)(tap[j] + rowdw);
+            tap_up[j] = (MODE == 2 && list_tile) ? list_tap_up[j] : 4u * (uint32_t)tap[j];
+            tap_lo[j] = (MODE == 2 && list_tile) ? list_tap_lo[j] : 4u * (uint32_t)(tap[j] + rowdw);
         }
         auto half = [&](int k, const Q16 (&qcur)[VIEWS_SLOTS], Q16 (&qnext)[VIEWS_SLOTS], uint4* tl4, uint32_t buf_bytes) {
             stage1(k, qcur, tl4);
@@ -988,7 +1124,7 @@ __device__ __forceinline__ void views_body(
             uint4* tl4 = tile4[buf];
 #pragma unroll
             for (int k = 0; k < VIEWS_SLOTS; ++k) {
-                if (wave_base + k * VIEWS_BLOCK < items) {
+                if (wave_base + k * VIEWS_BLOCK < n_items) {
                     const uint32_t p0 = q[k].d[0];
                     const uint32_t p1 = __builtin_amdgcn_alignbyte(q[k].d[1], q[k].d[0], 3);
                     const uint32_t p2 = __builtin_amdgcn_alignbyte(q[k].d[2], q[k].d[1], 2);
@@ -1033,11 +1169,15 @@ __device__ __forceinline__ void views_body(
             uint32_t ta[PXT][4];
 #pragma unroll
             for (int j = 0; j < PXT; ++j) {
-                const int b = tap[j] + joff;
+                int b = tap[j] + joff, b2 = b + rowdw;
+                if (MODE == 2 && list_tile) {
+                    b = (int)(list_tap_up[j] >> 2) + joff;
+                    b2 = (int)(list_tap_lo[j] >> 2) + joff;
+                }
                 ta[j][0] = tl[b];
                 ta[j][1] = tl[b + 1];
-                ta[j][2] = tl[b + rowdw];
-                ta[j][3] = tl[b + rowdw + 1];
+                ta[j][2] = tl[b2];
+                ta[j][3] = tl[b2 + 1];
             }
             STAMP(st3);
             // the next pair's source loads go out now; their latency hides behind stage 2
