@@ -5,7 +5,11 @@
 //     pitch map          P:114-175     -> pitch_map_eval (f32), pitch_map_kernel
 //     cv2.remap x2       P:192-199,212-218 -> remap_views_kernel (both stages fused, fixed point)
 //   L = /root/reference/app/legacy/panorama_to_plane.py
-//     panorama_to_plane  L:159-194     -> remap_maps_kernel (generic cv2.remap INTER_LINEAR, u8)
+//     precompute_mapping L:47-157      -> rot_map_kernel (combined yaw + pitch rotation, f32)
+//     panorama_to_plane  L:159-194     -> remap_maps_kernel (generic cv2.remap INTER_LINEAR, u8; 3-channel images
+//                                         go through remap_views_kernel with an identity yaw stage),
+//                                         remap_maps_nearest_kernel, remap_maps_cubic_kernel + cubic_tab_kernel
+//   not in the reference (opt-in): float_views_kernel (one float32 / float16 resample per view, wrap-around)
 // The fixed-point arithmetic is OpenCV 4.10's (imgwarp.cpp remapBilinear, INTER_BITS = 5,
 // INTER_REMAP_COEF_BITS = 15); see DESIGN.md "Arithmetic contract".
 //
