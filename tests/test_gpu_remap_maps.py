@@ -72,3 +72,29 @@ def test_three_channel_maps_through_the_view_kernel(gpu, mode):
     yy, xx = np.mgrid[0:70, 0:90].astype(np.float32)
     Us, Vs = (3.0 + xx * 0.97 + yy * 0.05).astype(np.float32), (2.0 + yy * 0.8 + xx * 0.03).astype(np.float32)
     assert np.array_equal(gpu.remap_maps(img, Us, Vs, border=mode), cpu_ref.remap(img, Us, Vs, mode))
+
+
+@pytest.mark.parametrize("mode", [cpu_ref.BORDER_CONSTANT, cpu_ref.BORDER_REFLECT])
+def test_scattered_maps_on_a_large_image(gpu, synth, mode):
+    """Random in-range coordinates on a big image: every tile's footprint rectangle is the whole image, so the
+    view kernel's plan turns the tiles into sub-tiles with compacted item lists (or direct gathers) -- the
+    result must still be cv2.remap's, byte for byte."""
+    rng = np.random.default_rng(900 + mode)
+    img = synth.synth_pano(2048, 1024, 2300, "N")
+    U = rng.uniform(0.0, 2046.0, size=(128, 256)).astype(np.float32)
+    V = rng.uniform(0.0, 1022.0, size=(128, 256)).astype(np.float32)
+    # a smooth region in the middle (fits the LDS scheme) and a stripe that leaves the image (border taps)
+    yy, xx = np.mgrid[0:48, 0:96].astype(np.float32)
+    U[40:88, 80:176] = 700.0 + 1.3 * xx + 0.1 * yy
+    V[40:88, 80:176] = 300.0 + 1.1 * yy
+    U[100:104, :] += 1500.0
+    got = gpu.remap_maps(img, U, V, border=mode)
+    assert np.array_equal(got, cpu_ref.remap(img, U, V, mode))
+    # the same maps as the pitch stage of the two-stage entry point, two yaws
+    rows = np.stack([maps.yaw_column_table(2048, y) for y in (0, 77)])
+    Uc, Vc = np.clip(U, 0, 2047), np.clip(V, 0, 1023)
+    got2 = gpu.remap_views_maps(img, rows, Uc[None], Vc[None])
+    from _util import oracle_views  # noqa: F401  (kept for symmetry with the other files)
+    for yi, yaw in enumerate((0, 77)):
+        rot = cpu_ref.yaw_stage(img, yaw)
+        assert np.array_equal(got2[yi, 0], cpu_ref.remap(rot, Uc, Vc, cpu_ref.BORDER_CONSTANT))
