@@ -549,9 +549,10 @@ __device__ __forceinline__ void views_body(
         if (inside[j]) {
             const size_t k = ((size_t)pitch_i * P.oh + py) * P.ow + px;
             if (MAPSRC == 2) {
-                const int2 sc = reinterpret_cast<const int2*>(coords)[k];
-                sx = sc.x;
-                sy = sc.y;
+                // streamed once per launch: non-temporal, so that the 8 bytes per pixel do not evict source lines
+                const long long sc = __builtin_nontemporal_load(reinterpret_cast<const long long*>(coords) + k);
+                sx = (int)(uint32_t)sc;
+                sy = (int)(sc >> 32);
             } else {
                 float U, V;
                 if (MAPSRC == 1) {
