@@ -259,6 +259,25 @@ def main():
         job.run()
     kms = job.kernel_ms_last(sample)
 
+    # what a plain device-to-device copy reaches on this GPU right now (read + written bytes per second):
+    # the practical ceiling next to the 8 TB/s specification peak
+    copy_gbs = None
+    try:
+        a = torch.empty(1 << 29, dtype=torch.uint8, device="cuda")
+        b = torch.empty_like(a)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            b.copy_(a)
+        ev0.record()
+        for _ in range(10):
+            b.copy_(a)
+        ev1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 10 * 2 * a.numel() / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+        del a, b
+    except Exception:
+        pass
+
     pix_per_step = views_per_rank * w["ow"] * w["oh"] * dist.world
     value = pix_per_step * steps / elapsed / 1e6
     b_alg = algorithmic_bytes(w, npg)
@@ -276,7 +295,9 @@ def main():
                      "kernel": "remap_views_kernel" if args.pixel_path == "u8" else "float_views_kernel", "kernel_ms_avg": k_avg_s * 1e3,
                      "kernel_ms_sample": {"n": int(sample), "mean": float(kms.mean()), "min": float(kms.min()),
                                           "max": float(kms.max()), "how": "own HIP event pair per launch, after the timed region"},
-                     "algorithmic_bytes_per_launch": b_alg},
+                     "algorithmic_bytes_per_launch": b_alg,
+                     "measured_copy_GBs": copy_gbs,
+                     "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None},
     }
     if dist.rank == 0 and dist.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w)
