@@ -182,20 +182,32 @@ class _PinnedPool:
         self.lock = threading.Lock()
         self.free = {}
         self.idle_bytes = 0
+        self.live_bytes = 0   # handed out and not yet returned
         self.cap = int(os.environ.get("P2P_PINNED_POOL_MB", "2048")) << 20
+        # page-locked memory is a limited resource: beyond this much in use, callers get ordinary arrays
+        self.max_live = int(os.environ.get("P2P_PINNED_MAX_MB", "8192")) << 20
 
     def take(self, nbytes):
         with self.lock:
+            if self.live_bytes + nbytes > self.max_live:
+                raise MemoryError("page-locked memory budget (P2P_PINNED_MAX_MB) exhausted")
+            self.live_bytes += nbytes
             lst = self.free.get(nbytes)
             if lst:
                 self.idle_bytes -= nbytes
                 return lst.pop()
         ptr = ctypes.c_void_p()
-        check(lib().p2p_host_alloc(int(nbytes), ctypes.byref(ptr)))
+        try:
+            check(lib().p2p_host_alloc(int(nbytes), ctypes.byref(ptr)))
+        except Exception:
+            with self.lock:
+                self.live_bytes -= nbytes
+            raise
         return ptr.value
 
     def give(self, ptr, nbytes):
         with self.lock:
+            self.live_bytes -= nbytes
             if self.idle_bytes + nbytes <= self.cap:
                 self.free.setdefault(nbytes, []).append(ptr)
                 self.idle_bytes += nbytes
@@ -255,7 +267,14 @@ def remap_views(pano, yaw_deg, pitch_deg, fov_deg, ow, oh, device=0, pinned=Fals
     yaw, pitch = _i32(yaw_deg), _i32(pitch_deg)
     ph, pw = pano.shape[:2]
     shape = (yaw.size, pitch.size, int(oh), int(ow), 3)
-    out = pinned_empty(shape) if pinned and yaw.size and pitch.size else np.empty(shape, dtype=np.uint8)
+    out = None
+    if pinned and yaw.size and pitch.size:
+        try:
+            out = pinned_empty(shape)
+        except MemoryError:  # budget of page-locked memory in use: an ordinary array is merely slower to fill
+            out = None
+    if out is None:
+        out = np.empty(shape, dtype=np.uint8)
     check(lib().p2p_remap_views_u8(pano.ctypes.data, pw, ph, pano.strides[0],
                                    yaw.ctypes.data, yaw.size, pitch.ctypes.data, pitch.size,
                                    int(fov_deg), int(ow), int(oh), out.ctypes.data, int(device), int(flags)))

@@ -170,7 +170,7 @@ def _to_bgr(rgb):
             dst = _native.pinned_empty(rgb.shape)
             dst[...] = rgb[:, :, ::-1]
             return dst
-        except (_native.P2PError, OSError):
+        except (_native.P2PError, OSError, MemoryError):
             pass
     return np.ascontiguousarray(rgb[:, :, ::-1])
 

@@ -176,3 +176,13 @@ def test_pinned_arrays_behave_like_numpy_arrays(gpu, pkg, synth):
     lst = pkg.process_yaw_and_pitchs(pano, 10, [80], 64, 48)
     del v1
     assert np.array_equal(lst[0], v2[0, 0])
+
+
+def test_pinned_budget_falls_back_to_ordinary_arrays(gpu, synth, monkeypatch):
+    pano = synth.synth_pano(256, 128, 3104, "N")
+    want = gpu.remap_views(pano, [0, 90], [90], 90, 64, 48)
+    monkeypatch.setattr(gpu._pool, "max_live", gpu._pool.live_bytes + 100)   # less than one result
+    got = gpu.remap_views(pano, [0, 90], [90], 90, 64, 48, pinned=True)
+    assert np.array_equal(got, want)
+    with pytest.raises(MemoryError):
+        gpu.pinned_empty((1 << 20,))
