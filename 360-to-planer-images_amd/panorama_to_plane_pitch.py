@@ -221,19 +221,14 @@ def process_single_image(
                            output_height, num_workers, output_format, fov_deg)
 
 
-def _process_decoded_image(input_image, input_image_path, output_dir, yaw_angles, pitch_angles, output_width,
-                           output_height, num_workers, output_format, fov_deg, device=None):
-    from concurrent.futures import ThreadPoolExecutor
-
-    from tqdm import tqdm
-
+def _submit_views(executor, input_image, input_image_path, output_dir, yaw_angles, pitch_angles, output_width,
+                  output_height, output_format, fov_deg, device=None):
+    """One kernel launch for every yaw and pitch of the image, then one write task per yaw on `executor`.
+    Returns [(yaw_angle, future-or-exception)], to be drained with _drain_views."""
     input_image_path = Path(input_image_path)
     output_dir = Path(output_dir)
     base_name = input_image_path.stem
     yaw_angles = list(yaw_angles)
-
-    views = None
-    error = None
     try:
         if device is None:
             views = process_views(input_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg)
@@ -241,23 +236,32 @@ def _process_decoded_image(input_image, input_image_path, output_dir, yaw_angles
             views = process_views(input_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg,
                                   device=device)
     except Exception as e:  # the reference reports task failures per yaw and carries on (P:279-280)
-        error = e
+        return [(yaw_angle, e) for yaw_angle in yaw_angles]
+    return [(yaw_angle, executor.submit(_write_yaw, views[yi], yaw_angle, pitch_angles, base_name, output_width,
+                                        output_height, output_format, output_dir))
+            for yi, yaw_angle in enumerate(yaw_angles)]
+
+
+def _drain_views(tasks):
+    """Wait for an image's write tasks; a failed yaw is logged and the others go on (P:271-280)."""
+    from tqdm import tqdm
+
+    for yaw_angle, task in tqdm(tasks, desc="Processing yaw angles"):
+        try:
+            if isinstance(task, Exception):
+                raise task
+            task.result()
+        except Exception as e:
+            logging.error(f"Error processing yaw_angle {yaw_angle}: {e}")
+
+
+def _process_decoded_image(input_image, input_image_path, output_dir, yaw_angles, pitch_angles, output_width,
+                           output_height, num_workers, output_format, fov_deg, device=None):
+    from concurrent.futures import ThreadPoolExecutor
 
     with ThreadPoolExecutor(max_workers=max(1, int(num_workers or 1))) as executor:
-        tasks = []
-        for yi, yaw_angle in enumerate(yaw_angles):
-            if error is None:
-                tasks.append(executor.submit(_write_yaw, views[yi], yaw_angle, pitch_angles, base_name,
-                                             output_width, output_height, output_format, output_dir))
-            else:
-                tasks.append(None)
-        for future, yaw_angle in zip(tqdm(tasks, desc="Processing yaw angles"), yaw_angles):
-            try:
-                if future is None:
-                    raise error
-                future.result()
-            except Exception as e:
-                logging.error(f"Error processing yaw_angle {yaw_angle}: {e}")
+        _drain_views(_submit_views(executor, input_image, input_image_path, output_dir, yaw_angles, pitch_angles,
+                                   output_width, output_height, output_format, fov_deg, device))
 
 
 def main(
@@ -305,20 +309,33 @@ def main(
         from concurrent.futures import ThreadPoolExecutor
 
         def run_share(image_files, device):
-            # images are processed serially, as in P:330-341, but the next file is decoded on a helper
-            # thread while the current one is resampled and written
-            with ThreadPoolExecutor(max_workers=1) as decoder:
-                pending = decoder.submit(_imread_bgr, image_files[0])
+            # The reference walks the images one after the other (P:330-341) with the yaws of one image in
+            # parallel.  Same order of work here, as a pipeline: files are decoded a few ahead on helper threads,
+            # each image is one kernel launch, and its files are encoded by the shared writer pool while the
+            # next image is already being resampled; at most `depth` images are in flight.
+            from collections import deque
+
+            depth = 3
+            n_dec = max(1, min(depth, int(num_workers or 1)))
+            with ThreadPoolExecutor(max_workers=n_dec) as decoder, \
+                    ThreadPoolExecutor(max_workers=max(1, int(num_workers or 1))) as writers:
+                decoding = deque(decoder.submit(_imread_bgr, f) for f in image_files[:depth])
+                in_flight = deque()
                 for k, image_file in enumerate(image_files):
-                    decoded = pending.result()
-                    if k + 1 < len(image_files):
-                        pending = decoder.submit(_imread_bgr, image_files[k + 1])
+                    decoded = decoding.popleft().result()
+                    if k + depth < len(image_files):
+                        decoding.append(decoder.submit(_imread_bgr, image_files[k + depth]))
                     logging.info(f"Loading image: {image_file}")
                     if decoded is None:
                         logging.error(f"Failed to read image: {image_file}")
                         continue
-                    _process_decoded_image(decoded, image_file, output_dir, yaw_angles, pitch_angles, output_width,
-                                           output_height, num_workers, output_format, fov_deg, device)
+                    in_flight.append(_submit_views(writers, decoded, image_file, output_dir, yaw_angles, pitch_angles,
+                                                   output_width, output_height, output_format, fov_deg, device))
+                    del decoded
+                    while len(in_flight) >= depth:
+                        _drain_views(in_flight.popleft())
+                while in_flight:
+                    _drain_views(in_flight.popleft())
 
         if _DEVICES and len(_DEVICES) > 1:
             # one host thread per GPU, images dealt round-robin, nothing exchanged between devices

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from PIL import Image
 synth = importlib.import_module("360-to-planer-images_amd.synth")
-n, pw, ph = 4, 4096, 2048
+n, pw, ph = int(os.environ.get("E2E_N", "4")), 4096, 2048
 with tempfile.TemporaryDirectory() as d:
     os.makedirs(os.path.join(d, "in"))
     for i in range(n):
