@@ -138,3 +138,26 @@ def test_single_channel_2d_input_and_size_assert():
     assert np.array_equal(cpu_ref.remap(img, U, V), img)
     with pytest.raises(ValueError):
         cpu_ref.remap(np.zeros((2, 32767, 1), np.uint8), U, V)  # cv::remap asserts cols < SHRT_MAX
+
+
+def test_against_scipy_float_bilinear_within_quantisation():
+    """Independent check of the geometric convention (integer coordinates are pixel centres, x = column,
+    y = row, no half-pixel offset): scipy's float bilinear agrees with the fixed-point restatement to within
+    the 1/32-px coordinate quantisation and the rounding, on a smooth image, for all three interpolations."""
+    from scipy import ndimage
+
+    yy, xx = np.mgrid[0:60, 0:80].astype(np.float64)
+    img = (127 + 90 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + 0.4 * xx).clip(0, 255).astype(np.uint8)
+    rng = np.random.default_rng(11)
+    U = rng.uniform(3, 75, size=(40, 50)).astype(np.float32)
+    V = rng.uniform(3, 55, size=(40, 50)).astype(np.float32)
+    ref = ndimage.map_coordinates(img.astype(np.float64), [V.astype(np.float64), U.astype(np.float64)], order=1)
+    got = cpu_ref.remap(img, U, V, cpu_ref.BORDER_CONSTANT)
+    # |d image / d coordinate| <= ~10 levels per pixel here, so 1/64 px of quantisation is < 0.2 level
+    assert np.abs(got.astype(np.float64) - ref).max() <= 1.0
+    near = cpu_ref.remap(img, U, V, cpu_ref.BORDER_CONSTANT, interpolation=cpu_ref.INTER_NEAREST)
+    ref0 = ndimage.map_coordinates(img.astype(np.float64), [np.rint(V), np.rint(U)], order=0)
+    assert np.array_equal(near.astype(np.float64), ref0)
+    cub = cpu_ref.remap(img, U, V, cpu_ref.BORDER_CONSTANT, interpolation=cpu_ref.INTER_CUBIC)
+    # cubic convolution (a = -0.75) on a smooth image stays close to the bilinear value
+    assert np.abs(cub.astype(np.float64) - ref).max() <= 3.0
