@@ -719,7 +719,12 @@ __device__ __forceinline__ void views_body(
     const int n_pairs = P.n_panos * P.n_yaw;
     if (pair1 > n_pairs)
         pair1 = n_pairs;
-    int pano_i = (int)__umulhi((uint32_t)pair0, P.n_yaw_magic);
+    // pair -> panorama: multiply-high by ceil(2^32 / n_yaw) (exact for the job's sizes, host check); with one yaw
+    // the constant would be 2^32, which does not fit, and the pair index is the panorama index anyway
+    auto pano_of = [&](int pair) {
+        return P.n_yaw == 1 ? pair : (int)__umulhi((uint32_t)pair, P.n_yaw_magic);
+    };
+    int pano_i = pano_of(pair0);
     int yaw_i = pair0 - pano_i * P.n_yaw;
 
     auto store_pixels = [&](int pair, const uint32_t (&pix)[PXT]) {
@@ -935,7 +940,7 @@ __device__ __forceinline__ void views_body(
         const int k = t & 63;
         if (k < pair1 - pair0) {
             // pair -> (panorama, yaw) by the host's multiply-high constant (exact for the job's sizes)
-            cw3 = (int)__umulhi((uint32_t)(pair0 + k), P.n_yaw_magic);
+            cw3 = pano_of(pair0 + k);
             const int yi = pair0 + k - cw3 * P.n_yaw;
             const YawDesc yd = ydesc[yi];
             int i_first = c0 + yd.s;

@@ -234,3 +234,21 @@ def test_sub_blocks_mixed_with_plain_tiles_in_one_launch(gpu, synth):
     _check(gpu, pano, [0, 13, 90], [30, 60, 90, 120, 150], 640, 480)
     _check(gpu, pano, [13], [30, 150], 333, 250)
     _check(gpu, pano, [5, 359], [25], 640, 480, fov=120)
+
+
+def test_single_yaw_jobs_with_several_panoramas(gpu, synth):
+    """n_yaw == 1 makes the pair -> panorama constant ceil(2^32 / n_yaw) overflow 32 bits (found by
+    tools/fuzz_parity.py: every panorama but the first came out as the first)."""
+    panos = [synth.synth_pano(512, 256, 1400 + i, "N") for i in range(4)]
+    for yaws in ([14], [0], [200]):
+        rows, U, V = oracle_maps(yaws, [60, 107], 169, 81, 512, 256, 90)
+        ctx = gpu.Context(0)
+        job = gpu.Job(ctx, 512, 256, len(panos), yaws, [60, 107], 90, 169, 81)
+        for i, p in enumerate(panos):
+            job.set_pano(i, p)
+        job.set_maps(rows, U, V)
+        job.run()
+        for i, p in enumerate(panos):
+            assert np.array_equal(job.get_views(i), oracle_views(p, yaws, [60, 107], 169, 81, 90)), (yaws, i)
+        job.close()
+        ctx.close()

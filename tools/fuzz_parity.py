@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""One-off fuzz of the integer path: random jobs (sizes, FOVs, yaw / pitch lists, several panoramas, odd widths)
+through p2p_job_* with the oracle's float maps, every byte compared with the CPU restatement.
+Usage: python tools/fuzz_parity.py [n_cases] [seed]"""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _util import oracle_maps, oracle_views
+pkg = importlib.import_module("360-to-planer-images_amd"); nat = pkg._native
+synth = importlib.import_module("360-to-planer-images_amd.synth")
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2026
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None      # re-run one case, checking every yaw
+ctx = nat.Context(0)
+t0 = time.time(); bad = 0
+for case in range(n_cases):
+    if only is not None and case != only:
+        continue
+    rng = np.random.default_rng(seed * 100003 + case)
+    pw = int(rng.choice([256, 500, 512, 1000, 1024, 2048, 2050, 4096]))
+    ph = max(16, pw // int(rng.choice([2, 2, 2, 3, 4])))
+    ow, oh = int(rng.integers(8, 420)), int(rng.integers(8, 300))
+    fov = int(rng.choice([30, 60, 90, 90, 120, 150]))
+    n_yaw = int(rng.integers(1, 20))
+    yaws = [int(v) for v in rng.integers(-360, 720, size=n_yaw)]
+    if rng.random() < 0.3:
+        yaws[0] = 14   # per-column weights on 8192; harmless elsewhere
+    pitches = [int(v) for v in rng.integers(1, 180, size=int(rng.integers(1, 4)))]
+    n_panos = int(rng.integers(1, 4))
+    panos = [synth.synth_pano(pw, ph, 9000 + 7 * case + i, "N") for i in range(n_panos)]
+    rows, U, V = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
+    job = nat.Job(ctx, pw, ph, n_panos, yaws, pitches, fov, ow, oh)
+    for i, p in enumerate(panos):
+        job.set_pano(i, p)
+    job.set_maps(rows, U, V)
+    job.run()
+    check_yaws = sorted(set([0, n_yaw - 1, int(rng.integers(0, n_yaw))])) if only is None else list(range(n_yaw))
+    if only is not None:
+        print(dict(pw=pw, ph=ph, ow=ow, oh=oh, fov=fov, yaws=yaws, pitches=pitches, n_panos=n_panos))
+    for i, p in enumerate(panos):
+        got = job.get_views(i)
+        for yi in check_yaws:
+            want = oracle_views(p, [yaws[yi]], pitches, ow, oh, fov)
+            if not np.array_equal(got[yi], want[0]):
+                bad += 1
+                print("MISMATCH", dict(case=case, pw=pw, ph=ph, ow=ow, oh=oh, fov=fov, yaw=yaws[yi], yaw_index=yi, n_yaw=n_yaw, pitches=pitches, pano=i,
+                                       n=int((got[yi] != want[0]).sum())), flush=True)
+    job.close()
+    if case % 10 == 9:
+        print("case %d done, %.0f s, mismatches %d" % (case + 1, time.time() - t0, bad), flush=True)
+print("fuzz finished: %d cases, %d mismatching views, %.0f s" % (n_cases, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
