@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """One-off fuzz of the integer path: random jobs (sizes, FOVs, yaw / pitch lists, several panoramas, odd widths)
 through p2p_job_* with the oracle's float maps, every byte compared with the CPU restatement.
-Usage: python tools/fuzz_parity.py [n_cases] [seed]"""
+Usage: python tools/fuzz_parity.py [n_cases] [seed] [only_case | -1] [big]
+With "big": large panoramas, views towards the poles, wide FOVs -- footprints that outgrow the LDS buffers
+(plan pass, sub-tiles, compacted item lists, direct gathers)."""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +13,8 @@ pkg = importlib.import_module("360-to-planer-images_amd"); nat = pkg._native
 synth = importlib.import_module("360-to-planer-images_amd.synth")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2026
-only = int(sys.argv[3]) if len(sys.argv) > 3 else None      # re-run one case, checking every yaw
+only = int(sys.argv[3]) if len(sys.argv) > 3 and int(sys.argv[3]) >= 0 else None      # re-run one case, checking every yaw
+big = len(sys.argv) > 4 and sys.argv[4] == "big"
 ctx = nat.Context(0)
 t0 = time.time(); bad = 0
 for case in range(n_cases):
@@ -28,6 +31,13 @@ for case in range(n_cases):
         yaws[0] = 14   # per-column weights on 8192; harmless elsewhere
     pitches = [int(v) for v in rng.integers(1, 180, size=int(rng.integers(1, 4)))]
     n_panos = int(rng.integers(1, 4))
+    if big:
+        pw = int(rng.choice([4096, 8192])); ph = pw // 2
+        ow, oh = int(rng.integers(200, 900)), int(rng.integers(100, 600))
+        fov = int(rng.choice([60, 90, 120, 140]))
+        n_yaw = int(rng.integers(1, 5)); yaws = [int(v) for v in rng.integers(0, 360, size=n_yaw)]
+        pitches = [int(v) for v in rng.choice([3, 10, 20, 30, 45, 60, 120, 150, 170, 177], size=int(rng.integers(1, 3)))]
+        n_panos = int(rng.integers(1, 3))
     panos = [synth.synth_pano(pw, ph, 9000 + 7 * case + i, "N") for i in range(n_panos)]
     rows, U, V = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
     job = nat.Job(ctx, pw, ph, n_panos, yaws, pitches, fov, ow, oh)
