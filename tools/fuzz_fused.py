@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Randomised look at the fused path's tolerance: in-kernel maps vs the NumPy-map oracle on band-limited ("S")
+panoramas.  Prints, per case, the largest channel difference and the fraction of differing bytes; north_star's
+bar is +-1.  Usage: python tools/fuzz_fused.py [n_cases] [seed]"""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _util import oracle_views
+pkg = importlib.import_module("360-to-planer-images_amd"); nat = pkg._native
+synth = importlib.import_module("360-to-planer-images_amd.synth")
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+worst = 0; over = 0; t0 = time.time()
+for case in range(n_cases):
+    rng = np.random.default_rng(seed * 100003 + case)
+    pw = int(rng.choice([512, 1024, 2048, 4096])); ph = pw // 2
+    ow, oh = int(rng.integers(16, 500)), int(rng.integers(16, 400))
+    fov = int(rng.choice([20, 45, 60, 90, 90, 120, 150, 170]))
+    yaws = [int(v) for v in rng.integers(-30, 400, size=int(rng.integers(1, 4)))]
+    pitches = [int(v) for v in rng.integers(1, 180, size=int(rng.integers(1, 3)))]
+    pano = synth.synth_pano(pw, ph, 700 + case, "S")
+    got = nat.remap_views(pano, yaws, pitches, fov, ow, oh)
+    want = oracle_views(pano, yaws, pitches, ow, oh, fov)
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    m = int(d.max()); frac = float((d > 0).mean()); big = int((d > 1).sum())
+    worst = max(worst, m)
+    if m > 1:
+        over += 1
+        print("case %d: max diff %d (%d bytes > 1 of %d), differing %.4f  " % (case, m, big, d.size, frac),
+              dict(pw=pw, ow=ow, oh=oh, fov=fov, yaws=yaws, pitches=pitches), flush=True)
+print("fuzz_fused finished: %d cases, worst difference %d, %d cases above 1, %.0f s" % (n_cases, worst, over, time.time() - t0))
