@@ -80,7 +80,10 @@ class Dist:
 
     def barrier(self):
         if self.pg is not None:
-            self.pg.barrier()
+            if self.backend == "nccl":
+                self.pg.barrier(device_ids=[self.local_rank])  # this rank's GPU, explicitly
+            else:
+                self.pg.barrier()
 
     def max_over_ranks(self, x):
         if self.pg is None:
