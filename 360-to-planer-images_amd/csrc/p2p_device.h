@@ -1,4 +1,4 @@
-// p2p_device.h -- structures and launchers shared by the device code (p2p_kernels.hip) and the
+// p2p_device.h -- structures and launchers shared by the device code (p2p_views / p2p_maps / p2p_remap / p2p_float .hip) and the
 // host side of the C ABI (p2p_host.cpp).  Not part of the public ABI (that is include/p2p_hip.h).
 #ifndef P2P_DEVICE_H
 #define P2P_DEVICE_H

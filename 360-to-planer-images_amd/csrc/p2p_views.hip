@@ -1,292 +1,14 @@
-// p2p_kernels.hip -- gfx950 (MI355X / CDNA4) device code for the equirectangular ->
-// perspective view-synthesis hot path.  Reference behaviour (cited, never copied):
-//   P = /root/reference/app/panorama_to_plane-pitch.py
-//     yaw map            P:79-108      -> yaw_table_kernel (bit-exact dtype flow: f32, then f64)
-//     pitch map          P:114-175     -> pitch_map_eval (f32), pitch_map_kernel
-//     cv2.remap x2       P:192-199,212-218 -> remap_views_kernel (both stages fused, fixed point)
-//   L = /root/reference/app/legacy/panorama_to_plane.py
-//     precompute_mapping L:47-157      -> rot_map_kernel (combined yaw + pitch rotation, f32)
-//     panorama_to_plane  L:159-194     -> remap_maps_kernel (generic cv2.remap INTER_LINEAR, u8; 3-channel images
-//                                         go through remap_views_kernel with an identity yaw stage),
-//                                         remap_maps_nearest_kernel, remap_maps_cubic_kernel + cubic_tab_kernel
-//   not in the reference (opt-in): float_views_kernel (one float32 / float16 resample per view, wrap-around)
+// p2p_views.hip -- the hot kernel: both cv2.remap stages of every (panorama, yaw, pitch) view in one launch
+//   cv2.remap x2       P:192-199, P:212-218 -> remap_views_kernel (both stages fused, fixed point; modes: draw,
+//                                            plan, sub-tile); 3-channel single remaps of the legacy tool (L:179) too
+// Reference behaviour (cited, never copied):
+//   P = /root/reference/app/panorama_to_plane-pitch.py, L = /root/reference/app/legacy/panorama_to_plane.py
 // The fixed-point arithmetic is OpenCV 4.10's (imgwarp.cpp remapBilinear, INTER_BITS = 5,
 // INTER_REMAP_COEF_BITS = 15); see DESIGN.md "Arithmetic contract".
-//
 // Compiled with -ffp-contract=off: every float operation below rounds where NumPy rounds.
-#include <hip/hip_runtime.h>
-#include <hip/hip_fp16.h>
-#include <stdint.h>
-#include "p2p_device.h"
+#include "p2p_inline.h"
 
 namespace p2p {
-
-// ---------------------------------------------------------------------------------------------
-// small helpers
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int cv_round_f32(float v)
-{
-    // cvRound(float) on x86-64 = cvtss2si: round-half-even, NaN / out of range -> INT_MIN
-    if (!(v >= -2147483648.0f && v < 2147483648.0f))
-        return INT32_MIN;
-    return (int)__builtin_rintf(v);
-}
-
-__device__ __forceinline__ int sat_short(int v)
-{
-    return v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
-}
-
-__device__ __forceinline__ float clip_keep_nan(float v, float lo, float hi)
-{
-    // np.clip propagates NaN; fminf/fmaxf would not
-    return v < lo ? lo : (v > hi ? hi : v);
-}
-
-// P:114-175 for one output pixel, float32 throughout, same operation order as NumPy:
-//   x**2 + y**2 + z**2 left to right, IEEE sqrt and divide, the 3x3 float32 sgemm as the
-//   sequential-FMA accumulation OpenBLAS performs (acc = fma(R[i][k], v[k], acc), k = 0..2),
-//   arccos / arctan2 % 2pi, scale, clip.
-__device__ __forceinline__ void pitch_map_eval(float u, float v, const MapGeom& g, float c, float s,
-                                               float& U, float& V)
-{
-    const float TWO_PI_F = 6.283185307179586f;  // float32(2*np.pi), the "weak" Python scalar
-    const float PI_F = 3.141592653589793f;
-    float x = u - g.half_w;  // P:129
-    float y = g.half_h - v;  // P:130
-    float z = g.focal;       // P:131
-    float n = __fsqrt_rn(x * x + y * y + z * z);  // P:134
-    // P:137-139: x/n, y/n, z/n.  One IEEE reciprocal, then q = a*r corrected by its exact FMA
-    // residual: RN(q + (a - q*n)*r) is the correctly rounded quotient (Markstein) -- the same bits as
-    // three IEEE divisions at half their cost.
-    const float r = __fdiv_rn(1.0f, n);
-    float xn = x * r, yn = y * r, zn = z * r;
-    xn = __builtin_fmaf(__builtin_fmaf(-xn, n, x), r, xn);
-    yn = __builtin_fmaf(__builtin_fmaf(-yn, n, y), r, yn);
-    zn = __builtin_fmaf(__builtin_fmaf(-zn, n, z), r, zn);
-    float yr = __builtin_fmaf(-s, zn, c * yn);  // P:155 row 1: [0, cos, -sin]
-    float zr = __builtin_fmaf(c, zn, s * yn);   // P:155 row 2: [0, sin,  cos]
-    float theta = acosf(zr);                    // P:162 (NaN if zr rounds above 1)
-    float phi = atan2f(yr, xn);                 // P:164
-    if (phi < 0.0f)
-        phi += TWO_PI_F;  // floored '%': |phi| <= pi so fmod is the identity; -0.0 -> +0.0 either way
-    else if (phi == 0.0f)
-        phi = 0.0f;
-    // P:167 / P:169: division by the constants float32(2 pi) / float32(pi), same correction scheme
-    const float R_TWO_PI = 0.15915494f, R_PI = 0.31830987f;  // RN(1 / 6.2831855f), RN(1 / 3.1415927f)
-    const float tu = phi * g.pw_f, tv = theta * g.ph_f;
-    U = tu * R_TWO_PI;
-    V = tv * R_PI;
-    U = __builtin_fmaf(__builtin_fmaf(-U, TWO_PI_F, tu), R_TWO_PI, U);
-    V = __builtin_fmaf(__builtin_fmaf(-V, PI_F, tv), R_PI, V);
-    U = clip_keep_nan(U, 0.0f, g.pw_f - 1.0f);  // P:172
-    V = clip_keep_nan(V, 0.0f, g.ph_f - 1.0f);  // P:173
-}
-
-// ---------------------------------------------------------------------------------------------
-// yaw tables: P:79-108 per column, then the cv::remap quantisation of that coordinate
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float yaw_row_eval(int col, int pw, double yaw_rad)
-{
-    const float TWO_PI_F = 6.283185307179586f;
-    const double TWO_PI_D = 6.283185307179586;
-    float u = (float)col;
-    float phi = __fdiv_rn(TWO_PI_F * u, (float)pw);  // P:95 (float32)
-    double pr = (double)phi + yaw_rad;                // P:98: float32 + np.float64 -> float64
-    double m = fmod(pr, TWO_PI_D);                    // NumPy's floored '%'
-    if (m != 0.0) {
-        if (m < 0.0)
-            m += TWO_PI_D;
-    } else {
-        m = 0.0;
-    }
-    double Ud = __ddiv_rn(m * (double)pw, TWO_PI_D);  // P:101
-    double hi = (double)(pw - 1);
-    Ud = Ud < 0.0 ? 0.0 : (Ud > hi ? hi : Ud);        // P:105
-    return (float)Ud;                                 // .astype(np.float32)
-}
-
-__device__ __forceinline__ uint32_t pack_yaw_entry(float U)
-{
-    int sx = cv_round_f32(U * 32.0f);
-    int ix = sat_short(sx >> 5);
-    int fx = sx & 31;
-    if (ix < 0) { ix = 0; fx = 0; }  // unreachable for clipped maps; keeps the gather in bounds
-    return (uint32_t)(3 * ix) | ((uint32_t)fx << 20);
-}
-
-__global__ void yaw_table_kernel(uint32_t* __restrict__ packed, float* __restrict__ rows,
-                                 int pw, const double* __restrict__ yaw_rad)
-{
-    int col = blockIdx.x * blockDim.x + threadIdx.x;
-    int yi = blockIdx.y;
-    if (col >= pw)
-        return;
-    float U = yaw_row_eval(col, pw, yaw_rad[yi]);
-    if (rows)
-        rows[(size_t)yi * pw + col] = U;
-    if (packed)
-        packed[(size_t)yi * pw + col] = pack_yaw_entry(U);
-}
-
-// caller-supplied float rows (p2p_job_set_maps) -> packed tables
-__global__ void yaw_pack_kernel(uint32_t* __restrict__ packed, const float* __restrict__ rows, size_t n)
-{
-    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n)
-        packed[k] = pack_yaw_entry(rows[k]);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Yaw descriptor: the yaw table of P:79-108 is a circular shift.  For rot column c the source
-// column is (c + s) mod pw and the two-tap weight is F[c] in 0..32 (F == 32 encodes "next pixel,
-// fraction 0"; (32-F)*a + F*b + 16 >> 5 then returns b exactly, which is what the table's entry
-// (i+1, 0) gives).  F is one value for the whole yaw except (a) the single column that P:105
-// clips to pw-1 and (b) yaws whose shift fraction sits within float noise of a 1/32-px rounding
-// tie, where F flickers between two neighbours column by column.  mode 0: uniform F (+ optional
-// clamp column); mode 1: per-column F (f4tab); mode 2: not a shift at all (only possible with
-// caller-supplied rows) -> the kernel's direct path uses the packed table.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int yaw_delta(uint32_t te, int c, int s, int pw)
-{
-    int off = (int)(te & 0xFFFFFu), f = (int)(te >> 20);
-    int col = c + s;
-    if (col >= pw)
-        col -= pw;
-    if (off == 3 * col)
-        return f;
-    if (off == 3 * (col + 1) && f == 0 && col + 1 < pw)
-        return 32;
-    return -1;
-}
-
-__global__ __launch_bounds__(256) void yaw_desc_kernel(YawDesc* __restrict__ desc, uint32_t* __restrict__ f4tab,
-                                                       const uint32_t* __restrict__ packed, int pw)
-{
-    __shared__ int bad[2];
-    __shared__ int dmin, dmax;
-    const int yi = blockIdx.x, t = threadIdx.x;
-    const uint32_t* T = packed + (size_t)yi * pw;
-    uint32_t* F4 = f4tab + (size_t)yi * pw;
-    const int i0 = (int)(T[0] & 0xFFFFFu) / 3;
-    if (t < 2)
-        bad[t] = 0;
-    if (t == 0) {
-        dmin = 64;
-        dmax = -1;
-    }
-    __syncthreads();
-    const int s_a = i0, s_b = (i0 + pw - 1) % pw;
-    int nb_a = 0, nb_b = 0;
-    for (int c = t; c < pw; c += 256) {
-        uint32_t te = T[c];
-        nb_a += yaw_delta(te, c, s_a, pw) < 0;
-        nb_b += yaw_delta(te, c, s_b, pw) < 0;
-    }
-    if (nb_a) atomicAdd(&bad[0], nb_a);
-    if (nb_b) atomicAdd(&bad[1], nb_b);
-    __syncthreads();
-    const bool ok_a = bad[0] == 0, ok_b = bad[1] == 0;
-    const int s = ok_a ? s_a : s_b;
-    if (!ok_a && !ok_b) {
-        for (int c = t; c < pw; c += 256)
-            F4[c] = 0u;
-        if (t == 0)
-            desc[yi] = YawDesc{0, 2, 0, -1};
-        return;
-    }
-    const int c_last = (pw - 1 - s + pw) % pw;  // the rot column whose source column is pw-1
-    int lmin = 64, lmax = -1;
-    for (int c = t; c < pw; c += 256) {
-        uint32_t w = 0;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            int cm = c + m;
-            if (cm >= pw)
-                cm -= pw;
-            int d = yaw_delta(T[cm], cm, s, pw);
-            w |= (uint32_t)d << (8 * m);
-            if (m == 0 && c != c_last) {
-                lmin = min(lmin, d);
-                lmax = max(lmax, d);
-            }
-        }
-        F4[c] = w;
-    }
-    atomicMin(&dmin, lmin);
-    atomicMax(&dmax, lmax);
-    __syncthreads();
-    if (t == 0) {
-        YawDesc d;
-        d.s = s;
-        if (dmin == dmax || pw == 1) {
-            d.mode = 0;
-            d.f = pw == 1 ? 0 : dmin;
-            int dl = yaw_delta(T[c_last], c_last, s, pw);
-            d.c_clamp = (pw > 1 && dl != d.f) ? c_last : -1;
-        } else {
-            d.mode = 1;
-            d.f = 0;
-            d.c_clamp = -1;
-        }
-        desc[yi] = d;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// pitch map as float32 arrays (get_pitch_mapping drop-in, and the 1e-5 map-parity check)
-// ---------------------------------------------------------------------------------------------
-__global__ void pitch_map_kernel(float* __restrict__ U, float* __restrict__ V, int ow, int oh,
-                                 MapGeom g, float c, float s)
-{
-    int x = blockIdx.x * blockDim.x + threadIdx.x;
-    int y = blockIdx.y;
-    if (x >= ow || y >= oh)
-        return;
-    float uu, vv;
-    pitch_map_eval((float)x, (float)y, g, c, s, uu, vv);
-    U[(size_t)y * ow + x] = uu;
-    V[(size_t)y * ow + x] = vv;
-}
-
-// ---------------------------------------------------------------------------------------------
-// legacy tool: one combined rotation R = R_pitch @ R_yaw (L:21-45) applied to the normalised pinhole
-// ray, then the same spherical mapping (precompute_mapping, L:47-157).  float32 throughout; the 3x3 by
-// 3xN sgemm as OpenBLAS accumulates it: acc = R[i][0]*v0; acc = fma(R[i][1], v1, acc); fma(R[i][2], v2, acc)
-// (bit-equal to the reference's output for the golden cases).
-// ---------------------------------------------------------------------------------------------
-struct Rot3 {
-    float m[9];
-};
-
-__global__ void rot_map_kernel(float* __restrict__ U, float* __restrict__ V, int ow, int oh, MapGeom g, Rot3 R)
-{
-    const int px = blockIdx.x * blockDim.x + threadIdx.x;
-    const int py = blockIdx.y;
-    if (px >= ow || py >= oh)
-        return;
-    const float TWO_PI_F = 6.283185307179586f, PI_F = 3.141592653589793f;
-    const float x = (float)px - g.half_w;  // L:107
-    const float y = g.half_h - (float)py;  // L:108
-    const float z = g.focal;               // L:109
-    const float n = __fsqrt_rn(x * x + y * y + z * z);  // L:113
-    const float xn = __fdiv_rn(x, n), yn = __fdiv_rn(y, n), zn = __fdiv_rn(z, n);  // L:114-116
-    const float xr = __builtin_fmaf(R.m[2], zn, __builtin_fmaf(R.m[1], yn, R.m[0] * xn));  // L:123
-    const float yr = __builtin_fmaf(R.m[5], zn, __builtin_fmaf(R.m[4], yn, R.m[3] * xn));
-    const float zr = __builtin_fmaf(R.m[8], zn, __builtin_fmaf(R.m[7], yn, R.m[6] * xn));
-    const float theta = acosf(zr);  // L:130
-    float phi = atan2f(yr, xr);     // L:145, floored '%' of a value in [-pi, pi]
-    if (phi < 0.0f)
-        phi += TWO_PI_F;
-    else if (phi == 0.0f)
-        phi = 0.0f;
-    float uu = __fdiv_rn(phi * g.pw_f, TWO_PI_F);  // L:157
-    float vv = __fdiv_rn(theta * g.ph_f, PI_F);    // L:158
-    uu = clip_keep_nan(uu, 0.0f, g.pw_f - 1.0f);   // L:161
-    vv = clip_keep_nan(vv, 0.0f, g.ph_f - 1.0f);   // L:162
-    U[(size_t)py * ow + px] = uu;
-    V[(size_t)py * ow + px] = vv;
-}
 
 // ---------------------------------------------------------------------------------------------
 // Stage 1, P:192-199: one pixel of the yaw-resampled panorama ("rot") from two horizontally
@@ -344,35 +66,6 @@ __device__ __forceinline__ uint32_t blend4(uint32_t a, uint32_t b, uint32_t c, u
     uint32_t vr = (gy * (h0br >> 16) + fy * (h1br >> 16) + 512u) >> 10;
     uint32_t vg = (gy * h0g + fy * h1g + 512u) >> 10;
     return vb | (vg << 8) | (vr << 16);
-}
-
-// cv::borderInterpolate (core/src/copy.cpp) for the border codes of include/p2p_hip.h
-__device__ __forceinline__ int border_interpolate(int p, int len, int border)
-{
-    if ((unsigned)p < (unsigned)len)
-        return p;
-    if (border == 1)  // REPLICATE
-        return p < 0 ? 0 : len - 1;
-    if (border == 2 || border == 4) {  // REFLECT / REFLECT_101
-        int delta = border == 4;
-        if (len == 1)
-            return 0;
-        do {
-            if (p < 0)
-                p = -p - 1 + delta;
-            else
-                p = len - 1 - (p - len) - delta;
-        } while ((unsigned)p >= (unsigned)len);
-        return p;
-    }
-    if (border == 3) {  // WRAP
-        if (p < 0)
-            p -= ((p - len + 1) / len) * len;
-        if (p >= len)
-            p %= len;
-        return p;
-    }
-    return -1;  // CONSTANT
 }
 
 struct __attribute__((aligned(4))) Q16 { uint32_t d[4]; };
@@ -1257,330 +950,8 @@ __global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Generic cv2.remap(src, U, V, INTER_LINEAR, border) for uint8, cn in {1,3,4}
-// (panorama_to_plane, L:159-194).  One thread per destination pixel.
+// launchers
 // ---------------------------------------------------------------------------------------------
-template <int CN>
-__global__ void remap_maps_kernel(RemapParams P)
-{
-    int x = blockIdx.x * blockDim.x + threadIdx.x;
-    int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= P.ow || y >= P.oh)
-        return;
-    size_t k = (size_t)y * P.ow + x;
-    int qx = cv_round_f32(P.U[k] * 32.0f);
-    int qy = cv_round_f32(P.V[k] * 32.0f);
-    int sx = sat_short(qx >> 5), sy = sat_short(qy >> 5);
-    int fx = qx & 31, fy = qy & 31;
-    int w0 = (32 - fx) * (32 - fy), w1 = fx * (32 - fy), w2 = (32 - fx) * fy, w3 = fx * fy;
-    uint8_t* D = P.dst + k * CN;
-    const uint8_t* cval = P.cval;
-    if (P.border == 0 && (sx >= P.sw || sx + 1 < 0 || sy >= P.sh || sy + 1 < 0)) {
-#pragma unroll
-        for (int ch = 0; ch < CN; ++ch)
-            D[ch] = cval[ch];
-        return;
-    }
-    int sx0, sx1, sy0, sy1;
-    if (P.border == 1) {
-        sx0 = min(max(sx, 0), P.sw - 1);
-        sx1 = min(max(sx + 1, 0), P.sw - 1);
-        sy0 = min(max(sy, 0), P.sh - 1);
-        sy1 = min(max(sy + 1, 0), P.sh - 1);
-    } else {
-        sx0 = border_interpolate(sx, P.sw, P.border);
-        sx1 = border_interpolate(sx + 1, P.sw, P.border);
-        sy0 = border_interpolate(sy, P.sh, P.border);
-        sy1 = border_interpolate(sy + 1, P.sh, P.border);
-    }
-    const uint8_t* v0 = (sx0 >= 0 && sy0 >= 0) ? P.src + (size_t)sy0 * P.src_pitch + (size_t)sx0 * CN : nullptr;
-    const uint8_t* v1 = (sx1 >= 0 && sy0 >= 0) ? P.src + (size_t)sy0 * P.src_pitch + (size_t)sx1 * CN : nullptr;
-    const uint8_t* v2 = (sx0 >= 0 && sy1 >= 0) ? P.src + (size_t)sy1 * P.src_pitch + (size_t)sx0 * CN : nullptr;
-    const uint8_t* v3 = (sx1 >= 0 && sy1 >= 0) ? P.src + (size_t)sy1 * P.src_pitch + (size_t)sx1 * CN : nullptr;
-#pragma unroll
-    for (int ch = 0; ch < CN; ++ch) {
-        int a = v0 ? v0[ch] : cval[ch];
-        int b = v1 ? v1[ch] : cval[ch];
-        int c = v2 ? v2[ch] : cval[ch];
-        int d = v3 ? v3[ch] : cval[ch];
-        // (32*sum + 16384) >> 15 == (sum + 512) >> 10; the table's {32767,0,0,1} cell for
-        // fx == fy == 0 yields the same byte (|p11 - p00| < 16384), see tests/test_oracle_remap.py
-        D[ch] = (uint8_t)((w0 * a + w1 * b + w2 * c + w3 * d + 512) >> 10);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Float pixel path (opt-in, BEYOND the reference: BASELINE config 5's "fp16 pixel path" and SURVEY 8(f)4's
-// quality mode).  One resample instead of two: the pitch map's float coordinate is shifted by the yaw's
-// column offset yaw * pw / 360 with true wrap-around at the seam, nothing is quantised to 1/32 pixel and no
-// intermediate image is rounded to uint8; the 2x2 blend runs in float32 or in packed float16.  The result
-// is rounded to uint8 once.  Not bit-comparable with cv2.remap by construction; tests bound it against a
-// float32 NumPy evaluation of the same formula and against the exact path on band-limited panoramas.
-// ---------------------------------------------------------------------------------------------
-template <bool HALF>
-__global__ __launch_bounds__(256) void float_views_kernel(ViewsParams P, const double* __restrict__ yaw_rad)
-{
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int pitch_i = blockIdx.z;
-    if (x >= P.ow || y >= P.oh)
-        return;
-    float U, V;
-    const PitchConst pc = P.pitch[pitch_i];
-    pitch_map_eval((float)x, (float)y, P.geom, pc.c, pc.s, U, V);
-    const bool dead = !(U == U) || !(V == V);  // NaN next to a pole: black, as in the exact path
-    const int y0 = dead ? 0 : (int)V;          // V in [0, ph - 1]
-    const float wy = dead ? 0.0f : V - (float)y0;
-    const int y1 = y0 + 1 < P.ph ? y0 + 1 : y0;
-    const size_t view_bytes = (size_t)P.oh * P.ow * 3;
-    const size_t px_off = ((size_t)y * P.ow + x) * 3;
-    for (int pano = 0; pano < P.n_panos; ++pano) {
-        const uint8_t* __restrict__ S = P.src + (size_t)pano * P.pano_stride;
-        const uint8_t* __restrict__ r0 = S + (size_t)y0 * P.src_pitch;
-        const uint8_t* __restrict__ r1 = S + (size_t)y1 * P.src_pitch;
-        for (int yi = 0; yi < P.n_yaw; ++yi) {
-            uint8_t* O = P.out + (((size_t)pano * P.n_yaw + yi) * P.n_pitch + pitch_i) * view_bytes + px_off;
-            if (dead) {
-                O[0] = O[1] = O[2] = 0;
-                continue;
-            }
-            // source column = U + yaw * pw / 2 pi (mod pw): P:98-101 without the clip at the seam
-            double sh = fmod(yaw_rad[yi] * (double)P.pw / 6.283185307179586, (double)P.pw);
-            if (sh < 0.0)
-                sh += (double)P.pw;
-            float xs = U + (float)sh;
-            if (xs >= (float)P.pw)
-                xs -= (float)P.pw;
-            int x0 = (int)xs;
-            if (x0 >= P.pw)
-                x0 = P.pw - 1;
-            const float wx = xs - (float)x0;
-            const int x1 = x0 + 1 < P.pw ? x0 + 1 : 0;  // wrap-around
-            uint32_t a, b, c, d;
-            {
-                uint2 q0, q1;
-                __builtin_memcpy(&q0, r0 + 3 * x0, 8);
-                __builtin_memcpy(&q1, r1 + 3 * x0, 8);
-                a = q0.x;
-                c = q1.x;
-                b = __builtin_amdgcn_alignbyte(q0.y, q0.x, 3);
-                d = __builtin_amdgcn_alignbyte(q1.y, q1.x, 3);
-                if (x1 == 0) {
-                    __builtin_memcpy(&b, r0, 4);
-                    __builtin_memcpy(&d, r1, 4);
-                }
-            }
-            uint32_t res = 0;
-            if (HALF) {
-                const __half2 hx = __float2half2_rn(wx), hy = __float2half2_rn(wy);
-                auto pair = [](uint32_t p, int s0, int s1) {
-                    return __halves2half2(__ushort2half_rn((unsigned short)((p >> s0) & 0xFFu)),
-                                          __ushort2half_rn((unsigned short)((p >> s1) & 0xFFu)));
-                };
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {  // (B, G) then (R, R)
-                    const int s0 = k ? 16 : 0, s1 = k ? 16 : 8;
-                    const __half2 pa = pair(a, s0, s1), pb = pair(b, s0, s1), pc2 = pair(c, s0, s1), pd = pair(d, s0, s1);
-                    const __half2 h0 = __hfma2(hx, __hsub2(pb, pa), pa);
-                    const __half2 h1 = __hfma2(hx, __hsub2(pd, pc2), pc2);
-                    const __half2 v = __hfma2(hy, __hsub2(h1, h0), h0);
-                    int lo = __half2int_rn(__low2half(v)), hi = __half2int_rn(__high2half(v));
-                    lo = lo < 0 ? 0 : (lo > 255 ? 255 : lo);
-                    hi = hi < 0 ? 0 : (hi > 255 ? 255 : hi);
-                    res |= k ? (uint32_t)lo << 16 : ((uint32_t)lo | (uint32_t)hi << 8);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float pa = (float)((a >> (8 * k)) & 0xFFu), pb = (float)((b >> (8 * k)) & 0xFFu);
-                    const float pc2 = (float)((c >> (8 * k)) & 0xFFu), pd = (float)((d >> (8 * k)) & 0xFFu);
-                    const float h0 = __builtin_fmaf(wx, pb - pa, pa);
-                    const float h1 = __builtin_fmaf(wx, pd - pc2, pc2);
-                    const float v = __builtin_fmaf(wy, h1 - h0, h0);
-                    int r = (int)__builtin_rintf(v);
-                    r = r < 0 ? 0 : (r > 255 ? 255 : r);
-                    res |= (uint32_t)r << (8 * k);
-                }
-            }
-            O[0] = (uint8_t)res;
-            O[1] = (uint8_t)(res >> 8);
-            O[2] = (uint8_t)(res >> 16);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// The other two rows of the legacy tool's method table (L:172-176): INTER_NEAREST and INTER_CUBIC, as
-// OpenCV 4.10 evaluates them for uint8 (remapNearest; remapBicubic with the 15-bit fixed-point table).
-// ---------------------------------------------------------------------------------------------
-template <int CN>
-__global__ void remap_maps_nearest_kernel(RemapParams P)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= P.ow || y >= P.oh)
-        return;
-    const size_t k = (size_t)y * P.ow + x;
-    // saturate_cast<short>(float): cvRound (half-even), then saturation
-    int sx = sat_short(cv_round_f32(P.U[k])), sy = sat_short(cv_round_f32(P.V[k]));
-    uint8_t* D = P.dst + k * CN;
-    const uint8_t* S = nullptr;
-    if ((unsigned)sx < (unsigned)P.sw && (unsigned)sy < (unsigned)P.sh) {
-        S = P.src + (size_t)sy * P.src_pitch + (size_t)sx * CN;
-    } else if (P.border != 0) {
-        sx = border_interpolate(sx, P.sw, P.border);
-        sy = border_interpolate(sy, P.sh, P.border);
-        S = P.src + (size_t)sy * P.src_pitch + (size_t)sx * CN;
-    }
-#pragma unroll
-    for (int ch = 0; ch < CN; ++ch)
-        D[ch] = S ? S[ch] : P.cval[ch];
-}
-
-// initInterTab2D(INTER_CUBIC, fixpt): thread (fy, fx) builds its 4x4 cell of shorts.  interpolateCubic with
-// A = -0.75 in float32, products scaled by 32768 and rounded half-even, then the cell sum forced to 32768 by
-// adjusting the largest (or smallest) of the four entries [2..3][2..3] -- the window OpenCV scans.
-__device__ __forceinline__ void cubic_coeffs(float x, float* c)
-{
-    const float A = -0.75f;
-    c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
-    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
-    c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
-    c[3] = 1.f - c[0] - c[1] - c[2];
-}
-
-__global__ void cubic_tab_kernel(short* __restrict__ tab)
-{
-    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
-    if (cell >= 1024)
-        return;
-    const float scale = 1.f / 32;
-    float cy[4], cx[4];
-    cubic_coeffs((cell >> 5) * scale, cy);
-    cubic_coeffs((cell & 31) * scale, cx);
-    short w[16];
-    int isum = 0;
-    for (int k1 = 0; k1 < 4; ++k1)
-        for (int k2 = 0; k2 < 4; ++k2) {
-            const float v = cy[k1] * cx[k2];
-            w[k1 * 4 + k2] = (short)sat_short(cv_round_f32(v * 32768.0f));
-            isum += w[k1 * 4 + k2];
-        }
-    if (isum != 32768) {
-        const int diff = isum - 32768;
-        int M = 2 * 4 + 2, m = 2 * 4 + 2;
-        for (int k1 = 2; k1 < 4; ++k1)
-            for (int k2 = 2; k2 < 4; ++k2) {
-                const int i = k1 * 4 + k2;
-                if (w[i] < w[m])
-                    m = i;
-                else if (w[i] > w[M])
-                    M = i;
-            }
-        if (diff < 0)
-            w[M] = (short)(w[M] - diff);
-        else
-            w[m] = (short)(w[m] - diff);
-    }
-    for (int i = 0; i < 16; ++i)
-        tab[cell * 16 + i] = w[i];
-}
-
-template <int CN>
-__global__ void remap_maps_cubic_kernel(RemapParams P)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= P.ow || y >= P.oh)
-        return;
-    const size_t k = (size_t)y * P.ow + x;
-    const int qx = cv_round_f32(P.U[k] * 32.0f), qy = cv_round_f32(P.V[k] * 32.0f);
-    const int sx = sat_short(qx >> 5) - 1, sy = sat_short(qy >> 5) - 1;
-    const short* __restrict__ w = P.ctab + ((qy & 31) * 32 + (qx & 31)) * 16;
-    uint8_t* D = P.dst + k * CN;
-    if (P.border == 0 && (sx >= P.sw || sx + 4 <= 0 || sy >= P.sh || sy + 4 <= 0)) {
-#pragma unroll
-        for (int ch = 0; ch < CN; ++ch)
-            D[ch] = P.cval[ch];
-        return;
-    }
-    int xs[4], ys[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        xs[i] = border_interpolate(sx + i, P.sw, P.border);
-        ys[i] = border_interpolate(sy + i, P.sh, P.border);
-    }
-#pragma unroll
-    for (int ch = 0; ch < CN; ++ch) {
-        // sum = cval * 32768 + sum (p - cval) * w over the taps that exist == sum p * w with cval at the missing
-        // taps, because the 16 weights add up to 32768
-        const int cv = P.cval[ch];
-        int sum = cv << 15;
-        for (int r = 0; r < 4; ++r) {
-            if (ys[r] < 0)
-                continue;
-            const uint8_t* S = P.src + (size_t)ys[r] * P.src_pitch;
-            for (int c = 0; c < 4; ++c)
-                if (xs[c] >= 0)
-                    sum += ((int)S[xs[c] * CN + ch] - cv) * (int)w[r * 4 + c];
-        }
-        sum = (sum + 16384) >> 15;
-        D[ch] = (uint8_t)(sum < 0 ? 0 : (sum > 255 ? 255 : sum));
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// launchers (called from p2p_host.cpp through p2p_device.h)
-// ---------------------------------------------------------------------------------------------
-hipError_t launch_yaw_tables(uint32_t* packed, float* rows, int pw, int n_yaw, const double* yaw_rad,
-                             hipStream_t st)
-{
-    dim3 grid((pw + 255) / 256, n_yaw);
-    hipLaunchKernelGGL(yaw_table_kernel, grid, dim3(256), 0, st, packed, rows, pw, yaw_rad);
-    return hipGetLastError();
-}
-
-hipError_t launch_yaw_pack(uint32_t* packed, const float* rows, size_t n, hipStream_t st)
-{
-    hipLaunchKernelGGL(yaw_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, packed, rows, n);
-    return hipGetLastError();
-}
-
-hipError_t launch_yaw_desc(YawDesc* desc, uint32_t* f4tab, const uint32_t* packed, int pw, int n_yaw,
-                           hipStream_t st)
-{
-    hipLaunchKernelGGL(yaw_desc_kernel, dim3(n_yaw), dim3(256), 0, st, desc, f4tab, packed, pw);
-    return hipGetLastError();
-}
-
-hipError_t launch_pitch_map(float* U, float* V, int ow, int oh, const MapGeom& g, float c, float s,
-                            hipStream_t st)
-{
-    dim3 grid((ow + 255) / 256, oh);
-    hipLaunchKernelGGL(pitch_map_kernel, grid, dim3(256), 0, st, U, V, ow, oh, g, c, s);
-    return hipGetLastError();
-}
-
-hipError_t launch_rot_map(float* U, float* V, int ow, int oh, const MapGeom& g, const float* R9, hipStream_t st)
-{
-    Rot3 R;
-    for (int i = 0; i < 9; ++i)
-        R.m[i] = R9[i];
-    dim3 grid((ow + 255) / 256, oh);
-    hipLaunchKernelGGL(rot_map_kernel, grid, dim3(256), 0, st, U, V, ow, oh, g, R);
-    return hipGetLastError();
-}
-
-hipError_t launch_float_views(const ViewsParams& P, const double* yaw_rad, bool half, hipStream_t st)
-{
-    dim3 grid((P.ow + 63) / 64, (P.oh + 3) / 4, P.n_pitch);
-    if (half)
-        hipLaunchKernelGGL(float_views_kernel<true>, grid, dim3(256), 0, st, P, yaw_rad);
-    else
-        hipLaunchKernelGGL(float_views_kernel<false>, grid, dim3(256), 0, st, P, yaw_rad);
-    return hipGetLastError();
-}
-
 template <int MODE>
 static void launch_views_mode(const ViewsParams& P, int mapsrc, dim3 grid, hipStream_t st)
 {
@@ -1609,43 +980,6 @@ hipError_t launch_remap_views(const ViewsParams& P, int mapsrc, int mode, hipStr
     return hipGetLastError();
 }
 
-hipError_t launch_cubic_tab(short* tab, hipStream_t st)
-{
-    hipLaunchKernelGGL(cubic_tab_kernel, dim3(4), dim3(256), 0, st, tab);
-    return hipGetLastError();
-}
-
-// interpolation: cv2's codes, 0 = INTER_NEAREST, 1 = INTER_LINEAR, 2 = INTER_CUBIC
-hipError_t launch_remap_maps(const RemapParams& P, int cn, int interpolation, hipStream_t st)
-{
-    dim3 block(64, 4);
-    dim3 grid((P.ow + 63) / 64, (P.oh + 3) / 4);
-    if (interpolation == 0) {
-        if (cn == 1)
-            hipLaunchKernelGGL(remap_maps_nearest_kernel<1>, grid, block, 0, st, P);
-        else if (cn == 3)
-            hipLaunchKernelGGL(remap_maps_nearest_kernel<3>, grid, block, 0, st, P);
-        else
-            hipLaunchKernelGGL(remap_maps_nearest_kernel<4>, grid, block, 0, st, P);
-        return hipGetLastError();
-    }
-    if (interpolation == 2) {
-        if (cn == 1)
-            hipLaunchKernelGGL(remap_maps_cubic_kernel<1>, grid, block, 0, st, P);
-        else if (cn == 3)
-            hipLaunchKernelGGL(remap_maps_cubic_kernel<3>, grid, block, 0, st, P);
-        else
-            hipLaunchKernelGGL(remap_maps_cubic_kernel<4>, grid, block, 0, st, P);
-        return hipGetLastError();
-    }
-    if (cn == 1)
-        hipLaunchKernelGGL(remap_maps_kernel<1>, grid, block, 0, st, P);
-    else if (cn == 3)
-        hipLaunchKernelGGL(remap_maps_kernel<3>, grid, block, 0, st, P);
-    else
-        hipLaunchKernelGGL(remap_maps_kernel<4>, grid, block, 0, st, P);
-    return hipGetLastError();
-}
 
 hipError_t read_stamps(unsigned long long* out16, bool reset)
 {
