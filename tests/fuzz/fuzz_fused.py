@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Randomised look at the fused path's tolerance: in-kernel maps vs the NumPy-map oracle on band-limited ("S")
 panoramas.  Prints, per case, the largest channel difference and the fraction of differing bytes; north_star's
-bar is +-1.  Usage: python tools/fuzz_fused.py [n_cases] [seed]"""
+bar is +-1.  Usage: python tests/fuzz/fuzz_fused.py [n_cases] [seed]"""
 import importlib, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from _util import oracle_views
 pkg = importlib.import_module("360-to-planer-images_amd"); nat = pkg._native

@@ -4,7 +4,7 @@ over a few geometries (in-kernel maps / caller maps / float pixel paths / legacy
 yaws and panoramas), from several threads at once; every result is compared with a fresh resident job."""
 import importlib, os, sys, threading, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import maps
 pkg = importlib.import_module("360-to-planer-images_amd"); nat = pkg._native

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """One-off fuzz of the integer path: random jobs (sizes, FOVs, yaw / pitch lists, several panoramas, odd widths)
 through p2p_job_* with the oracle's float maps, every byte compared with the CPU restatement.
-Usage: python tools/fuzz_parity.py [n_cases] [seed] [only_case | -1] [big]
+Usage: python tests/fuzz/fuzz_parity.py [n_cases] [seed] [only_case | -1] [big]
 With "big": large panoramas, views towards the poles, wide FOVs -- footprints that outgrow the LDS buffers
 (plan pass, sub-tiles, compacted item lists, direct gathers)."""
 import importlib, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from _util import oracle_maps, oracle_views
 pkg = importlib.import_module("360-to-planer-images_amd"); nat = pkg._native

@@ -2,10 +2,10 @@
 """One-off fuzz of p2p_remap_maps_interp_u8 (generic cv2.remap: three interpolations x five border modes x
 1 / 3 / 4 channels, random sizes and maps incl. NaN / huge / out-of-range coordinates) and of the fused view path's
 self-consistency (in-kernel coordinates re-fed as caller maps reproduce the fused output).
-Usage: python tools/fuzz_remap.py [n_cases] [seed]"""
+Usage: python tests/fuzz/fuzz_remap.py [n_cases] [seed]"""
 import importlib, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from _util import coords_to_maps
 from oracle import cpu_ref, maps

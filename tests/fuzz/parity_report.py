@@ -3,7 +3,7 @@
 oracle's NumPy maps, and pixel differences of the fused path on band-limited and noise panoramas."""
 import importlib, json, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from _util import diff_stats, oracle_views
 from oracle import cpu_ref, maps

@@ -238,7 +238,7 @@ def test_sub_blocks_mixed_with_plain_tiles_in_one_launch(gpu, synth):
 
 def test_single_yaw_jobs_with_several_panoramas(gpu, synth):
     """n_yaw == 1 makes the pair -> panorama constant ceil(2^32 / n_yaw) overflow 32 bits (found by
-    tools/fuzz_parity.py: every panorama but the first came out as the first)."""
+    tests/fuzz/fuzz_parity.py: every panorama but the first came out as the first)."""
     panos = [synth.synth_pano(512, 256, 1400 + i, "N") for i in range(4)]
     for yaws in ([14], [0], [200]):
         rows, U, V = oracle_maps(yaws, [60, 107], 169, 81, 512, 256, 90)
