@@ -21,6 +21,7 @@ FLAG_KEEP_COORDS = 1
 FLAG_CACHE_COORDS = 2
 FLAG_PIXELS_F32 = 4   # opt-in float pixel path (beyond the reference): one float32 resample per view
 FLAG_PIXELS_F16 = 8   # the same with the 2x2 blend in packed float16
+FLAG_PIXEL_CENTRES = 16  # float paths only: sample through pixel centres (not the reference's convention)
 
 # every symbol include/p2p_hip.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (

@@ -63,6 +63,7 @@ struct ViewsParams {
     int plan_n;              // entries in plan (host copy)
     int plan_gx;             // sub-tile workgroups per view row of the grid: 8 * ceil(plan_n / n_pitch / 8)
     int use_plan;            // the main pass leaves the listed tiles to the sub-tile pass
+    float centre;            // float pixel path only: 0 = the reference's sampling convention, 0.5 = pixel centres
 };
 
 struct RemapParams {

@@ -28,8 +28,13 @@ __global__ __launch_bounds__(256) void float_views_kernel(ViewsParams P, const d
         return;
     float U, V;
     const PitchConst pc = P.pitch[pitch_i];
-    pitch_map_eval((float)x, (float)y, P.geom, pc.c, pc.s, U, V);
+    // P.centre = 0: the reference's convention (integer coordinates are sample points, P:122-131);
+    // 0.5 (P2P_FLAG_PIXEL_CENTRES): rays through output-pixel centres, panorama texel i centred at i + 0.5
+    pitch_map_eval((float)x + P.centre, (float)y + P.centre, P.geom, pc.c, pc.s, U, V);
     const bool dead = !(U == U) || !(V == V);  // NaN next to a pole: black, as in the exact path
+    V -= P.centre;
+    if (V < 0.0f)
+        V = 0.0f;
     const int y0 = dead ? 0 : (int)V;          // V in [0, ph - 1]
     const float wy = dead ? 0.0f : V - (float)y0;
     const int y1 = y0 + 1 < P.ph ? y0 + 1 : y0;
@@ -49,7 +54,9 @@ __global__ __launch_bounds__(256) void float_views_kernel(ViewsParams P, const d
             double sh = fmod(yaw_rad[yi] * (double)P.pw / 6.283185307179586, (double)P.pw);
             if (sh < 0.0)
                 sh += (double)P.pw;
-            float xs = U + (float)sh;
+            float xs = U + (float)sh - P.centre;
+            if (xs < 0.0f)
+                xs += (float)P.pw;
             if (xs >= (float)P.pw)
                 xs -= (float)P.pw;
             int x0 = (int)xs;

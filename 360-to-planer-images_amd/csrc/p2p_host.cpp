@@ -281,6 +281,8 @@ int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out)
         return fail(P2P_ERR_INVALID, "need at least one panorama, yaw and pitch");
     if (d.n_pitch > 64 || d.n_yaw > 65535)
         return fail(P2P_ERR_INVALID, "at most 64 pitch angles and 65535 yaw angles per job (got %d, %d)", d.n_pitch, d.n_yaw);
+    if ((d.flags & P2P_FLAG_PIXEL_CENTRES) && !(d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)))
+        return fail(P2P_ERR_INVALID, "P2P_FLAG_PIXEL_CENTRES needs one of the float pixel paths (the uint8 path is the reference's arithmetic)");
     if (d.n_panos >= (1 << 26))
         return fail(P2P_ERR_INVALID, "at most 2^26 - 1 panoramas per job");
     if ((unsigned long long)d.n_panos * d.n_yaw * d.n_yaw >= (1ull << 32))
@@ -479,6 +481,7 @@ int p2p_job_run(p2p_job* j)
         // opt-in float pixel path (beyond the reference): one float resample per view, see float_views_kernel
         if (j->host_maps)
             return fail(P2P_ERR_STATE, "the float pixel path evaluates its own maps; caller maps are not supported");
+        P.centre = (j->d.flags & P2P_FLAG_PIXEL_CENTRES) ? 0.5f : 0.0f;
         if (timed)
             HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
         HIP_TRY(p2p::launch_float_views(P, j->d_yaw_rad, (j->d.flags & P2P_FLAG_PIXELS_F16) != 0, j->ctx->stream));

@@ -62,7 +62,10 @@ enum {
        the 2x2 blend in float32 or packed float16, rounded to uint8 once.  Not comparable bit for bit with
        cv2.remap; within 1-2 levels of the exact path on band-limited panoramas. */
     P2P_FLAG_PIXELS_F32 = 4,
-    P2P_FLAG_PIXELS_F16 = 8
+    P2P_FLAG_PIXELS_F16 = 8,
+    /* With a float pixel path only: rays through the centres of the output pixels and panorama texels centred at
+       i + 0.5 (the reference samples at integer coordinates, P:122-131, which shifts the picture by half a pixel). */
+    P2P_FLAG_PIXEL_CENTRES = 16
 };
 
 const char* p2p_version(void);

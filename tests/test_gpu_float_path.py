@@ -113,3 +113,35 @@ def test_float_path_rejects_caller_maps(gpu, synth):
     assert e.value.code == gpu.P2P_ERR_STATE
     job.close()
     ctx.close()
+
+
+def test_pixel_centre_convention(gpu, synth):
+    """P2P_FLAG_PIXEL_CENTRES (float paths only): rays through output-pixel centres, texel i centred at i + 0.5."""
+    pw, ph, ow, oh, fov, pitch, yaw = 1024, 512, 200, 120, 90, 75, 33
+    pano = synth.synth_pano(pw, ph, 5100, "S")
+    got = gpu.remap_views(pano, [yaw], [pitch], fov, ow, oh, flags=gpu.FLAG_PIXELS_F32 | gpu.FLAG_PIXEL_CENTRES)
+    # NumPy float32 evaluation of the same formula (P:114-175 with u + 0.5, v + 0.5)
+    f = np.float32((0.5 * ow) / np.tan(np.radians(fov) / 2))
+    u, v = np.meshgrid(np.arange(ow, dtype=np.float32) + np.float32(0.5), np.arange(oh, dtype=np.float32) + np.float32(0.5))
+    x, y, z = u - np.float32(ow / 2.0), np.float32(oh / 2.0) - v, np.full((oh, ow), f, np.float32)
+    n = np.sqrt(x * x + y * y + z * z)
+    x, y, z = x / n, y / n, z / n
+    c, s = np.float32(np.cos(np.radians(pitch))), np.float32(np.sin(np.radians(pitch)))
+    yr, zr = c * y - s * z, s * y + c * z
+    U = (np.arctan2(yr, x) % np.float32(2 * np.pi)) * np.float32(pw) / np.float32(2 * np.pi)
+    V = np.arccos(zr) * np.float32(ph) / np.float32(np.pi)
+    U, V = np.clip(U, 0, pw - 1), np.clip(V, 0, ph - 1)
+    xs = (U + np.float32(yaw * pw / 360.0) - np.float32(0.5)) % np.float32(pw)
+    ys = np.maximum(V - np.float32(0.5), 0)
+    x0 = np.minimum(xs.astype(np.int32), pw - 1); wx = (xs - x0)[..., None]
+    x1 = (x0 + 1) % pw
+    y0 = ys.astype(np.int32); wy = (ys - y0)[..., None]; y1 = np.minimum(y0 + 1, ph - 1)
+    P = pano.astype(np.float32)
+    h0 = P[y0, x0] + wx * (P[y0, x1] - P[y0, x0]); h1 = P[y1, x0] + wx * (P[y1, x1] - P[y1, x0])
+    want = np.rint(h0 + wy * (h1 - h0)).clip(0, 255).astype(np.uint8)
+    assert np.abs(got[0, 0].astype(int) - want.astype(int)).max() <= 1
+    plain = gpu.remap_views(pano, [yaw], [pitch], fov, ow, oh, flags=gpu.FLAG_PIXELS_F32)
+    assert (plain != got).mean() > 0.2                       # it is a different picture (half a pixel apart)
+    with pytest.raises(gpu.P2PError) as e:
+        gpu.remap_views(pano, [yaw], [pitch], fov, ow, oh, flags=gpu.FLAG_PIXEL_CENTRES)
+    assert e.value.code == gpu.P2P_ERR_INVALID
