@@ -26,11 +26,11 @@ FLAG_PIXEL_CENTRES = 16  # float paths only: sample through pixel centres (not t
 # every symbol include/p2p_hip.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (
     "p2p_version", "p2p_last_error", "p2p_device_count",
-    "p2p_remap_views_u8", "p2p_remap_views_maps_u8", "p2p_remap_maps_u8", "p2p_remap_maps_interp_u8",
+    "p2p_remap_views_u8", "p2p_remap_views_f64", "p2p_remap_views_maps_u8", "p2p_remap_maps_u8", "p2p_remap_maps_interp_u8",
     "p2p_build_pitch_map", "p2p_build_yaw_row", "p2p_build_rot_map",
     "p2p_ctx_create", "p2p_ctx_destroy", "p2p_ctx_synchronize", "p2p_ctx_mark", "p2p_ctx_marked_ms",
     "p2p_job_time_launches",
-    "p2p_job_create", "p2p_job_destroy", "p2p_job_set_pano", "p2p_job_set_maps", "p2p_job_run",
+    "p2p_job_create", "p2p_job_create_f64", "p2p_job_set_yaws_f64", "p2p_job_destroy", "p2p_job_set_pano", "p2p_job_set_maps", "p2p_job_run",
     "p2p_job_get_views", "p2p_job_kernel_ms", "p2p_job_kernel_ms_last", "p2p_job_device_out", "p2p_job_get_coords",
     "p2p_job_get_yaw_tables", "p2p_job_set_yaws", "p2p_host_alloc", "p2p_host_free", "p2p_release_cache",
     "p2p_debug_stamps",
@@ -77,6 +77,9 @@ def lib():
     L.p2p_remap_views_u8.restype = c_int
     L.p2p_remap_views_u8.argtypes = [c_vp, c_int, c_int, c_i64, c_vp, c_int, c_vp, c_int, c_int,
                                      c_int, c_int, c_vp, c_int, c_int]
+    L.p2p_remap_views_f64.restype = c_int
+    L.p2p_remap_views_f64.argtypes = [c_vp, c_int, c_int, c_i64, c_vp, c_int, c_vp, c_int, c_dbl,
+                                      c_int, c_int, c_vp, c_int, c_int]
     L.p2p_remap_views_maps_u8.restype = c_int
     L.p2p_remap_views_maps_u8.argtypes = [c_vp, c_int, c_int, c_i64, c_vp, c_int, c_vp, c_vp, c_int,
                                           c_int, c_int, c_vp, c_int]
@@ -106,6 +109,10 @@ def lib():
     L.p2p_job_time_launches.argtypes = [c_vp, c_int]
     L.p2p_job_create.restype = c_int
     L.p2p_job_create.argtypes = [c_vp, ctypes.POINTER(JobDesc), ctypes.POINTER(c_vp)]
+    L.p2p_job_create_f64.restype = c_int
+    L.p2p_job_create_f64.argtypes = [c_vp, ctypes.POINTER(JobDescF64), ctypes.POINTER(c_vp)]
+    L.p2p_job_set_yaws_f64.restype = c_int
+    L.p2p_job_set_yaws_f64.argtypes = [c_vp, c_vp]
     L.p2p_job_destroy.restype = None
     L.p2p_job_destroy.argtypes = [c_vp]
     L.p2p_job_set_pano.restype = c_int
@@ -171,6 +178,16 @@ def as_image(a, what="image"):
     if a.strides[2] != 1 or a.strides[1] != 3 or a.strides[0] < 3 * a.shape[1]:
         a = np.ascontiguousarray(a)
     return a
+
+
+class JobDescF64(ctypes.Structure):
+    _fields_ = [
+        ("pw", ctypes.c_int32), ("ph", ctypes.c_int32), ("n_panos", ctypes.c_int32),
+        ("n_yaw", ctypes.c_int32), ("yaw_deg", ctypes.POINTER(ctypes.c_double)),
+        ("n_pitch", ctypes.c_int32), ("pitch_deg", ctypes.POINTER(ctypes.c_double)),
+        ("fov_deg", ctypes.c_double), ("ow", ctypes.c_int32), ("oh", ctypes.c_int32),
+        ("flags", ctypes.c_int32),
+    ]
 
 
 class _PinnedPool:

@@ -9,12 +9,36 @@
 
 namespace p2p {
 
-constexpr int TILE_W = 32;          // output tile of one workgroup
+constexpr int TILE_W = 64;          // output tile of one workgroup (main pass)
 constexpr int TILE_H = 16;
 constexpr int VIEWS_BLOCK = 256;
 constexpr int VIEWS_PXT = TILE_W * TILE_H / VIEWS_BLOCK;  // output pixels per thread (rows ROWSTEP apart)
+constexpr int XTRA_PXT = VIEWS_PXT > 1 ? VIEWS_PXT / 2 : 1;  // pieces of split tiles: at most half a tile
 constexpr int VIEWS_SLOTS = 2;      // 16-byte footprint items one thread produces per (panorama, yaw) pair
 constexpr int LDS_ITEMS_CAP = VIEWS_SLOTS * VIEWS_BLOCK;  // items (4 rot pixels each) per LDS buffer
+constexpr int VIEWS_WAVES_PER_SIMD = 4;  // __launch_bounds__ of the view kernel: 128 VGPRs
+constexpr int PLAN_MAX_ROWS = 256;  // rot rows a piece's footprint may span (one plan thread per row)
+constexpr int PLAN_MIN_W = 16;      // tiles whose footprint outgrows the LDS buffers are halved in width down to
+constexpr int PLAN_MIN_H = 8;       // PLAN_MIN_W, then once in height; what still does not fit gathers directly
+
+// One piece of work of the view kernel: a w x h rectangle of output pixels of one pitch view (a whole tile, or a
+// part of a tile that had to be split), with everything that depends on the maps only worked out once by the plan
+// pass: its footprint in the yaw-resampled panorama as a list of 4-pixel items (per-row spans) and, per pixel,
+// the LDS offsets of its taps and its two 5-bit weights.  32 bytes, read with scalar loads.
+struct PieceHdr {
+    uint32_t xy;          // x0 | y0 << 16
+    uint32_t geom;        // w | h << 8 | pitch index << 16
+    uint32_t mode_items;  // mode (0: nothing to draw here, 1: LDS scheme, 2: direct gathers) | n_items << 8
+    int32_t c0, c1;       // rot columns of the footprint (mode 1): LDS position 0 of every row is a column
+                          // congruent to c0 mod 4; c1 + 1 is the last column any tap reads
+    uint32_t px_block;    // index of the piece's block of per-pixel words (blocks of 256 * PXT dwords)
+    uint32_t item_block;  // index of its item list (blocks of LDS_ITEMS_CAP dwords)
+    uint32_t pad;
+};
+static_assert(sizeof(PieceHdr) == 32, "PieceHdr is read as one s_load_dwordx8");
+// per-pixel word: tap_up (dwords into an LDS buffer, 11 bits) | (tap_lo - tap_up) << 11 (11 bits, 0 = the pixel
+// has no footprint: NaN coordinate) | fx << 22 | fy << 27
+// item word: rot row << 16 | 4-pixel group relative to the group of column c0
 
 // how the yaw map of one yaw angle acts on columns (see yaw_desc_kernel)
 struct YawDesc {
@@ -53,17 +77,35 @@ struct ViewsParams {
     MapGeom geom;
     int ow, oh;
     uint8_t* out;            // [n_panos][n_yaw][n_pitch][oh][ow][3]
-    int32_t* coords;         // optional [n_pitch][oh][ow][2] dump of (sx, sy)
     int border;              // stage-2 border mode (0 = BORDER_CONSTANT 0, the reference's current tool)
-    uint8_t pitch_order[64]; // blockIdx.y -> pitch index, heaviest view first (n_pitch <= 64 per job)
-    uint2* plan;             // sub-tiles of the tiles whose footprint outgrows the LDS buffers: x0 | y0 << 15 |
-                             // (16 wide) << 30, pitch index; written by the plan pass, read by the sub-tile pass
-    uint32_t* plan_count;
-    uint8_t* plan_flag;      // [n_pitch][tiles]: 1 = the tile is in the plan (the main pass skips it)
-    int plan_n;              // entries in plan (host copy)
-    int plan_gx;             // sub-tile workgroups per view row of the grid: 8 * ceil(plan_n / n_pitch / 8)
-    int use_plan;            // the main pass leaves the listed tiles to the sub-tile pass
+    const uint16_t* pitch_order;  // [n_pitch] blockIdx.y -> pitch index, heaviest view first
+    const int2* coords;      // [n_pitch][oh][ow] quantised pitch-stage coordinates (sx, sy), written by the plan pass
+    const PieceHdr* hdr_main;   // [n_pitch][tiles]
+    const uint32_t* px_main;    // [n_pitch][tiles][256 * VIEWS_PXT]
+    const uint32_t* items_main; // [n_pitch][tiles][LDS_ITEMS_CAP]
+    const PieceHdr* hdr_x;      // pieces of split tiles ("extras"), x_n of them
+    const uint32_t* px_x;       // [x_n][256 * XTRA_PXT]
+    const uint32_t* items_x;    // [x_n][LDS_ITEMS_CAP]
+    int x_n;
+    int plan_gx;             // extra workgroups per view row of the grid: 8 * ceil(x_n / n_pitch / 8)
     float centre;            // float pixel path only: 0 = the reference's sampling convention, 0.5 = pixel centres
+};
+
+struct PlanParams {
+    int pw, ph, ow, oh, n_pitch, border;
+    MapGeom geom;
+    const PitchConst* pitch;
+    const float* mapU;       // caller maps [n_pitch][oh][ow] or nullptr (then pitch_map_eval)
+    const float* mapV;
+    int2* coords;
+    PieceHdr* hdr_main;
+    uint32_t* px_main;
+    uint32_t* items_main;
+    PieceHdr* hdr_x;
+    uint32_t* px_x;
+    uint32_t* items_x;
+    uint32_t* x_count;       // extras wanted (may exceed x_cap: the host then grows the pools and re-runs)
+    uint32_t x_cap;
 };
 
 struct RemapParams {
@@ -86,7 +128,8 @@ hipError_t launch_yaw_desc(YawDesc* desc, uint32_t* f4tab, const uint32_t* packe
 hipError_t launch_rot_map(float* U, float* V, int ow, int oh, const MapGeom& g, const float* R9, hipStream_t st);
 hipError_t launch_pitch_map(float* U, float* V, int ow, int oh, const MapGeom& g, float c, float s,
                             hipStream_t st);
-hipError_t launch_remap_views(const ViewsParams& P, int mapsrc, int mode, hipStream_t st);
+hipError_t launch_plan(const PlanParams& P, hipStream_t st);
+hipError_t launch_remap_views(const ViewsParams& P, hipStream_t st);
 hipError_t launch_remap_maps(const RemapParams& P, int cn, int interpolation, hipStream_t st);
 hipError_t launch_cubic_tab(short* tab, hipStream_t st);
 hipError_t launch_float_views(const ViewsParams& P, const double* yaw_rad, bool half, hipStream_t st);

@@ -61,8 +61,9 @@ struct p2p_ctx {
 
 struct p2p_job {
     p2p_ctx* ctx = nullptr;
-    p2p_job_desc d{};
-    std::vector<int32_t> yaw, pitch;
+    p2p_job_desc d{};              // sizes and flags (the angle pointers are not kept: see yaw / pitch / fov)
+    std::vector<double> yaw, pitch;  // degrees, any real value (P:85 and P:64-68 go through np.radians)
+    double fov = 90.0;
     uint8_t* d_src = nullptr;
     size_t pano_stride = 0;
     int src_pitch = 0;
@@ -76,18 +77,25 @@ struct p2p_job {
     float* d_mapU = nullptr;
     float* d_mapV = nullptr;
     float* d_rows = nullptr;
-    int32_t* d_coords = nullptr;
-    uint2* d_plan = nullptr;          // sub-tiles of tiles whose footprint outgrows the LDS buffers
-    uint32_t* d_plan_count = nullptr;
-    uint8_t* d_plan_flag = nullptr;
-    size_t plan_flag_bytes = 0;
-    int plan_n = -1;                  // -1: not built yet for the current maps
+    // the plan (p2p_plan.hip): what depends on the maps only, built once per job geometry like the reference's
+    // pitch_mapping_cache (P:17-18, P:55-73)
+    int2* d_coords = nullptr;            // [n_pitch][oh][ow] quantised coordinates
+    p2p::PieceHdr* d_hdr_main = nullptr; // [n_pitch][tiles]
+    uint32_t* d_px_main = nullptr;       // [n_pitch][tiles][256 * VIEWS_PXT]
+    uint32_t* d_items_main = nullptr;    // [n_pitch][tiles][LDS_ITEMS_CAP]
+    p2p::PieceHdr* d_hdr_x = nullptr;    // pieces of split tiles
+    uint32_t* d_px_x = nullptr;
+    uint32_t* d_items_x = nullptr;
+    uint32_t* d_x_count = nullptr;
+    uint32_t x_cap = 0;
+    int x_n = -1;                        // -1: the plan has not been built for the current maps
+    uint16_t* d_pitch_order = nullptr;   // [n_pitch] heaviest view first
+    size_t n_tiles = 0;
     p2p::MapGeom geom{};
     bool host_maps = false;
     bool rows_from_host = false;  // yaw tables were packed from caller float rows, not built from yaw_deg
     bool time_launches = true;  // bracket every launch with its own event pair (p2p_job_kernel_ms*)
     int border = 0;             // stage-2 border mode; non-zero only for the legacy single-remap entry point
-    bool coords_valid = false;  // d_coords holds what the last in-kernel evaluation produced
     bool ran = false;
     std::vector<char> pano_set;
     // ring of event pairs: one per p2p_job_run, so a caller can time K back-to-back launches
@@ -259,37 +267,45 @@ void p2p_job_destroy(p2p_job* j)
     (void)hipFree(j->d_mapV);
     (void)hipFree(j->d_rows);
     (void)hipFree(j->d_coords);
-    (void)hipFree(j->d_plan);
-    (void)hipFree(j->d_plan_count);
-    (void)hipFree(j->d_plan_flag);
+    (void)hipFree(j->d_hdr_main);
+    (void)hipFree(j->d_px_main);
+    (void)hipFree(j->d_items_main);
+    (void)hipFree(j->d_hdr_x);
+    (void)hipFree(j->d_px_x);
+    (void)hipFree(j->d_items_x);
+    (void)hipFree(j->d_x_count);
+    (void)hipFree(j->d_pitch_order);
     for (hipEvent_t e : j->ev_ring)
         (void)hipEventDestroy(e);
     delete j;
 }
 
-int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out)
+static int job_create_core(p2p_ctx* ctx, const p2p_job_desc& d, const double* yaw_deg, const double* pitch_deg,
+                           double fov_deg, p2p_job** out)
 {
-    if (!ctx || !desc || !out)
-        return fail(P2P_ERR_INVALID, "p2p_job_create: NULL argument");
     *out = nullptr;
-    const p2p_job_desc& d = *desc;
     if (!dims_ok(d.pw, d.ph))
         return fail(P2P_ERR_INVALID, "panorama %dx%d: both sides must be in 1..32766 (cv::remap asserts < SHRT_MAX)", d.pw, d.ph);
     if (!dims_ok(d.ow, d.oh))
         return fail(P2P_ERR_INVALID, "output %dx%d: both sides must be in 1..32766", d.ow, d.oh);
-    if (d.n_panos < 1 || d.n_yaw < 1 || d.n_pitch < 1 || !d.yaw_deg || !d.pitch_deg)
+    if (d.n_panos < 1 || d.n_yaw < 1 || d.n_pitch < 1 || !yaw_deg || !pitch_deg)
         return fail(P2P_ERR_INVALID, "need at least one panorama, yaw and pitch");
-    if (d.n_pitch > 64 || d.n_yaw > 65535)
-        return fail(P2P_ERR_INVALID, "at most 64 pitch angles and 65535 yaw angles per job (got %d, %d)", d.n_pitch, d.n_yaw);
+    if (d.n_pitch > 65535 || d.n_yaw > 65535)
+        return fail(P2P_ERR_INVALID, "at most 65535 pitch angles and 65535 yaw angles per job (got %d, %d)", d.n_pitch, d.n_yaw);
     if ((d.flags & P2P_FLAG_PIXEL_CENTRES) && !(d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)))
         return fail(P2P_ERR_INVALID, "P2P_FLAG_PIXEL_CENTRES needs one of the float pixel paths (the uint8 path is the reference's arithmetic)");
     if (d.n_panos >= (1 << 26))
         return fail(P2P_ERR_INVALID, "at most 2^26 - 1 panoramas per job");
     if ((unsigned long long)d.n_panos * d.n_yaw * d.n_yaw >= (1ull << 32))
         return fail(P2P_ERR_INVALID, "n_panos * n_yaw^2 must stay below 2^32 (got %d panoramas, %d yaws)", d.n_panos, d.n_yaw);
+    if (!std::isfinite(fov_deg))
+        return fail(P2P_ERR_INVALID, "FOV must be a finite number of degrees");
+    for (int i = 0; i < d.n_yaw; ++i)
+        if (!std::isfinite(yaw_deg[i]))
+            return fail(P2P_ERR_INVALID, "yaw angle %d is not finite", i);
     for (int i = 0; i < d.n_pitch; ++i)
-        if (d.pitch_deg[i] < 1 || d.pitch_deg[i] > 179)
-            return fail(P2P_ERR_INVALID, "Pitch angle must be between 1 and 179 degrees, got %d.", d.pitch_deg[i]);
+        if (!std::isfinite(pitch_deg[i]))
+            return fail(P2P_ERR_INVALID, "pitch angle %d is not finite", i);
     HIP_TRY(hipSetDevice(ctx->device));
 
     p2p_job* j = new (std::nothrow) p2p_job();
@@ -297,10 +313,11 @@ int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out)
         return fail(P2P_ERR_OOM, "host allocation failed");
     j->ctx = ctx;
     j->d = d;
-    j->yaw.assign(d.yaw_deg, d.yaw_deg + d.n_yaw);
-    j->pitch.assign(d.pitch_deg, d.pitch_deg + d.n_pitch);
-    j->d.yaw_deg = j->yaw.data();
-    j->d.pitch_deg = j->pitch.data();
+    j->d.yaw_deg = nullptr;
+    j->d.pitch_deg = nullptr;
+    j->yaw.assign(yaw_deg, yaw_deg + d.n_yaw);
+    j->pitch.assign(pitch_deg, pitch_deg + d.n_pitch);
+    j->fov = fov_deg;
     j->pano_set.assign(d.n_panos, 0);
 
     j->src_pitch = (3 * d.pw + 15) & ~15;
@@ -308,7 +325,7 @@ int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out)
     j->out_bytes = (size_t)d.n_panos * d.n_yaw * d.n_pitch * d.oh * d.ow * 3;
 
     // scalars NumPy evaluates in float64 once per map (P:64-68, P:119, P:129-131, P:142-149)
-    const double fov_rad = deg2rad((double)d.fov_deg);
+    const double fov_rad = deg2rad(fov_deg);
     j->geom.half_w = (float)(d.ow / 2.0);
     j->geom.half_h = (float)(d.oh / 2.0);
     j->geom.focal = (float)((0.5 * d.ow) / std::tan(fov_rad / 2));
@@ -316,13 +333,13 @@ int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out)
     j->geom.ph_f = (float)d.ph;
     std::vector<p2p::PitchConst> pc(d.n_pitch);
     for (int i = 0; i < d.n_pitch; ++i) {
-        double pr = deg2rad((double)j->pitch[i]);
+        double pr = deg2rad(j->pitch[i]);
         pc[i].c = (float)std::cos(pr);
         pc[i].s = (float)std::sin(pr);
     }
     std::vector<double> yr(d.n_yaw);
     for (int i = 0; i < d.n_yaw; ++i)
-        yr[i] = deg2rad((double)j->yaw[i]);  // P:85
+        yr[i] = deg2rad(j->yaw[i]);  // P:85
 
     hipError_t e = hipMalloc((void**)&j->d_src, j->pano_stride * d.n_panos);
     if (e == hipSuccess) e = hipMalloc((void**)&j->d_out, j->out_bytes + 16);
@@ -331,14 +348,25 @@ int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out)
     if (e == hipSuccess) e = hipMalloc((void**)&j->d_ydesc, (size_t)d.n_yaw * sizeof(p2p::YawDesc));
     if (e == hipSuccess) e = hipMalloc((void**)&j->d_yaw_rad, (size_t)d.n_yaw * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&j->d_pitch, (size_t)d.n_pitch * sizeof(p2p::PitchConst));
-    if (e == hipSuccess && (d.flags & (P2P_FLAG_KEEP_COORDS | P2P_FLAG_CACHE_COORDS)))
-        e = hipMalloc((void**)&j->d_coords, (size_t)d.n_pitch * d.oh * d.ow * 2 * sizeof(int32_t));
-    {
-        const size_t tiles = (size_t)((d.ow + p2p::TILE_W - 1) / p2p::TILE_W) * ((d.oh + p2p::TILE_H - 1) / p2p::TILE_H);
-        if (e == hipSuccess) e = hipMalloc((void**)&j->d_plan, tiles * d.n_pitch * 4 * sizeof(uint2));
-        if (e == hipSuccess) e = hipMalloc((void**)&j->d_plan_count, sizeof(uint32_t));
-        j->plan_flag_bytes = tiles * d.n_pitch;
-        if (e == hipSuccess) e = hipMalloc((void**)&j->d_plan_flag, j->plan_flag_bytes);
+    const bool float_path = (d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)) != 0;
+    j->n_tiles = (size_t)((d.ow + p2p::TILE_W - 1) / p2p::TILE_W) * ((d.oh + p2p::TILE_H - 1) / p2p::TILE_H);
+    if (!float_path) {
+        const size_t slots = j->n_tiles * d.n_pitch;
+        if (e == hipSuccess) e = hipMalloc((void**)&j->d_coords, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2));
+        if (e == hipSuccess) e = hipMalloc((void**)&j->d_hdr_main, slots * sizeof(p2p::PieceHdr));
+        if (e == hipSuccess) e = hipMalloc((void**)&j->d_px_main, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&j->d_items_main, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&j->d_x_count, sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&j->d_pitch_order, (size_t)d.n_pitch * sizeof(uint16_t));
+        // views looking further from the horizon have larger source footprints: launch them first
+        std::vector<uint16_t> ord(d.n_pitch);
+        for (int i = 0; i < d.n_pitch; ++i)
+            ord[i] = (uint16_t)i;
+        std::stable_sort(ord.begin(), ord.end(), [&](uint16_t a, uint16_t b) {
+            return std::fabs(j->pitch[a] - 90.0) > std::fabs(j->pitch[b] - 90.0);
+        });
+        if (e == hipSuccess)
+            e = hipMemcpy(j->d_pitch_order, ord.data(), ord.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess)
         e = hipMemcpyAsync(j->d_yaw_rad, yr.data(), yr.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
@@ -356,6 +384,34 @@ int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out)
     }
     *out = j;
     return P2P_OK;
+}
+
+int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out)
+{
+    if (!ctx || !desc || !out)
+        return fail(P2P_ERR_INVALID, "p2p_job_create: NULL argument");
+    *out = nullptr;
+    const p2p_job_desc& d = *desc;
+    if (d.n_yaw < 1 || d.n_pitch < 1 || !d.yaw_deg || !d.pitch_deg)
+        return fail(P2P_ERR_INVALID, "need at least one panorama, yaw and pitch");
+    // the integer entry point keeps the CLI's validation (check_pitch, P:362-376)
+    for (int i = 0; i < d.n_pitch; ++i)
+        if (d.pitch_deg[i] < 1 || d.pitch_deg[i] > 179)
+            return fail(P2P_ERR_INVALID, "Pitch angle must be between 1 and 179 degrees, got %d.", d.pitch_deg[i]);
+    std::vector<double> yaw(d.yaw_deg, d.yaw_deg + d.n_yaw), pitch(d.pitch_deg, d.pitch_deg + d.n_pitch);
+    return job_create_core(ctx, d, yaw.data(), pitch.data(), (double)d.fov_deg, out);
+}
+
+int p2p_job_create_f64(p2p_ctx* ctx, const p2p_job_desc_f64* desc, p2p_job** out)
+{
+    if (!ctx || !desc || !out)
+        return fail(P2P_ERR_INVALID, "p2p_job_create_f64: NULL argument");
+    p2p_job_desc d{};
+    d.pw = desc->pw; d.ph = desc->ph; d.n_panos = desc->n_panos;
+    d.n_yaw = desc->n_yaw; d.n_pitch = desc->n_pitch;
+    d.fov_deg = (int32_t)std::lround(std::isfinite(desc->fov_deg) ? desc->fov_deg : 0.0);
+    d.ow = desc->ow; d.oh = desc->oh; d.flags = desc->flags;
+    return job_create_core(ctx, d, desc->yaw_deg, desc->pitch_deg, desc->fov_deg, out);
 }
 
 int p2p_job_set_pano(p2p_job* j, int index, const uint8_t* pano, int64_t row_stride)
@@ -376,22 +432,33 @@ int p2p_job_set_pano(p2p_job* j, int index, const uint8_t* pano, int64_t row_str
     return P2P_OK;
 }
 
-int p2p_job_set_yaws(p2p_job* j, const int32_t* yaw_deg)
+int p2p_job_set_yaws_f64(p2p_job* j, const double* yaw_deg)
 {
     if (!j || !yaw_deg)
         return fail(P2P_ERR_INVALID, "p2p_job_set_yaws: NULL argument");
     const p2p_job_desc& d = j->d;
+    for (int i = 0; i < d.n_yaw; ++i)
+        if (!std::isfinite(yaw_deg[i]))
+            return fail(P2P_ERR_INVALID, "yaw angle %d is not finite", i);
     HIP_TRY(hipSetDevice(j->ctx->device));
     j->yaw.assign(yaw_deg, yaw_deg + d.n_yaw);
-    j->d.yaw_deg = j->yaw.data();
     std::vector<double> yr(d.n_yaw);
     for (int i = 0; i < d.n_yaw; ++i)
-        yr[i] = deg2rad((double)j->yaw[i]);  // P:85
+        yr[i] = deg2rad(j->yaw[i]);  // P:85
     HIP_TRY(hipMemcpyAsync(j->d_yaw_rad, yr.data(), yr.size() * sizeof(double), hipMemcpyHostToDevice, j->ctx->stream));
     HIP_TRY(p2p::launch_yaw_tables(j->d_ytab, nullptr, d.pw, d.n_yaw, j->d_yaw_rad, j->ctx->stream));
     HIP_TRY(p2p::launch_yaw_desc(j->d_ydesc, j->d_f4tab, j->d_ytab, d.pw, d.n_yaw, j->ctx->stream));
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));  // yr is a stack-lifetime host buffer
+    j->rows_from_host = false;
     return P2P_OK;
+}
+
+int p2p_job_set_yaws(p2p_job* j, const int32_t* yaw_deg)
+{
+    if (!j || !yaw_deg)
+        return fail(P2P_ERR_INVALID, "p2p_job_set_yaws: NULL argument");
+    std::vector<double> y(yaw_deg, yaw_deg + j->d.n_yaw);
+    return p2p_job_set_yaws_f64(j, y.data());
 }
 
 int p2p_job_set_maps(p2p_job* j, const float* yaw_rows, const float* U, const float* V)
@@ -419,9 +486,63 @@ int p2p_job_set_maps(p2p_job* j, const float* yaw_rows, const float* U, const fl
     }
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));
     j->host_maps = true;
-    j->coords_valid = false;
-    j->plan_n = -1;
+    j->x_n = -1;  // the plan follows the maps
     return P2P_OK;
+}
+
+// Build the job's plan (p2p_plan.hip) for its current maps: once per job geometry, like the yaw tables.  It
+// depends on the maps only, never on pixel data -- the device counterpart of the reference's
+// pitch_mapping_cache (P:17-18, P:55-73), which lives as long as the process.
+static int job_build_plan(p2p_job* j)
+{
+    const p2p_job_desc& d = j->d;
+    hipStream_t st = j->ctx->stream;
+    p2p::PlanParams Q{};
+    Q.pw = d.pw; Q.ph = d.ph; Q.ow = d.ow; Q.oh = d.oh; Q.n_pitch = d.n_pitch; Q.border = j->border;
+    Q.geom = j->geom;
+    Q.pitch = j->d_pitch;
+    Q.mapU = j->host_maps ? j->d_mapU : nullptr;
+    Q.mapV = j->host_maps ? j->d_mapV : nullptr;
+    Q.coords = j->d_coords;
+    Q.hdr_main = j->d_hdr_main;
+    Q.px_main = j->d_px_main;
+    Q.items_main = j->d_items_main;
+    Q.x_count = j->d_x_count;
+    const size_t slots = j->n_tiles * d.n_pitch;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!j->d_hdr_x) {
+            // first guess: one tile in eight is split in two (grown below if the plan wants more)
+            if (j->x_cap == 0)
+                j->x_cap = (uint32_t)std::min<size_t>(slots / 4 + 64, 0x7FFFFFFFu);
+            HIP_TRY(hipMalloc((void**)&j->d_hdr_x, (size_t)j->x_cap * sizeof(p2p::PieceHdr)));
+            HIP_TRY(hipMalloc((void**)&j->d_px_x, (size_t)j->x_cap * 256 * p2p::XTRA_PXT * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void**)&j->d_items_x, (size_t)j->x_cap * p2p::LDS_ITEMS_CAP * sizeof(uint32_t)));
+        }
+        Q.hdr_x = j->d_hdr_x;
+        Q.px_x = j->d_px_x;
+        Q.items_x = j->d_items_x;
+        Q.x_cap = j->x_cap;
+        HIP_TRY(hipMemsetAsync(j->d_x_count, 0, sizeof(uint32_t), st));
+        // pixels outside the view (partial tiles) and unused item slots read as zero
+        HIP_TRY(hipMemsetAsync(j->d_px_main, 0, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(j->d_items_main, 0, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(j->d_px_x, 0, (size_t)j->x_cap * 256 * p2p::XTRA_PXT * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(j->d_items_x, 0, (size_t)j->x_cap * p2p::LDS_ITEMS_CAP * sizeof(uint32_t), st));
+        HIP_TRY(p2p::launch_plan(Q, st));
+        uint32_t n = 0;
+        HIP_TRY(hipMemcpyAsync(&n, j->d_x_count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (n <= j->x_cap) {
+            j->x_n = (int)n;
+            return P2P_OK;
+        }
+        // more pieces than the pools hold (views full of poles): size them exactly and plan again
+        (void)hipFree(j->d_hdr_x); j->d_hdr_x = nullptr;
+        (void)hipFree(j->d_px_x); j->d_px_x = nullptr;
+        (void)hipFree(j->d_items_x); j->d_items_x = nullptr;
+        j->x_cap = n;
+    }
+    return fail(P2P_ERR_HIP, "the plan pass did not converge");
 }
 
 int p2p_job_run(p2p_job* j)
@@ -453,7 +574,6 @@ int p2p_job_run(p2p_job* j)
     P.ow = j->d.ow;
     P.oh = j->d.oh;
     P.out = j->d_out;
-    P.coords = j->d_coords;
     P.border = j->border;
     if (j->ev_ring.empty()) {
         j->ev_ring.resize(2 * kEvRing, nullptr);
@@ -461,22 +581,7 @@ int p2p_job_run(p2p_job* j)
             HIP_TRY(hipEventCreate(&e));
     }
     const int slot = (int)(j->runs % kEvRing);
-    // views looking further from the horizon have larger source footprints: launch them first
-    {
-        std::vector<int> ord(j->d.n_pitch);
-        for (int i = 0; i < j->d.n_pitch; ++i)
-            ord[i] = i;
-        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
-            return std::abs(j->pitch[a] - 90) > std::abs(j->pitch[b] - 90);
-        });
-        for (int i = 0; i < j->d.n_pitch; ++i)
-            P.pitch_order[i] = (uint8_t)ord[i];
-    }
     const bool timed = j->time_launches;
-    // coordinate cache (opt-in): the first launch evaluates the maps in-kernel and stores the quantised
-    // coordinates, later launches of the job load them -- the reference's pitch_mapping_cache (P:62-73)
-    const bool use_cache = (j->d.flags & P2P_FLAG_CACHE_COORDS) && j->coords_valid && !j->host_maps;
-    const int mapsrc = j->host_maps ? 1 : (use_cache ? 2 : 0);
     if (j->d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)) {
         // opt-in float pixel path (beyond the reference): one float resample per view, see float_views_kernel
         if (j->host_maps)
@@ -491,31 +596,24 @@ int p2p_job_run(p2p_job* j)
         j->ran = true;
         return P2P_OK;
     }
-    P.plan = j->d_plan;
-    P.plan_count = j->d_plan_count;
-    P.plan_flag = j->d_plan_flag;
-    if (j->plan_n < 0 && env_int("P2P_NO_PLAN", 0) == 0) {
-        // once per job geometry (like the yaw tables): which tiles outgrow the LDS buffers, as a list of
-        // sub-tiles for the second pass.  It depends on the maps only, never on pixel data.
-        uint32_t n = 0;
-        HIP_TRY(hipMemsetAsync(j->d_plan_count, 0, sizeof(uint32_t), j->ctx->stream));
-        HIP_TRY(hipMemsetAsync(j->d_plan_flag, 0, j->plan_flag_bytes, j->ctx->stream));
-        P.plan_n = 0;
-        P.plan_gx = 0;
-        P.use_plan = 0;
-        HIP_TRY(p2p::launch_remap_views(P, j->host_maps ? 1 : 0, 1, j->ctx->stream));
-        HIP_TRY(hipMemcpyAsync(&n, j->d_plan_count, sizeof(uint32_t), hipMemcpyDeviceToHost, j->ctx->stream));
-        HIP_TRY(hipStreamSynchronize(j->ctx->stream));
-        j->plan_n = (int)n;
+    if (j->x_n < 0) {
+        int rc = job_build_plan(j);
+        if (rc != P2P_OK)
+            return rc;
     }
-    P.plan_n = j->plan_n > 0 ? j->plan_n : 0;
-    P.plan_gx = 8 * ((((P.plan_n + j->d.n_pitch - 1) / j->d.n_pitch) + 7) / 8);
-    P.use_plan = j->plan_n >= 0;
+    P.pitch_order = j->d_pitch_order;
+    P.coords = j->d_coords;
+    P.hdr_main = j->d_hdr_main;
+    P.px_main = j->d_px_main;
+    P.items_main = j->d_items_main;
+    P.hdr_x = j->d_hdr_x;
+    P.px_x = j->d_px_x;
+    P.items_x = j->d_items_x;
+    P.x_n = j->x_n;
+    P.plan_gx = 8 * ((((P.x_n + j->d.n_pitch - 1) / j->d.n_pitch) + 7) / 8);
     if (timed)
         HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
-    HIP_TRY(p2p::launch_remap_views(P, mapsrc, 0, j->ctx->stream));
-    if (!j->host_maps && j->d_coords)
-        j->coords_valid = true;
+    HIP_TRY(p2p::launch_remap_views(P, j->ctx->stream));
     if (timed)
         HIP_TRY(hipEventRecord(j->ev_ring[2 * slot + 1], j->ctx->stream));
     j->runs++;
@@ -608,12 +706,12 @@ int p2p_job_get_coords(p2p_job* j, int32_t* sxsy)
     if (!j || !sxsy)
         return fail(P2P_ERR_INVALID, "NULL argument");
     if (!j->d_coords)
-        return fail(P2P_ERR_STATE, "job was not created with P2P_FLAG_KEEP_COORDS");
+        return fail(P2P_ERR_STATE, "the float pixel paths keep no quantised coordinates");
     if (!j->ran)
         return fail(P2P_ERR_STATE, "p2p_job_run has not been called");
     HIP_TRY(hipSetDevice(j->ctx->device));
     const size_t n = (size_t)j->d.n_pitch * j->d.oh * j->d.ow * 2 * sizeof(int32_t);
-    HIP_TRY(hipMemcpyAsync(sxsy, j->d_coords, n, hipMemcpyDeviceToHost, j->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(sxsy, (const void*)j->d_coords, n, hipMemcpyDeviceToHost, j->ctx->stream));
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));
     return P2P_OK;
 }
@@ -672,8 +770,8 @@ int p2p_debug_stamps(uint64_t* out16, int reset)
 // one-shot entry points
 // ------------------------------------------------------------------------------------------
 static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride,
-                         const int32_t* yaw_deg, int n_yaw, const int32_t* pitch_deg, int n_pitch,
-                         int fov_deg, int ow, int oh, uint8_t* out, int device, int flags,
+                         const double* yaw_deg, int n_yaw, const double* pitch_deg, int n_pitch,
+                         double fov_deg, int ow, int oh, uint8_t* out, int device, int flags,
                          const float* yaw_rows, const float* U, const float* V, int border = 0)
 {
     if (!pano || !out)
@@ -684,16 +782,16 @@ static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride
     int rc = thread_ctx(device, &ctx);
     if (rc != P2P_OK)
         return rc;
-    std::vector<int32_t> dummy_yaw, dummy_pitch;
+    std::vector<double> dummy_yaw, dummy_pitch;
     if (!yaw_deg) {  // caller-supplied rows: degrees are irrelevant
-        dummy_yaw.assign(n_yaw, 0);
+        dummy_yaw.assign(n_yaw, 0.0);
         yaw_deg = dummy_yaw.data();
     }
     if (!pitch_deg) {
-        dummy_pitch.assign(n_pitch, 90);
+        dummy_pitch.assign(n_pitch, 90.0);
         pitch_deg = dummy_pitch.data();
     }
-    p2p_job_desc d{};
+    p2p_job_desc_f64 d{};
     d.pw = pw; d.ph = ph; d.n_panos = 1;
     d.n_yaw = n_yaw; d.yaw_deg = yaw_deg;
     d.n_pitch = n_pitch; d.pitch_deg = pitch_deg;
@@ -706,16 +804,14 @@ static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride
         p2p_job* c = it->second;
         const p2p_job_desc& k = c->d;
         const bool same = k.pw == pw && k.ph == ph && k.n_yaw == n_yaw && k.n_pitch == n_pitch &&
-                          k.fov_deg == fov_deg && k.ow == ow && k.oh == oh && k.flags == flags &&
+                          c->fov == fov_deg && k.ow == ow && k.oh == oh && k.flags == flags &&
                           c->border == border && c->host_maps == (U != nullptr) &&
                           std::equal(c->pitch.begin(), c->pitch.end(), pitch_deg);
         if (same) {
             j = c;
             // caller rows replace the tables below; otherwise rebuild them only when the yaws changed
-            if (!yaw_rows && (c->rows_from_host || !std::equal(c->yaw.begin(), c->yaw.end(), yaw_deg))) {
-                rc = p2p_job_set_yaws(c, yaw_deg);
-                c->rows_from_host = false;
-            }
+            if (!yaw_rows && (c->rows_from_host || !std::equal(c->yaw.begin(), c->yaw.end(), yaw_deg)))
+                rc = p2p_job_set_yaws_f64(c, yaw_deg);
         } else {
             p2p_job_destroy(c);
             g_tctx.cached.erase(it);
@@ -723,7 +819,7 @@ static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride
     }
     const bool fresh = (j == nullptr);
     if (fresh) {
-        rc = p2p_job_create(ctx, &d, &j);
+        rc = p2p_job_create_f64(ctx, &d, &j);
         if (rc != P2P_OK)
             return rc;
         j->border = border;
@@ -738,7 +834,7 @@ static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride
         rc = p2p_job_get_views(j, 0, out);
 
     const size_t held = j->pano_stride + j->out_bytes + (size_t)n_yaw * pw * 8 +
-                        (U ? (size_t)n_pitch * ow * oh * 8 : 0);
+                        (size_t)n_pitch * ow * oh * (U ? 28 : 20);
     const bool keep = rc == P2P_OK && env_int("P2P_ONESHOT_CACHE", 1) != 0 &&
                       held <= (size_t)env_int("P2P_ONESHOT_CACHE_MAX_MB", 4096) * 1048576ull;
     if (keep) {
@@ -751,14 +847,29 @@ static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride
     return rc;
 }
 
+int p2p_remap_views_f64(const uint8_t* pano, int pw, int ph, int64_t row_stride,
+                        const double* yaw_deg, int n_yaw, const double* pitch_deg, int n_pitch,
+                        double fov_deg, int ow, int oh, uint8_t* out, int device, int flags)
+{
+    if (n_yaw < 0 || n_pitch < 0 || (n_yaw > 0 && !yaw_deg) || (n_pitch > 0 && !pitch_deg))
+        return fail(P2P_ERR_INVALID, "bad yaw/pitch list");
+    return views_oneshot(pano, pw, ph, row_stride, yaw_deg, n_yaw, pitch_deg, n_pitch, fov_deg, ow, oh,
+                         out, device, flags & ~(P2P_FLAG_KEEP_COORDS | P2P_FLAG_CACHE_COORDS), nullptr, nullptr, nullptr);
+}
+
 int p2p_remap_views_u8(const uint8_t* pano, int pw, int ph, int64_t row_stride,
                        const int32_t* yaw_deg, int n_yaw, const int32_t* pitch_deg, int n_pitch,
                        int fov_deg, int ow, int oh, uint8_t* out, int device, int flags)
 {
     if (n_yaw < 0 || n_pitch < 0 || (n_yaw > 0 && !yaw_deg) || (n_pitch > 0 && !pitch_deg))
         return fail(P2P_ERR_INVALID, "bad yaw/pitch list");
-    return views_oneshot(pano, pw, ph, row_stride, yaw_deg, n_yaw, pitch_deg, n_pitch, fov_deg, ow, oh,
-                         out, device, flags & ~(P2P_FLAG_KEEP_COORDS | P2P_FLAG_CACHE_COORDS), nullptr, nullptr, nullptr);
+    // the integer entry point keeps the CLI's validation (check_pitch, P:362-376)
+    for (int i = 0; i < n_pitch; ++i)
+        if (pitch_deg[i] < 1 || pitch_deg[i] > 179)
+            return fail(P2P_ERR_INVALID, "Pitch angle must be between 1 and 179 degrees, got %d.", pitch_deg[i]);
+    std::vector<double> yaw(yaw_deg, yaw_deg + n_yaw), pitch(pitch_deg, pitch_deg + n_pitch);
+    return p2p_remap_views_f64(pano, pw, ph, row_stride, yaw.data(), n_yaw, pitch.data(), n_pitch, (double)fov_deg,
+                               ow, oh, out, device, flags);
 }
 
 int p2p_remap_views_maps_u8(const uint8_t* pano, int pw, int ph, int64_t row_stride,
@@ -767,7 +878,7 @@ int p2p_remap_views_maps_u8(const uint8_t* pano, int pw, int ph, int64_t row_str
 {
     if (n_yaw < 0 || n_pitch < 0 || (n_yaw > 0 && !yaw_rows) || (n_pitch > 0 && (!U || !V)))
         return fail(P2P_ERR_INVALID, "bad map arguments");
-    return views_oneshot(pano, pw, ph, row_stride, nullptr, n_yaw, nullptr, n_pitch, 90, ow, oh, out,
+    return views_oneshot(pano, pw, ph, row_stride, nullptr, n_yaw, nullptr, n_pitch, 90.0, ow, oh, out,
                          device, 0, yaw_rows, U, V);
 }
 
@@ -802,8 +913,8 @@ int p2p_remap_maps_interp_u8(const uint8_t* src, int sw, int sh, int64_t row_str
         // three interleaved channels: the view kernel with an identity yaw stage (yaw 0 quantises to
         // "column x, fraction 0", so stage 1 is a copy) and the caller's maps as its pitch stage --
         // LDS-staged taps instead of per-pixel byte gathers
-        const int32_t yaw0 = 0;
-        return views_oneshot(src, sw, sh, row_stride, &yaw0, 1, nullptr, 1, 90, ow, oh, out, device, 0,
+        const double yaw0 = 0.0;
+        return views_oneshot(src, sw, sh, row_stride, &yaw0, 1, nullptr, 1, 90.0, ow, oh, out, device, 0,
                              nullptr, U, V, border_mode);
     }
     p2p_ctx* ctx = nullptr;

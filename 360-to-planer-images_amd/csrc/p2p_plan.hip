@@ -1,0 +1,287 @@
+// p2p_plan.hip -- the plan pass of the view kernel: everything that depends on the coordinate maps only
+//   get_pitch_mapping / pitch_mapping_cache  P:17-18, P:55-73  -> plan_kernel (once per job geometry)
+// Reference behaviour (cited, never copied):
+//   P = /root/reference/app/panorama_to_plane-pitch.py
+// The reference evaluates each pitch map once and keeps it for the life of the process (pitch_mapping_cache,
+// key (ow, oh, pitch, pw, ph, fov)); every later yaw and every later image re-uses it.  The device analogue:
+// one pass per job geometry evaluates (or reads, for caller maps) the float32 map of every output pixel,
+// quantises it as cv::remap does (INTER_BITS = 5) and stores
+//   * the quantised coordinates (sx, sy), for the direct-gather path and for p2p_job_get_coords;
+//   * per tile: the footprint of the tile in the yaw-resampled panorama as per-row spans of 4-pixel items, and
+//     per pixel the LDS offsets of its 2x2 taps inside that footprint plus its two 5-bit weights (one dword);
+//   * for tiles whose footprint does not fit the LDS buffers: the same for halves / quarters ... of the tile
+//     ("extras"), down to 16x8 pieces; what still does not fit is marked for direct gathers.
+// No pixel data is touched here.  The view kernel (p2p_views.hip) then starts every launch from these tables.
+// Compiled with -ffp-contract=off: every float operation rounds where NumPy rounds.
+#include "p2p_inline.h"
+
+namespace p2p {
+
+namespace {
+
+constexpr int LOG2_TILE_W = TILE_W == 64 ? 6 : (TILE_W == 32 ? 5 : 4);
+static_assert((1 << LOG2_TILE_W) == TILE_W, "TILE_W must be 16, 32 or 64");
+constexpr int N_WSPLIT = LOG2_TILE_W - 4;          // width halvings down to PLAN_MIN_W = 16
+constexpr int N_LEVELS = N_WSPLIT + 2;             // whole tile, width halvings, one height halving
+static_assert(TILE_H == 2 * PLAN_MIN_H && PLAN_MIN_W == 16, "piece geometry below assumes 16-row tiles");
+static_assert((TILE_W >> 1) * TILE_H <= 256 * XTRA_PXT, "a half tile must fit an extra piece");
+
+struct Rect {
+    int x, y, w, h;  // relative to the tile origin
+};
+
+__device__ __forceinline__ Rect piece_rect(int level, int idx)
+{
+    Rect r;
+    if (level <= N_WSPLIT) {
+        r.w = TILE_W >> level;
+        r.h = TILE_H;
+        r.x = idx * r.w;
+        r.y = 0;
+    } else {
+        r.w = PLAN_MIN_W;
+        r.h = PLAN_MIN_H;
+        r.x = (idx >> 1) * PLAN_MIN_W;
+        r.y = (idx & 1) * PLAN_MIN_H;
+    }
+    return r;
+}
+
+// block-wide exclusive scan of one value per thread (256 threads); returns the exclusive prefix, total in *total
+__device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* s_scan, uint32_t* total)
+{
+    const int t = threadIdx.x;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+        if ((t & 63) >= d)
+            incl += up;
+    }
+    __syncthreads();  // s_scan may still be read from the previous use
+    if ((t & 63) == 63)
+        s_scan[t >> 6] = incl;
+    __syncthreads();
+    uint32_t base = incl - v;
+    for (int w = 0; w < (t >> 6); ++w)
+        base += s_scan[w];
+    *total = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+    return base;
+}
+
+}  // namespace
+
+template <bool CALLER_MAPS>
+__global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
+{
+    __shared__ int s_box[4];    // min ix, max ix, min iy, max iy of the piece's live pixels
+    __shared__ int s_flags[2];  // any live pixel, any pixel outside the panorama under a non-constant border
+    __shared__ int s_rmin[PLAN_MAX_ROWS], s_rmax[PLAN_MAX_ROWS];
+    __shared__ uint32_t s_rbase[PLAN_MAX_ROWS + 1];
+    __shared__ uint32_t s_scan[4];
+    __shared__ uint32_t s_slot;
+
+    constexpr int PXT = VIEWS_PXT;
+    constexpr int ROWSTEP = VIEWS_BLOCK / TILE_W;
+    const int t = threadIdx.x;
+    const int tiles_x = (P.ow + TILE_W - 1) / TILE_W;
+    const int tiles_y = (P.oh + TILE_H - 1) / TILE_H;
+    const int tile_id = blockIdx.x, pitch_i = blockIdx.y;
+    const int x0 = (tile_id % tiles_x) * TILE_W, y0 = (tile_id / tiles_x) * TILE_H;
+    const int tx = t % TILE_W, ty0 = t / TILE_W;
+    const int px = x0 + tx;
+
+    // ---- the pitch-stage coordinate of every pixel of the tile, quantised as cv::remap does ----
+    int ix[PXT], iy[PXT];
+    uint32_t fx[PXT], fy[PXT];
+    bool inside[PXT], inrange[PXT];
+#pragma unroll
+    for (int j = 0; j < PXT; ++j) {
+        const int py = y0 + ty0 + j * ROWSTEP;
+        inside[j] = px < P.ow && py < P.oh;
+        int sx = INT32_MIN, sy = INT32_MIN;
+        if (inside[j]) {
+            const size_t k = ((size_t)pitch_i * P.oh + py) * P.ow + px;
+            float U, V;
+            if (CALLER_MAPS) {
+                U = P.mapU[k];
+                V = P.mapV[k];
+            } else {
+                const PitchConst pc = P.pitch[pitch_i];
+                pitch_map_eval((float)px, (float)py, P.geom, pc.c, pc.s, U, V);
+            }
+            sx = cv_round_f32(U * 32.0f);
+            sy = cv_round_f32(V * 32.0f);
+            P.coords[k] = make_int2(sx, sy);
+        }
+        ix[j] = sat_short(sx >> 5);
+        iy[j] = sat_short(sy >> 5);
+        fx[j] = (uint32_t)sx & 31u;
+        fy[j] = (uint32_t)sy & 31u;
+        // A pixel contributes only if its 2x2 footprint touches the panorama (BORDER_CONSTANT 0: cv::remap writes
+        // borderValue when sx >= w || sx+1 < 0 || sy >= h || sy+1 < 0).  For the reference's clipped maps that is
+        // every pixel except NaN ones (ix = iy = -32768).
+        inrange[j] = inside[j] && ix[j] >= -1 && iy[j] >= -1 && ix[j] < P.pw && iy[j] < P.ph;
+    }
+
+    const int slot_main = pitch_i * tiles_x * tiles_y + tile_id;
+    uint32_t pending = 1u;  // pieces of the current level still to be placed, one bit per index
+    for (int level = 0; level < N_LEVELS; ++level) {
+        uint32_t next = 0u;
+        for (int idx = 0; idx < (1 << level); ++idx) {
+            if (!((pending >> idx) & 1u))
+                continue;
+            const Rect rc = piece_rect(level, idx);
+            if (x0 + rc.x >= P.ow || y0 + rc.y >= P.oh)
+                continue;  // no pixel of the view in this piece
+            bool member[PXT];
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) {
+                const int ry = ty0 + j * ROWSTEP;
+                member[j] = inside[j] && tx >= rc.x && tx < rc.x + rc.w && ry >= rc.y && ry < rc.y + rc.h;
+            }
+            // ---- bounding box of the live pixels' coordinates ----
+            __syncthreads();
+            if (t == 0) {
+                s_box[0] = INT32_MAX; s_box[1] = INT32_MIN; s_box[2] = INT32_MAX; s_box[3] = INT32_MIN;
+                s_flags[0] = 0; s_flags[1] = 0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) {
+                if (member[j] && inrange[j]) {
+                    atomicMin(&s_box[0], ix[j]); atomicMax(&s_box[1], ix[j]);
+                    atomicMin(&s_box[2], iy[j]); atomicMax(&s_box[3], iy[j]);
+                    s_flags[0] = 1;
+                } else if (member[j] && P.border != 0) {
+                    s_flags[1] = 1;  // reads reflected / wrapped / replicated pixels: cv::borderInterpolate, direct path
+                }
+            }
+            __syncthreads();
+            const int c0 = s_box[0], c1 = s_box[1], r0 = s_box[2], r1 = s_box[3];
+            const bool any_live = s_flags[0] != 0, stray = s_flags[1] != 0;
+            const int nrow = any_live ? r1 - r0 + 2 : 0;
+            // The LDS scheme needs the whole footprint strictly inside the panorama (no tap is a border tap) and a
+            // panorama width divisible by 4 (12-byte items never straddle a row end).
+            bool ok = any_live && !stray && (P.pw & 3) == 0 && c0 >= 0 && r0 >= 0 && c1 + 1 < P.pw && r1 + 1 < P.ph &&
+                      nrow <= PLAN_MAX_ROWS;
+            uint32_t n_items = 0;
+            if (ok) {
+                // ---- per rot row: the span of columns the taps read ----
+                if (t < nrow) {
+                    s_rmin[t] = INT32_MAX;
+                    s_rmax[t] = -1;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < PXT; ++j)
+                    if (member[j] && inrange[j]) {
+                        const int r = iy[j] - r0;
+                        atomicMin(&s_rmin[r], ix[j]);     atomicMax(&s_rmax[r], ix[j] + 1);
+                        atomicMin(&s_rmin[r + 1], ix[j]); atomicMax(&s_rmax[r + 1], ix[j] + 1);
+                    }
+                __syncthreads();
+                // a row's LDS span starts at a column congruent to c0 mod 4 (so that one per-yaw alignment serves
+                // every row) and leaves room for the yaw's alignment 0..3 within the first item
+                int o = 0;
+                uint32_t width = 0;
+                if (t < nrow && s_rmax[t] >= 0) {
+                    o = s_rmin[t] - ((s_rmin[t] - c0) & 3);
+                    width = (uint32_t)(((3 + s_rmax[t] - o) >> 2) + 1);
+                }
+                const uint32_t base = block_scan_excl(width, s_scan, &n_items);
+                ok = n_items <= (uint32_t)LDS_ITEMS_CAP;
+                if (ok && t < nrow) {
+                    s_rmin[t] = o;
+                    s_rbase[t] = base;
+                    s_rmax[t] = (int)width;
+                }
+                __syncthreads();
+            }
+            const bool deepest = level + 1 == N_LEVELS;
+            // splitting helps only where a smaller piece can fit: not when no pixel has a footprint at all, and not
+            // when the panorama width rules the LDS scheme out
+            if (!ok && !deepest && (P.pw & 3) == 0 && (any_live || stray)) {
+                next |= 3u << (2 * idx);
+                if (level == 0 && t == 0)
+                    P.hdr_main[slot_main] = PieceHdr{0u, 0u, 0u, 0, 0, 0u, 0u, 0u};  // drawn by its pieces
+                continue;
+            }
+            // ---- place the piece: the tile's own slot at level 0, an extras slot otherwise ----
+            uint32_t blk;
+            PieceHdr* hdr;
+            uint32_t* pxw;
+            uint32_t* itw;
+            bool store = true;
+            if (level == 0) {
+                blk = (uint32_t)slot_main;
+                hdr = P.hdr_main + blk;
+                pxw = P.px_main + (size_t)blk * (256 * VIEWS_PXT);
+                itw = P.items_main + (size_t)blk * LDS_ITEMS_CAP;
+            } else {
+                if (t == 0)
+                    s_slot = atomicAdd(P.x_count, 1u);
+                __syncthreads();
+                blk = s_slot;
+                store = blk < P.x_cap;  // beyond the pools: counted only, the host grows them and runs again
+                hdr = P.hdr_x + blk;
+                pxw = P.px_x + (size_t)blk * (256 * XTRA_PXT);
+                itw = P.items_x + (size_t)blk * LDS_ITEMS_CAP;
+            }
+            if (!store)
+                continue;
+            if (ok) {
+                // per-pixel words, in the piece's own thread order: thread t' = (row % rows_per_j) * w + col
+                // draws pixel j' = row / rows_per_j (rows_per_j = 256 / w)
+                const int lw = 31 - __clz(rc.w);
+                const int rows_per_j = VIEWS_BLOCK >> lw;
+#pragma unroll
+                for (int j = 0; j < PXT; ++j)
+                    if (member[j]) {
+                        const int col = tx - rc.x, row = ty0 + j * ROWSTEP - rc.y;
+                        const int jp = row / rows_per_j, tp = (row - jp * rows_per_j) * rc.w + col;
+                        uint32_t word = 0u;
+                        if (inrange[j]) {
+                            const int r = iy[j] - r0;
+                            const uint32_t up = 4u * s_rbase[r] + (uint32_t)(ix[j] - s_rmin[r]);
+                            const uint32_t lo = 4u * s_rbase[r + 1] + (uint32_t)(ix[j] - s_rmin[r + 1]);
+                            word = up | (lo - up) << 11 | fx[j] << 22 | fy[j] << 27;
+                        }
+                        pxw[jp * VIEWS_BLOCK + tp] = word;
+                    }
+                if (t < nrow) {
+                    const uint32_t g0 = (uint32_t)((s_rmin[t] - c0) >> 2);
+                    for (int g = 0; g < s_rmax[t]; ++g)
+                        itw[s_rbase[t] + g] = (uint32_t)(r0 + t) << 16 | (g0 + (uint32_t)g);
+                }
+            }
+            if (t == 0) {
+                PieceHdr h;
+                h.xy = (uint32_t)(x0 + rc.x) | (uint32_t)(y0 + rc.y) << 16;
+                h.geom = (uint32_t)rc.w | (uint32_t)rc.h << 8 | (uint32_t)pitch_i << 16;
+                h.mode_items = ok ? (1u | n_items << 8) : 2u;
+                h.c0 = ok ? c0 : 0;
+                h.c1 = ok ? c1 : 0;
+                h.px_block = blk;
+                h.item_block = blk;
+                h.pad = 0u;
+                *hdr = h;
+            }
+        }
+        pending = next;
+        if (!pending)
+            break;
+    }
+}
+
+hipError_t launch_plan(const PlanParams& P, hipStream_t st)
+{
+    const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
+    if (P.mapU)
+        hipLaunchKernelGGL(plan_kernel<true>, dim3(tiles, P.n_pitch), dim3(VIEWS_BLOCK), 0, st, P);
+    else
+        hipLaunchKernelGGL(plan_kernel<false>, dim3(tiles, P.n_pitch), dim3(VIEWS_BLOCK), 0, st, P);
+    return hipGetLastError();
+}
+
+}  // namespace p2p

@@ -1,6 +1,7 @@
 // p2p_views.hip -- the hot kernel: both cv2.remap stages of every (panorama, yaw, pitch) view in one launch
-//   cv2.remap x2       P:192-199, P:212-218 -> remap_views_kernel (both stages fused, fixed point; modes: draw,
-//                                            plan, sub-tile); 3-channel single remaps of the legacy tool (L:179) too
+//   cv2.remap x2       P:192-199, P:212-218 -> remap_views_kernel (both stages fused, fixed point), driven by the
+//                                            tables of the plan pass (p2p_plan.hip); 3-channel single remaps of the
+//                                            legacy tool (L:179) too
 // Reference behaviour (cited, never copied):
 //   P = /root/reference/app/panorama_to_plane-pitch.py, L = /root/reference/app/legacy/panorama_to_plane.py
 // The fixed-point arithmetic is OpenCV 4.10's (imgwarp.cpp remapBilinear, INTER_BITS = 5,
@@ -70,19 +71,6 @@ __device__ __forceinline__ uint32_t blend4(uint32_t a, uint32_t b, uint32_t c, u
 
 struct __attribute__((aligned(4))) Q16 { uint32_t d[4]; };
 
-// ---- diagnostic build only: in-kernel phase stamps (never compiled into the shipped library) ----
-__device__ unsigned long long g_stamps[8 * 4096];  // [counter][slot]: spread, same-address atomics crawl
-#ifdef P2P_STAMPS
-#define STAMP(var)                                                                              \
-    do {                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");            \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-    } while (0)
-#else
-#define STAMP(var) do { } while (0)
-#endif
-
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
@@ -120,59 +108,30 @@ __device__ __forceinline__ uint32_t blend4_packed(uint32_t a, uint32_t b, uint32
 }
 
 // ---------------------------------------------------------------------------------------------
-// The hot kernel.  One workgroup = one TILE_W x TILE_H tile of output pixels of one pitch view,
-// VIEWS_PXT pixels per thread.  Once per tile: every thread evaluates (or loads) the pitch-stage
-// coordinates of its pixels and quantises them as cv::remap does; the workgroup reduces the
-// tile's footprint [c0..c1+1] x [r0..r1+1] in the yaw-resampled panorama ("rot") and cuts it into
-// items of 4 horizontally adjacent rot pixels.  Then, per (panorama, yaw) pair of its chunk:
-//   stage 1  the yaw map is a circular column shift (YawDesc), so a footprint row is one
-//            contiguous run of source bytes: each thread loads one 4-byte-aligned 16-byte piece
-//            (5 1/3 source pixels: fully coalesced, no per-pixel table lookup), blends 4 rot
-//            pixels in registers with the exact uint8 arithmetic and writes them to the LDS tile
-//            (double-buffered) with one ds_write_b128; the loads of the NEXT pair are issued
-//            before stage 2 so that their latency hides behind it;
-//   stage 2  after one barrier each thread reads the 2x2 taps of its pixels from LDS, blends
-//            with cv::remap's fixed-point weights, and the tile is stored as aligned dwords.
-// Whatever does not fit that scheme takes the direct path (same arithmetic, taps gathered from
-// global memory through the packed yaw table): footprints too large for LDS or touching the
-// panorama border (views containing a pole), panorama widths not divisible by 4, yaw rows that
-// are not a shift.  Blocks map to tiles XCD-aware: each of the 8 XCDs owns a contiguous run of
-// the tile raster, so neighbouring tiles (shared source halo and output lines) meet in one L2.
+// The hot kernel.  One workgroup = one piece of the plan (p2p_plan.hip): a tile of TILE_W x TILE_H output pixels
+// of one pitch view (VIEWS_PXT pixels per thread), or a part of a tile whose footprint did not fit.  The plan
+// pass has already worked out everything that depends on the maps only, so a workgroup starts with a handful
+// of loads: the piece header (scalar), one dword per pixel (LDS offsets of its 2x2 taps + the two 5-bit weights)
+// and one dword per footprint item (rot row, 4-pixel group).  Then, per (panorama, yaw) pair of its chunk:
+//   stage 1  the yaw map is a circular column shift (YawDesc), so a footprint row is one contiguous run of
+//            source bytes: each thread loads one 4-byte-aligned 16-byte piece (5 1/3 source pixels: fully
+//            coalesced, no per-pixel table lookup), blends 4 rot pixels in registers with the exact uint8
+//            arithmetic and writes them to the LDS tile (double-buffered) with one ds_write_b128; the loads of
+//            the NEXT pair are issued before stage 2 so that their latency hides behind it;
+//   stage 2  after one barrier each thread reads the 2x2 taps of its pixels from LDS, blends with cv::remap's
+//            fixed-point weights, and the tile is stored as aligned dwords.
+// The footprint is kept as per-row spans (each rot row only as wide as the taps of that row need), not as the
+// bounding rectangle: 1.4 .. 1.7 rot pixels per output pixel instead of 1.7 .. 2.3 on config 2.
+// Pieces the plan marks "direct" take the direct path (same arithmetic, taps gathered from global memory through
+// the packed yaw table): a pole inside the piece (the footprint spans every column), footprints touching the
+// panorama border (seam without wrap), widths not divisible by 4, general caller maps with border taps; so do
+// yaw rows that are not a shift.  Blocks map to tiles XCD-aware: each of the 8 XCDs owns a contiguous run of the
+// tile raster, so neighbouring tiles (shared source halo and output lines) meet in one L2.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b)
-{
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(as_u16x2(a), as_u16x2(b)));
-}
-__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b)
-{
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(as_u16x2(a), as_u16x2(b)));
-}
-
-// Wave-wide packed-u16 min / max; the result is valid in lane 63.  gfx9 DPP: two quad permutes, the
-// two row mirrors, then row_bcast15 / row_bcast31 carry the row results up to the last row.
-template <bool MIN>
-__device__ __forceinline__ uint32_t wave_reduce_pk(uint32_t v)
-{
-    const int ident = MIN ? -1 : 0;
-#define P2P_STEP(ctrl, rmask)                                                                        \
-    {                                                                                               \
-        uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(ident, (int)v, ctrl, rmask, 0xF, false); \
-        v = MIN ? pk_min(v, o) : pk_max(v, o);                                                      \
-    }
-    P2P_STEP(0xB1, 0xF)   // quad_perm [1,0,3,2]
-    P2P_STEP(0x4E, 0xF)   // quad_perm [2,3,0,1]
-    P2P_STEP(0x141, 0xF)  // row_half_mirror
-    P2P_STEP(0x140, 0xF)  // row_mirror
-    P2P_STEP(0x142, 0xA)  // row_bcast15 -> rows 1 and 3
-    P2P_STEP(0x143, 0xC)  // row_bcast31 -> rows 2 and 3
-#undef P2P_STEP
-    return v;
-}
-
-struct PairCtx {      // uniform per (tile, pair); precomputed per lane at tile set-up, read back with v_readlane
+struct PairCtx {      // uniform per (piece, pair); precomputed per lane at piece set-up, read back with v_readlane
     bool fast;        // LDS scheme applies (the yaw row is a circular shift)
     bool per_column;  // per-column weights (f4tab) instead of one f
-    int joff;         // tile column of rot column c0
+    int joff;         // LDS position of rot column c0 within its row's first item
     uint32_t goff;    // byte offset of the first item of a footprint row within a source row
     uint32_t wrap_g;  // items with g >= wrap_g wrap to the start of the row
     uint32_t f;       // uniform weight
@@ -182,228 +141,34 @@ struct PairCtx {      // uniform per (tile, pair); precomputed per lane at tile 
     int korig;        // pair index inside the chunk (its output slot is pair0 + korig)
 };
 
-// MAPSRC: 0 = coordinates computed in-kernel (pitch_map_eval), 1 = caller float maps, 2 = the job's
-// coordinate cache (what an earlier MAPSRC 0 launch stored; the reference's pitch_mapping_cache, P:62-73)
-// MODE: 0 = the view kernel proper (32x16 tiles, 2 pixels per thread); 1 = plan: classify the tiles whose
-// footprint outgrows the LDS buffers and list their sub-tiles (once per job geometry, nothing is drawn);
-// 2 = sub-tile pass: one listed 32x8 or 16x8 sub-tile per workgroup, 1 pixel per thread
-template <int MAPSRC, int MODE>
-__device__ __forceinline__ void views_body(
+template <int PXT>
+__device__ __forceinline__ void draw_piece(
     const ViewsParams& P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab,
-    const YawDesc* __restrict__ ydesc, const uint32_t* __restrict__ f4tab,
-    const PitchConst* __restrict__ pitch, const float* __restrict__ mapU,
-    const float* __restrict__ mapV, uint8_t* __restrict__ out, int32_t* __restrict__ coords,
-    uint4 (*tile4)[LDS_ITEMS_CAP], int* bbox, uint32_t (*half_box)[4], const int bx, const int gx)
+    const YawDesc* __restrict__ ydesc, const uint32_t* __restrict__ f4tab, uint8_t* __restrict__ out,
+    const PieceHdr h, const uint32_t* __restrict__ pxw, const uint32_t* __restrict__ itw,
+    uint4 (*tile4)[LDS_ITEMS_CAP])
 {
-    constexpr int PXT = MODE == 2 ? 1 : VIEWS_PXT;
     const int t = threadIdx.x;
-    int pitch_i, x0, y0, sub_w = TILE_W, plan_slot = 0;
-    if (MODE == 2) {
-        // the sub-tile workgroups of view row y: entries y * gx .. y * gx + gx - 1 of the plan
-        const int ei = (int)blockIdx.y * gx + bx;
-        if (ei >= P.plan_n)
-            return;
-        const uint2 e = P.plan[ei];  // x0 | y0 << 15 | (16-wide) << 30, pitch index
-        x0 = (int)(e.x & 0x7FFFu);
-        y0 = (int)((e.x >> 15) & 0x7FFFu);
-        sub_w = (e.x >> 30) ? TILE_W / 2 : TILE_W;
-        pitch_i = (int)e.y;
-    } else {
-        const int tiles_x = (P.ow + TILE_W - 1) / TILE_W;
-        const int tiles_y = (P.oh + TILE_H - 1) / TILE_H;
-        const int chunk = gx >> 3;  // gx == 8 * ceil(tiles / 8)
-        const int tile_id = (bx & 7) * chunk + (bx >> 3);
-        if (tile_id >= tiles_x * tiles_y)
-            return;
-        // heaviest views first (the host orders pitch_order by |pitch - 90| descending): a smoother tail
-        pitch_i = P.pitch_order[blockIdx.y];
-        x0 = (tile_id % tiles_x) * TILE_W;
-        y0 = (tile_id / tiles_x) * TILE_H;
-        plan_slot = pitch_i * tiles_x * tiles_y + tile_id;
-        // a tile the plan lists is drawn by the sub-tile workgroups: each pixel's map is evaluated by exactly
-        // one compiled instance of pitch_map_eval (two inlined copies can differ in the last bit)
-        if (MODE == 0 && P.use_plan && P.plan_flag[plan_slot])
-            return;
-    }
-    const int px = x0 + (MODE == 2 ? t % sub_w : t % TILE_W);
-    const int py0 = y0 + (MODE == 2 ? t / sub_w : t / TILE_W);
-    constexpr int ROWSTEP = VIEWS_BLOCK / TILE_W;  // rows between a thread's pixels
-    constexpr int SUB_H = TILE_H / 2;              // sub-tiles are 32x8 or 16x8
-
-    // ---- pitch-stage coordinates of this thread's pixels, quantised as cv::remap does ----
-    int ix[PXT], iy[PXT];
-    uint32_t fx[PXT], fy[PXT];
-    bool inside[PXT], live[PXT], inrange[PXT];
-#pragma unroll
-    for (int j = 0; j < PXT; ++j) {
-        const int py = py0 + j * ROWSTEP;
-        inside[j] = px < P.ow && py < P.oh && (MODE != 2 || py < y0 + SUB_H);
-        int sx = INT32_MIN, sy = INT32_MIN;
-        if (inside[j]) {
-            const size_t k = ((size_t)pitch_i * P.oh + py) * P.ow + px;
-            if (MAPSRC == 2) {
-                // streamed once per launch: non-temporal, so that the 8 bytes per pixel do not evict source lines
-                const long long sc = __builtin_nontemporal_load(reinterpret_cast<const long long*>(coords) + k);
-                sx = (int)(uint32_t)sc;
-                sy = (int)(sc >> 32);
-            } else {
-                float U, V;
-                if (MAPSRC == 1) {
-                    U = mapU[k];
-                    V = mapV[k];
-                } else {
-                    PitchConst pc = pitch[pitch_i];
-                    pitch_map_eval((float)px, (float)py, P.geom, pc.c, pc.s, U, V);
-                }
-                sx = cv_round_f32(U * 32.0f);
-                sy = cv_round_f32(V * 32.0f);
-                if (coords && blockIdx.z == 0)
-                    reinterpret_cast<int2*>(coords)[k] = make_int2(sx, sy);
-            }
-        }
-        ix[j] = sat_short(sx >> 5);
-        iy[j] = sat_short(sy >> 5);
-        fx[j] = (uint32_t)sx & 31u;
-        fy[j] = (uint32_t)sy & 31u;
-        // A pixel contributes only if its 2x2 footprint touches the panorama (BORDER_CONSTANT 0:
-        // cv::remap writes borderValue when sx >= w || sx+1 < 0 || sy >= h || sy+1 < 0).  For the
-        // reference's clipped maps that is every pixel except NaN ones (ix = iy = -32768).
-        inrange[j] = inside[j] && ix[j] >= -1 && iy[j] >= -1 && ix[j] < P.pw && iy[j] < P.ph;
-        // other border modes (legacy entry point, L:179) resolve every tap to some pixel
-        live[j] = P.border == 0 ? inrange[j] : inside[j];
-    }
-
-    // ---- footprint of the tile in rot space: packed (ix+1, iy+1) u16 pairs, one min and one max
-    // reduction per wave with DPP (v_pk_min_u16 / v_pk_max_u16), then across the 4 waves through LDS ----
-    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    const int x0 = (int)(h.xy & 0xFFFFu), y0 = (int)(h.xy >> 16);
+    const int pw_ = (int)(h.geom & 0xFFu), ph_ = (int)((h.geom >> 8) & 0xFFu);  // piece width (16 / 32 / 64) and height
+    const int pitch_i = (int)(h.geom >> 16);
+    const int mode = (int)(h.mode_items & 3u);
+    const int n_items = (int)(h.mode_items >> 8);
+    const int lw = __builtin_ctz((unsigned)pw_);
+    const int col = t & (pw_ - 1), row0 = t >> lw;
+    const int rstep = VIEWS_BLOCK >> lw;  // rows between a thread's pixels
+    const int px = x0 + col, py0 = y0 + row0;
+    bool inside[PXT];
 #pragma unroll
     for (int j = 0; j < PXT; ++j)
-        if (inrange[j]) {
-            const uint32_t key = (uint32_t)(ix[j] + 1) | (uint32_t)(iy[j] + 1) << 16;  // both in 0..32767
-            kmin = pk_min(kmin, key);
-            kmax = pk_max(kmax, key);
-        }
-    kmin = wave_reduce_pk<true>(kmin);
-    kmax = wave_reduce_pk<false>(kmax);
-    if ((t & 63) == 63) {
-        bbox[(t >> 6) * 2] = (int)kmin;
-        bbox[(t >> 6) * 2 + 1] = (int)kmax;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < VIEWS_BLOCK / 64; ++w) {
-        kmin = w == 0 ? (uint32_t)bbox[0] : pk_min(kmin, (uint32_t)bbox[2 * w]);
-        kmax = w == 0 ? (uint32_t)bbox[1] : pk_max(kmax, (uint32_t)bbox[2 * w + 1]);
-    }
-    const int c0 = (int)(kmin & 0xFFFFu) - 1, r0 = (int)(kmin >> 16) - 1;
-    const int c1 = kmax ? (int)(kmax & 0xFFFFu) - 1 : -2, r1 = kmax ? (int)(kmax >> 16) - 1 : -2;
-    const bool any_live = c1 >= -1;
-    // footprint -> 4-pixel items per row (+3: alignment slack; +1 column and row for the right / lower taps)
-    auto items_of = [](int a0, int a1, int b0, int b1, int& g) {
-        g = (a1 - a0 + 2 + 6) >> 2;
-        return (b1 - b0 + 2) * g;
-    };
-    int G;
-    const int items = items_of(c0, c1, r0, r1, G);
-    const int rowdw = 4 * G;  // LDS tile row stride in dwords
-    // the LDS scheme needs the whole footprint strictly inside the panorama (so that no tap is a
-    // border tap) and a width divisible by 4 (so that 12-byte items never straddle a row end)
-    // with a non-constant border a pixel outside the panorama still reads pixels (reflected, wrapped ...):
-    // such tiles go the direct way, where the taps are resolved by cv::borderInterpolate
-    bool stray = false;
-    if (P.border != 0) {
-        bool mine = false;
-#pragma unroll
-        for (int j = 0; j < PXT; ++j)
-            mine |= inside[j] && !inrange[j];
-        stray = __syncthreads_or(mine) != 0;
-    }
-    const bool lds_ok = any_live && !stray && (P.pw & 3) == 0 && c0 >= 0 && r0 >= 0 && c1 + 1 < P.pw &&
-                        r1 + 1 < P.ph;
-    const bool fast_tile = lds_ok && G <= 255 && items <= LDS_ITEMS_CAP;
+        inside[j] = row0 + j * rstep < ph_ && px < P.ow && py0 + j * rstep < P.oh;
 
-    // A tile that is fine except that its footprint outgrows the LDS buffers (views towards a pole: the rows
-    // stretch by 1 / sin(theta)) is drawn by the sub-tile pass instead: as two 32x8 halves if both fit, else
-    // as four 16x8 quarters (each of which decides again between the LDS scheme and direct gathers).
-    if (MODE == 1) {
-        if (lds_ok && !fast_tile) {
-            // half_box: per half (pixel j): min / max of ix + 1, min / max of iy + 1
-            if (t < 2) {
-                half_box[t][0] = 0xFFFFu; half_box[t][1] = 0u; half_box[t][2] = 0xFFFFu; half_box[t][3] = 0u;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < PXT; ++j)
-                if (inrange[j]) {
-                    atomicMin(&half_box[j][0], (uint32_t)(ix[j] + 1));
-                    atomicMax(&half_box[j][1], (uint32_t)(ix[j] + 1));
-                    atomicMin(&half_box[j][2], (uint32_t)(iy[j] + 1));
-                    atomicMax(&half_box[j][3], (uint32_t)(iy[j] + 1));
-                }
-            __syncthreads();
-            // a half is fine if its footprint rectangle fits, or if the items its taps can touch do (the
-            // sub-tile pass then keeps a compacted item list, see there); count those with the same bitmap
-            bool halves = true;
-            for (int h = 0; h < 2; ++h) {
-                if (half_box[h][1] == 0u)
-                    continue;  // no live pixel
-                const int hc0 = (int)half_box[h][0] - 1, hr0 = (int)half_box[h][2] - 1;
-                int g;
-                const int n = items_of(hc0, (int)half_box[h][1] - 1, hr0, (int)half_box[h][3] - 1, g);
-                if (g <= 255 && n <= LDS_ITEMS_CAP)
-                    continue;
-                if (n > 65536 || g >= 65536) {
-                    halves = false;
-                    continue;
-                }
-                uint32_t* bm = reinterpret_cast<uint32_t*>(&tile4[0][0]);
-                __syncthreads();
-                for (int i = 0; i < 8; ++i)
-                    bm[t * 8 + i] = 0u;
-                if (t == 0)
-                    half_box[h][1] = 0u;  // reused as the counter below (its value is already in n, g)
-                __syncthreads();
-#pragma unroll
-                for (int j = 0; j < PXT; ++j)
-                    if (j == h && inrange[j]) {
-                        const uint32_t b0 = (uint32_t)((iy[j] - hr0) * g + ((ix[j] - hc0) >> 2));
-                        for (int dr = 0; dr < 2; ++dr)
-                            for (int dg = 0; dg < 2; ++dg) {
-                                const uint32_t b = b0 + (uint32_t)(dr * g + dg);
-                                atomicOr(&bm[b >> 5], 1u << (b & 31u));
-                            }
-                    }
-                __syncthreads();
-                uint32_t cnt = 0u;
-                for (int i = 0; i < 8; ++i)
-                    cnt += (uint32_t)__popc(bm[t * 8 + i]);
-                atomicAdd(&half_box[h][1], cnt);
-                __syncthreads();
-                halves = halves && half_box[h][1] <= (uint32_t)LDS_ITEMS_CAP;
-            }
-            if (t == 0) {
-                uint2 e[4];
-                int n = 0;
-                for (int sy = 0; sy < 2; ++sy)
-                    for (int sx = 0; sx < (halves ? 1 : 2); ++sx) {
-                        const int ex = x0 + sx * (TILE_W / 2), ey = y0 + sy * SUB_H;
-                        if (ex < P.ow && ey < P.oh)
-                            e[n++] = make_uint2((uint32_t)ex | (uint32_t)ey << 15 | (halves ? 0u : 1u << 30), (uint32_t)pitch_i);
-                    }
-                const uint32_t base = atomicAdd(P.plan_count, (uint32_t)n);
-                for (int i = 0; i < n; ++i)
-                    P.plan[base + i] = e[i];
-                P.plan_flag[plan_slot] = 1;
-            }
-        }
-        return;
-    }
     // output addressing: 4 horizontally adjacent pixels = 12 bytes = 3 aligned dwords
     const int lane4 = t & 3;
     const bool fast_store = (P.ow & 3) == 0;
     const size_t view_bytes = (size_t)P.oh * P.ow * 3;
     const uint32_t pix_off = (uint32_t)(((size_t)py0 * P.ow + px) * 3);  // < 3 * 32766^2 < 2^32
-    const uint32_t pix_step = (uint32_t)ROWSTEP * (uint32_t)P.ow * 3u;
+    const uint32_t pix_step = (uint32_t)rstep * (uint32_t)P.ow * 3u;
     // dword lane4 of the 12 bytes P0 P1 P2 P3: bytes of the own pixel (0-2) and of the next lane's (4-6)
     const uint32_t store_sel = lane4 == 0 ? 0x04020100u : (lane4 == 1 ? 0x05040201u : 0x06050402u);
 
@@ -417,8 +182,6 @@ __device__ __forceinline__ void views_body(
     auto pano_of = [&](int pair) {
         return P.n_yaw == 1 ? pair : (int)__umulhi((uint32_t)pair, P.n_yaw_magic);
     };
-    int pano_i = pano_of(pair0);
-    int yaw_i = pair0 - pano_i * P.n_yaw;
 
     auto store_pixels = [&](int pair, const uint32_t (&pix)[PXT]) {
         // [pano][yaw][pitch][oh][ow][3]
@@ -446,134 +209,63 @@ __device__ __forceinline__ void views_body(
         }
     };
 
-    auto direct_pixels = [&](const uint8_t* __restrict__ S, int yi, uint32_t (&pix)[PXT]) {
+    // ---- direct path: the quantised coordinates come from the plan's coordinate dump ----
+    struct DirectPx {
+        int ix[PXT], iy[PXT];
+        uint32_t fx[PXT], fy[PXT];
+        bool live[PXT];
+    };
+    auto load_direct = [&](DirectPx& d) {
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) {
+            int2 c = make_int2(INT32_MIN, INT32_MIN);
+            if (inside[j])
+                c = P.coords[((size_t)pitch_i * P.oh + (py0 + j * rstep)) * P.ow + px];
+            d.ix[j] = sat_short(c.x >> 5);
+            d.iy[j] = sat_short(c.y >> 5);
+            d.fx[j] = (uint32_t)c.x & 31u;
+            d.fy[j] = (uint32_t)c.y & 31u;
+            const bool inrange = inside[j] && d.ix[j] >= -1 && d.iy[j] >= -1 && d.ix[j] < P.pw && d.iy[j] < P.ph;
+            // other border modes (legacy entry point, L:179) resolve every tap to some pixel
+            d.live[j] = P.border == 0 ? inrange : inside[j];
+        }
+    };
+    auto direct_pixels = [&](const DirectPx& d, const uint8_t* __restrict__ S, int yi, uint32_t (&pix)[PXT]) {
         // same arithmetic, taps gathered from global memory through the packed yaw table
         const uint32_t* __restrict__ T = ytab + (size_t)yi * P.pw;
 #pragma unroll
         for (int j = 0; j < PXT; ++j) {
             pix[j] = 0;
-            if (live[j] && P.border != 0) {
-                const int xa = border_interpolate(ix[j], P.pw, P.border), xb = border_interpolate(ix[j] + 1, P.pw, P.border);
-                const int ya = border_interpolate(iy[j], P.ph, P.border), yb = border_interpolate(iy[j] + 1, P.ph, P.border);
-                const uint8_t* row0 = S + (size_t)ya * P.src_pitch;
-                const uint8_t* row1 = S + (size_t)yb * P.src_pitch;
+            if (d.live[j] && P.border != 0) {
+                const int xa = border_interpolate(d.ix[j], P.pw, P.border), xb = border_interpolate(d.ix[j] + 1, P.pw, P.border);
+                const int ya = border_interpolate(d.iy[j], P.ph, P.border), yb = border_interpolate(d.iy[j] + 1, P.ph, P.border);
+                const uint8_t* row0p = S + (size_t)ya * P.src_pitch;
+                const uint8_t* row1p = S + (size_t)yb * P.src_pitch;
                 const uint32_t t0 = T[xa], t1 = T[xb];
-                pix[j] = blend4(rot_pixel(row0, t0), rot_pixel(row0, t1), rot_pixel(row1, t0), rot_pixel(row1, t1),
-                                fx[j], fy[j]);
-            } else if (live[j]) {
-                const bool c0in = ix[j] >= 0, c1in = ix[j] + 1 < P.pw, r0in = iy[j] >= 0, r1in = iy[j] + 1 < P.ph;
-                const uint8_t* row0 = S + (ptrdiff_t)iy[j] * P.src_pitch;
-                const uint8_t* row1 = row0 + P.src_pitch;
-                const uint32_t t0 = c0in ? T[ix[j]] : 0u, t1 = c1in ? T[ix[j] + 1] : 0u;
-                uint32_t a = (c0in && r0in) ? rot_pixel(row0, t0) : 0u;
-                uint32_t b = (c1in && r0in) ? rot_pixel(row0, t1) : 0u;
-                uint32_t c = (c0in && r1in) ? rot_pixel(row1, t0) : 0u;
-                uint32_t d = (c1in && r1in) ? rot_pixel(row1, t1) : 0u;
-                pix[j] = blend4(a, b, c, d, fx[j], fy[j]);
+                pix[j] = blend4(rot_pixel(row0p, t0), rot_pixel(row0p, t1), rot_pixel(row1p, t0), rot_pixel(row1p, t1),
+                                d.fx[j], d.fy[j]);
+            } else if (d.live[j]) {
+                const bool c0in = d.ix[j] >= 0, c1in = d.ix[j] + 1 < P.pw, r0in = d.iy[j] >= 0, r1in = d.iy[j] + 1 < P.ph;
+                const uint8_t* row0p = S + (ptrdiff_t)d.iy[j] * P.src_pitch;
+                const uint8_t* row1p = row0p + P.src_pitch;
+                const uint32_t t0 = c0in ? T[d.ix[j]] : 0u, t1 = c1in ? T[d.ix[j] + 1] : 0u;
+                uint32_t a = (c0in && r0in) ? rot_pixel(row0p, t0) : 0u;
+                uint32_t b = (c1in && r0in) ? rot_pixel(row0p, t1) : 0u;
+                uint32_t c = (c0in && r1in) ? rot_pixel(row1p, t0) : 0u;
+                uint32_t dd = (c1in && r1in) ? rot_pixel(row1p, t1) : 0u;
+                pix[j] = blend4(a, b, c, dd, d.fx[j], d.fy[j]);
             }
         }
     };
 
-    // ---- sub-tile pass only: a footprint RECTANGLE too large for the LDS buffers is usually sparse (towards a
-    // pole the rows stretch, neighbouring pixels hit items far apart).  Mark the items the taps can touch in a
-    // bitmap (each pixel: items g0, g0 + 1 of rows rr, rr + 1 -- every alignment joff = 0..3 stays inside them),
-    // rank them, and keep only those in LDS: slot k of the buffer holds the k-th needed item, and a pixel's two
-    // consecutive items are consecutive slots, so the tap reads stay "two dwords at base + 4 * joff".
-    // The tile buffers themselves serve as scratch: bitmap 8 KB | per-word ranks 4 KB | item list 2 KB | scan 1 KB.
-    bool list_tile = false;
-    int n_need = 0;
-    uint32_t list_item[VIEWS_SLOTS] = {0u, 0u};
-    uint32_t list_tap_up[PXT], list_tap_lo[PXT];
-#pragma unroll
-    for (int j = 0; j < PXT; ++j)
-        list_tap_up[j] = list_tap_lo[j] = 0u;
-    if (MODE == 2) {
-        constexpr int MAX_BITS = 65536, WPT = MAX_BITS / 32 / VIEWS_BLOCK;  // 8 bitmap words per thread
-        const int Ht = r1 - r0 + 2;
-        // (only when the rectangle does not fit: for rectangles that fit, building the list costs more than the
-        // empty items it saves at 12 yaws per workgroup -- measured)
-        if (lds_ok && !fast_tile && Ht * G <= MAX_BITS && G < 65536) {
-            uint32_t* bm = reinterpret_cast<uint32_t*>(&tile4[0][0]);
-            unsigned short* wpre = reinterpret_cast<unsigned short*>(bm + MAX_BITS / 32);
-            uint32_t* lst = bm + MAX_BITS / 32 + MAX_BITS / 64;
-            uint32_t* scan = lst + LDS_ITEMS_CAP;
-            const int nw = (Ht * G + 31) >> 5;
-#pragma unroll
-            for (int i = 0; i < WPT; ++i)
-                bm[t * WPT + i] = 0u;
-            __syncthreads();
-            uint32_t bit0[PXT];
-#pragma unroll
-            for (int j = 0; j < PXT; ++j) {
-                bit0[j] = 0u;
-                if (live[j]) {
-                    bit0[j] = (uint32_t)((iy[j] - r0) * G + ((ix[j] - c0) >> 2));
-                    for (int dr = 0; dr < 2; ++dr)
-                        for (int dg = 0; dg < 2; ++dg) {
-                            const uint32_t b = bit0[j] + (uint32_t)(dr * G + dg);
-                            atomicOr(&bm[b >> 5], 1u << (b & 31u));
-                        }
-                }
-            }
-            __syncthreads();
-            // ranks: per-thread popcount of its 8 words, block-wide exclusive scan, then per word
-            uint32_t wv[WPT];
-            uint32_t mine = 0u;
-#pragma unroll
-            for (int i = 0; i < WPT; ++i) {
-                wv[i] = t * WPT + i < nw ? bm[t * WPT + i] : 0u;
-                mine += (uint32_t)__popc(wv[i]);
-            }
-            uint32_t incl = mine;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
-                if ((t & 63) >= d)
-                    incl += up;
-            }
-            if ((t & 63) == 63)
-                scan[t >> 6] = incl;
-            __syncthreads();
-            uint32_t base = incl - mine;
-            for (int w = 0; w < (t >> 6); ++w)
-                base += scan[w];
-            n_need = (int)(scan[0] + scan[1] + scan[2] + scan[3]);
-            if (n_need <= LDS_ITEMS_CAP) {
-#pragma unroll
-                for (int i = 0; i < WPT; ++i) {
-                    if (t * WPT + i < nw)
-                        wpre[t * WPT + i] = (unsigned short)base;
-                    uint32_t v = wv[i];
-                    while (v) {
-                        const int b = __ffs((int)v) - 1;
-                        v &= v - 1u;
-                        lst[base++] = (uint32_t)((t * WPT + i) * 32 + b);
-                    }
-                }
-                __syncthreads();
-                auto rank_of = [&](uint32_t b) {
-                    return (uint32_t)wpre[b >> 5] + (uint32_t)__popc(bm[b >> 5] & ((1u << (b & 31u)) - 1u));
-                };
-#pragma unroll
-                for (int j = 0; j < PXT; ++j)
-                    if (live[j]) {
-                        const uint32_t within = 4u * (uint32_t)((ix[j] - c0) & 3);
-                        list_tap_up[j] = 16u * rank_of(bit0[j]) + within;
-                        list_tap_lo[j] = 16u * rank_of(bit0[j] + (uint32_t)G) + within;
-                    }
-#pragma unroll
-                for (int k = 0; k < VIEWS_SLOTS; ++k)
-                    list_item[k] = t + k * VIEWS_BLOCK < n_need ? lst[t + k * VIEWS_BLOCK] : lst[0];
-                list_tile = true;
-            }
-            __syncthreads();  // the scratch becomes tile storage again
-        }
-    }
-
-    if (!fast_tile && !list_tile) {
+    if (mode != 1) {
+        DirectPx d;
+        load_direct(d);
+        int pano_i = pano_of(pair0);
+        int yaw_i = pair0 - pano_i * P.n_yaw;
         for (int pair = pair0; pair < pair1; ++pair) {
             uint32_t pix[PXT];
-            direct_pixels(src + (size_t)pano_i * P.pano_stride, yaw_i, pix);
+            direct_pixels(d, src + (size_t)pano_i * P.pano_stride, yaw_i, pix);
             store_pixels(pair, pix);
             if (++yaw_i == P.n_yaw) {
                 yaw_i = 0;
@@ -583,44 +275,35 @@ __device__ __forceinline__ void views_body(
         return;
     }
 
-    // ---- LDS scheme: the items this thread produces (same for every pair) ----
-    // A wave runs slot k only if its first lane has an item there (wave-uniform test).
-    const int wave_base = __builtin_amdgcn_readfirstlane(t & ~63);
-    uint32_t slot_off[VIEWS_SLOTS];  // (r0 + rr) * src_pitch + 12 * g
-    uint32_t slot_g[VIEWS_SLOTS];
-    const int n_items = (MODE == 2 && list_tile) ? n_need : items;  // LDS slots in use
-    if (MODE == 2 && list_tile) {
-#pragma unroll
-        for (int k = 0; k < VIEWS_SLOTS; ++k) {  // the k-th needed item: rectangle index rr * G + g
-            const uint32_t rr = list_item[k] / (uint32_t)G;
-            slot_g[k] = list_item[k] - rr * (uint32_t)G;
-            slot_off[k] = (uint32_t)(r0 + (int)rr) * (uint32_t)P.src_pitch + 12u * slot_g[k];
-        }
-    } else {
-        // item / G by multiply-shift: exact for item * G < 2^20 (item < 512, G < 256)
-        const uint32_t magic = ((1u << 20) + (uint32_t)G - 1u) / (uint32_t)G;
-#pragma unroll
-        for (int k = 0; k < VIEWS_SLOTS; ++k) {
-            int item = t + k * VIEWS_BLOCK;
-            if (item >= items)
-                item = 0;  // surplus lanes redo item 0 into LDS space nobody reads
-            const uint32_t rr = ((uint32_t)item * magic) >> 20;
-            slot_g[k] = (uint32_t)item - rr * (uint32_t)G;
-            slot_off[k] = (uint32_t)(r0 + (int)rr) * (uint32_t)P.src_pitch + 12u * slot_g[k];
-        }
-    }
-    int tap[PXT];
+    // ---- LDS scheme: this thread's pixels (tap offsets, weights) and items, straight from the plan ----
+    uint32_t tap_up[PXT], tap_lo[PXT];  // byte offsets of the upper / lower tap pair inside one LDS buffer
     TapWeights tw[PXT];
 #pragma unroll
     for (int j = 0; j < PXT; ++j) {
-        tap[j] = live[j] ? (iy[j] - r0) * rowdw + (ix[j] - c0) : 0;
-        const uint32_t gx = 32u - fx[j], gy = 32u - fy[j];
+        const uint32_t wd = pxw[j * VIEWS_BLOCK + t];
+        const uint32_t dl = (wd >> 11) & 0x7FFu;
+        tap_up[j] = (wd & 0x7FFu) << 2;
+        tap_lo[j] = tap_up[j] + (dl << 2);
+        const uint32_t fx = (wd >> 22) & 31u, fy = wd >> 27;
+        const uint32_t gx = 32u - fx, gy = 32u - fy;
         tw[j].gx2 = gx | (gx << 16);
-        tw[j].fx2 = fx[j] | (fx[j] << 16);
+        tw[j].fx2 = fx | (fx << 16);
         // a pixel with no footprint in the panorama (NaN coordinate) gets weight 0 everywhere:
         // (0 + 512) >> 10 == 0, the BORDER_CONSTANT value
-        tw[j].wy = live[j] ? 64u * (gy | (fy[j] << 16)) : 0u;
+        tw[j].wy = dl ? 64u * (gy | (fy << 16)) : 0u;
     }
+    // A wave runs slot k only if its first lane has an item there (wave-uniform test).
+    const int wave_base = __builtin_amdgcn_readfirstlane(t & ~63);
+    uint32_t slot_off[VIEWS_SLOTS];  // rot row * src_pitch + 12 * g
+    uint32_t slot_g[VIEWS_SLOTS];
+#pragma unroll
+    for (int k = 0; k < VIEWS_SLOTS; ++k) {
+        const int item = t + k * VIEWS_BLOCK;
+        const uint32_t iw = itw[item < n_items ? item : 0];  // surplus lanes redo item 0 into LDS space nobody reads
+        slot_g[k] = iw & 0xFFFFu;
+        slot_off[k] = (iw >> 16) * (uint32_t)P.src_pitch + 12u * slot_g[k];
+    }
+    const int c0 = h.c0, c1 = h.c1;
     const uint32_t row_bytes = 3u * (uint32_t)P.pw;
     const int ngroups = P.pw >> 2;
 
@@ -628,11 +311,10 @@ __device__ __forceinline__ void views_body(
     // back with v_readlane, so no descriptor load sits on the per-pair critical path ----
     uint32_t cw0 = 0, cw1 = 0;
     int cw2 = 0, cw3 = 0;
-    bool ctx_plain = true;  // this lane's pair: circular-shift yaw with one weight for the whole tile
+    bool ctx_plain = true;  // this lane's pair: circular-shift yaw with one weight for the whole piece
     {
         const int k = t & 63;
         if (k < pair1 - pair0) {
-            // pair -> (panorama, yaw) by the host's multiply-high constant (exact for the job's sizes)
             cw3 = pano_of(pair0 + k);
             const int yi = pair0 + k - cw3 * P.n_yaw;
             const YawDesc yd = ydesc[yi];
@@ -640,7 +322,7 @@ __device__ __forceinline__ void views_body(
             if (i_first >= P.pw)
                 i_first -= P.pw;
             const int g0 = i_first >> 2;
-            // uniform weight unless this yaw flickers or the tile holds the column clipped to pw-1
+            // uniform weight unless this yaw flickers or the piece holds the column clipped to pw-1
             const bool per_column = yd.mode == 1 || (yd.c_clamp >= c0 && yd.c_clamp <= c1 + 1);
             cw0 = 12u * (uint32_t)g0 | (uint32_t)(i_first & 3) << 20 | (uint32_t)(yd.mode != 2) << 22 |
                   (uint32_t)per_column << 23 | (uint32_t)yd.f << 24;
@@ -760,18 +442,10 @@ __device__ __forceinline__ void views_body(
                     tl4[t + sl * VIEWS_BLOCK] = o;
                 }
         };
-        // byte offsets of this thread's upper / lower tap pairs inside one LDS buffer; per pair only the
-        // scalar (buffer base + 4 * joff) is added
-        uint32_t tap_up[PXT], tap_lo[PXT];
-#pragma unroll
-        for (int j = 0; j < PXT; ++j) {
-            tap_up[j] = (MODE == 2 && list_tile) ? list_tap_up[j] : 4u * (uint32_t)tap[j];
-            tap_lo[j] = (MODE == 2 && list_tile) ? list_tap_lo[j] : 4u * (uint32_t)(tap[j] + rowdw);
-        }
         auto half = [&](int k, const Q16 (&qcur)[VIEWS_SLOTS], Q16 (&qnext)[VIEWS_SLOTS], uint4* tl4, uint32_t buf_bytes) {
             stage1(k, qcur, tl4);
             uint32_t soff = buf_bytes + 4u * (((uint32_t)__builtin_amdgcn_readlane((int)cw0, k) >> 20) & 3u);
-            asm volatile("" : "+s"(soff));  // one scalar: keeps the buffer base out of four separate vector adds
+            asm volatile("" : "+s"(soff));  // one scalar: keeps the buffer base out of separate vector adds
             __syncthreads();
             const unsigned char* tl = reinterpret_cast<const unsigned char*>(&tile4[0][0]);
             uint32_t ta[PXT][4];
@@ -805,18 +479,15 @@ __device__ __forceinline__ void views_body(
         __syncthreads();  // the last plain pair's taps are read before the general loop writes the buffers
     }
 
+    // ---- general loop: yaws with per-column weights (flickering fraction, the clipped column inside the
+    // piece) and yaw rows that are not a shift (direct gathers) ----
     PairCtx pc = pair_ctx(nplain);
     Q16 q[VIEWS_SLOTS];
     uint32_t fw[VIEWS_SLOTS];
     if (pc.fast)
         issue_loads(pc, src + (size_t)pc.pano * P.pano_stride, q, fw);
-
-    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0;
-    unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
-    (void)st0; (void)st1; (void)st2; (void)st3; (void)st4; (void)st5; (void)st6; (void)acc;
     int buf = 0;
     for (int ki = nplain; ki < npairs; ++ki) {
-        STAMP(st0);
         const uint8_t* __restrict__ S = src + (size_t)pc.pano * P.pano_stride;
         const int cur_yaw = pc.yaw_i;
         const int pair = pair0 + pc.korig;
@@ -863,43 +534,34 @@ __device__ __forceinline__ void views_body(
                     tl4[t + k * VIEWS_BLOCK] = o;
                 }
             }
-            const int joff = pc.joff;
-            STAMP(st1);
+            const uint32_t boff = 4u * (uint32_t)pc.joff;
             __syncthreads();
-            STAMP(st2);
             // the 2x2 taps of this thread's pixels
-            const uint32_t* tl = reinterpret_cast<const uint32_t*>(tl4);
+            const unsigned char* tl = reinterpret_cast<const unsigned char*>(tl4);
             uint32_t ta[PXT][4];
 #pragma unroll
             for (int j = 0; j < PXT; ++j) {
-                int b = tap[j] + joff, b2 = b + rowdw;
-                if (MODE == 2 && list_tile) {
-                    b = (int)(list_tap_up[j] >> 2) + joff;
-                    b2 = (int)(list_tap_lo[j] >> 2) + joff;
-                }
-                ta[j][0] = tl[b];
-                ta[j][1] = tl[b + 1];
-                ta[j][2] = tl[b2];
-                ta[j][3] = tl[b2 + 1];
+                const uint32_t* up = reinterpret_cast<const uint32_t*>(tl + (tap_up[j] + boff));
+                const uint32_t* lo = reinterpret_cast<const uint32_t*>(tl + (tap_lo[j] + boff));
+                ta[j][0] = up[0];
+                ta[j][1] = up[1];
+                ta[j][2] = lo[0];
+                ta[j][3] = lo[1];
             }
-            STAMP(st3);
             // the next pair's source loads go out now; their latency hides behind stage 2
             if (has_next) {
                 pc = pair_ctx(ki + 1);
                 if (pc.fast)
                     issue_loads(pc, src + (size_t)pc.pano * P.pano_stride, q, fw);
             }
-#ifdef P2P_STAMPS
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-            STAMP(st4);
 #pragma unroll
             for (int j = 0; j < PXT; ++j)
                 pix[j] = blend4_packed(ta[j][0], ta[j][1], ta[j][2], ta[j][3], tw[j]);
-            STAMP(st5);
             buf ^= 1;  // the next pair writes the other buffer; its readers are past this barrier
         } else {
-            direct_pixels(S, cur_yaw, pix);
+            DirectPx d;
+            load_direct(d);
+            direct_pixels(d, S, cur_yaw, pix);
             if (has_next) {
                 pc = pair_ctx(ki + 1);
                 if (pc.fast)
@@ -907,95 +569,60 @@ __device__ __forceinline__ void views_body(
             }
         }
         store_pixels(pair, pix);
-#ifdef P2P_STAMPS
-        STAMP(st6);
-        acc[0] += st1 - st0;
-        acc[1] += st2 - st1;
-        acc[2] += st3 - st2;
-        acc[3] += st4 - st3;
-        acc[4] += st5 - st4;
-        acc[5] += st6 - st5;
-#endif
     }
-#ifdef P2P_STAMPS
-    if ((t & 63) == 0) {
-        const int slot = (int)(((uint32_t)bx * 7u + blockIdx.y * 131u + blockIdx.z * 977u + (t >> 6) * 1031u) & 4095u);
-        for (int i = 0; i < 6; ++i)
-            atomicAdd(&g_stamps[i * 4096 + slot], acc[i]);
-        atomicAdd(&g_stamps[6 * 4096 + slot], 1ull);
-        atomicAdd(&g_stamps[7 * 4096 + slot], (unsigned long long)(pair1 - pair0));
-    }
-#endif
 }
 
-// MODE 0 launches carry the sub-tile workgroups in front of the tile workgroups (blockIdx.x < P.plan_gx):
-// one launch, so the few long-running sub-tile passes overlap with the bulk instead of trailing it.
-template <int MAPSRC, int MODE>
-__global__ __launch_bounds__(VIEWS_BLOCK, 6) void remap_views_kernel(
+// The extra workgroups (pieces of split tiles) sit in front of the tile workgroups (blockIdx.x < P.plan_gx):
+// one launch, so the few long-running ones overlap with the bulk instead of trailing it.
+__global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views_kernel(
     ViewsParams P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab,
-    const YawDesc* __restrict__ ydesc, const uint32_t* __restrict__ f4tab,
-    const PitchConst* __restrict__ pitch, const float* __restrict__ mapU,
-    const float* __restrict__ mapV, uint8_t* __restrict__ out, int32_t* __restrict__ coords)
+    const YawDesc* __restrict__ ydesc, const uint32_t* __restrict__ f4tab, uint8_t* __restrict__ out,
+    const PieceHdr* __restrict__ hdr_main, const uint32_t* __restrict__ px_main, const uint32_t* __restrict__ items_main,
+    const PieceHdr* __restrict__ hdr_x, const uint32_t* __restrict__ px_x, const uint32_t* __restrict__ items_x)
 {
     __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
-    __shared__ int bbox[2 * VIEWS_BLOCK / 64];
-    __shared__ uint32_t half_box[2][4];
-    if (MODE == 0 && (int)blockIdx.x < P.plan_gx) {
-        views_body<MAPSRC, 2>(P, src, ytab, ydesc, f4tab, pitch, mapU, mapV, out, coords, tile4, bbox, half_box,
-                              (int)blockIdx.x, P.plan_gx);
+    if ((int)blockIdx.x < P.plan_gx) {
+        const int ei = (int)blockIdx.y * P.plan_gx + (int)blockIdx.x;
+        if (ei >= P.x_n)
+            return;
+        const PieceHdr h = hdr_x[ei];
+        draw_piece<XTRA_PXT>(P, src, ytab, ydesc, f4tab, out, h, px_x + (size_t)h.px_block * (VIEWS_BLOCK * XTRA_PXT),
+                             items_x + (size_t)h.item_block * LDS_ITEMS_CAP, tile4);
         return;
     }
-    views_body<MAPSRC, MODE>(P, src, ytab, ydesc, f4tab, pitch, mapU, mapV, out, coords, tile4, bbox, half_box,
-                             (int)blockIdx.x - (MODE == 0 ? P.plan_gx : 0), (int)gridDim.x - (MODE == 0 ? P.plan_gx : 0));
+    const int bx = (int)blockIdx.x - P.plan_gx, gx = (int)gridDim.x - P.plan_gx;
+    const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
+    const int chunk = gx >> 3;  // gx == 8 * ceil(tiles / 8)
+    const int tile_id = (bx & 7) * chunk + (bx >> 3);
+    if (tile_id >= tiles)
+        return;
+    // heaviest views first (the host orders pitch_order by |pitch - 90| descending): a smoother tail
+    const int pitch_i = P.pitch_order[blockIdx.y];
+    const PieceHdr h = hdr_main[(size_t)pitch_i * tiles + tile_id];
+    if ((h.mode_items & 3u) == 0u)
+        return;  // a split tile: drawn by its pieces
+    draw_piece<VIEWS_PXT>(P, src, ytab, ydesc, f4tab, out, h, px_main + (size_t)h.px_block * (VIEWS_BLOCK * VIEWS_PXT),
+                          items_main + (size_t)h.item_block * LDS_ITEMS_CAP, tile4);
 }
 
-// ---------------------------------------------------------------------------------------------
-// launchers
-// ---------------------------------------------------------------------------------------------
-template <int MODE>
-static void launch_views_mode(const ViewsParams& P, int mapsrc, dim3 grid, hipStream_t st)
-{
-    if (mapsrc == 1)
-        hipLaunchKernelGGL((remap_views_kernel<1, MODE>), grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc,
-                           P.f4tab, P.pitch, P.mapU, P.mapV, P.out, P.coords);
-    else if (mapsrc == 2)
-        hipLaunchKernelGGL((remap_views_kernel<2, MODE>), grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc,
-                           P.f4tab, P.pitch, P.mapU, P.mapV, P.out, P.coords);
-    else
-        hipLaunchKernelGGL((remap_views_kernel<0, MODE>), grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc,
-                           P.f4tab, P.pitch, P.mapU, P.mapV, P.out, P.coords);
-}
-
-// mode 0: every tile of every view, preceded by the P.plan_n listed sub-tiles; mode 1: the plan pass (one
-// workgroup per tile and pitch, nothing drawn)
-hipError_t launch_remap_views(const ViewsParams& P, int mapsrc, int mode, hipStream_t st)
+hipError_t launch_remap_views(const ViewsParams& P, hipStream_t st)
 {
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
     const int n_pairs = P.n_panos * P.n_yaw;
     const int zblocks = (n_pairs + P.pairs_per_block - 1) / P.pairs_per_block;
-    if (mode == 1)
-        launch_views_mode<1>(P, mapsrc, dim3(8 * ((tiles + 7) / 8), P.n_pitch, 1), st);
-    else  // 8 XCDs, each a contiguous run of tiles; P.plan_gx is a multiple of 8 too
-        launch_views_mode<0>(P, mapsrc, dim3(P.plan_gx + 8 * ((tiles + 7) / 8), P.n_pitch, zblocks), st);
+    // 8 XCDs, each a contiguous run of tiles; P.plan_gx is a multiple of 8 too
+    hipLaunchKernelGGL(remap_views_kernel, dim3(P.plan_gx + 8 * ((tiles + 7) / 8), P.n_pitch, zblocks), dim3(VIEWS_BLOCK),
+                       0, st, P, P.src, P.ytab, P.ydesc, P.f4tab, P.out, P.hdr_main, P.px_main, P.items_main, P.hdr_x,
+                       P.px_x, P.items_x);
     return hipGetLastError();
 }
 
-
 hipError_t read_stamps(unsigned long long* out16, bool reset)
 {
-    static unsigned long long host[8 * 4096];
-    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(host));
+    (void)reset;
     for (int i = 0; i < 16; ++i)
         out16[i] = 0;
-    for (int i = 0; i < 8; ++i)
-        for (int k = 0; k < 4096; ++k)
-            out16[i] += host[i * 4096 + k];
-    if (e == hipSuccess && reset) {
-        for (auto& v : host)
-            v = 0;
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), host, sizeof(host));
-    }
-    return e;
+    return hipSuccess;
 }
 
 }  // namespace p2p

@@ -93,6 +93,17 @@ int p2p_remap_views_u8(const uint8_t* pano, int pw, int ph, int64_t row_stride,
                        int ow, int oh, uint8_t* out, int device, int flags);
 
 /*
+ * The same with real-valued angles: process_yaw_and_pitchs() (P:181-221) and get_pitch_mapping() (P:55-73) hand
+ * their yaw / pitch / FOV arguments to np.radians (P:85, P:64-68), so any finite number of degrees is legal input
+ * to the reference's functions (only the CLI narrows them to integers and the pitch to 1..179, P:362-376,
+ * P:406-437).  This entry point accepts what the functions accept; the integer one above keeps the CLI's checks.
+ */
+int p2p_remap_views_f64(const uint8_t* pano, int pw, int ph, int64_t row_stride,
+                        const double* yaw_deg, int n_yaw,
+                        const double* pitch_deg, int n_pitch, double fov_deg,
+                        int ow, int oh, uint8_t* out, int device, int flags);
+
+/*
  * The same two-stage synthesis with caller-supplied float32 maps instead of in-kernel ones:
  *   yaw_rows : [n_yaw][pw]      = U_yaw[0, :] of precompute_yaw_mapping (P:79-108; V_yaw[y,x] == y)
  *   U, V     : [n_pitch][oh][ow] = precompute_pitch_mapping outputs (P:114-175)
@@ -160,6 +171,19 @@ typedef struct p2p_job_desc {
     int32_t flags;
 } p2p_job_desc;
 
+/* p2p_job_desc with real-valued angles (see p2p_remap_views_f64) */
+typedef struct p2p_job_desc_f64 {
+    int32_t pw, ph;
+    int32_t n_panos;
+    int32_t n_yaw;
+    const double* yaw_deg;
+    int32_t n_pitch;
+    const double* pitch_deg;
+    double fov_deg;
+    int32_t ow, oh;
+    int32_t flags;
+} p2p_job_desc_f64;
+
 int p2p_ctx_create(int device, p2p_ctx** out);
 void p2p_ctx_destroy(p2p_ctx* ctx);
 int p2p_ctx_synchronize(p2p_ctx* ctx);
@@ -169,6 +193,7 @@ int p2p_ctx_mark(p2p_ctx* ctx, int which);
 int p2p_ctx_marked_ms(p2p_ctx* ctx, float* ms);
 
 int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out);
+int p2p_job_create_f64(p2p_ctx* ctx, const p2p_job_desc_f64* desc, p2p_job** out);
 void p2p_job_destroy(p2p_job* job);
 /* H2D copy of panorama `index` (uint8 [ph][pw][3]) on the job's stream; returns once the host buffer may
    be reused or freed. */
@@ -177,6 +202,7 @@ int p2p_job_set_pano(p2p_job* job, int index, const uint8_t* pano, int64_t row_s
    the reference's yaw_mapping_cache sees between two process_yaw_and_pitchs calls on one image size
    (P:42-52: key (pano_width, pano_height, yaw_angle)); panoramas and pitch constants stay resident. */
 int p2p_job_set_yaws(p2p_job* job, const int32_t* yaw_deg);
+int p2p_job_set_yaws_f64(p2p_job* job, const double* yaw_deg);
 /* Optional: use caller float maps instead of in-kernel ones (see p2p_remap_views_maps_u8).  yaw_rows may be
    NULL to keep the yaw tables built from yaw_deg. */
 int p2p_job_set_maps(p2p_job* job, const float* yaw_rows, const float* U, const float* V);
