@@ -17,18 +17,21 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp
          "-mllvm", "-amdgpu-atomic-optimizer-strategy=DPP"]
 
 
-def build(force=False, verbose=False):
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
-        return OUT
+def build(force=False, verbose=False, out=None, extra_flags=None):
+    """Build the library.  `out` / `extra_flags` make a variant next to the shipped one (tools/variants.py:
+    tile shape, occupancy ... for A/B timing; load it with P2P_LIB_PATH)."""
+    out = out or OUT
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS):
+        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    tmp = OUT + ".tmp.%d" % os.getpid()
-    extra = os.environ.get("P2P_EXTRA_FLAGS", "").split()  # e.g. -DP2P_STAMPS for the diagnostic build
+    tmp = out + ".tmp.%d" % os.getpid()
+    extra = list(extra_flags) if extra_flags is not None else os.environ.get("P2P_EXTRA_FLAGS", "").split()
     cmd = [hipcc] + FLAGS + extra + ["-o", tmp] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    os.replace(tmp, OUT)
-    return OUT
+    os.replace(tmp, out)
+    return out
 
 
 if __name__ == "__main__":

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libp2p_hip.so")
+# P2P_LIB_PATH: load another build of the same library (A/B timing of kernel variants, diagnostic builds)
+LIB_PATH = os.environ.get("P2P_LIB_PATH") or os.path.join(_HERE, "libp2p_hip.so")
 
 P2P_OK = 0
 P2P_ERR_INVALID, P2P_ERR_NO_DEVICE, P2P_ERR_HIP, P2P_ERR_OOM, P2P_ERR_STATE = -1, -2, -3, -4, -5

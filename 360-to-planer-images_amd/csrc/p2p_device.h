@@ -9,14 +9,20 @@
 
 namespace p2p {
 
-constexpr int TILE_W = 64;          // output tile of one workgroup (main pass)
+#ifndef P2P_TILE_W
+#define P2P_TILE_W 64
+#endif
+#ifndef P2P_WAVES
+#define P2P_WAVES 5
+#endif
+constexpr int TILE_W = P2P_TILE_W;  // output tile of one workgroup (main pass)
 constexpr int TILE_H = 16;
 constexpr int VIEWS_BLOCK = 256;
 constexpr int VIEWS_PXT = TILE_W * TILE_H / VIEWS_BLOCK;  // output pixels per thread (rows ROWSTEP apart)
 constexpr int XTRA_PXT = VIEWS_PXT > 1 ? VIEWS_PXT / 2 : 1;  // pieces of split tiles: at most half a tile
 constexpr int VIEWS_SLOTS = 2;      // 16-byte footprint items one thread produces per (panorama, yaw) pair
 constexpr int LDS_ITEMS_CAP = VIEWS_SLOTS * VIEWS_BLOCK;  // items (4 rot pixels each) per LDS buffer
-constexpr int VIEWS_WAVES_PER_SIMD = 4;  // __launch_bounds__ of the view kernel: 128 VGPRs
+constexpr int VIEWS_WAVES_PER_SIMD = P2P_WAVES;  // __launch_bounds__ of the view kernel: 128 VGPRs
 constexpr int PLAN_MAX_ROWS = 256;  // rot rows a piece's footprint may span (one plan thread per row)
 constexpr int PLAN_MIN_W = 16;      // tiles whose footprint outgrows the LDS buffers are halved in width down to
 constexpr int PLAN_MIN_H = 8;       // PLAN_MIN_W, then once in height; what still does not fit gathers directly

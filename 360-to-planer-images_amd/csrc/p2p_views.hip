@@ -7,6 +7,7 @@
 // The fixed-point arithmetic is OpenCV 4.10's (imgwarp.cpp remapBilinear, INTER_BITS = 5,
 // INTER_REMAP_COEF_BITS = 15); see DESIGN.md "Arithmetic contract".
 // Compiled with -ffp-contract=off: every float operation below rounds where NumPy rounds.
+#include <type_traits>
 #include "p2p_inline.h"
 
 namespace p2p {
@@ -146,7 +147,7 @@ __device__ __forceinline__ void draw_piece(
     const ViewsParams& P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab,
     const YawDesc* __restrict__ ydesc, const uint32_t* __restrict__ f4tab, uint8_t* __restrict__ out,
     const PieceHdr h, const uint32_t* __restrict__ pxw, const uint32_t* __restrict__ itw,
-    uint4 (*tile4)[LDS_ITEMS_CAP])
+    uint4 (*tile4)[LDS_ITEMS_CAP], uint32_t* stage)
 {
     const int t = threadIdx.x;
     const int x0 = (int)(h.xy & 0xFFFFu), y0 = (int)(h.xy >> 16);
@@ -183,6 +184,8 @@ __device__ __forceinline__ void draw_piece(
         return P.n_yaw == 1 ? pair : (int)__umulhi((uint32_t)pair, P.n_yaw_magic);
     };
 
+    // generic store (pieces at the image border, narrow pieces, widths not divisible by 4): per pixel row, lanes
+    // 4k..4k+3 assemble 12 bytes into 3 aligned dwords
     auto store_pixels = [&](int pair, const uint32_t (&pix)[PXT]) {
         // [pano][yaw][pitch][oh][ow][3]
         uint8_t* O = out + ((size_t)pair * P.n_pitch + pitch_i) * view_bytes;
@@ -199,7 +202,7 @@ __device__ __forceinline__ void draw_piece(
                 uint32_t voff = off + (uint32_t)lane4;
                 asm volatile("" : "+v"(voff));
                 if (inside[j] && lane4 < 3)
-                    *reinterpret_cast<uint32_t*>(O + voff) = dw;
+                    __builtin_nontemporal_store(dw, reinterpret_cast<uint32_t*>(O + voff));
             } else if (inside[j]) {
                 uint8_t* o = O + off;
                 o[0] = (uint8_t)pix[j];
@@ -280,7 +283,11 @@ __device__ __forceinline__ void draw_piece(
     TapWeights tw[PXT];
 #pragma unroll
     for (int j = 0; j < PXT; ++j) {
+#ifdef P2P_NT_PLAN
+        const uint32_t wd = __builtin_nontemporal_load(pxw + j * VIEWS_BLOCK + t);
+#else
         const uint32_t wd = pxw[j * VIEWS_BLOCK + t];
+#endif
         const uint32_t dl = (wd >> 11) & 0x7FFu;
         tap_up[j] = (wd & 0x7FFu) << 2;
         tap_lo[j] = tap_up[j] + (dl << 2);
@@ -311,7 +318,7 @@ __device__ __forceinline__ void draw_piece(
     // back with v_readlane, so no descriptor load sits on the per-pair critical path ----
     uint32_t cw0 = 0, cw1 = 0;
     int cw2 = 0, cw3 = 0;
-    bool ctx_plain = true;  // this lane's pair: circular-shift yaw with one weight for the whole piece
+    int ctx_class = 2;  // 0: whole-column shift (stage 1 is a copy), 1: one blend weight for the whole piece, 2: the rest
     {
         const int k = t & 63;
         if (k < pair1 - pair0) {
@@ -329,28 +336,30 @@ __device__ __forceinline__ void draw_piece(
             cw1 = (uint32_t)(ngroups - g0) | (uint32_t)yi << 16;
             cw2 = 4 * g0 - yd.s;
             cw3 |= k << 26;  // n_panos < 2^26 (host check): the chunk-local pair index rides along
-            ctx_plain = yd.mode != 2 && !per_column;
+            ctx_class = (yd.mode == 2 || per_column) ? 2 : (yd.f == 0 ? 0 : 1);
         }
     }
-    // Plain pairs (the common case) run in the tight loop below, the others in the general loop after it:
-    // the contexts are sorted plain-first across the lanes, so that one odd yaw in a chunk (6 of the 360
-    // one-degree yaws on 8192 columns have per-column weights) does not slow its whole chunk down.
+    // The contexts are sorted by class across the lanes: the whole-column yaws run in one branch-free loop, the
+    // blended ones in a second, and the odd ones (6 of the 360 one-degree yaws on 8192 columns have per-column
+    // weights) in the general loop after them, so that they do not slow their whole chunk down.
     const int npairs = pair1 - pair0;
-    int nplain;
+    int n_copy, nplain;
     {
         const int k = t & 63;
         const bool valid = k < npairs;
-        const unsigned long long plain_mask = __ballot(valid && ctx_plain);
-        const unsigned long long other_mask = __ballot(valid && !ctx_plain);
-        nplain = __popcll(plain_mask);
-        if (other_mask != 0ull) {
-            const unsigned long long below = (1ull << k) - 1ull;
-            const int r = !valid ? k : (ctx_plain ? __popcll(plain_mask & below) : nplain + __popcll(other_mask & below));
-            cw0 = (uint32_t)__builtin_amdgcn_ds_permute(4 * r, (int)cw0);
-            cw1 = (uint32_t)__builtin_amdgcn_ds_permute(4 * r, (int)cw1);
-            cw2 = __builtin_amdgcn_ds_permute(4 * r, cw2);
-            cw3 = __builtin_amdgcn_ds_permute(4 * r, cw3);
-        }
+        const unsigned long long m0 = __ballot(valid && ctx_class == 0);
+        const unsigned long long m1 = __ballot(valid && ctx_class == 1);
+        const unsigned long long m2 = __ballot(valid && ctx_class == 2);
+        n_copy = __popcll(m0);
+        nplain = n_copy + __popcll(m1);
+        const unsigned long long below = (1ull << k) - 1ull;
+        const int r = !valid ? k
+                             : (ctx_class == 0 ? __popcll(m0 & below)
+                                               : (ctx_class == 1 ? n_copy + __popcll(m1 & below) : nplain + __popcll(m2 & below)));
+        cw0 = (uint32_t)__builtin_amdgcn_ds_permute(4 * r, (int)cw0);
+        cw1 = (uint32_t)__builtin_amdgcn_ds_permute(4 * r, (int)cw1);
+        cw2 = __builtin_amdgcn_ds_permute(4 * r, cw2);
+        cw3 = __builtin_amdgcn_ds_permute(4 * r, cw3);
     }
     auto pair_ctx = [&](int k) {
         const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)cw0, k);
@@ -392,88 +401,155 @@ __device__ __forceinline__ void draw_piece(
         }
     };
 
-    if (nplain > 0) {
-        // ---- tight loop: no per-pair mode branches, source pieces ping-pong between two register
-        // sets (pair loop unrolled by two), so nothing is copied and nothing is re-decided per pair ----
-        auto load_pieces = [&](int k, Q16 (&qq)[VIEWS_SLOTS]) {
+    // ---- tight loops: one per (number of items this wave produces, copy / blend), each free of branches on
+    // the vector-memory path, so that the compiler's s_waitcnt vmcnt stay counted (with a conditional load or
+    // store in the loop it falls back to vmcnt(0), and every pair then waits for the previous pair's stores
+    // to be acknowledged: loads, stores included, retire in issue order) ----
+    // whole pieces of a 64-wide tile: all 4 rows of a wave leave through LDS as one 12-byte store per lane
+    const bool full = PXT == 4 && fast_store && pw_ == 64 && ph_ == 16 && x0 + 64 <= P.ow && y0 + 16 <= P.oh;
+    const int wv = t >> 6, ln = t & 63;
+    uint32_t* const stg = stage + wv * (PXT * 64);
+    const uint32_t out_off12 = (uint32_t)(((size_t)(y0 + wv + (VIEWS_BLOCK / 64) * (ln >> 4)) * P.ow + x0) * 3) + 12u * (uint32_t)(ln & 15);
+    const int ns_wave = n_items > wave_base + VIEWS_BLOCK ? 2 : (n_items > wave_base ? 1 : 0);
+
+    int kdone = 0;  // pairs drawn by the tight loops
+    if (nplain > 0 && (full || PXT < 4)) {
+        uint32_t buf_bytes = 0u;
+        Q16 qc[VIEWS_SLOTS], qn[VIEWS_SLOTS];
+        auto load_pieces = [&](auto ns_c, int k, Q16 (&qq)[VIEWS_SLOTS]) {
+            constexpr int NS = decltype(ns_c)::value;
             const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)cw0, k);
             const uint32_t wrap_g = (uint32_t)__builtin_amdgcn_readlane((int)cw1, k) & 0xFFFFu;
             const uint8_t* __restrict__ S = src + (size_t)(__builtin_amdgcn_readlane(cw3, k) & 0x3FFFFFF) * P.pano_stride;
             const uint32_t goff = w0 & 0xFFFFFu;
 #pragma unroll
-            for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
-                if (wave_base + sl * VIEWS_BLOCK < n_items) {
-                    uint32_t off = slot_off[sl] + goff;
-                    if (slot_g[sl] >= wrap_g)
-                        off -= row_bytes;
-                    qq[sl] = *reinterpret_cast<const Q16*>(S + off);
-                }
+            for (int sl = 0; sl < NS; ++sl) {
+                uint32_t off = slot_off[sl] + goff;
+                off = slot_g[sl] >= wrap_g ? off - row_bytes : off;
+                qq[sl] = *reinterpret_cast<const Q16*>(S + off);
+            }
         };
-        auto stage1 = [&](int k, const Q16 (&qq)[VIEWS_SLOTS], uint4* tl4) {
+        auto stage1 = [&](auto ns_c, auto copy_c, int k, const Q16 (&qq)[VIEWS_SLOTS], uint4* tl4) {
+            constexpr int NS = decltype(ns_c)::value;
+            constexpr bool COPY = decltype(copy_c)::value;
             const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)cw0, k) >> 24;
 #pragma unroll
-            for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
-                if (wave_base + sl * VIEWS_BLOCK < n_items) {
-                    // the piece holds source pixels 0..4 at byte offsets 0, 3, 6, 9, 12; one v_perm_b32
-                    // both fetches a pixel across the dword seam and masks it
-                    // (selector bytes 0-3 pick the second operand's bytes, 4-7 the first's, 0x0c is zero)
-                    const uint32_t d0 = qq[sl].d[0], d1 = qq[sl].d[1], d2 = qq[sl].d[2], d3 = qq[sl].d[3];
-                    uint4 o;
-                    if (f != 0) {
-                        const uint32_t f8 = 8u * f, g8 = 256u - f8;
-                        const uint32_t m0 = d0 & 0x00FF00FFu, n0 = d0 & 0x0000FF00u;                    // bytes 0,1,2
-                        const uint32_t m1 = __builtin_amdgcn_perm(d1, d0, 0x0C050C03u);                  // 3,(4),5
-                        const uint32_t n1 = __builtin_amdgcn_perm(d1, d0, 0x0C0C040Cu);
-                        const uint32_t m2 = __builtin_amdgcn_perm(d2, d1, 0x0C040C02u);                  // 6,(7),8
-                        const uint32_t n2 = __builtin_amdgcn_perm(d2, d1, 0x0C0C030Cu);
-                        const uint32_t m3 = __builtin_amdgcn_perm(d3, d2, 0x0C030C01u);                  // 9,(10),11
-                        const uint32_t n3 = __builtin_amdgcn_perm(d3, d2, 0x0C0C020Cu);
-                        const uint32_t m4 = d3 & 0x00FF00FFu, n4 = d3 & 0x0000FF00u;                    // 12,13,14
-                        o.x = rot_blend8(m0, n0, m1, n1, f8, g8);
-                        o.y = rot_blend8(m1, n1, m2, n2, f8, g8);
-                        o.z = rot_blend8(m2, n2, m3, n3, f8, g8);
-                        o.w = rot_blend8(m3, n3, m4, n4, f8, g8);
-                    } else {
-                        o.x = d0 & 0x00FFFFFFu;
-                        o.y = __builtin_amdgcn_perm(d1, d0, 0x0C050403u);
-                        o.z = __builtin_amdgcn_perm(d2, d1, 0x0C040302u);
-                        o.w = __builtin_amdgcn_perm(d3, d2, 0x0C030201u);
-                    }
-                    tl4[t + sl * VIEWS_BLOCK] = o;
+            for (int sl = 0; sl < NS; ++sl) {
+                // the piece holds source pixels 0..4 at byte offsets 0, 3, 6, 9, 12; one v_perm_b32
+                // both fetches a pixel across the dword seam and masks it
+                // (selector bytes 0-3 pick the second operand's bytes, 4-7 the first's, 0x0c is zero)
+                const uint32_t d0 = qq[sl].d[0], d1 = qq[sl].d[1], d2 = qq[sl].d[2], d3 = qq[sl].d[3];
+                uint4 o;
+                if (!COPY) {
+                    const uint32_t f8 = 8u * f, g8 = 256u - f8;
+                    const uint32_t m0 = d0 & 0x00FF00FFu, n0 = d0 & 0x0000FF00u;                    // bytes 0,1,2
+                    const uint32_t m1 = __builtin_amdgcn_perm(d1, d0, 0x0C050C03u);                  // 3,(4),5
+                    const uint32_t n1 = __builtin_amdgcn_perm(d1, d0, 0x0C0C040Cu);
+                    const uint32_t m2 = __builtin_amdgcn_perm(d2, d1, 0x0C040C02u);                  // 6,(7),8
+                    const uint32_t n2 = __builtin_amdgcn_perm(d2, d1, 0x0C0C030Cu);
+                    const uint32_t m3 = __builtin_amdgcn_perm(d3, d2, 0x0C030C01u);                  // 9,(10),11
+                    const uint32_t n3 = __builtin_amdgcn_perm(d3, d2, 0x0C0C020Cu);
+                    const uint32_t m4 = d3 & 0x00FF00FFu, n4 = d3 & 0x0000FF00u;                    // 12,13,14
+                    o.x = rot_blend8(m0, n0, m1, n1, f8, g8);
+                    o.y = rot_blend8(m1, n1, m2, n2, f8, g8);
+                    o.z = rot_blend8(m2, n2, m3, n3, f8, g8);
+                    o.w = rot_blend8(m3, n3, m4, n4, f8, g8);
+                } else {
+                    o.x = d0 & 0x00FFFFFFu;
+                    o.y = __builtin_amdgcn_perm(d1, d0, 0x0C050403u);
+                    o.z = __builtin_amdgcn_perm(d2, d1, 0x0C040302u);
+                    o.w = __builtin_amdgcn_perm(d3, d2, 0x0C030201u);
                 }
-        };
-        auto half = [&](int k, const Q16 (&qcur)[VIEWS_SLOTS], Q16 (&qnext)[VIEWS_SLOTS], uint4* tl4, uint32_t buf_bytes) {
-            stage1(k, qcur, tl4);
-            uint32_t soff = buf_bytes + 4u * (((uint32_t)__builtin_amdgcn_readlane((int)cw0, k) >> 20) & 3u);
-            asm volatile("" : "+s"(soff));  // one scalar: keeps the buffer base out of separate vector adds
-            __syncthreads();
-            const unsigned char* tl = reinterpret_cast<const unsigned char*>(&tile4[0][0]);
-            uint32_t ta[PXT][4];
-#pragma unroll
-            for (int j = 0; j < PXT; ++j) {
-                const uint32_t* up = reinterpret_cast<const uint32_t*>(tl + (tap_up[j] + soff));
-                const uint32_t* lo = reinterpret_cast<const uint32_t*>(tl + (tap_lo[j] + soff));
-                ta[j][0] = up[0];
-                ta[j][1] = up[1];
-                ta[j][2] = lo[0];
-                ta[j][3] = lo[1];
+                tl4[t + sl * VIEWS_BLOCK] = o;
             }
-            if (k + 1 < nplain)
-                load_pieces(k + 1, qnext);
-            uint32_t pix[PXT];
-#pragma unroll
-            for (int j = 0; j < PXT; ++j)
-                pix[j] = blend4_packed(ta[j][0], ta[j][1], ta[j][2], ta[j][3], tw[j]);
-            store_pixels(pair0 + (int)((uint32_t)__builtin_amdgcn_readlane(cw3, k) >> 26), pix);
         };
-        Q16 qa[VIEWS_SLOTS], qb[VIEWS_SLOTS];
-        load_pieces(0, qa);
-        for (int k = 0; k < nplain; k += 2) {
-            half(k, qa, qb, tile4[0], 0u);
-            if (k + 1 >= nplain)
-                break;
-            half(k + 1, qb, qa, tile4[1], (uint32_t)sizeof(tile4[0]));
-        }
+        auto tight = [&](auto ns_c, auto copy_c, int kbeg, int kend) {
+            for (int k = kbeg; k < kend; ++k) {
+                uint4* tl4 = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(&tile4[0][0]) + buf_bytes);
+                stage1(ns_c, copy_c, k, qc, tl4);
+                uint32_t soff = buf_bytes + 4u * (((uint32_t)__builtin_amdgcn_readlane((int)cw0, k) >> 20) & 3u);
+                asm volatile("" : "+s"(soff));  // one scalar: keeps the buffer base out of separate vector adds
+#ifndef P2P_ABLATE_BARRIER
+                __syncthreads();
+#endif
+                const unsigned char* tl = reinterpret_cast<const unsigned char*>(&tile4[0][0]);
+                uint32_t ta[PXT][4];
+#pragma unroll
+                for (int j = 0; j < PXT; ++j) {
+                    const uint32_t* up = reinterpret_cast<const uint32_t*>(tl + (tap_up[j] + soff));
+                    const uint32_t* lo = reinterpret_cast<const uint32_t*>(tl + (tap_lo[j] + soff));
+                    ta[j][0] = up[0];
+                    ta[j][1] = up[1];
+                    ta[j][2] = lo[0];
+                    ta[j][3] = lo[1];
+                }
+                // the next pair's pieces (the last pair asks for its own again: no branch on the memory path)
+                const int kn = k + 1 < nplain ? k + 1 : k;
+#ifndef P2P_ABLATE_LOADS
+                load_pieces(ns_c, kn, qn);
+#else
+                (void)kn;
+#pragma unroll
+                for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
+                    qn[sl] = qc[sl];
+#endif
+                uint32_t pix[PXT];
+#pragma unroll
+                for (int j = 0; j < PXT; ++j)
+                    pix[j] = blend4_packed(ta[j][0], ta[j][1], ta[j][2], ta[j][3], tw[j]);
+                const int pair = pair0 + (int)((uint32_t)__builtin_amdgcn_readlane(cw3, k) >> 26);
+#ifdef P2P_ABLATE_STORES
+                if (pix[0] == 0x12345678u && pix[PXT - 1] == 0x9ABCDEF0u)
+#endif
+                if (PXT == 4 && full) {
+                    // the wave's 4 x 64 pixels -> LDS (a dword per pixel) -> 4 pixels of one row per lane -> 12 bytes
+                    uint8_t* O = out + ((size_t)pair * P.n_pitch + pitch_i) * view_bytes;
+#pragma unroll
+                    for (int j = 0; j < PXT; ++j)
+                        stg[j * 64 + ln] = pix[j];
+                    // DS operations of one wave execute in order: the read below sees the four writes above
+                    const uint4 v = *reinterpret_cast<const uint4*>(stg + 4 * ln);
+                    const uint32_t o0 = __builtin_amdgcn_perm(v.y, v.x, 0x04020100u);  // B0 G0 R0 B1
+                    const uint32_t o1 = __builtin_amdgcn_perm(v.z, v.y, 0x05040201u);  // G1 R1 B2 G2
+                    const uint32_t o2 = __builtin_amdgcn_perm(v.w, v.z, 0x06050402u);  // R2 B3 G3 R3
+                    uint32_t voff = out_off12;
+                    asm volatile("" : "+v"(voff));
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(O + voff);
+                    __builtin_nontemporal_store(o0, dst);
+                    __builtin_nontemporal_store(o1, dst + 1);
+                    __builtin_nontemporal_store(o2, dst + 2);
+                } else {
+                    store_pixels(pair, pix);
+                }
+#pragma unroll
+                for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
+                    qc[sl] = qn[sl];
+                buf_bytes ^= (uint32_t)sizeof(tile4[0]);
+            }
+        };
+        auto run_ns = [&](auto ns_c) {
+            load_pieces(ns_c, 0, qc);
+            if (PXT == 4 && full) {
+                // Loads and stores retire in issue order and the compiler counts them per path: inside the loop the
+                // pieces of pair k + 1 are followed by the store of pair k, so "pieces landed" is vmcnt(1).  Entering
+                // the loop straight after the first loads it would have to assume vmcnt(0) -- and then every pair
+                // waits for the previous pair's store to be acknowledged.  One store instruction that writes nothing
+                // gives both paths the same shape.
+                __builtin_amdgcn_sched_barrier(0);
+                // a buffer store through a descriptor of zero records: counted like any store, dropped by the hardware
+                __builtin_amdgcn_raw_buffer_store_b32(0u, __builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0x00020000), 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            tight(ns_c, std::true_type{}, 0, n_copy);
+            tight(ns_c, std::false_type{}, n_copy, nplain);
+        };
+        if (ns_wave == 2)
+            run_ns(std::integral_constant<int, 2>{});
+        else if (ns_wave == 1)
+            run_ns(std::integral_constant<int, 1>{});
+        else
+            run_ns(std::integral_constant<int, 0>{});
+        kdone = nplain;
         if (nplain == npairs)
             return;
         __syncthreads();  // the last plain pair's taps are read before the general loop writes the buffers
@@ -481,13 +557,13 @@ __device__ __forceinline__ void draw_piece(
 
     // ---- general loop: yaws with per-column weights (flickering fraction, the clipped column inside the
     // piece) and yaw rows that are not a shift (direct gathers) ----
-    PairCtx pc = pair_ctx(nplain);
+    PairCtx pc = pair_ctx(kdone);
     Q16 q[VIEWS_SLOTS];
     uint32_t fw[VIEWS_SLOTS];
     if (pc.fast)
         issue_loads(pc, src + (size_t)pc.pano * P.pano_stride, q, fw);
     int buf = 0;
-    for (int ki = nplain; ki < npairs; ++ki) {
+    for (int ki = kdone; ki < npairs; ++ki) {
         const uint8_t* __restrict__ S = src + (size_t)pc.pano * P.pano_stride;
         const int cur_yaw = pc.yaw_i;
         const int pair = pair0 + pc.korig;
@@ -581,13 +657,14 @@ __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views
     const PieceHdr* __restrict__ hdr_x, const uint32_t* __restrict__ px_x, const uint32_t* __restrict__ items_x)
 {
     __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[(VIEWS_BLOCK / 64) * VIEWS_PXT * 64];  // store staging: a dword per pixel
     if ((int)blockIdx.x < P.plan_gx) {
         const int ei = (int)blockIdx.y * P.plan_gx + (int)blockIdx.x;
         if (ei >= P.x_n)
             return;
         const PieceHdr h = hdr_x[ei];
         draw_piece<XTRA_PXT>(P, src, ytab, ydesc, f4tab, out, h, px_x + (size_t)h.px_block * (VIEWS_BLOCK * XTRA_PXT),
-                             items_x + (size_t)h.item_block * LDS_ITEMS_CAP, tile4);
+                             items_x + (size_t)h.item_block * LDS_ITEMS_CAP, tile4, stage);
         return;
     }
     const int bx = (int)blockIdx.x - P.plan_gx, gx = (int)gridDim.x - P.plan_gx;
@@ -602,7 +679,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views
     if ((h.mode_items & 3u) == 0u)
         return;  // a split tile: drawn by its pieces
     draw_piece<VIEWS_PXT>(P, src, ytab, ydesc, f4tab, out, h, px_main + (size_t)h.px_block * (VIEWS_BLOCK * VIEWS_PXT),
-                          items_main + (size_t)h.item_block * LDS_ITEMS_CAP, tile4);
+                          items_main + (size_t)h.item_block * LDS_ITEMS_CAP, tile4, stage);
 }
 
 hipError_t launch_remap_views(const ViewsParams& P, hipStream_t st)

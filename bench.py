@@ -17,10 +17,15 @@ Rank 0 prints ONE JSON line (contract in the task statement) with two extra obje
                   host cores on a bounded sample of the same workload (N = 1 only)
 """
 import argparse
+import csv
+import glob
 import importlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -166,6 +171,74 @@ def cpu_baseline(w, budget_s=12.0):
     }
 
 
+def read_sclk_mhz():
+    """Current shader clock of each GPU from sysfs (pp_dpm_sclk marks the active level with '*'), or None."""
+    out = []
+    for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        try:
+            for line in open(path):
+                if "*" in line:
+                    out.append(int(line.split(":")[1].strip().lower().replace("mhz", "").replace("*", "").strip()))
+        except (OSError, ValueError, IndexError):
+            pass
+    return out or None
+
+
+PMC_PASSES = (  # one rocprofv3 run each: FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2
+    ["FETCH_SIZE"], ["WRITE_SIZE"],
+    ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CU_CYCLES", "SQ_WAVES", "SQ_INSTS_SALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES"],
+)
+
+
+def measure_counters(args):
+    """HBM-side bytes and VALU instruction counts of the hot kernel of THIS build, per launch: this script re-run
+    under `rocprofv3 --pmc` (counters only: no tracing in the same run), a few launches, one pass per counter
+    group.  Returns {counter: mean per launch} or None when the profiler is not usable."""
+    kernel = "remap_views_kernel" if args.pixel_path == "u8" else "float_views_kernel"
+    base = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2", "--no-preroll", "--no-cpu-baseline",
+            "--counters", "none", "--workload", args.workload, "--panos-per-gpu", str(args.panos_per_gpu),
+            "--maps", args.maps, "--kind", args.kind, "--pixel-path", args.pixel_path]
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="p2p_pmc_")
+    try:
+        for i, group in enumerate(PMC_PASSES):
+            d = os.path.join(tmp, "p%d" % i)
+            try:
+                subprocess.run(["rocprofv3", "--pmc"] + group + ["--output-format", "csv", "-d", d, "--"] + base,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, cwd=tmp,
+                               env=dict(os.environ, TMPDIR=tmp))
+            except (OSError, subprocess.SubprocessError):
+                continue
+            acc = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if kernel in row.get("Kernel_Name", ""):
+                            acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for k, v in acc.items():
+                vals[k] = sum(v) / len(v)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return vals or None
+
+
+def traffic_from_counters(c):
+    """Guide (MI355X_MICROARCH.md, HBM): FETCH_SIZE / WRITE_SIZE are KiB at the L2's memory side; on gfx950
+    FETCH_SIZE tallies the 128-B requests of wide reads at 64 B.  The factor for this kernel's read pattern
+    (4-byte-aligned 16-byte pieces 12 bytes apart) was calibrated on a known-bytes read, tools/ubench/fetch_calib.hip:
+    x1.92 (x2.00 for plain dwordx4 streaming); WRITE_SIZE is used as reported."""
+    if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        return None
+    corr = 1.92
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            corr = float(json.load(f).get("cfg2", {}).get("fetch_correction", corr))
+    except (OSError, ValueError):
+        pass
+    rd, wr = c["FETCH_SIZE"] * 1024.0 * corr, c["WRITE_SIZE"] * 1024.0
+    return {"bytes": rd + wr, "read_bytes": rd, "write_bytes": wr, "fetch_correction": corr}
+
+
 def load_traffic(workload):
     """HBM bytes per launch from the PMC passes (profiles/traffic.json, written from rocprofv3
     --pmc FETCH_SIZE / WRITE_SIZE runs with the guide's gfx950 corrections), or None."""
@@ -197,7 +270,24 @@ def main():
                     help="u8: the reference's two fixed-point remap stages (default; the parity path). "
                          "f32 / f16: the opt-in single float resample, which the reference does not have")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preroll-s", type=float, default=0.5,
+                    help="seconds of untimed launches BEFORE the --warmup steps, whatever --steps / --warmup are: an idle "
+                         "MI355X sits at a low shader clock and needs a few hundred ms of load to reach its working "
+                         "clock (a 25-launch run is over in 4 ms).  Reported as preroll_s; 0 turns it off")
+    ap.add_argument("--no-preroll", action="store_true")
+    ap.add_argument("--counters", default="auto", choices=["auto", "measure", "file", "none"],
+                    help="roofline.traffic / roofline.valu: measure = rocprofv3 --pmc child runs of this script (one pass "
+                         "per counter group, before this process touches the GPU); file = profiles/traffic.json; "
+                         "auto = measure at --gpus 1 when rocprofv3 is on PATH, else file")
     args = ap.parse_args()
+    if args.no_preroll:
+        args.preroll_s = 0.0
+    counters = None
+    mode = args.counters
+    if mode == "auto":
+        mode = "measure" if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and shutil.which("rocprofv3")) else "file"
+    if mode == "measure":
+        counters = measure_counters(args)  # child processes; nothing in THIS process has touched the GPU yet
 
     import torch
 
@@ -254,7 +344,18 @@ def main():
         if state["n"] == args.warmup + steps:
             ctx.mark(1)
 
+    # disclosed pre-roll: launches for at least --preroll-s seconds before the --warmup steps, so that the timed
+    # region sees the clock the GPU holds under this load and not the ramp from idle
+    sclk_before = read_sclk_mhz()
+    preroll_launches, t_pre = 0, time.perf_counter()
+    while time.perf_counter() - t_pre < args.preroll_s:
+        for _ in range(50):
+            job.run()
+        ctx.synchronize()
+        preroll_launches += 50
+    preroll_s = time.perf_counter() - t_pre if preroll_launches else 0.0
     elapsed = run_timed(step, device_sync, dist, steps, args.warmup)
+    sclk_after = read_sclk_mhz()
     k_avg_s = ctx.marked_ms() / steps / 1e3
     job.time_launches(True)
     sample = min(32, steps)
@@ -285,6 +386,30 @@ def main():
     value = pix_per_step * steps / elapsed / 1e6
     b_alg = algorithmic_bytes(w, npg)
     achieved = b_alg / k_avg_s / 1e9
+    if mode == "measure":
+        tr = traffic_from_counters(counters)
+        traffic = tr["bytes"] if tr else None
+        traffic_how = dict(tr, source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this build") if tr else \
+            {"source": "rocprofv3 passes failed"}
+    elif mode == "file":
+        traffic, traffic_how = load_traffic(args.workload), {"source": "profiles/traffic.json (an earlier build's passes)"}
+    else:
+        traffic, traffic_how = None, {"source": "not collected"}
+    valu = None
+    if counters and "SQ_INSTS_VALU" in counters:
+        px = views_per_rank * w["ow"] * w["oh"]
+        # SQ counters on gfx950 sample a share of the waves (SQ_WAVES says how many): scale by launched / sampled
+        tiles = -(-w["ow"] // 64) * -(-w["oh"] // 16) * len(w["pitches"])
+        waves = counters.get("SQ_WAVES")
+        busy = counters.get("SQ_BUSY_CU_CYCLES")
+        valu = {"SQ_INSTS_VALU": counters["SQ_INSTS_VALU"], "SQ_INSTS_SALU": counters.get("SQ_INSTS_SALU"),
+                "SQ_WAVES": waves,
+                "valu_wave_insts_per_wave": counters["SQ_INSTS_VALU"] / waves if waves else None,
+                "valu_lane_insts_per_output_px_sampled": (counters["SQ_INSTS_VALU"] * 64.0 / px) if px else None,
+                "active_inst_valu_over_busy_cu_cycles": (counters.get("SQ_ACTIVE_INST_VALU", 0.0) / busy) if busy else None,
+                "issue_ceiling_of_that_ratio": {"slow_class_only": 0.97, "fast_class_only": 1.80,
+                                                "source": "profiles/r01_valu_counter_calibration.txt"},
+                "note": "secondary ceiling: the exact two-stage fixed-point emulation is VALU-issue bound, not HBM bound"}
     out = {
         "metric": "Mpix/s remapped, 8K equirect->1080p x36 views" if args.workload == "cfg2"
                   else "Mpix/s remapped (%s)" % args.workload,
@@ -294,13 +419,15 @@ def main():
         "config": {"workload": w["name"], "panos_per_gpu": npg, "views_per_gpu": views_per_rank,
                    "maps": args.maps + ("+coordinate cache" if args.cache_coords else ""), "pano_kind": args.kind, "sharding": "independent panoramas per rank, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_how": traffic_how, "valu": valu,
                      "kernel": "remap_views_kernel" if args.pixel_path == "u8" else "float_views_kernel", "kernel_ms_avg": k_avg_s * 1e3,
                      "kernel_ms_sample": {"n": int(sample), "mean": float(kms.mean()), "min": float(kms.min()),
                                           "max": float(kms.max()), "how": "own HIP event pair per launch, after the timed region"},
                      "algorithmic_bytes_per_launch": b_alg,
                      "measured_copy_GBs": copy_gbs,
                      "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None},
+        "preroll_s": preroll_s, "preroll_launches": preroll_launches,
+        "sclk_mhz": {"before_preroll": sclk_before, "after_timed_region": sclk_after},
     }
     if dist.rank == 0 and dist.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w)
