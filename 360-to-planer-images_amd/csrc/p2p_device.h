@@ -13,15 +13,25 @@ namespace p2p {
 #define P2P_TILE_W 64
 #endif
 #ifndef P2P_WAVES
-#define P2P_WAVES 5
+#define P2P_WAVES 6
 #endif
 constexpr int TILE_W = P2P_TILE_W;  // output tile of one workgroup (main pass)
 constexpr int TILE_H = 16;
 constexpr int VIEWS_BLOCK = 256;
 constexpr int VIEWS_PXT = TILE_W * TILE_H / VIEWS_BLOCK;  // output pixels per thread (rows ROWSTEP apart)
 constexpr int XTRA_PXT = VIEWS_PXT > 1 ? VIEWS_PXT / 2 : 1;  // pieces of split tiles: at most half a tile
-constexpr int VIEWS_SLOTS = 2;      // 16-byte footprint items one thread produces per (panorama, yaw) pair
-constexpr int LDS_ITEMS_CAP = VIEWS_SLOTS * VIEWS_BLOCK;  // items (4 rot pixels each) per LDS buffer
+#ifndef P2P_SLOTS
+#define P2P_SLOTS 3
+#endif
+#ifndef P2P_CAP
+#define P2P_CAP 704  // 6 workgroups (waves per SIMD) fit the 160 KB of LDS; the largest tile footprint of config 2 is 678
+#endif
+constexpr int VIEWS_SLOTS = P2P_SLOTS;  // 16-byte footprint items one thread produces per (panorama, yaw) pair, at most
+constexpr int LDS_ITEMS_CAP = P2P_CAP;  // items (4 rot pixels each) per LDS buffer
+static_assert(LDS_ITEMS_CAP <= VIEWS_SLOTS * VIEWS_BLOCK && LDS_ITEMS_CAP > (VIEWS_SLOTS - 1) * VIEWS_BLOCK, "slots vs cap");
+constexpr int PXW_UP_BITS = 12;     // per-pixel word: bits of the upper tap's LDS offset (dwords; 4 * LDS_ITEMS_CAP <= 4096)
+constexpr int PXW_DL_BITS = 10;     //                 bits of (lower tap - upper tap)
+static_assert(4 * LDS_ITEMS_CAP <= (1 << PXW_UP_BITS), "tap offsets must fit the per-pixel word");
 constexpr int VIEWS_WAVES_PER_SIMD = P2P_WAVES;  // __launch_bounds__ of the view kernel: 128 VGPRs
 constexpr int PLAN_MAX_ROWS = 256;  // rot rows a piece's footprint may span (one plan thread per row)
 constexpr int PLAN_MIN_W = 16;      // tiles whose footprint outgrows the LDS buffers are halved in width down to
@@ -42,8 +52,8 @@ struct PieceHdr {
     uint32_t pad;
 };
 static_assert(sizeof(PieceHdr) == 32, "PieceHdr is read as one s_load_dwordx8");
-// per-pixel word: tap_up (dwords into an LDS buffer, 11 bits) | (tap_lo - tap_up) << 11 (11 bits, 0 = the pixel
-// has no footprint: NaN coordinate) | fx << 22 | fy << 27
+// per-pixel word: tap_up (dwords into an LDS buffer, PXW_UP_BITS) | (tap_lo - tap_up) << 12 (PXW_DL_BITS, 0 = the
+// pixel has no footprint: NaN coordinate) | fx << 22 | fy << 27
 // item word: rot row << 16 | 4-pixel group relative to the group of column c0
 
 // how the yaw map of one yaw angle acts on columns (see yaw_desc_kernel)
@@ -110,7 +120,8 @@ struct PlanParams {
     PieceHdr* hdr_x;
     uint32_t* px_x;
     uint32_t* items_x;
-    uint32_t* x_count;       // extras wanted (may exceed x_cap: the host then grows the pools and re-runs)
+    uint32_t* x_count;       // [0] extras wanted (may exceed x_cap: the host then grows the pools and re-runs),
+                             // [1] pieces marked for direct gathers
     uint32_t x_cap;
 };
 
@@ -135,7 +146,7 @@ hipError_t launch_rot_map(float* U, float* V, int ow, int oh, const MapGeom& g, 
 hipError_t launch_pitch_map(float* U, float* V, int ow, int oh, const MapGeom& g, float c, float s,
                             hipStream_t st);
 hipError_t launch_plan(const PlanParams& P, hipStream_t st);
-hipError_t launch_remap_views(const ViewsParams& P, hipStream_t st);
+hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st);
 hipError_t launch_remap_maps(const RemapParams& P, int cn, int interpolation, hipStream_t st);
 hipError_t launch_cubic_tab(short* tab, hipStream_t st);
 hipError_t launch_float_views(const ViewsParams& P, const double* yaw_rad, bool half, hipStream_t st);

@@ -89,6 +89,8 @@ struct p2p_job {
     uint32_t* d_x_count = nullptr;
     uint32_t x_cap = 0;
     int x_n = -1;                        // -1: the plan has not been built for the current maps
+    int n_direct = 0;                    // pieces the plan marks for direct gathers
+    int n_odd_yaws = 0;                  // yaws that are not a plain shift with one weight (YawDesc.mode != 0)
     uint16_t* d_pitch_order = nullptr;   // [n_pitch] heaviest view first
     size_t n_tiles = 0;
     p2p::MapGeom geom{};
@@ -280,6 +282,18 @@ void p2p_job_destroy(p2p_job* j)
     delete j;
 }
 
+// how many of the job's yaws need the rest kernel (per-column weights, or a caller row that is not a shift)
+static int count_odd_yaws(p2p_job* j)
+{
+    std::vector<p2p::YawDesc> yd(j->d.n_yaw);
+    HIP_TRY(hipMemcpyAsync(yd.data(), j->d_ydesc, yd.size() * sizeof(p2p::YawDesc), hipMemcpyDeviceToHost, j->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+    j->n_odd_yaws = 0;
+    for (const auto& d : yd)
+        j->n_odd_yaws += d.mode != 0;
+    return P2P_OK;
+}
+
 static int job_create_core(p2p_ctx* ctx, const p2p_job_desc& d, const double* yaw_deg, const double* pitch_deg,
                            double fov_deg, p2p_job** out)
 {
@@ -356,7 +370,7 @@ static int job_create_core(p2p_ctx* ctx, const p2p_job_desc& d, const double* ya
         if (e == hipSuccess) e = hipMalloc((void**)&j->d_hdr_main, slots * sizeof(p2p::PieceHdr));
         if (e == hipSuccess) e = hipMalloc((void**)&j->d_px_main, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void**)&j->d_items_main, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&j->d_x_count, sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&j->d_x_count, 2 * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void**)&j->d_pitch_order, (size_t)d.n_pitch * sizeof(uint16_t));
         // views looking further from the horizon have larger source footprints: launch them first
         std::vector<uint16_t> ord(d.n_pitch);
@@ -381,6 +395,10 @@ static int job_create_core(p2p_ctx* ctx, const p2p_job_desc& d, const double* ya
     if (e != hipSuccess) {
         p2p_job_destroy(j);
         return fail(e == hipErrorOutOfMemory ? P2P_ERR_OOM : P2P_ERR_HIP, "p2p_job_create: %s", hipGetErrorString(e));
+    }
+    if (int rc = count_odd_yaws(j)) {
+        p2p_job_destroy(j);
+        return rc;
     }
     *out = j;
     return P2P_OK;
@@ -450,7 +468,7 @@ int p2p_job_set_yaws_f64(p2p_job* j, const double* yaw_deg)
     HIP_TRY(p2p::launch_yaw_desc(j->d_ydesc, j->d_f4tab, j->d_ytab, d.pw, d.n_yaw, j->ctx->stream));
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));  // yr is a stack-lifetime host buffer
     j->rows_from_host = false;
-    return P2P_OK;
+    return count_odd_yaws(j);
 }
 
 int p2p_job_set_yaws(p2p_job* j, const int32_t* yaw_deg)
@@ -487,7 +505,7 @@ int p2p_job_set_maps(p2p_job* j, const float* yaw_rows, const float* U, const fl
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));
     j->host_maps = true;
     j->x_n = -1;  // the plan follows the maps
-    return P2P_OK;
+    return yaw_rows ? count_odd_yaws(j) : P2P_OK;
 }
 
 // Build the job's plan (p2p_plan.hip) for its current maps: once per job geometry, like the yaw tables.  It
@@ -522,18 +540,20 @@ static int job_build_plan(p2p_job* j)
         Q.px_x = j->d_px_x;
         Q.items_x = j->d_items_x;
         Q.x_cap = j->x_cap;
-        HIP_TRY(hipMemsetAsync(j->d_x_count, 0, sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(j->d_x_count, 0, 2 * sizeof(uint32_t), st));
         // pixels outside the view (partial tiles) and unused item slots read as zero
         HIP_TRY(hipMemsetAsync(j->d_px_main, 0, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(j->d_items_main, 0, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(j->d_px_x, 0, (size_t)j->x_cap * 256 * p2p::XTRA_PXT * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(j->d_items_x, 0, (size_t)j->x_cap * p2p::LDS_ITEMS_CAP * sizeof(uint32_t), st));
         HIP_TRY(p2p::launch_plan(Q, st));
-        uint32_t n = 0;
-        HIP_TRY(hipMemcpyAsync(&n, j->d_x_count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        uint32_t cnt[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(cnt, j->d_x_count, sizeof(cnt), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        const uint32_t n = cnt[0];
         if (n <= j->x_cap) {
             j->x_n = (int)n;
+            j->n_direct = (int)cnt[1];
             return P2P_OK;
         }
         // more pieces than the pools hold (views full of poles): size them exactly and plan again
@@ -613,7 +633,14 @@ int p2p_job_run(p2p_job* j)
     P.plan_gx = 8 * ((((P.x_n + j->d.n_pitch - 1) / j->d.n_pitch) + 7) / 8);
     if (timed)
         HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
-    HIP_TRY(p2p::launch_remap_views(P, j->ctx->stream));
+    // The main kernel draws every LDS-scheme piece for every yaw that is a plain shift -- on the reference's own
+    // workloads that is everything.  The rest kernel (direct gathers, per-column yaw weights, view widths not
+    // divisible by 4) is launched only when the plan or the yaw tables call for it; the two write disjoint pixels.
+    const bool need_rest = j->n_direct > 0 || j->n_odd_yaws > 0 || (j->d.ow & 3) != 0 || env_int("P2P_FORCE_REST", 0) != 0;
+    if (need_rest)
+        HIP_TRY(p2p::launch_remap_views(P, 1, j->ctx->stream));
+    if ((j->d.ow & 3) == 0)
+        HIP_TRY(p2p::launch_remap_views(P, 0, j->ctx->stream));
     if (timed)
         HIP_TRY(hipEventRecord(j->ev_ring[2 * slot + 1], j->ctx->stream));
     j->runs++;

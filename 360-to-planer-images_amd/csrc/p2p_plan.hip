@@ -197,6 +197,20 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
                     s_rmax[t] = (int)width;
                 }
                 __syncthreads();
+                if (ok) {
+                    // the per-pixel word keeps (lower tap - upper tap) in PXW_DL_BITS bits: the distance between the
+                    // same column in two consecutive rows (about one row's width) -- a piece with a longer row is split
+                    bool far = false;
+#pragma unroll
+                    for (int j = 0; j < PXT; ++j)
+                        if (member[j] && inrange[j]) {
+                            const int r = iy[j] - r0;
+                            const uint32_t up = 4u * s_rbase[r] + (uint32_t)(ix[j] - s_rmin[r]);
+                            const uint32_t lo = 4u * s_rbase[r + 1] + (uint32_t)(ix[j] - s_rmin[r + 1]);
+                            far |= lo - up >= (1u << PXW_DL_BITS);
+                        }
+                    ok = __syncthreads_or(far) == 0;
+                }
             }
             const bool deepest = level + 1 == N_LEVELS;
             // splitting helps only where a smaller piece can fit: not when no pixel has a footprint at all, and not
@@ -245,7 +259,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
                             const int r = iy[j] - r0;
                             const uint32_t up = 4u * s_rbase[r] + (uint32_t)(ix[j] - s_rmin[r]);
                             const uint32_t lo = 4u * s_rbase[r + 1] + (uint32_t)(ix[j] - s_rmin[r + 1]);
-                            word = up | (lo - up) << 11 | fx[j] << 22 | fy[j] << 27;
+                            word = up | (lo - up) << PXW_UP_BITS | fx[j] << 22 | fy[j] << 27;
                         }
                         pxw[jp * VIEWS_BLOCK + tp] = word;
                     }
@@ -256,6 +270,8 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
                 }
             }
             if (t == 0) {
+                if (!ok)
+                    atomicAdd(P.x_count + 1, 1u);  // pieces for the direct-gather path (the rest kernel's work)
                 PieceHdr h;
                 h.xy = (uint32_t)(x0 + rc.x) | (uint32_t)(y0 + rc.y) << 16;
                 h.geom = (uint32_t)rc.w | (uint32_t)rc.h << 8 | (uint32_t)pitch_i << 16;

@@ -1,7 +1,8 @@
 // p2p_views.hip -- the hot kernel: both cv2.remap stages of every (panorama, yaw, pitch) view in one launch
-//   cv2.remap x2       P:192-199, P:212-218 -> remap_views_kernel (both stages fused, fixed point), driven by the
-//                                            tables of the plan pass (p2p_plan.hip); 3-channel single remaps of the
-//                                            legacy tool (L:179) too
+//   cv2.remap x2       P:192-199, P:212-218 -> remap_views_kernel (both stages fused, fixed point) and
+//                                            remap_views_rest_kernel (the odd cases), driven by the tables of the
+//                                            plan pass (p2p_plan.hip); 3-channel single remaps of the legacy tool
+//                                            (L:179) too
 // Reference behaviour (cited, never copied):
 //   P = /root/reference/app/panorama_to_plane-pitch.py, L = /root/reference/app/legacy/panorama_to_plane.py
 // The fixed-point arithmetic is OpenCV 4.10's (imgwarp.cpp remapBilinear, INTER_BITS = 5,
@@ -44,6 +45,30 @@ __device__ __forceinline__ uint32_t rot_blend8(uint32_t a_br, uint32_t a_g, uint
     return __builtin_amdgcn_perm(br, gg, 0x0C070205u);
 }
 
+// The tight loops' form: v_mad_u32_u24 twice per field pair.  Left to itself the compiler shares the products
+// between neighbouring pixels and adds them with v_add3_u32 (24 instructions per 4-pixel item instead of 16),
+// because a mad with the scalar weight AND a literal rounding constant would need two constant-bus reads: the
+// constants are therefore handed in as VGPRs.
+__device__ __forceinline__ uint32_t vmad24(uint32_t s_w, uint32_t v, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "s"(s_w), "v"(v), "v"(c));
+    return r;
+}
+
+__device__ __forceinline__ uint32_t rot_blend8_mad(uint32_t a_br, uint32_t a_g, uint32_t b_br, uint32_t b_g,
+                                                   uint32_t f8, uint32_t g8, uint32_t bias_br, uint32_t bias_g)
+{
+#ifdef P2P_NO_ASM_MAD
+    (void)bias_br; (void)bias_g;
+    return rot_blend8(a_br, a_g, b_br, b_g, f8, g8);
+#else
+    const uint32_t br = vmad24(f8, b_br, vmad24(g8, a_br, bias_br));
+    const uint32_t gg = vmad24(f8, b_g, vmad24(g8, a_g, bias_g));
+    return __builtin_amdgcn_perm(br, gg, 0x0C070205u);
+#endif
+}
+
 // direct path: (3*i | f << 20) table entry, unaligned 8-byte load of pixels i and i+1
 __device__ __forceinline__ uint32_t rot_pixel(const uint8_t* __restrict__ row, uint32_t te)
 {
@@ -73,6 +98,10 @@ __device__ __forceinline__ uint32_t blend4(uint32_t a, uint32_t b, uint32_t c, u
 struct __attribute__((aligned(4))) Q16 { uint32_t d[4]; };
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+#ifndef P2P_STORE_AUX
+#define P2P_STORE_AUX 2  // cache policy of the view stores: 2 = nt
+#endif
 
 __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 
@@ -109,9 +138,9 @@ __device__ __forceinline__ uint32_t blend4_packed(uint32_t a, uint32_t b, uint32
 }
 
 // ---------------------------------------------------------------------------------------------
-// The hot kernel.  One workgroup = one piece of the plan (p2p_plan.hip): a tile of TILE_W x TILE_H output pixels
-// of one pitch view (VIEWS_PXT pixels per thread), or a part of a tile whose footprint did not fit.  The plan
-// pass has already worked out everything that depends on the maps only, so a workgroup starts with a handful
+// The view kernels.  One workgroup = one piece of the plan (p2p_plan.hip): a tile of TILE_W x TILE_H output
+// pixels of one pitch view (VIEWS_PXT pixels per thread), or a part of a tile whose footprint did not fit.  The
+// plan pass has already worked out everything that depends on the maps only, so a workgroup starts with a handful
 // of loads: the piece header (scalar), one dword per pixel (LDS offsets of its 2x2 taps + the two 5-bit weights)
 // and one dword per footprint item (rot row, 4-pixel group).  Then, per (panorama, yaw) pair of its chunk:
 //   stage 1  the yaw map is a circular column shift (YawDesc), so a footprint row is one contiguous run of
@@ -120,16 +149,354 @@ __device__ __forceinline__ uint32_t blend4_packed(uint32_t a, uint32_t b, uint32
 //            arithmetic and writes them to the LDS tile (double-buffered) with one ds_write_b128; the loads of
 //            the NEXT pair are issued before stage 2 so that their latency hides behind it;
 //   stage 2  after one barrier each thread reads the 2x2 taps of its pixels from LDS, blends with cv::remap's
-//            fixed-point weights, and the tile is stored as aligned dwords.
+//            fixed-point weights; the pixels of a wave go through LDS once more so that every lane ends up with
+//            4 adjacent pixels of one row = one 12-byte non-temporal store.
 // The footprint is kept as per-row spans (each rot row only as wide as the taps of that row need), not as the
 // bounding rectangle: 1.4 .. 1.7 rot pixels per output pixel instead of 1.7 .. 2.3 on config 2.
-// Pieces the plan marks "direct" take the direct path (same arithmetic, taps gathered from global memory through
-// the packed yaw table): a pole inside the piece (the footprint spans every column), footprints touching the
-// panorama border (seam without wrap), widths not divisible by 4, general caller maps with border taps; so do
-// yaw rows that are not a shift.  Blocks map to tiles XCD-aware: each of the 8 XCDs owns a contiguous run of the
-// tile raster, so neighbouring tiles (shared source halo and output lines) meet in one L2.
+//
+// Two kernels share this scheme:
+//   remap_views_kernel       whole interior pieces x yaws that are plain shifts -- nothing but three branch-free
+//                            loops (copy / blend / blend with the clipped column patched), 66 VGPRs, no spills;
+//   remap_views_rest_kernel  everything else, with all the case distinctions: pieces at the image border, pieces
+//                            the plan marks for direct gathers (a pole inside the piece: the footprint spans every
+//                            column; footprints touching the panorama border; widths not divisible by 4; general
+//                            caller maps with border taps), yaws with per-column weights, yaw rows that are not a shift.
+// Kept in one kernel, the rare paths set the register allocation (96 VGPRs + spills) and tripled the ISA; the
+// common path ran at 110 us instead of 75 on config 2.  The two kernels write disjoint pixels and run on two streams.
+// Blocks map to tiles XCD-aware: each of the 8 XCDs owns a contiguous run of the tile raster, so neighbouring
+// tiles (shared source halo and output lines) meet in one L2.
 // ---------------------------------------------------------------------------------------------
-struct PairCtx {      // uniform per (piece, pair); precomputed per lane at piece set-up, read back with v_readlane
+struct PieceGeo {
+    int x0, y0, w, h, pitch_i, mode, n_items, lw;
+    int col, row0, rstep;  // this thread's column and first row inside the piece; rows between its pixels
+};
+
+__device__ __forceinline__ PieceGeo piece_geo(const PieceHdr& h, int t)
+{
+    PieceGeo g;
+    g.x0 = (int)(h.xy & 0xFFFFu);
+    g.y0 = (int)(h.xy >> 16);
+    g.w = (int)(h.geom & 0xFFu);
+    g.h = (int)((h.geom >> 8) & 0xFFu);
+    g.pitch_i = (int)(h.geom >> 16);
+    g.mode = (int)(h.mode_items & 3u);
+    g.n_items = (int)(h.mode_items >> 8);
+    g.lw = __builtin_ctz((unsigned)g.w);
+    g.col = t & (g.w - 1);
+    g.row0 = t >> g.lw;
+    g.rstep = VIEWS_BLOCK >> g.lw;
+    return g;
+}
+
+// the pieces the main kernel draws: LDS scheme, view rows of whole dwords (its stores are 12 bytes = 4 pixels)
+template <int PXT>
+__device__ __forceinline__ bool tight_piece(const PieceGeo& g, const ViewsParams& P)
+{
+    return g.mode == 1 && (P.ow & 3) == 0 && (PXT == 4 ? g.w == 64 : (g.w == 32 || g.w == 16));
+}
+
+// ---- per-pair contexts: lane k of every wave works out pair pair0 + k once; the loops read them back with
+// v_readlane, so no descriptor load sits on the per-pair critical path.  Sorted by class across the lanes:
+//   0  whole-column shift: stage 1 is a copy                      } tight loops
+//   1  one blend weight for the whole piece                       }
+//   2  the same, but the piece holds the column P:105 clips to    }  (one rot pixel is a copy instead)
+//      pw - 1
+//   3  per-column weights (a shift fraction within float noise of a rounding tie: 6 of the 360 one-degree
+//      yaws on 8192 columns) or a caller row that is not a shift -> general loop of the rest kernel
+struct PairCtxs {
+    uint32_t cw0, cw1;
+    int cw2, cw3;
+    int n0, n1, n2;  // pairs of class 0, of classes 0..1, of classes 0..2
+    int npairs, pair0;
+};
+
+__device__ __forceinline__ int pano_of_pair(const ViewsParams& P, int pair)
+{
+    // pair -> panorama: multiply-high by ceil(2^32 / n_yaw) (exact for the job's sizes, host check); with one yaw
+    // the constant would be 2^32, which does not fit, and the pair index is the panorama index anyway
+    return P.n_yaw == 1 ? pair : (int)__umulhi((uint32_t)pair, P.n_yaw_magic);
+}
+
+__device__ __forceinline__ PairCtxs pair_contexts(const ViewsParams& P, const YawDesc* __restrict__ ydesc, int c0, int c1, int t)
+{
+    PairCtxs X;
+    X.pair0 = blockIdx.z * P.pairs_per_block;
+    int pair1 = X.pair0 + P.pairs_per_block;
+    const int n_pairs = P.n_panos * P.n_yaw;
+    if (pair1 > n_pairs)
+        pair1 = n_pairs;
+    X.npairs = pair1 - X.pair0;
+    const int ngroups = P.pw >> 2;
+    uint32_t cw0 = 0, cw1 = 0;
+    int cw2 = 0, cw3 = 0, cls = 3;
+    const int k = t & 63;
+    if (k < X.npairs) {
+        cw3 = pano_of_pair(P, X.pair0 + k);
+        const int yi = X.pair0 + k - cw3 * P.n_yaw;
+        const YawDesc yd = ydesc[yi];
+        int i_first = c0 + yd.s;
+        if (i_first >= P.pw)
+            i_first -= P.pw;
+        const int g0 = i_first >> 2;
+        const bool clamp_in = yd.c_clamp >= c0 && yd.c_clamp <= c1 + 1;
+        // uniform weight unless this yaw flickers or the piece holds the column clipped to pw-1
+        const bool per_column = yd.mode == 1 || clamp_in;
+        cw0 = 12u * (uint32_t)g0 | (uint32_t)(i_first & 3) << 20 | (uint32_t)(yd.mode != 2) << 22 |
+              (uint32_t)per_column << 23 | (uint32_t)yd.f << 24;
+        cw1 = (uint32_t)(ngroups - g0) | (uint32_t)yi << 16;
+        cw2 = 4 * g0 - yd.s;
+        cw3 |= k << 26;  // n_panos < 2^26 (host check): the chunk-local pair index rides along
+        cls = yd.mode != 0 ? 3 : (clamp_in ? 2 : (yd.f == 0 ? 0 : 1));
+    }
+    const bool valid = k < X.npairs;
+    const unsigned long long m0 = __ballot(valid && cls == 0), m1 = __ballot(valid && cls == 1);
+    const unsigned long long m2 = __ballot(valid && cls == 2), m3 = __ballot(valid && cls == 3);
+    X.n0 = __popcll(m0);
+    X.n1 = X.n0 + __popcll(m1);
+    X.n2 = X.n1 + __popcll(m2);
+    const unsigned long long below = (1ull << k) - 1ull;
+    int r = k;
+    if (valid)
+        r = cls == 0 ? __popcll(m0 & below)
+                     : (cls == 1 ? X.n0 + __popcll(m1 & below)
+                                 : (cls == 2 ? X.n1 + __popcll(m2 & below) : X.n2 + __popcll(m3 & below)));
+    X.cw0 = (uint32_t)__builtin_amdgcn_ds_permute(4 * r, (int)cw0);
+    X.cw1 = (uint32_t)__builtin_amdgcn_ds_permute(4 * r, (int)cw1);
+    X.cw2 = __builtin_amdgcn_ds_permute(4 * r, cw2);
+    X.cw3 = __builtin_amdgcn_ds_permute(4 * r, cw3);
+    return X;
+}
+
+// per-pixel words of the plan -> tap offsets (bytes inside one LDS buffer) and packed weights
+template <int PXT>
+__device__ __forceinline__ void decode_px(const uint32_t* __restrict__ pxw, int t, uint32_t (&tap_up)[PXT],
+                                          uint32_t (&tap_lo)[PXT], TapWeights (&tw)[PXT])
+{
+#pragma unroll
+    for (int j = 0; j < PXT; ++j) {
+        const uint32_t wd = pxw[j * VIEWS_BLOCK + t];
+        const uint32_t dl = (wd >> PXW_UP_BITS) & ((1u << PXW_DL_BITS) - 1u);
+        tap_up[j] = (wd & ((1u << PXW_UP_BITS) - 1u)) << 2;
+        tap_lo[j] = tap_up[j] + (dl << 2);
+        const uint32_t fx = (wd >> 22) & 31u, fy = wd >> 27;
+        const uint32_t gx = 32u - fx, gy = 32u - fy;
+        tw[j].gx2 = gx | (gx << 16);
+        tw[j].fx2 = fx | (fx << 16);
+        // a pixel with no footprint in the panorama (NaN coordinate) gets weight 0 everywhere:
+        // (0 + 512) >> 10 == 0, the BORDER_CONSTANT value
+        tw[j].wy = dl ? 64u * (gy | (fy << 16)) : 0u;
+    }
+}
+
+__device__ __forceinline__ void decode_items(const uint32_t* __restrict__ itw, int t, int n_items, int src_pitch,
+                                             uint32_t (&slot_off)[VIEWS_SLOTS], uint32_t (&slot_g)[VIEWS_SLOTS])
+{
+#pragma unroll
+    for (int k = 0; k < VIEWS_SLOTS; ++k) {
+        const int item = t + k * VIEWS_BLOCK;
+        const uint32_t iw = itw[item < n_items ? item : 0];  // surplus lanes redo item 0 into LDS space nobody reads
+        slot_g[k] = iw & 0xFFFFu;
+        slot_off[k] = (iw >> 16) * (uint32_t)src_pitch + 12u * slot_g[k];  // rot row * src_pitch + 12 * g
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Main kernel body: the three tight loops.  Free of branches on the vector-memory path, so that the compiler's
+// s_waitcnt vmcnt stay counted (with a conditional load or store in the loop it falls back to vmcnt(0), and every
+// pair then waits for the previous pair's stores to be acknowledged: loads and stores retire in issue order).
+// ---------------------------------------------------------------------------------------------
+template <int PXT>
+__device__ __forceinline__ void draw_tight(
+    const ViewsParams& P, const uint8_t* __restrict__ src, const YawDesc* __restrict__ ydesc,
+    uint8_t* __restrict__ out, const PieceHdr h, const uint32_t* __restrict__ pxw, const uint32_t* __restrict__ itw,
+    uint4 (*tile4)[LDS_ITEMS_CAP], uint32_t* stage)
+{
+    const int t = threadIdx.x;
+    const PieceGeo G = piece_geo(h, t);
+    if (!tight_piece<PXT>(G, P))
+        return;  // the rest kernel's
+    const PairCtxs X = pair_contexts(P, ydesc, h.c0, h.c1, t);
+    const int nplain = X.n2;
+    if (nplain == 0)
+        return;
+    uint32_t tap_up[PXT], tap_lo[PXT];
+    TapWeights tw[PXT];
+    decode_px<PXT>(pxw, t, tap_up, tap_lo, tw);
+    uint32_t slot_off[VIEWS_SLOTS], slot_g[VIEWS_SLOTS];
+    decode_items(itw, t, G.n_items, P.src_pitch, slot_off, slot_g);
+    const uint32_t row_bytes = 3u * (uint32_t)P.pw;
+    const size_t view_bytes = (size_t)P.oh * P.ow * 3;
+
+    // the way out: a wave's pixels -> LDS (a dword per pixel) -> 4 adjacent pixels of one row per lane -> 12 bytes,
+    // written with a buffer store whose descriptor covers exactly this view: lanes with nothing to store (rows past
+    // the piece or the view, four-pixel groups the piece does not have) get an offset beyond it and the hardware
+    // drops them.  No lane is masked off: a masked store brings a branch, and with it vmcnt(0).
+    const int wv = t >> 6, ln = t & 63;
+    uint32_t* const stg = stage + wv * (PXT * 64);
+    const int x4 = 4 * (ln & 15), sj = ln >> 4;    // the group's first pixel as a lane of this wave; which of the thread's pixels
+    const int srow = ((wv * 64 + x4) >> G.lw) + sj * G.rstep, scol = x4 & (G.w - 1);
+    const bool s_ok = sj < PXT && srow < G.h && G.y0 + srow < P.oh && G.x0 + scol < P.ow;
+    const uint32_t out_off12 = s_ok ? (uint32_t)(((size_t)(G.y0 + srow) * P.ow + G.x0 + scol) * 3) : 0xFFFFFFFFu;
+    const uint32_t stg_rd = (uint32_t)(sj * 64 + x4);
+
+    const int wave_base = __builtin_amdgcn_readfirstlane(t & ~63);
+    int ns_wave = 0;  // items this wave produces per pair (wave-uniform)
+#pragma unroll
+    for (int k = 0; k < VIEWS_SLOTS; ++k)
+        ns_wave += G.n_items > wave_base + k * VIEWS_BLOCK;
+
+    uint32_t bias_br = 0x00800080u, bias_g = 0x00008000u;
+    asm volatile("" : "+v"(bias_br), "+v"(bias_g));
+
+    uint32_t buf_bytes = 0u;
+    Q16 qc[VIEWS_SLOTS], qn[VIEWS_SLOTS];
+    auto load_pieces = [&](auto ns_c, int k, Q16 (&qq)[VIEWS_SLOTS]) {
+        constexpr int NS = decltype(ns_c)::value;
+        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)X.cw0, k);
+        const uint32_t wrap_g = (uint32_t)__builtin_amdgcn_readlane((int)X.cw1, k) & 0xFFFFu;
+        const uint8_t* __restrict__ S = src + (size_t)(__builtin_amdgcn_readlane(X.cw3, k) & 0x3FFFFFF) * P.pano_stride;
+        const uint32_t goff = w0 & 0xFFFFFu;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            uint32_t off = slot_off[sl] + goff;
+            off = slot_g[sl] >= wrap_g ? off - row_bytes : off;  // items past the end of the row continue at its start
+            qq[sl] = *reinterpret_cast<const Q16*>(S + off);
+        }
+    };
+    // MODE 0: copy, 1: blend, 2: blend, and the rot pixel whose source column is pw - 1 (P:105's clip) is a copy
+    auto stage1 = [&](auto ns_c, auto mode_c, int k, const Q16 (&qq)[VIEWS_SLOTS], uint4* tl4) {
+        constexpr int NS = decltype(ns_c)::value;
+        constexpr int MODE = decltype(mode_c)::value;
+        const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)X.cw0, k) >> 24;
+        const uint32_t last_g = ((uint32_t)__builtin_amdgcn_readlane((int)X.cw1, k) & 0xFFFFu) - 1u;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            // the piece holds source pixels 0..4 at byte offsets 0, 3, 6, 9, 12; one v_perm_b32
+            // both fetches a pixel across the dword seam and masks it
+            // (selector bytes 0-3 pick the second operand's bytes, 4-7 the first's, 0x0c is zero)
+            const uint32_t d0 = qq[sl].d[0], d1 = qq[sl].d[1], d2 = qq[sl].d[2], d3 = qq[sl].d[3];
+            uint4 o;
+            if (MODE != 0) {
+                const uint32_t f8 = 8u * f, g8 = 256u - f8;
+                const uint32_t m0 = d0 & 0x00FF00FFu, n0 = d0 & 0x0000FF00u;                    // bytes 0,1,2
+                const uint32_t m1 = __builtin_amdgcn_perm(d1, d0, 0x0C050C03u);                  // 3,(4),5
+                const uint32_t n1 = __builtin_amdgcn_perm(d1, d0, 0x0C0C040Cu);
+                const uint32_t m2 = __builtin_amdgcn_perm(d2, d1, 0x0C040C02u);                  // 6,(7),8
+                const uint32_t n2 = __builtin_amdgcn_perm(d2, d1, 0x0C0C030Cu);
+                const uint32_t m3 = __builtin_amdgcn_perm(d3, d2, 0x0C030C01u);                  // 9,(10),11
+                const uint32_t n3 = __builtin_amdgcn_perm(d3, d2, 0x0C0C020Cu);
+                const uint32_t m4 = d3 & 0x00FF00FFu, n4 = d3 & 0x0000FF00u;                    // 12,13,14
+                o.x = rot_blend8_mad(m0, n0, m1, n1, f8, g8, bias_br, bias_g);
+                o.y = rot_blend8_mad(m1, n1, m2, n2, f8, g8, bias_br, bias_g);
+                o.z = rot_blend8_mad(m2, n2, m3, n3, f8, g8, bias_br, bias_g);
+                o.w = rot_blend8_mad(m3, n3, m4, n4, f8, g8, bias_br, bias_g);
+                if (MODE == 2) {
+                    // source column pw - 1 is pixel 3 of the row's last item; its right neighbour is not a pixel
+                    // of this row, and the clipped map gives it weight 0 anyway
+                    const uint32_t cp = __builtin_amdgcn_perm(d3, d2, 0x0C030201u);
+                    o.w = slot_g[sl] == last_g ? cp : o.w;
+                }
+            } else {
+                o.x = d0 & 0x00FFFFFFu;
+                o.y = __builtin_amdgcn_perm(d1, d0, 0x0C050403u);
+                o.z = __builtin_amdgcn_perm(d2, d1, 0x0C040302u);
+                o.w = __builtin_amdgcn_perm(d3, d2, 0x0C030201u);
+            }
+            tl4[t + sl * VIEWS_BLOCK] = o;
+        }
+    };
+    auto tight = [&](auto ns_c, auto mode_c, int kbeg, int kend) {
+        for (int k = kbeg; k < kend; ++k) {
+            uint4* tl4 = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(&tile4[0][0]) + buf_bytes);
+            stage1(ns_c, mode_c, k, qc, tl4);
+            // LDS position of rot column c0 within its row's first item: 0..3, from the yaw's shift
+            uint32_t soff = buf_bytes + 4u * (((uint32_t)__builtin_amdgcn_readlane((int)X.cw0, k) >> 20) & 3u);
+            asm volatile("" : "+s"(soff));  // one scalar: keeps the buffer base out of separate vector adds
+#ifndef P2P_ABLATE_BARRIER
+            __syncthreads();
+#endif
+            const unsigned char* tl = reinterpret_cast<const unsigned char*>(&tile4[0][0]);
+            uint32_t ta[PXT][4];
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) {
+                const uint32_t* up = reinterpret_cast<const uint32_t*>(tl + (tap_up[j] + soff));
+                const uint32_t* lo = reinterpret_cast<const uint32_t*>(tl + (tap_lo[j] + soff));
+                ta[j][0] = up[0];
+                ta[j][1] = up[1];
+                ta[j][2] = lo[0];
+                ta[j][3] = lo[1];
+            }
+            // the next pair's pieces (the last pair asks for its own again: no branch on the memory path)
+            const int kn = k + 1 < nplain ? k + 1 : k;
+#ifndef P2P_ABLATE_LOADS
+            load_pieces(ns_c, kn, qn);
+#else
+            (void)kn;
+#pragma unroll
+            for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
+                qn[sl] = qc[sl];
+#endif
+            uint32_t pix[PXT];
+#pragma unroll
+            for (int j = 0; j < PXT; ++j)
+                pix[j] = blend4_packed(ta[j][0], ta[j][1], ta[j][2], ta[j][3], tw[j]);
+            const int pair = X.pair0 + (int)((uint32_t)__builtin_amdgcn_readlane(X.cw3, k) >> 26);
+#ifdef P2P_ABLATE_STORES
+            if (pix[0] == 0x12345678u && pix[PXT - 1] == 0x9ABCDEF0u)
+#endif
+            {
+                uint8_t* O = out + ((size_t)pair * P.n_pitch + G.pitch_i) * view_bytes;  // [pano][yaw][pitch][oh][ow][3]
+#pragma unroll
+                for (int j = 0; j < PXT; ++j)
+                    stg[j * 64 + ln] = pix[j];
+                // DS operations of one wave execute in order: the read below sees the writes above
+                const uint4 v = *reinterpret_cast<const uint4*>(stg + stg_rd);
+                u32x3 o;
+                o.x = __builtin_amdgcn_perm(v.y, v.x, 0x04020100u);  // B0 G0 R0 B1
+                o.y = __builtin_amdgcn_perm(v.z, v.y, 0x05040201u);  // G1 R1 B2 G2
+                o.z = __builtin_amdgcn_perm(v.w, v.z, 0x06050402u);  // R2 B3 G3 R3
+#ifdef P2P_ABLATE_STORES2
+                if (o.x == 0x12345678u && o.z == 0x9ABCDEF0u)
+#endif
+                // aux 2 = nt: the views are written once and not read by this kernel, they should not displace
+                // the panorama from the caches
+                __builtin_amdgcn_raw_buffer_store_b96(o, __builtin_amdgcn_make_buffer_rsrc(O, 0, (int)view_bytes, 0x00020000),
+                                                      (int)out_off12, 0, P2P_STORE_AUX);
+            }
+#pragma unroll
+            for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
+                qc[sl] = qn[sl];
+            buf_bytes ^= (uint32_t)sizeof(tile4[0]);
+        }
+    };
+    auto run_ns = [&](auto ns_c) {
+        load_pieces(ns_c, 0, qc);
+        // Inside the loops the pieces of pair k + 1 are followed by the store of pair k, so "pieces landed" is
+        // vmcnt(1).  Entering the first loop straight after the first loads the compiler would have to assume
+        // vmcnt(0) for both paths.  One store that writes nothing (a buffer store through a descriptor of zero
+        // records: counted like any store, dropped by the hardware) gives both paths the same shape.
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_raw_buffer_store_b32(0u, __builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0x00020000), 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        tight(ns_c, std::integral_constant<int, 0>{}, 0, X.n0);
+        tight(ns_c, std::integral_constant<int, 1>{}, X.n0, X.n1);
+        tight(ns_c, std::integral_constant<int, 2>{}, X.n1, X.n2);
+    };
+    static_assert(VIEWS_SLOTS == 2 || VIEWS_SLOTS == 3, "dispatch below");
+    if (ns_wave == 0)
+        run_ns(std::integral_constant<int, 0>{});
+    else if (ns_wave == 1)
+        run_ns(std::integral_constant<int, 1>{});
+    else if (VIEWS_SLOTS == 2 || ns_wave == 2)
+        run_ns(std::integral_constant<int, 2>{});
+    else
+        run_ns(std::integral_constant<int, VIEWS_SLOTS>{});
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rest kernel body: same arithmetic, every case distinction.
+// ---------------------------------------------------------------------------------------------
+struct PairCtx {      // uniform per (piece, pair)
     bool fast;        // LDS scheme applies (the yaw row is a circular shift)
     bool per_column;  // per-column weights (f4tab) instead of one f
     int joff;         // LDS position of rot column c0 within its row's first item
@@ -143,52 +510,32 @@ struct PairCtx {      // uniform per (piece, pair); precomputed per lane at piec
 };
 
 template <int PXT>
-__device__ __forceinline__ void draw_piece(
+__device__ __forceinline__ void draw_rest(
     const ViewsParams& P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab,
     const YawDesc* __restrict__ ydesc, const uint32_t* __restrict__ f4tab, uint8_t* __restrict__ out,
     const PieceHdr h, const uint32_t* __restrict__ pxw, const uint32_t* __restrict__ itw,
-    uint4 (*tile4)[LDS_ITEMS_CAP], uint32_t* stage)
+    uint4 (*tile4)[LDS_ITEMS_CAP])
 {
     const int t = threadIdx.x;
-    const int x0 = (int)(h.xy & 0xFFFFu), y0 = (int)(h.xy >> 16);
-    const int pw_ = (int)(h.geom & 0xFFu), ph_ = (int)((h.geom >> 8) & 0xFFu);  // piece width (16 / 32 / 64) and height
-    const int pitch_i = (int)(h.geom >> 16);
-    const int mode = (int)(h.mode_items & 3u);
-    const int n_items = (int)(h.mode_items >> 8);
-    const int lw = __builtin_ctz((unsigned)pw_);
-    const int col = t & (pw_ - 1), row0 = t >> lw;
-    const int rstep = VIEWS_BLOCK >> lw;  // rows between a thread's pixels
-    const int px = x0 + col, py0 = y0 + row0;
+    const PieceGeo G = piece_geo(h, t);
+    const bool main_draws_plain = tight_piece<PXT>(G, P);
+    const int px = G.x0 + G.col, py0 = G.y0 + G.row0;
     bool inside[PXT];
 #pragma unroll
     for (int j = 0; j < PXT; ++j)
-        inside[j] = row0 + j * rstep < ph_ && px < P.ow && py0 + j * rstep < P.oh;
+        inside[j] = G.row0 + j * G.rstep < G.h && px < P.ow && py0 + j * G.rstep < P.oh;
 
     // output addressing: 4 horizontally adjacent pixels = 12 bytes = 3 aligned dwords
     const int lane4 = t & 3;
     const bool fast_store = (P.ow & 3) == 0;
     const size_t view_bytes = (size_t)P.oh * P.ow * 3;
     const uint32_t pix_off = (uint32_t)(((size_t)py0 * P.ow + px) * 3);  // < 3 * 32766^2 < 2^32
-    const uint32_t pix_step = (uint32_t)rstep * (uint32_t)P.ow * 3u;
+    const uint32_t pix_step = (uint32_t)G.rstep * (uint32_t)P.ow * 3u;
     // dword lane4 of the 12 bytes P0 P1 P2 P3: bytes of the own pixel (0-2) and of the next lane's (4-6)
     const uint32_t store_sel = lane4 == 0 ? 0x04020100u : (lane4 == 1 ? 0x05040201u : 0x06050402u);
 
-    const int pair0 = blockIdx.z * P.pairs_per_block;
-    int pair1 = pair0 + P.pairs_per_block;
-    const int n_pairs = P.n_panos * P.n_yaw;
-    if (pair1 > n_pairs)
-        pair1 = n_pairs;
-    // pair -> panorama: multiply-high by ceil(2^32 / n_yaw) (exact for the job's sizes, host check); with one yaw
-    // the constant would be 2^32, which does not fit, and the pair index is the panorama index anyway
-    auto pano_of = [&](int pair) {
-        return P.n_yaw == 1 ? pair : (int)__umulhi((uint32_t)pair, P.n_yaw_magic);
-    };
-
-    // generic store (pieces at the image border, narrow pieces, widths not divisible by 4): per pixel row, lanes
-    // 4k..4k+3 assemble 12 bytes into 3 aligned dwords
     auto store_pixels = [&](int pair, const uint32_t (&pix)[PXT]) {
-        // [pano][yaw][pitch][oh][ow][3]
-        uint8_t* O = out + ((size_t)pair * P.n_pitch + pitch_i) * view_bytes;
+        uint8_t* O = out + ((size_t)pair * P.n_pitch + G.pitch_i) * view_bytes;  // [pano][yaw][pitch][oh][ow][3]
 #pragma unroll
         for (int j = 0; j < PXT; ++j) {
             const uint32_t off = pix_off + (uint32_t)j * pix_step;
@@ -197,8 +544,6 @@ __device__ __forceinline__ void draw_piece(
                 // neighbour lane's pixel: row_shl:1 DPP (lane4 groups never straddle a 16-lane row)
                 uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pix[j], 0x101, 0xF, 0xF, true);
                 uint32_t dw = __builtin_amdgcn_perm(nxt, pix[j], store_sel);
-                // the byte offset stays a 32-bit VGPR next to the scalar view base (saddr store form): the
-                // empty asm keeps the compiler from hoisting a 64-bit copy of it out of the pair loop
                 uint32_t voff = off + (uint32_t)lane4;
                 asm volatile("" : "+v"(voff));
                 if (inside[j] && lane4 < 3)
@@ -223,11 +568,13 @@ __device__ __forceinline__ void draw_piece(
         for (int j = 0; j < PXT; ++j) {
             int2 c = make_int2(INT32_MIN, INT32_MIN);
             if (inside[j])
-                c = P.coords[((size_t)pitch_i * P.oh + (py0 + j * rstep)) * P.ow + px];
+                c = P.coords[((size_t)G.pitch_i * P.oh + (py0 + j * G.rstep)) * P.ow + px];
             d.ix[j] = sat_short(c.x >> 5);
             d.iy[j] = sat_short(c.y >> 5);
             d.fx[j] = (uint32_t)c.x & 31u;
             d.fy[j] = (uint32_t)c.y & 31u;
+            // A pixel contributes only if its 2x2 footprint touches the panorama (BORDER_CONSTANT 0: cv::remap
+            // writes borderValue when sx >= w || sx+1 < 0 || sy >= h || sy+1 < 0)
             const bool inrange = inside[j] && d.ix[j] >= -1 && d.iy[j] >= -1 && d.ix[j] < P.pw && d.iy[j] < P.ph;
             // other border modes (legacy entry point, L:179) resolve every tap to some pixel
             d.live[j] = P.border == 0 ? inrange : inside[j];
@@ -261,10 +608,14 @@ __device__ __forceinline__ void draw_piece(
         }
     };
 
-    if (mode != 1) {
+    if (G.mode != 1) {
         DirectPx d;
         load_direct(d);
-        int pano_i = pano_of(pair0);
+        const int pair0 = blockIdx.z * P.pairs_per_block;
+        int pair1 = pair0 + P.pairs_per_block;
+        if (pair1 > P.n_panos * P.n_yaw)
+            pair1 = P.n_panos * P.n_yaw;
+        int pano_i = pano_of_pair(P, pair0);
         int yaw_i = pair0 - pano_i * P.n_yaw;
         for (int pair = pair0; pair < pair1; ++pair) {
             uint32_t pix[PXT];
@@ -278,92 +629,23 @@ __device__ __forceinline__ void draw_piece(
         return;
     }
 
-    // ---- LDS scheme: this thread's pixels (tap offsets, weights) and items, straight from the plan ----
-    uint32_t tap_up[PXT], tap_lo[PXT];  // byte offsets of the upper / lower tap pair inside one LDS buffer
+    // ---- LDS scheme, general loop ----
+    const PairCtxs X = pair_contexts(P, ydesc, h.c0, h.c1, t);
+    const int kfirst = main_draws_plain ? X.n2 : 0;  // the main kernel has classes 0..2 of its pieces
+    if (kfirst >= X.npairs)
+        return;
+    uint32_t tap_up[PXT], tap_lo[PXT];
     TapWeights tw[PXT];
-#pragma unroll
-    for (int j = 0; j < PXT; ++j) {
-#ifdef P2P_NT_PLAN
-        const uint32_t wd = __builtin_nontemporal_load(pxw + j * VIEWS_BLOCK + t);
-#else
-        const uint32_t wd = pxw[j * VIEWS_BLOCK + t];
-#endif
-        const uint32_t dl = (wd >> 11) & 0x7FFu;
-        tap_up[j] = (wd & 0x7FFu) << 2;
-        tap_lo[j] = tap_up[j] + (dl << 2);
-        const uint32_t fx = (wd >> 22) & 31u, fy = wd >> 27;
-        const uint32_t gx = 32u - fx, gy = 32u - fy;
-        tw[j].gx2 = gx | (gx << 16);
-        tw[j].fx2 = fx | (fx << 16);
-        // a pixel with no footprint in the panorama (NaN coordinate) gets weight 0 everywhere:
-        // (0 + 512) >> 10 == 0, the BORDER_CONSTANT value
-        tw[j].wy = dl ? 64u * (gy | (fy << 16)) : 0u;
-    }
-    // A wave runs slot k only if its first lane has an item there (wave-uniform test).
+    decode_px<PXT>(pxw, t, tap_up, tap_lo, tw);
+    uint32_t slot_off[VIEWS_SLOTS], slot_g[VIEWS_SLOTS];
+    decode_items(itw, t, G.n_items, P.src_pitch, slot_off, slot_g);
     const int wave_base = __builtin_amdgcn_readfirstlane(t & ~63);
-    uint32_t slot_off[VIEWS_SLOTS];  // rot row * src_pitch + 12 * g
-    uint32_t slot_g[VIEWS_SLOTS];
-#pragma unroll
-    for (int k = 0; k < VIEWS_SLOTS; ++k) {
-        const int item = t + k * VIEWS_BLOCK;
-        const uint32_t iw = itw[item < n_items ? item : 0];  // surplus lanes redo item 0 into LDS space nobody reads
-        slot_g[k] = iw & 0xFFFFu;
-        slot_off[k] = (iw >> 16) * (uint32_t)P.src_pitch + 12u * slot_g[k];
-    }
-    const int c0 = h.c0, c1 = h.c1;
+    const int n_items = G.n_items;
     const uint32_t row_bytes = 3u * (uint32_t)P.pw;
-    const int ngroups = P.pw >> 2;
 
-    // ---- per-pair contexts: lane k of every wave works out pair0 + k once; the loop reads them
-    // back with v_readlane, so no descriptor load sits on the per-pair critical path ----
-    uint32_t cw0 = 0, cw1 = 0;
-    int cw2 = 0, cw3 = 0;
-    int ctx_class = 2;  // 0: whole-column shift (stage 1 is a copy), 1: one blend weight for the whole piece, 2: the rest
-    {
-        const int k = t & 63;
-        if (k < pair1 - pair0) {
-            cw3 = pano_of(pair0 + k);
-            const int yi = pair0 + k - cw3 * P.n_yaw;
-            const YawDesc yd = ydesc[yi];
-            int i_first = c0 + yd.s;
-            if (i_first >= P.pw)
-                i_first -= P.pw;
-            const int g0 = i_first >> 2;
-            // uniform weight unless this yaw flickers or the piece holds the column clipped to pw-1
-            const bool per_column = yd.mode == 1 || (yd.c_clamp >= c0 && yd.c_clamp <= c1 + 1);
-            cw0 = 12u * (uint32_t)g0 | (uint32_t)(i_first & 3) << 20 | (uint32_t)(yd.mode != 2) << 22 |
-                  (uint32_t)per_column << 23 | (uint32_t)yd.f << 24;
-            cw1 = (uint32_t)(ngroups - g0) | (uint32_t)yi << 16;
-            cw2 = 4 * g0 - yd.s;
-            cw3 |= k << 26;  // n_panos < 2^26 (host check): the chunk-local pair index rides along
-            ctx_class = (yd.mode == 2 || per_column) ? 2 : (yd.f == 0 ? 0 : 1);
-        }
-    }
-    // The contexts are sorted by class across the lanes: the whole-column yaws run in one branch-free loop, the
-    // blended ones in a second, and the odd ones (6 of the 360 one-degree yaws on 8192 columns have per-column
-    // weights) in the general loop after them, so that they do not slow their whole chunk down.
-    const int npairs = pair1 - pair0;
-    int n_copy, nplain;
-    {
-        const int k = t & 63;
-        const bool valid = k < npairs;
-        const unsigned long long m0 = __ballot(valid && ctx_class == 0);
-        const unsigned long long m1 = __ballot(valid && ctx_class == 1);
-        const unsigned long long m2 = __ballot(valid && ctx_class == 2);
-        n_copy = __popcll(m0);
-        nplain = n_copy + __popcll(m1);
-        const unsigned long long below = (1ull << k) - 1ull;
-        const int r = !valid ? k
-                             : (ctx_class == 0 ? __popcll(m0 & below)
-                                               : (ctx_class == 1 ? n_copy + __popcll(m1 & below) : nplain + __popcll(m2 & below)));
-        cw0 = (uint32_t)__builtin_amdgcn_ds_permute(4 * r, (int)cw0);
-        cw1 = (uint32_t)__builtin_amdgcn_ds_permute(4 * r, (int)cw1);
-        cw2 = __builtin_amdgcn_ds_permute(4 * r, cw2);
-        cw3 = __builtin_amdgcn_ds_permute(4 * r, cw3);
-    }
     auto pair_ctx = [&](int k) {
-        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)cw0, k);
-        const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)cw1, k);
+        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)X.cw0, k);
+        const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)X.cw1, k);
         PairCtx c;
         c.goff = w0 & 0xFFFFFu;
         c.joff = (int)((w0 >> 20) & 3u);
@@ -372,18 +654,17 @@ __device__ __forceinline__ void draw_piece(
         c.f = w0 >> 24;
         c.wrap_g = w1 & 0xFFFFu;
         c.yaw_i = (int)(w1 >> 16);
-        c.cf0 = __builtin_amdgcn_readlane(cw2, k);
-        const int w3 = __builtin_amdgcn_readlane(cw3, k);
+        c.cf0 = __builtin_amdgcn_readlane(X.cw2, k);
+        const int w3 = __builtin_amdgcn_readlane(X.cw3, k);
         c.pano = w3 & 0x3FFFFFF;
         c.korig = (int)((uint32_t)w3 >> 26);
         return c;
     };
-
     auto issue_loads = [&](const PairCtx& pc, const uint8_t* __restrict__ S, Q16 (&q)[VIEWS_SLOTS],
                            uint32_t (&fw)[VIEWS_SLOTS]) {
 #pragma unroll
         for (int k = 0; k < VIEWS_SLOTS; ++k) {
-            if (wave_base + k * VIEWS_BLOCK < n_items) {
+            if (wave_base + k * VIEWS_BLOCK < n_items) {  // a wave runs slot k only if its first lane has an item there
                 uint32_t off = slot_off[k] + pc.goff;
                 if (slot_g[k] >= pc.wrap_g)
                     off -= row_bytes;
@@ -401,173 +682,17 @@ __device__ __forceinline__ void draw_piece(
         }
     };
 
-    // ---- tight loops: one per (number of items this wave produces, copy / blend), each free of branches on
-    // the vector-memory path, so that the compiler's s_waitcnt vmcnt stay counted (with a conditional load or
-    // store in the loop it falls back to vmcnt(0), and every pair then waits for the previous pair's stores
-    // to be acknowledged: loads, stores included, retire in issue order) ----
-    // whole pieces of a 64-wide tile: all 4 rows of a wave leave through LDS as one 12-byte store per lane
-    const bool full = PXT == 4 && fast_store && pw_ == 64 && ph_ == 16 && x0 + 64 <= P.ow && y0 + 16 <= P.oh;
-    const int wv = t >> 6, ln = t & 63;
-    uint32_t* const stg = stage + wv * (PXT * 64);
-    const uint32_t out_off12 = (uint32_t)(((size_t)(y0 + wv + (VIEWS_BLOCK / 64) * (ln >> 4)) * P.ow + x0) * 3) + 12u * (uint32_t)(ln & 15);
-    const int ns_wave = n_items > wave_base + VIEWS_BLOCK ? 2 : (n_items > wave_base ? 1 : 0);
-
-    int kdone = 0;  // pairs drawn by the tight loops
-    if (nplain > 0 && (full || PXT < 4)) {
-        uint32_t buf_bytes = 0u;
-        Q16 qc[VIEWS_SLOTS], qn[VIEWS_SLOTS];
-        auto load_pieces = [&](auto ns_c, int k, Q16 (&qq)[VIEWS_SLOTS]) {
-            constexpr int NS = decltype(ns_c)::value;
-            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)cw0, k);
-            const uint32_t wrap_g = (uint32_t)__builtin_amdgcn_readlane((int)cw1, k) & 0xFFFFu;
-            const uint8_t* __restrict__ S = src + (size_t)(__builtin_amdgcn_readlane(cw3, k) & 0x3FFFFFF) * P.pano_stride;
-            const uint32_t goff = w0 & 0xFFFFFu;
-#pragma unroll
-            for (int sl = 0; sl < NS; ++sl) {
-                uint32_t off = slot_off[sl] + goff;
-                off = slot_g[sl] >= wrap_g ? off - row_bytes : off;
-                qq[sl] = *reinterpret_cast<const Q16*>(S + off);
-            }
-        };
-        auto stage1 = [&](auto ns_c, auto copy_c, int k, const Q16 (&qq)[VIEWS_SLOTS], uint4* tl4) {
-            constexpr int NS = decltype(ns_c)::value;
-            constexpr bool COPY = decltype(copy_c)::value;
-            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)cw0, k) >> 24;
-#pragma unroll
-            for (int sl = 0; sl < NS; ++sl) {
-                // the piece holds source pixels 0..4 at byte offsets 0, 3, 6, 9, 12; one v_perm_b32
-                // both fetches a pixel across the dword seam and masks it
-                // (selector bytes 0-3 pick the second operand's bytes, 4-7 the first's, 0x0c is zero)
-                const uint32_t d0 = qq[sl].d[0], d1 = qq[sl].d[1], d2 = qq[sl].d[2], d3 = qq[sl].d[3];
-                uint4 o;
-                if (!COPY) {
-                    const uint32_t f8 = 8u * f, g8 = 256u - f8;
-                    const uint32_t m0 = d0 & 0x00FF00FFu, n0 = d0 & 0x0000FF00u;                    // bytes 0,1,2
-                    const uint32_t m1 = __builtin_amdgcn_perm(d1, d0, 0x0C050C03u);                  // 3,(4),5
-                    const uint32_t n1 = __builtin_amdgcn_perm(d1, d0, 0x0C0C040Cu);
-                    const uint32_t m2 = __builtin_amdgcn_perm(d2, d1, 0x0C040C02u);                  // 6,(7),8
-                    const uint32_t n2 = __builtin_amdgcn_perm(d2, d1, 0x0C0C030Cu);
-                    const uint32_t m3 = __builtin_amdgcn_perm(d3, d2, 0x0C030C01u);                  // 9,(10),11
-                    const uint32_t n3 = __builtin_amdgcn_perm(d3, d2, 0x0C0C020Cu);
-                    const uint32_t m4 = d3 & 0x00FF00FFu, n4 = d3 & 0x0000FF00u;                    // 12,13,14
-                    o.x = rot_blend8(m0, n0, m1, n1, f8, g8);
-                    o.y = rot_blend8(m1, n1, m2, n2, f8, g8);
-                    o.z = rot_blend8(m2, n2, m3, n3, f8, g8);
-                    o.w = rot_blend8(m3, n3, m4, n4, f8, g8);
-                } else {
-                    o.x = d0 & 0x00FFFFFFu;
-                    o.y = __builtin_amdgcn_perm(d1, d0, 0x0C050403u);
-                    o.z = __builtin_amdgcn_perm(d2, d1, 0x0C040302u);
-                    o.w = __builtin_amdgcn_perm(d3, d2, 0x0C030201u);
-                }
-                tl4[t + sl * VIEWS_BLOCK] = o;
-            }
-        };
-        auto tight = [&](auto ns_c, auto copy_c, int kbeg, int kend) {
-            for (int k = kbeg; k < kend; ++k) {
-                uint4* tl4 = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(&tile4[0][0]) + buf_bytes);
-                stage1(ns_c, copy_c, k, qc, tl4);
-                uint32_t soff = buf_bytes + 4u * (((uint32_t)__builtin_amdgcn_readlane((int)cw0, k) >> 20) & 3u);
-                asm volatile("" : "+s"(soff));  // one scalar: keeps the buffer base out of separate vector adds
-#ifndef P2P_ABLATE_BARRIER
-                __syncthreads();
-#endif
-                const unsigned char* tl = reinterpret_cast<const unsigned char*>(&tile4[0][0]);
-                uint32_t ta[PXT][4];
-#pragma unroll
-                for (int j = 0; j < PXT; ++j) {
-                    const uint32_t* up = reinterpret_cast<const uint32_t*>(tl + (tap_up[j] + soff));
-                    const uint32_t* lo = reinterpret_cast<const uint32_t*>(tl + (tap_lo[j] + soff));
-                    ta[j][0] = up[0];
-                    ta[j][1] = up[1];
-                    ta[j][2] = lo[0];
-                    ta[j][3] = lo[1];
-                }
-                // the next pair's pieces (the last pair asks for its own again: no branch on the memory path)
-                const int kn = k + 1 < nplain ? k + 1 : k;
-#ifndef P2P_ABLATE_LOADS
-                load_pieces(ns_c, kn, qn);
-#else
-                (void)kn;
-#pragma unroll
-                for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
-                    qn[sl] = qc[sl];
-#endif
-                uint32_t pix[PXT];
-#pragma unroll
-                for (int j = 0; j < PXT; ++j)
-                    pix[j] = blend4_packed(ta[j][0], ta[j][1], ta[j][2], ta[j][3], tw[j]);
-                const int pair = pair0 + (int)((uint32_t)__builtin_amdgcn_readlane(cw3, k) >> 26);
-#ifdef P2P_ABLATE_STORES
-                if (pix[0] == 0x12345678u && pix[PXT - 1] == 0x9ABCDEF0u)
-#endif
-                if (PXT == 4 && full) {
-                    // the wave's 4 x 64 pixels -> LDS (a dword per pixel) -> 4 pixels of one row per lane -> 12 bytes
-                    uint8_t* O = out + ((size_t)pair * P.n_pitch + pitch_i) * view_bytes;
-#pragma unroll
-                    for (int j = 0; j < PXT; ++j)
-                        stg[j * 64 + ln] = pix[j];
-                    // DS operations of one wave execute in order: the read below sees the four writes above
-                    const uint4 v = *reinterpret_cast<const uint4*>(stg + 4 * ln);
-                    const uint32_t o0 = __builtin_amdgcn_perm(v.y, v.x, 0x04020100u);  // B0 G0 R0 B1
-                    const uint32_t o1 = __builtin_amdgcn_perm(v.z, v.y, 0x05040201u);  // G1 R1 B2 G2
-                    const uint32_t o2 = __builtin_amdgcn_perm(v.w, v.z, 0x06050402u);  // R2 B3 G3 R3
-                    uint32_t voff = out_off12;
-                    asm volatile("" : "+v"(voff));
-                    uint32_t* dst = reinterpret_cast<uint32_t*>(O + voff);
-                    __builtin_nontemporal_store(o0, dst);
-                    __builtin_nontemporal_store(o1, dst + 1);
-                    __builtin_nontemporal_store(o2, dst + 2);
-                } else {
-                    store_pixels(pair, pix);
-                }
-#pragma unroll
-                for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
-                    qc[sl] = qn[sl];
-                buf_bytes ^= (uint32_t)sizeof(tile4[0]);
-            }
-        };
-        auto run_ns = [&](auto ns_c) {
-            load_pieces(ns_c, 0, qc);
-            if (PXT == 4 && full) {
-                // Loads and stores retire in issue order and the compiler counts them per path: inside the loop the
-                // pieces of pair k + 1 are followed by the store of pair k, so "pieces landed" is vmcnt(1).  Entering
-                // the loop straight after the first loads it would have to assume vmcnt(0) -- and then every pair
-                // waits for the previous pair's store to be acknowledged.  One store instruction that writes nothing
-                // gives both paths the same shape.
-                __builtin_amdgcn_sched_barrier(0);
-                // a buffer store through a descriptor of zero records: counted like any store, dropped by the hardware
-                __builtin_amdgcn_raw_buffer_store_b32(0u, __builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0x00020000), 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            tight(ns_c, std::true_type{}, 0, n_copy);
-            tight(ns_c, std::false_type{}, n_copy, nplain);
-        };
-        if (ns_wave == 2)
-            run_ns(std::integral_constant<int, 2>{});
-        else if (ns_wave == 1)
-            run_ns(std::integral_constant<int, 1>{});
-        else
-            run_ns(std::integral_constant<int, 0>{});
-        kdone = nplain;
-        if (nplain == npairs)
-            return;
-        __syncthreads();  // the last plain pair's taps are read before the general loop writes the buffers
-    }
-
-    // ---- general loop: yaws with per-column weights (flickering fraction, the clipped column inside the
-    // piece) and yaw rows that are not a shift (direct gathers) ----
-    PairCtx pc = pair_ctx(kdone);
+    PairCtx pc = pair_ctx(kfirst);
     Q16 q[VIEWS_SLOTS];
     uint32_t fw[VIEWS_SLOTS];
     if (pc.fast)
         issue_loads(pc, src + (size_t)pc.pano * P.pano_stride, q, fw);
     int buf = 0;
-    for (int ki = kdone; ki < npairs; ++ki) {
+    for (int ki = kfirst; ki < X.npairs; ++ki) {
         const uint8_t* __restrict__ S = src + (size_t)pc.pano * P.pano_stride;
         const int cur_yaw = pc.yaw_i;
-        const int pair = pair0 + pc.korig;
-        const bool has_next = ki + 1 < npairs;
+        const int pair = X.pair0 + pc.korig;
+        const bool has_next = ki + 1 < X.npairs;
         uint32_t pix[PXT];
 
         if (pc.fast) {
@@ -648,22 +773,23 @@ __device__ __forceinline__ void draw_piece(
     }
 }
 
-// The extra workgroups (pieces of split tiles) sit in front of the tile workgroups (blockIdx.x < P.plan_gx):
-// one launch, so the few long-running ones overlap with the bulk instead of trailing it.
+// ---------------------------------------------------------------------------------------------
+// kernels: the pieces of split tiles sit in front of the tile workgroups (blockIdx.x < P.plan_gx), so that
+// the few long-running ones overlap with the bulk instead of trailing it
+// ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views_kernel(
-    ViewsParams P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab,
-    const YawDesc* __restrict__ ydesc, const uint32_t* __restrict__ f4tab, uint8_t* __restrict__ out,
+    ViewsParams P, const uint8_t* __restrict__ src, const YawDesc* __restrict__ ydesc, uint8_t* __restrict__ out,
     const PieceHdr* __restrict__ hdr_main, const uint32_t* __restrict__ px_main, const uint32_t* __restrict__ items_main,
     const PieceHdr* __restrict__ hdr_x, const uint32_t* __restrict__ px_x, const uint32_t* __restrict__ items_x)
 {
     __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
-    __shared__ __attribute__((aligned(16))) uint32_t stage[(VIEWS_BLOCK / 64) * VIEWS_PXT * 64];  // store staging: a dword per pixel
+    __shared__ __attribute__((aligned(16))) uint32_t stage[(VIEWS_BLOCK / 64) * VIEWS_PXT * 64];  // a dword per pixel
     if ((int)blockIdx.x < P.plan_gx) {
         const int ei = (int)blockIdx.y * P.plan_gx + (int)blockIdx.x;
         if (ei >= P.x_n)
             return;
         const PieceHdr h = hdr_x[ei];
-        draw_piece<XTRA_PXT>(P, src, ytab, ydesc, f4tab, out, h, px_x + (size_t)h.px_block * (VIEWS_BLOCK * XTRA_PXT),
+        draw_tight<XTRA_PXT>(P, src, ydesc, out, h, px_x + (size_t)h.px_block * (VIEWS_BLOCK * XTRA_PXT),
                              items_x + (size_t)h.item_block * LDS_ITEMS_CAP, tile4, stage);
         return;
     }
@@ -676,21 +802,54 @@ __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views
     // heaviest views first (the host orders pitch_order by |pitch - 90| descending): a smoother tail
     const int pitch_i = P.pitch_order[blockIdx.y];
     const PieceHdr h = hdr_main[(size_t)pitch_i * tiles + tile_id];
-    if ((h.mode_items & 3u) == 0u)
-        return;  // a split tile: drawn by its pieces
-    draw_piece<VIEWS_PXT>(P, src, ytab, ydesc, f4tab, out, h, px_main + (size_t)h.px_block * (VIEWS_BLOCK * VIEWS_PXT),
+    draw_tight<VIEWS_PXT>(P, src, ydesc, out, h, px_main + (size_t)h.px_block * (VIEWS_BLOCK * VIEWS_PXT),
                           items_main + (size_t)h.item_block * LDS_ITEMS_CAP, tile4, stage);
 }
 
-hipError_t launch_remap_views(const ViewsParams& P, hipStream_t st)
+__global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_rest_kernel(
+    ViewsParams P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab,
+    const YawDesc* __restrict__ ydesc, const uint32_t* __restrict__ f4tab, uint8_t* __restrict__ out,
+    const PieceHdr* __restrict__ hdr_main, const uint32_t* __restrict__ px_main, const uint32_t* __restrict__ items_main,
+    const PieceHdr* __restrict__ hdr_x, const uint32_t* __restrict__ px_x, const uint32_t* __restrict__ items_x)
+{
+    __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
+    if ((int)blockIdx.x < P.plan_gx) {
+        const int ei = (int)blockIdx.y * P.plan_gx + (int)blockIdx.x;
+        if (ei >= P.x_n)
+            return;
+        const PieceHdr h = hdr_x[ei];
+        draw_rest<XTRA_PXT>(P, src, ytab, ydesc, f4tab, out, h, px_x + (size_t)h.px_block * (VIEWS_BLOCK * XTRA_PXT),
+                            items_x + (size_t)h.item_block * LDS_ITEMS_CAP, tile4);
+        return;
+    }
+    const int bx = (int)blockIdx.x - P.plan_gx, gx = (int)gridDim.x - P.plan_gx;
+    const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
+    const int chunk = gx >> 3;
+    const int tile_id = (bx & 7) * chunk + (bx >> 3);
+    if (tile_id >= tiles)
+        return;
+    const int pitch_i = P.pitch_order[blockIdx.y];
+    const PieceHdr h = hdr_main[(size_t)pitch_i * tiles + tile_id];
+    if ((h.mode_items & 3u) == 0u)
+        return;  // a split tile: drawn by its pieces
+    draw_rest<VIEWS_PXT>(P, src, ytab, ydesc, f4tab, out, h, px_main + (size_t)h.px_block * (VIEWS_BLOCK * VIEWS_PXT),
+                         items_main + (size_t)h.item_block * LDS_ITEMS_CAP, tile4);
+}
+
+// which = 0: the main kernel, 1: the rest (they write disjoint pixels: the host runs them on two streams)
+hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
 {
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
     const int n_pairs = P.n_panos * P.n_yaw;
     const int zblocks = (n_pairs + P.pairs_per_block - 1) / P.pairs_per_block;
     // 8 XCDs, each a contiguous run of tiles; P.plan_gx is a multiple of 8 too
-    hipLaunchKernelGGL(remap_views_kernel, dim3(P.plan_gx + 8 * ((tiles + 7) / 8), P.n_pitch, zblocks), dim3(VIEWS_BLOCK),
-                       0, st, P, P.src, P.ytab, P.ydesc, P.f4tab, P.out, P.hdr_main, P.px_main, P.items_main, P.hdr_x,
-                       P.px_x, P.items_x);
+    const dim3 grid(P.plan_gx + 8 * ((tiles + 7) / 8), P.n_pitch, zblocks);
+    if (which == 0)
+        hipLaunchKernelGGL(remap_views_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.hdr_main,
+                           P.px_main, P.items_main, P.hdr_x, P.px_x, P.items_x);
+    else
+        hipLaunchKernelGGL(remap_views_rest_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc, P.f4tab,
+                           P.out, P.hdr_main, P.px_main, P.items_main, P.hdr_x, P.px_x, P.items_x);
     return hipGetLastError();
 }
 
