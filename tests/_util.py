@@ -15,6 +15,27 @@ def oracle_views(pano, yaws, pitches, ow, oh, fov=90):
     return out
 
 
+def oracle_views_threaded(pano, yaws, pitches, ow, oh, fov=90, threads=None):
+    """oracle_views with one task per yaw on a thread pool, the reference's own parallel unit (P:252-265); the C
+    restatement releases the GIL.  For the full-size configurations, where one thread would take minutes."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    ph, pw = pano.shape[:2]
+    cache = {(ow, oh, p, pw, ph, fov): maps.pitch_map_deg(ow, oh, p, pw, ph, fov) for p in pitches}
+    out = np.empty((len(yaws), len(pitches), oh, ow, 3), dtype=np.uint8)
+
+    def one(yi):
+        sl = cpu_ref.process_yaw_and_pitchs(pano, yaws[yi], pitches, ow, oh, fov, _pitch_cache=cache)
+        for pi in range(len(pitches)):
+            out[yi, pi] = sl[pi]
+
+    n = threads or max(1, min(len(yaws), int((os.cpu_count() or 1) * 0.9)))
+    with ThreadPoolExecutor(max_workers=n) as ex:
+        list(ex.map(one, range(len(yaws))))
+    return out
+
+
 def oracle_maps(yaws, pitches, ow, oh, pw, ph, fov=90):
     rows = np.stack([maps.yaw_column_table(pw, y) for y in yaws])
     UV = [maps.pitch_map_deg(ow, oh, p, pw, ph, fov) for p in pitches]

@@ -17,6 +17,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Say it in every run's summary while it is true: the gather oracle has no reference-held vector behind it."""
+    golden = os.path.join(ROOT, "tests", "golden", "views_golden.npz")
+    try:
+        import cv2  # noqa: F401
+        have_cv2 = True
+    except Exception:
+        have_cv2 = False
+    if not os.path.exists(golden) and not have_cv2:
+        terminalreporter.write_sep("=", "PARITY UNPINNED (gather)")
+        terminalreporter.write_line(
+            "oracle/cv_remap_oracle.c restates OpenCV 4.10's cv::remap; neither cv2 nor reference-run goldens are\n"
+            "available here, so every 'GPU == oracle' result rests on that restatement.  To pin it: run\n"
+            "tests/golden/make_golden_views.py and tests/test_oracle_vs_cv2.py where opencv-python==4.10.0.84 installs.")
+
+
 @pytest.fixture(scope="session")
 def pkg():
     b = importlib.import_module(PKG + "._build")

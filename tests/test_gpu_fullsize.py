@@ -1,13 +1,17 @@
-"""GPU, BASELINE.json's full sizes, through size-independent properties (the CPU oracle would take minutes
-per case here, so only one yaw of config 2 is compared pixel by pixel):
-  * a whole-column yaw shift equals rolling the panorama (exact);
-  * a constant panorama gives constant views (the weights sum to 1 in both stages);
-  * caller-map mode fed the fused kernel's own coordinates reproduces the fused output (exact);
-  * one yaw of config 2 against the oracle: fused within +-1, caller-map mode bit-exact."""
+"""GPU, BASELINE.json's configurations at their full sizes.
+  config 2  every one of the 36 views against the oracle (caller-map mode bit-exact, fused within +-1), the
+            roll property of whole-column yaws, fused == caller-map mode fed the kernel's own coordinates;
+  config 3  one GPU's share of the 64-panorama batch (8 panoramas resident, 288 views in one launch): two
+            panoramas x two yaws against the oracle, the rest self-consistent;
+  config 4  16384x8192 -> 4096x4096, FOV 60, NOISE panorama: pitch 30 (pole in view: split tiles, direct
+            gathers) and pitch 90 for one yaw against the oracle, plus the constant-colour property;
+  config 5  the 360-yaw sweep at 8K: four yaws (whole-column, fractional, flickering fraction) against the
+            oracle, and the float16 pixel path against the float32 one over the whole sweep.
+The oracle runs one task per yaw on the host's cores (the reference's own parallelism, P:252-265)."""
 import numpy as np
 import pytest
 
-from _util import coords_to_maps, diff_stats, oracle_maps, oracle_views
+from _util import coords_to_maps, diff_stats, oracle_maps, oracle_views, oracle_views_threaded
 from oracle import maps
 
 pytestmark = pytest.mark.gpu
@@ -20,15 +24,18 @@ def pano8k(synth):
     return synth.synth_pano(CFG2["pw"], CFG2["ph"], 1000, "S")
 
 
-def test_cfg2_one_yaw_vs_oracle(gpu, pkg, pano8k):
+def test_cfg2_all_36_views_vs_oracle(gpu, pkg, pano8k):
     c = CFG2
-    want = oracle_views(pano8k, [30], c["pitches"], c["ow"], c["oh"], c["fov"])
-    fused = pkg.process_views(pano8k, [30], c["pitches"], c["ow"], c["oh"], c["fov"])
+    yaws = list(range(0, 360, 30))
+    want = oracle_views_threaded(pano8k, yaws, c["pitches"], c["ow"], c["oh"], c["fov"])
+    rows, U, V = oracle_maps(yaws, c["pitches"], c["ow"], c["oh"], c["pw"], c["ph"], c["fov"])
+    exact = gpu.remap_views_maps(pano8k, rows, U, V)
+    bad = np.argwhere(exact != want)
+    assert bad.size == 0, (len(bad), bad[:4].tolist())  # 74.6 Mpix x 3 channels, every byte
+    fused = pkg.process_views(pano8k, yaws, c["pitches"], c["ow"], c["oh"], c["fov"])
     mx, gt1, anyd = diff_stats(fused, want)
-    print("cfg2 yaw 30 fused vs oracle: max %d, >1: %.3g, any: %.3g" % (mx, gt1, anyd))
+    print("cfg2 all views, fused vs oracle: max %d, >1: %.3g, any: %.3g" % (mx, gt1, anyd))
     assert mx <= 1
-    rows, U, V = oracle_maps([30], c["pitches"], c["ow"], c["oh"], c["pw"], c["ph"], c["fov"])
-    assert np.array_equal(gpu.remap_views_maps(pano8k, rows, U, V), want)
 
 
 def test_cfg2_whole_column_shift_equals_roll(gpu, pkg, pano8k):
@@ -62,3 +69,87 @@ def test_constant_panorama_constant_views_cfg4_size(gpu, pkg):
     pano[:] = (7, 130, 251)
     v = pkg.process_views(pano, [5, 200], [30, 90], 4096, 4096, 60)
     assert (v == np.array([7, 130, 251], np.uint8)).all()
+
+
+def test_cfg3_one_gpu_share_of_the_64_panorama_batch(gpu, synth):
+    """8 panoramas (seeds as bench.py deals them to rank 0 of 8) x 36 views resident, one launch."""
+    c = CFG2
+    yaws = list(range(0, 360, 30))
+    n = 8
+    panos = [synth.synth_pano(c["pw"], c["ph"], 1000 + i, "N") for i in range(n)]
+    rows, U, V = oracle_maps(yaws, c["pitches"], c["ow"], c["oh"], c["pw"], c["ph"], c["fov"])
+    ctx = gpu.Context(0)
+    fused = gpu.Job(ctx, c["pw"], c["ph"], n, yaws, c["pitches"], c["fov"], c["ow"], c["oh"], flags=gpu.FLAG_KEEP_COORDS)
+    exact = gpu.Job(ctx, c["pw"], c["ph"], n, yaws, c["pitches"], c["fov"], c["ow"], c["oh"])
+    for i, p in enumerate(panos):
+        fused.set_pano(i, p)
+        exact.set_pano(i, p)
+    fused.run()
+    coords = fused.get_coords()
+    Uk, Vk = zip(*(coords_to_maps(coords[p]) for p in range(len(c["pitches"]))))
+    # caller-map mode with the ORACLE's maps: bit-exact against the oracle on a sample
+    exact.set_maps(rows, U, V)
+    exact.run()
+    for i, ysel in ((0, [0, 5]), (7, [3, 11])):
+        got = exact.get_views(i)
+        want = oracle_views_threaded(panos[i], [yaws[y] for y in ysel], c["pitches"], c["ow"], c["oh"], c["fov"])
+        for k, y in enumerate(ysel):
+            assert np.array_equal(got[y], want[k]), (i, yaws[y])
+    # caller-map mode with the fused kernel's own coordinates: every one of the 288 views, byte for byte
+    exact.set_maps(rows, np.stack(Uk), np.stack(Vk))
+    exact.run()
+    for i in range(n):
+        assert np.array_equal(fused.get_views(i), exact.get_views(i)), i
+    fused.close()
+    exact.close()
+    ctx.close()
+
+
+def test_cfg4_noise_panorama_pole_and_horizon_vs_oracle(gpu, synth):
+    pw, ph, ow, oh, fov = 16384, 8192, 4096, 4096, 60
+    pano = synth.synth_pano(pw, ph, 1000, "N")
+    yaws, pitches = [35], [30, 90]
+    want = oracle_views_threaded(pano, yaws, pitches, ow, oh, fov)
+    rows, U, V = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
+    got = gpu.remap_views_maps(pano, rows, U, V)
+    for pi, pitch in enumerate(pitches):
+        bad = np.argwhere(got[0, pi] != want[0, pi])
+        assert bad.size == 0, (pitch, len(bad), bad[:4].tolist())
+
+
+def test_cfg5_yaw_sweep_at_8k(gpu, pkg, pano8k):
+    c = CFG2
+    pitches = [90]
+    sample = [0, 1, 14, 200]  # whole-column, fractional, flickering fraction (per-column weights), fractional
+    want = oracle_views_threaded(pano8k, sample, pitches, c["ow"], c["oh"], c["fov"])
+    ctx = gpu.Context(0)
+    sweep = list(range(360))
+    job = gpu.Job(ctx, c["pw"], c["ph"], 1, sweep, pitches, c["fov"], c["ow"], c["oh"])
+    job.set_pano(0, pano8k)
+    job.run()
+    got = job.get_views(0)
+    for k, y in enumerate(sample):
+        mx, gt1, _ = diff_stats(got[y], want[k])
+        assert mx <= 1, (y, mx, gt1)
+    rows, U, V = oracle_maps(sweep, pitches, c["ow"], c["oh"], c["pw"], c["ph"], c["fov"])
+    job.set_maps(rows, U, V)
+    job.run()
+    got = job.get_views(0)
+    for k, y in enumerate(sample):
+        assert np.array_equal(got[y], want[k]), y
+    del got
+    job.close()
+    # float16 pixel path against the float32 one over the whole sweep (config 5's tolerance: 1 level)
+    worst = 0
+    for lo in range(0, 360, 90):
+        ys = sweep[lo:lo + 90]
+        res = []
+        for flag in (gpu.FLAG_PIXELS_F32, gpu.FLAG_PIXELS_F16):
+            j = gpu.Job(ctx, c["pw"], c["ph"], 1, ys, pitches, c["fov"], c["ow"], c["oh"], flags=flag)
+            j.set_pano(0, pano8k)
+            j.run()
+            res.append(j.get_views(0))
+            j.close()
+        worst = max(worst, int(np.abs(res[0].astype(np.int16) - res[1].astype(np.int16)).max()))
+    assert worst <= 1, worst
+    ctx.close()
