@@ -170,6 +170,16 @@ def _i32(seq):
     return a.astype(np.int32)
 
 
+def _f64(seq):
+    """Angle lists for the real-valued entry points: any finite numbers of degrees (np.radians takes them, P:85, P:64-68)."""
+    a = np.ascontiguousarray(np.asarray(seq, dtype=np.float64))
+    if a.ndim != 1:
+        raise ValueError("angle lists must be one-dimensional")
+    if a.size and not np.isfinite(a).all():
+        raise ValueError("angles must be finite")
+    return a
+
+
 def as_image(a, what="image"):
     a = np.asarray(a)
     if a.dtype != np.uint8:
@@ -290,13 +300,33 @@ def remap_views(pano, yaw_deg, pitch_deg, fov_deg, ow, oh, device=0, pinned=Fals
     if pinned and yaw.size and pitch.size:
         try:
             out = pinned_empty(shape)
-        except MemoryError:  # budget of page-locked memory in use: an ordinary array is merely slower to fill
+        except (MemoryError, P2PError, OSError):  # no page-locked memory to be had: an ordinary array is merely slower to fill
             out = None
     if out is None:
         out = np.empty(shape, dtype=np.uint8)
     check(lib().p2p_remap_views_u8(pano.ctypes.data, pw, ph, pano.strides[0],
                                    yaw.ctypes.data, yaw.size, pitch.ctypes.data, pitch.size,
                                    int(fov_deg), int(ow), int(oh), out.ctypes.data, int(device), int(flags)))
+    return out
+
+
+def remap_views_f64(pano, yaw_deg, pitch_deg, fov_deg, ow, oh, device=0, pinned=False, flags=0):
+    """p2p_remap_views_f64: as remap_views with real-valued yaw / pitch / FOV (what the reference's functions accept)."""
+    pano = as_image(pano, "pano_image")
+    yaw, pitch = _f64(yaw_deg), _f64(pitch_deg)
+    ph, pw = pano.shape[:2]
+    shape = (yaw.size, pitch.size, int(oh), int(ow), 3)
+    out = None
+    if pinned and yaw.size and pitch.size:
+        try:
+            out = pinned_empty(shape)
+        except (MemoryError, P2PError, OSError):  # no page-locked memory to be had: an ordinary array is merely slower to fill
+            out = None
+    if out is None:
+        out = np.empty(shape, dtype=np.uint8)
+    check(lib().p2p_remap_views_f64(pano.ctypes.data, pw, ph, pano.strides[0],
+                                    yaw.ctypes.data, yaw.size, pitch.ctypes.data, pitch.size,
+                                    float(fov_deg), int(ow), int(oh), out.ctypes.data, int(device), int(flags)))
     return out
 
 
@@ -414,15 +444,23 @@ class Context:
 class Job:
     """p2p_job: n_panos resident panoramas of one size x (yaw x pitch) views, outputs resident in HBM."""
 
-    def __init__(self, ctx, pw, ph, n_panos, yaw_deg, pitch_deg, fov_deg, ow, oh, flags=0):
+    def __init__(self, ctx, pw, ph, n_panos, yaw_deg, pitch_deg, fov_deg, ow, oh, flags=0, integer_abi=False):
         self.ctx = ctx
-        self._yaw, self._pitch = _i32(yaw_deg), _i32(pitch_deg)
-        d = JobDesc(int(pw), int(ph), int(n_panos),
-                    self._yaw.size, self._yaw.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
-                    self._pitch.size, self._pitch.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
-                    int(fov_deg), int(ow), int(oh), int(flags))
         self._h = ctypes.c_void_p()
-        check(lib().p2p_job_create(ctx._h, ctypes.byref(d), ctypes.byref(self._h)))
+        if integer_abi:  # p2p_job_create: integer degrees, pitch checked against 1..179 as the CLI does
+            self._yaw, self._pitch = _i32(yaw_deg), _i32(pitch_deg)
+            d = JobDesc(int(pw), int(ph), int(n_panos),
+                        self._yaw.size, self._yaw.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                        self._pitch.size, self._pitch.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                        int(fov_deg), int(ow), int(oh), int(flags))
+            check(lib().p2p_job_create(ctx._h, ctypes.byref(d), ctypes.byref(self._h)))
+        else:
+            self._yaw, self._pitch = _f64(yaw_deg), _f64(pitch_deg)
+            d = JobDescF64(int(pw), int(ph), int(n_panos),
+                           self._yaw.size, self._yaw.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                           self._pitch.size, self._pitch.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                           float(fov_deg), int(ow), int(oh), int(flags))
+            check(lib().p2p_job_create_f64(ctx._h, ctypes.byref(d), ctypes.byref(self._h)))
         self.pw, self.ph, self.n_panos = int(pw), int(ph), int(n_panos)
         self.n_yaw, self.n_pitch, self.ow, self.oh = self._yaw.size, self._pitch.size, int(ow), int(oh)
 
@@ -433,10 +471,10 @@ class Job:
         check(lib().p2p_job_set_pano(self._h, int(index), pano.ctypes.data, pano.strides[0]))
 
     def set_yaws(self, yaw_deg):
-        yaw = _i32(yaw_deg)
+        yaw = _f64(yaw_deg)
         if yaw.size != self.n_yaw:
             raise ValueError("the job was created with %d yaws, got %d" % (self.n_yaw, yaw.size))
-        check(lib().p2p_job_set_yaws(self._h, yaw.ctypes.data))
+        check(lib().p2p_job_set_yaws_f64(self._h, yaw.ctypes.data))
         self._yaw = yaw
 
     def set_maps(self, yaw_rows, U, V):
@@ -470,7 +508,14 @@ class Job:
 
     def get_views(self, index=0, pinned=False):
         shape = (self.n_yaw, self.n_pitch, self.oh, self.ow, 3)
-        out = pinned_empty(shape) if pinned else np.empty(shape, dtype=np.uint8)
+        out = None
+        if pinned:
+            try:
+                out = pinned_empty(shape)
+            except (MemoryError, P2PError, OSError):
+                out = None
+        if out is None:
+            out = np.empty(shape, dtype=np.uint8)
         check(lib().p2p_job_get_views(self._h, int(index), out.ctypes.data))
         return out
 

@@ -105,14 +105,15 @@ def get_pitch_mapping(output_width, output_height, pitch_angle, pano_width, pano
 # ----------------------------------------------------------------------------------------------
 # view synthesis
 # ----------------------------------------------------------------------------------------------
-def _int_angle(value, what):
-    if isinstance(value, (bool, np.bool_)):
-        raise TypeError(f"{what} must be an integer number of degrees")
-    if isinstance(value, (int, np.integer)):
-        return int(value)
-    if isinstance(value, (float, np.floating)) and float(value).is_integer():
-        return int(value)
-    raise TypeError(f"{what} must be an integer number of degrees, got {value!r}")
+def _angle(value, what):
+    """Degrees as the reference's functions take them: any real number -- they go through np.radians (P:85,
+    P:64-68); only the CLI narrows yaw / FOV to int and the pitch to 1..179 (check_pitch)."""
+    if isinstance(value, (bool, np.bool_)) or not isinstance(value, (int, float, np.integer, np.floating)):
+        raise TypeError(f"{what} must be a number of degrees, got {value!r}")
+    v = float(value)
+    if not np.isfinite(v):
+        raise ValueError(f"{what} must be finite, got {value!r}")
+    return v
 
 
 _PINNED = os.environ.get("P2P_PINNED", "1") != "0"
@@ -128,11 +129,11 @@ def process_views(pano_image, yaw_angles, pitch_angles, output_width, output_hei
     memory (pooled; P2P_PINNED=0 for ordinary memory) so that the copy back from the GPU is one DMA.
     pixel_path: "u8" = the reference's arithmetic (two fixed-point cv2.remap stages, the default and the only
     parity mode); "f32" / "f16" = the opt-in single float resample with wrap-around (not in the reference)."""
-    yaws = [_int_angle(y, "yaw angle") for y in yaw_angles]
-    pitches = [_int_angle(p, "pitch angle") for p in pitch_angles]
-    return _native.remap_views(pano_image, yaws, pitches, _int_angle(fov_deg, "FOV"),
-                               output_width, output_height, _DEVICE if device is None else device,
-                               pinned=_PINNED, flags=_PIXEL_PATHS[pixel_path])
+    yaws = [_angle(y, "yaw angle") for y in yaw_angles]
+    pitches = [_angle(p, "pitch angle") for p in pitch_angles]
+    return _native.remap_views_f64(pano_image, yaws, pitches, _angle(fov_deg, "FOV"),
+                                   output_width, output_height, _DEVICE if device is None else device,
+                                   pinned=_PINNED, flags=_PIXEL_PATHS[pixel_path])
 
 
 def process_yaw_and_pitchs(pano_image, yaw_angle, pitch_angles, output_width, output_height, fov_deg=90):

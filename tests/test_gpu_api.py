@@ -22,7 +22,47 @@ def test_process_yaw_and_pitchs_contract(gpu, pkg, synth):
     b = pkg.process_yaw_and_pitchs(pano, 30.0, [90], 160, 120, fov_deg=90)
     assert np.array_equal(a[0], out[1]) and np.array_equal(b[0], out[1])
     with pytest.raises(TypeError):
-        pkg.process_yaw_and_pitchs(pano, 30.5, [90], 160, 120)
+        pkg.process_yaw_and_pitchs(pano, "30", [90], 160, 120)
+
+
+def test_real_valued_angles_like_the_reference_functions(gpu, pkg, synth):
+    """P:85 and P:64-68 hand yaw, pitch and FOV to np.radians: any real number is legal input to the reference's
+    functions (only its CLI narrows them).  Caller-map mode on the oracle's maps is bit-exact, fused mode within +-1."""
+    from _util import oracle_maps
+    pw, ph, ow, oh = 1024, 512, 200, 120
+    yaws, pitches, fov = [30.5, -0.25, 359.9], [44.5, 90.0, 0.5, 179.75], 72.5
+    for kind in ("N", "S"):
+        pano = synth.synth_pano(pw, ph, 3050, kind)
+        want = oracle_views(pano, yaws, pitches, ow, oh, fov)
+        rows, U, V = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
+        assert np.array_equal(gpu.remap_views_maps(pano, rows, U, V), want)
+        if kind == "S":
+            got = pkg.process_views(pano, yaws, pitches, ow, oh, fov)
+            assert diff_stats(got, want)[0] <= 1
+    one = pkg.process_yaw_and_pitchs(pano, 30.5, [44.5], ow, oh, fov_deg=72.5)
+    assert np.array_equal(one[0], got[0, 0])
+    ctx = gpu.Context(0)
+    job = gpu.Job(ctx, pw, ph, 1, yaws, pitches, fov, ow, oh)
+    job.set_pano(0, pano)
+    job.run()
+    assert np.array_equal(job.get_views(0), got)
+    job.set_yaws([10.125, 20.25, 30.5])
+    job.run()
+    assert np.array_equal(job.get_views(0)[2], got[0])
+    job.close()
+    ctx.close()
+
+
+def test_more_than_64_pitch_angles_in_one_call(gpu, pkg, synth):
+    # P:424-430: --pitch_angles takes any list of 1..179; `seq 1 2 179` is 90 of them
+    pano = synth.synth_pano(512, 256, 3060, "S")
+    pitches = list(range(1, 180, 2)) + [90, 45, 17, 163, 2, 4, 6, 8, 10, 12]
+    assert len(pitches) == 100
+    got = pkg.process_views(pano, [0, 77], pitches, 64, 48, 90)
+    assert got.shape == (2, 100, 48, 64, 3)
+    for pi in (0, 1, 44, 45, 89, 90, 99):
+        want = oracle_views(pano, [0, 77], [pitches[pi]], 64, 48, 90)
+        assert diff_stats(got[:, pi:pi + 1], want)[0] <= 1, pitches[pi]
 
 
 def test_thread_pool_fan_out_like_the_reference(gpu, pkg, synth):
@@ -44,10 +84,18 @@ def test_thread_pool_fan_out_like_the_reference(gpu, pkg, synth):
 
 def test_error_codes(gpu, pkg, synth):
     pano = synth.synth_pano(64, 32, 3002, "N")
+    # the integer entry points keep the CLI's pitch check (check_pitch, P:362-376); the functions themselves
+    # take any pitch, as the reference's do
     for bad in (0, 180, -5):
         with pytest.raises(gpu.P2PError) as e:
-            pkg.process_yaw_and_pitchs(pano, 0, [bad], 16, 16)
+            gpu.remap_views(pano, [0], [bad], 90, 16, 16)
         assert e.value.code == gpu.P2P_ERR_INVALID and "between 1 and 179" in str(e.value)
+        with pytest.raises(gpu.P2PError) as e:
+            gpu.Job(gpu.Context(0), 64, 32, 1, [0], [bad], 90, 16, 16, integer_abi=True)
+        assert e.value.code == gpu.P2P_ERR_INVALID
+    assert pkg.process_yaw_and_pitchs(pano, 0, [0, 180], 16, 16)[0].shape == (16, 16, 3)
+    with pytest.raises(ValueError):
+        pkg.process_yaw_and_pitchs(pano, float("nan"), [90], 16, 16)
     with pytest.raises(gpu.P2PError) as e:
         gpu.remap_views(pano, [0], [90], 90, 40000, 16)
     assert e.value.code == gpu.P2P_ERR_INVALID
