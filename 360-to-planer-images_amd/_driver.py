@@ -1,0 +1,149 @@
+"""Device-side scheduling for the drop-in tool: how images and views are dealt to GPUs and how PCIe copies hide
+behind kernels.  No pixel arithmetic here -- that is libp2p_hip.so; no collective either: every (image, yaw,
+pitch) view is independent work, exactly as the reference treats its per-yaw tasks
+(/root/reference/app/panorama_to_plane-pitch.py:252-265) and its per-image loop (P:330-341).
+
+  DevicePipeline   one GPU, two resident jobs used alternately: while image k is resampled, image k+1 is already
+                   uploading (its own stream) and the views of image k-1 are downloading (a third stream)
+                   -- the cv2.imread (P:244) / cv2.imwrite (P:277) boundary of the reference, overlapped;
+  shard_views      the (yaw x pitch) view list of ONE image dealt round-robin to N devices, pitch-major, so that a
+                   device's share falls into few (pitch, yaw subset) groups and keeps few pitch plans;
+  process_views_sharded
+                   one image on several GPUs: one host thread per device, the panorama uploaded once per device
+                   (the groups of a device share it: p2p_job_share_panos), results stitched on the host.
+"""
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import _native
+
+
+def shard_round_robin(n_items, world, rank):
+    """Items (panoramas, or views when there are fewer panoramas than GPUs) dealt round-robin."""
+    return list(range(rank, n_items, world))
+
+
+def shard_views(n_yaw, n_pitch, world, rank):
+    """This rank's views of one image as {pitch index: [yaw indices]}: the pitch-major list
+    (p0,y0), (p0,y1) ... (p1,y0) ... dealt round-robin, so consecutive ranks get consecutive yaws of one pitch."""
+    groups = {}
+    for v in shard_round_robin(n_yaw * n_pitch, world, rank):
+        groups.setdefault(v // n_yaw, []).append(v % n_yaw)
+    return groups
+
+
+class _Ticket:
+    """One image in flight on a DevicePipeline; result() waits for its download."""
+
+    def __init__(self, job, views):
+        self._job, self._views = job, views
+
+    def result(self):
+        if self._job is not None:
+            self._job.wait()
+            self._job = None
+        return self._views
+
+
+class DevicePipeline:
+    """Two resident jobs on one device, used alternately, copies asynchronous.  Not thread-safe: one submitting
+    thread per pipeline (the tool keeps one per device)."""
+
+    def __init__(self, device=0, slots=2):
+        self.device = int(device)
+        self.ctx = _native.Context(self.device)
+        self.slots = [None] * int(slots)  # (key, Job, last ticket)
+        self.turn = 0
+
+    def submit(self, pano, yaws, pitches, fov, ow, oh, flags=0):
+        """Enqueue upload -> kernel -> download of every (yaw, pitch) view of `pano`; returns a ticket at once."""
+        pano = _native.as_image(pano, "pano_image")
+        ph, pw = pano.shape[:2]
+        key = (pw, ph, tuple(float(y) for y in yaws), tuple(float(p) for p in pitches), float(fov), int(ow), int(oh), int(flags))
+        i = self.turn % len(self.slots)
+        self.turn += 1
+        slot = self.slots[i]
+        if slot is not None:
+            slot[2].result()  # the slot's previous image must be out before its buffers are reused
+            if slot[0] != key:
+                slot[1].close()
+                slot = None
+        if slot is None:
+            job = _native.Job(self.ctx, pw, ph, 1, key[2], key[3], fov, ow, oh, flags=flags)
+        else:
+            job = slot[1]
+        job.set_pano(0, pano, wait=False)
+        job.run()
+        views = job.get_views_async(0)
+        ticket = _Ticket(job, views)
+        self.slots[i] = (key, job, ticket)
+        return ticket
+
+    def close(self):
+        for slot in self.slots:
+            if slot is not None:
+                try:
+                    slot[2].result()
+                finally:
+                    slot[1].close()
+        self.slots = [None] * len(self.slots)
+        self.ctx.close()
+
+
+_ctx_lock = threading.Lock()
+_ctxs = {}
+
+
+def _shared_ctx(slot):
+    """One context per (device slot) for the sharded path, kept for the life of the process."""
+    with _ctx_lock:
+        c = _ctxs.get(slot)
+        if c is None:
+            c = _ctxs[slot] = _native.Context(slot[1])
+        return c
+
+
+def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0):
+    """Every (yaw, pitch) view of ONE panorama drawn by several GPUs: views dealt round-robin, pitch-major
+    (shard_views); each device uploads the panorama once, draws its (pitch, yaw subset) groups and downloads them;
+    the host stitches [n_yaw][n_pitch][oh][ow][3].  `devices` may name a device twice (two contexts on one GPU)."""
+    pano = _native.as_image(pano, "pano_image")
+    ph, pw = pano.shape[:2]
+    yaws, pitches = [float(y) for y in yaws], [float(p) for p in pitches]
+    out = np.empty((len(yaws), len(pitches), int(oh), int(ow), 3), dtype=np.uint8)
+    world = len(devices)
+
+    def one_device(rank):
+        groups = shard_views(len(yaws), len(pitches), world, rank)
+        if not groups:
+            return
+        ctx = _shared_ctx((rank, int(devices[rank])))
+        jobs, owner = [], None
+        try:
+            for pi, yis in sorted(groups.items()):
+                job = _native.Job(ctx, pw, ph, 1, [yaws[y] for y in yis], [pitches[pi]], fov, ow, oh, flags=flags)
+                jobs.append((job, pi, yis))
+                if owner is None:
+                    owner = job
+                    owner.set_pano(0, pano, wait=False)  # once per device
+                else:
+                    job.share_panos(owner)
+            pending = []
+            for job, pi, yis in jobs:
+                job.run()
+                pending.append((job.get_views_async(0), pi, yis))
+            for job, _, _ in jobs:
+                job.wait()
+            for views, pi, yis in pending:
+                for k, y in enumerate(yis):
+                    out[y, pi] = views[k, 0]
+        finally:
+            for job, _, _ in reversed(jobs):  # borrowers before the owner
+                job.close()
+
+    with ThreadPoolExecutor(max_workers=world) as ex:
+        for f in [ex.submit(one_device, r) for r in range(world)]:
+            f.result()
+    return out

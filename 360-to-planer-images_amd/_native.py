@@ -31,7 +31,8 @@ ABI_SYMBOLS = (
     "p2p_build_pitch_map", "p2p_build_yaw_row", "p2p_build_rot_map",
     "p2p_ctx_create", "p2p_ctx_destroy", "p2p_ctx_synchronize", "p2p_ctx_mark", "p2p_ctx_marked_ms",
     "p2p_job_time_launches",
-    "p2p_job_create", "p2p_job_create_f64", "p2p_job_set_yaws_f64", "p2p_job_destroy", "p2p_job_set_pano", "p2p_job_set_maps", "p2p_job_run",
+    "p2p_job_create", "p2p_job_create_f64", "p2p_job_set_yaws_f64", "p2p_job_destroy", "p2p_job_set_pano",
+    "p2p_job_set_pano_async", "p2p_job_share_panos", "p2p_job_get_views_async", "p2p_job_wait", "p2p_job_set_maps", "p2p_job_run",
     "p2p_job_get_views", "p2p_job_kernel_ms", "p2p_job_kernel_ms_last", "p2p_job_device_out", "p2p_job_get_coords",
     "p2p_job_get_yaw_tables", "p2p_job_set_yaws", "p2p_host_alloc", "p2p_host_free", "p2p_release_cache",
     "p2p_debug_stamps",
@@ -118,6 +119,14 @@ def lib():
     L.p2p_job_destroy.argtypes = [c_vp]
     L.p2p_job_set_pano.restype = c_int
     L.p2p_job_set_pano.argtypes = [c_vp, c_int, c_vp, c_i64]
+    L.p2p_job_set_pano_async.restype = c_int
+    L.p2p_job_set_pano_async.argtypes = [c_vp, c_int, c_vp, c_i64]
+    L.p2p_job_share_panos.restype = c_int
+    L.p2p_job_share_panos.argtypes = [c_vp, c_vp]
+    L.p2p_job_get_views_async.restype = c_int
+    L.p2p_job_get_views_async.argtypes = [c_vp, c_int, c_vp]
+    L.p2p_job_wait.restype = c_int
+    L.p2p_job_wait.argtypes = [c_vp]
     L.p2p_job_set_maps.restype = c_int
     L.p2p_job_set_maps.argtypes = [c_vp, c_vp, c_vp, c_vp]
     L.p2p_job_run.restype = c_int
@@ -463,12 +472,28 @@ class Job:
             check(lib().p2p_job_create_f64(ctx._h, ctypes.byref(d), ctypes.byref(self._h)))
         self.pw, self.ph, self.n_panos = int(pw), int(ph), int(n_panos)
         self.n_yaw, self.n_pitch, self.ow, self.oh = self._yaw.size, self._pitch.size, int(ow), int(oh)
+        self._inflight = []  # host arrays of asynchronous copies still in flight
+        self._owner = None
 
-    def set_pano(self, index, pano):
+    def set_pano(self, index, pano, wait=True):
+        """wait=False: the upload is only enqueued (p2p_job_set_pano_async); the array is kept alive here until
+        wait() / the next synchronous call, and must not be modified meanwhile."""
         pano = as_image(pano, "pano_image")
         if pano.shape[:2] != (self.ph, self.pw):
             raise ValueError("panorama is %s, job expects (%d, %d)" % (pano.shape[:2], self.ph, self.pw))
-        check(lib().p2p_job_set_pano(self._h, int(index), pano.ctypes.data, pano.strides[0]))
+        if wait:
+            check(lib().p2p_job_set_pano(self._h, int(index), pano.ctypes.data, pano.strides[0]))
+        else:
+            check(lib().p2p_job_set_pano_async(self._h, int(index), pano.ctypes.data, pano.strides[0]))
+            self._inflight.append(pano)
+
+    def share_panos(self, owner):
+        check(lib().p2p_job_share_panos(self._h, owner._h))
+        self._owner = owner  # keeps it alive
+
+    def wait(self):
+        check(lib().p2p_job_wait(self._h))
+        self._inflight.clear()
 
     def set_yaws(self, yaw_deg):
         yaw = _f64(yaw_deg)
@@ -517,6 +542,18 @@ class Job:
         if out is None:
             out = np.empty(shape, dtype=np.uint8)
         check(lib().p2p_job_get_views(self._h, int(index), out.ctypes.data))
+        return out
+
+    def get_views_async(self, index=0, out=None, pinned=True):
+        """Enqueue the download (p2p_job_get_views_async); the returned array is complete after wait()."""
+        shape = (self.n_yaw, self.n_pitch, self.oh, self.ow, 3)
+        if out is None:
+            try:
+                out = pinned_empty(shape) if pinned else np.empty(shape, dtype=np.uint8)
+            except (MemoryError, P2PError, OSError):
+                out = np.empty(shape, dtype=np.uint8)
+        check(lib().p2p_job_get_views_async(self._h, int(index), out.ctypes.data))
+        self._inflight.append(out)
         return out
 
     def get_coords(self):

@@ -54,7 +54,9 @@ int env_int(const char* name, int dflt)
 
 struct p2p_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // kernels
+    hipStream_t stream_up = nullptr;   // asynchronous panorama uploads (p2p_job_set_pano_async)
+    hipStream_t stream_down = nullptr; // asynchronous view downloads (p2p_job_get_views_async)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     short* d_ctab = nullptr;  // INTER_CUBIC weight table, built on first use
 };
@@ -65,6 +67,14 @@ struct p2p_job {
     std::vector<double> yaw, pitch;  // degrees, any real value (P:85 and P:64-68 go through np.radians)
     double fov = 90.0;
     uint8_t* d_src = nullptr;
+    bool owns_src = true;            // false: the panoramas are another job's (p2p_job_share_panos)
+    p2p_job* src_owner = nullptr;
+    // ordering between the context's three streams (all created with hipEventDisableTiming):
+    hipEvent_t ev_up = nullptr;      // last asynchronous upload into d_src     -> the next run waits for it
+    hipEvent_t ev_run = nullptr;     // last run                                -> uploads and downloads wait for it
+    hipEvent_t ev_down = nullptr;    // last asynchronous download from d_out   -> the next run waits for it
+    bool up_pending = false, down_pending = false;
+    bool ev_run_recorded = false;    // some run (of this job or of one that borrows its panoramas) has been enqueued
     size_t pano_stride = 0;
     int src_pitch = 0;
     uint8_t* d_out = nullptr;
@@ -216,6 +226,8 @@ int p2p_ctx_create(int device, p2p_ctx** out)
         return fail(P2P_ERR_OOM, "host allocation failed");
     c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_down, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e != hipSuccess) {
@@ -231,10 +243,11 @@ void p2p_ctx_destroy(p2p_ctx* c)
     if (!c)
         return;
     (void)hipSetDevice(c->device);
-    if (c->stream) {
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipStreamDestroy(c->stream);
-    }
+    for (hipStream_t* st : {&c->stream_up, &c->stream_down, &c->stream})
+        if (*st) {
+            (void)hipStreamSynchronize(*st);
+            (void)hipStreamDestroy(*st);
+        }
     (void)hipFree(c->d_ctab);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -246,7 +259,9 @@ int p2p_ctx_synchronize(p2p_ctx* c)
     if (!c)
         return fail(P2P_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream_up));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream_down));
     return P2P_OK;
 }
 
@@ -256,9 +271,14 @@ void p2p_job_destroy(p2p_job* j)
         return;
     if (j->ctx) {
         (void)hipSetDevice(j->ctx->device);
+        (void)hipStreamSynchronize(j->ctx->stream_up);
         (void)hipStreamSynchronize(j->ctx->stream);
+        (void)hipStreamSynchronize(j->ctx->stream_down);
     }
-    (void)hipFree(j->d_src);
+    for (hipEvent_t e : {j->ev_up, j->ev_run, j->ev_down})
+        if (e) (void)hipEventDestroy(e);
+    if (j->owns_src)
+        (void)hipFree(j->d_src);
     (void)hipFree(j->d_out);
     (void)hipFree(j->d_ytab);
     (void)hipFree(j->d_f4tab);
@@ -356,6 +376,9 @@ static int job_create_core(p2p_ctx* ctx, const p2p_job_desc& d, const double* ya
         yr[i] = deg2rad(j->yaw[i]);  // P:85
 
     hipError_t e = hipMalloc((void**)&j->d_src, j->pano_stride * d.n_panos);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&j->ev_up, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&j->ev_run, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&j->ev_down, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&j->d_out, j->out_bytes + 16);
     if (e == hipSuccess) e = hipMalloc((void**)&j->d_ytab, (size_t)d.n_yaw * d.pw * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&j->d_f4tab, (size_t)d.n_yaw * d.pw * sizeof(uint32_t));
@@ -432,21 +455,54 @@ int p2p_job_create_f64(p2p_ctx* ctx, const p2p_job_desc_f64* desc, p2p_job** out
     return job_create_core(ctx, d, desc->yaw_deg, desc->pitch_deg, desc->fov_deg, out);
 }
 
-int p2p_job_set_pano(p2p_job* j, int index, const uint8_t* pano, int64_t row_stride)
+int p2p_job_set_pano_async(p2p_job* j, int index, const uint8_t* pano, int64_t row_stride)
 {
     if (!j || !pano)
         return fail(P2P_ERR_INVALID, "p2p_job_set_pano: NULL argument");
+    if (!j->owns_src)
+        return fail(P2P_ERR_STATE, "this job borrows its panoramas (p2p_job_share_panos): set them on the owning job");
     if (index < 0 || index >= j->d.n_panos)
         return fail(P2P_ERR_INVALID, "panorama index %d out of range", index);
     if (row_stride < (int64_t)3 * j->d.pw)
         return fail(P2P_ERR_INVALID, "row_stride %lld < 3*pw", (long long)row_stride);
     HIP_TRY(hipSetDevice(j->ctx->device));
+    // on the upload stream, behind the last kernel that reads this job's panoramas: the copy overlaps whatever
+    // other jobs of the context are running (the driver keeps two jobs per device and alternates)
+    if (j->ev_run_recorded)
+        HIP_TRY(hipStreamWaitEvent(j->ctx->stream_up, j->ev_run, 0));
     HIP_TRY(hipMemcpy2DAsync(j->d_src + (size_t)index * j->pano_stride, (size_t)j->src_pitch, pano,
                              (size_t)row_stride, (size_t)3 * j->d.pw, (size_t)j->d.ph,
-                             hipMemcpyHostToDevice, j->ctx->stream));
-    // the caller may release `pano` when we return
-    HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+                             hipMemcpyHostToDevice, j->ctx->stream_up));
+    HIP_TRY(hipEventRecord(j->ev_up, j->ctx->stream_up));
+    j->up_pending = true;
     j->pano_set[index] = 1;
+    return P2P_OK;
+}
+
+int p2p_job_set_pano(p2p_job* j, int index, const uint8_t* pano, int64_t row_stride)
+{
+    int rc = p2p_job_set_pano_async(j, index, pano, row_stride);
+    if (rc != P2P_OK)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream_up));  // the caller may release `pano` when we return
+    return P2P_OK;
+}
+
+int p2p_job_share_panos(p2p_job* j, p2p_job* owner)
+{
+    if (!j || !owner || j == owner)
+        return fail(P2P_ERR_INVALID, "p2p_job_share_panos: bad argument");
+    if (!owner->owns_src)
+        owner = owner->src_owner;
+    if (j->ctx != owner->ctx || j->d.pw != owner->d.pw || j->d.ph != owner->d.ph || j->d.n_panos != owner->d.n_panos)
+        return fail(P2P_ERR_INVALID, "jobs that share panoramas need one context, one panorama size and one panorama count");
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+    if (j->owns_src)
+        (void)hipFree(j->d_src);
+    j->d_src = owner->d_src;
+    j->owns_src = false;
+    j->src_owner = owner;
     return P2P_OK;
 }
 
@@ -569,10 +625,18 @@ int p2p_job_run(p2p_job* j)
 {
     if (!j)
         return fail(P2P_ERR_INVALID, "job is NULL");
+    const p2p_job* so = j->owns_src ? j : j->src_owner;
     for (int i = 0; i < j->d.n_panos; ++i)
-        if (!j->pano_set[i])
+        if (!so->pano_set[i])
             return fail(P2P_ERR_STATE, "panorama %d was never set", i);
     HIP_TRY(hipSetDevice(j->ctx->device));
+    // behind the uploads into the panoramas it reads and the downloads of the views it is about to overwrite
+    if (so->up_pending)
+        HIP_TRY(hipStreamWaitEvent(j->ctx->stream, so->ev_up, 0));
+    if (j->down_pending) {
+        HIP_TRY(hipStreamWaitEvent(j->ctx->stream, j->ev_down, 0));
+        j->down_pending = false;
+    }
     p2p::ViewsParams P{};
     P.src = j->d_src;
     P.pano_stride = j->pano_stride;
@@ -612,6 +676,8 @@ int p2p_job_run(p2p_job* j)
         HIP_TRY(p2p::launch_float_views(P, j->d_yaw_rad, (j->d.flags & P2P_FLAG_PIXELS_F16) != 0, j->ctx->stream));
         if (timed)
             HIP_TRY(hipEventRecord(j->ev_ring[2 * slot + 1], j->ctx->stream));
+        HIP_TRY(hipEventRecord(j->ev_run, j->ctx->stream));
+        j->ev_run_recorded = true;
         j->runs++;
         j->ran = true;
         return P2P_OK;
@@ -643,6 +709,12 @@ int p2p_job_run(p2p_job* j)
         HIP_TRY(p2p::launch_remap_views(P, 0, j->ctx->stream));
     if (timed)
         HIP_TRY(hipEventRecord(j->ev_ring[2 * slot + 1], j->ctx->stream));
+    HIP_TRY(hipEventRecord(j->ev_run, j->ctx->stream));
+    j->ev_run_recorded = true;
+    if (!j->owns_src) {
+        HIP_TRY(hipEventRecord(j->src_owner->ev_run, j->ctx->stream));  // uploads into the shared panoramas wait for this run too
+        j->src_owner->ev_run_recorded = true;
+    }
     j->runs++;
     j->ran = true;
     return P2P_OK;
@@ -704,7 +776,7 @@ int p2p_job_kernel_ms_last(p2p_job* j, float* ms, int n)
     return P2P_OK;
 }
 
-int p2p_job_get_views(p2p_job* j, int index, uint8_t* out)
+int p2p_job_get_views_async(p2p_job* j, int index, uint8_t* out)
 {
     if (!j || !out)
         return fail(P2P_ERR_INVALID, "NULL argument");
@@ -714,8 +786,37 @@ int p2p_job_get_views(p2p_job* j, int index, uint8_t* out)
         return fail(P2P_ERR_STATE, "p2p_job_run has not been called");
     HIP_TRY(hipSetDevice(j->ctx->device));
     const size_t per = j->out_bytes / j->d.n_panos;
-    HIP_TRY(hipMemcpyAsync(out, j->d_out + per * index, per, hipMemcpyDeviceToHost, j->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+    // on the download stream, behind the job's last run: the copy overlaps other jobs' kernels and uploads
+    HIP_TRY(hipStreamWaitEvent(j->ctx->stream_down, j->ev_run, 0));
+    HIP_TRY(hipMemcpyAsync(out, j->d_out + per * index, per, hipMemcpyDeviceToHost, j->ctx->stream_down));
+    HIP_TRY(hipEventRecord(j->ev_down, j->ctx->stream_down));
+    j->down_pending = true;
+    return P2P_OK;
+}
+
+int p2p_job_wait(p2p_job* j)
+{
+    if (!j)
+        return fail(P2P_ERR_INVALID, "job is NULL");
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    if (j->up_pending)
+        HIP_TRY(hipEventSynchronize(j->ev_up));
+    if (j->ev_run_recorded)
+        HIP_TRY(hipEventSynchronize(j->ev_run));
+    if (j->down_pending)
+        HIP_TRY(hipEventSynchronize(j->ev_down));
+    j->up_pending = false;
+    j->down_pending = false;
+    return P2P_OK;
+}
+
+int p2p_job_get_views(p2p_job* j, int index, uint8_t* out)
+{
+    int rc = p2p_job_get_views_async(j, index, out);
+    if (rc != P2P_OK)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream_down));
+    j->down_pending = false;
     return P2P_OK;
 }
 

@@ -34,6 +34,10 @@ if __package__ in (None, ""):  # executed as a script: make the sibling module i
     import _native  # type: ignore
 else:
     from . import _native
+try:
+    from . import _driver
+except ImportError:  # executed as a script
+    import _driver  # type: ignore
 
 VERSION = "0.3.2"  # the reference release this file mirrors (P:20)
 
@@ -222,25 +226,72 @@ def process_single_image(
                            output_height, num_workers, output_format, fov_deg)
 
 
-def _submit_views(executor, input_image, input_image_path, output_dir, yaw_angles, pitch_angles, output_width,
-                  output_height, output_format, fov_deg, device=None):
-    """One kernel launch for every yaw and pitch of the image, then one write task per yaw on `executor`.
+def _views_of(input_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg, device=None):
+    """Every view of one image.  With several devices selected (set_devices) and this single image to draw, the
+    (yaw x pitch) views are dealt round-robin, pitch-major, to all of them; otherwise one device."""
+    if device is None and _DEVICES and len(_DEVICES) > 1:
+        return _driver.process_views_sharded(input_image, [_angle(y, "yaw angle") for y in yaw_angles],
+                                             [_angle(p, "pitch angle") for p in pitch_angles], output_width,
+                                             output_height, _angle(fov_deg, "FOV"), _DEVICES)
+    if device is None:
+        return process_views(input_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg)
+    return process_views(input_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg, device=device)
+
+
+class _SyncPipeline:
+    """The folder walk's device stage without overlap: one synchronous call per image (P2P_PIPELINE=0, and what the
+    host-logic tests substitute)."""
+
+    slots = (None,)
+
+    def __init__(self, device=None):
+        self.device = device
+
+    def submit(self, pano, yaws, pitches, fov, ow, oh):
+        if self.device is None:
+            return process_views(pano, yaws, pitches, ow, oh, fov)
+        return process_views(pano, yaws, pitches, ow, oh, fov, device=self.device)
+
+    def close(self):
+        pass
+
+
+def _make_pipeline(device):
+    if os.environ.get("P2P_PIPELINE", "1") == "0":
+        return _SyncPipeline(device)
+    return _driver.DevicePipeline(_DEVICE if device is None else device)
+
+
+def _submit_writes(executor, views, input_image_path, output_dir, yaw_angles, pitch_angles, output_width,
+                   output_height, output_format):
+    """One write task per yaw on `executor` (the reference's parallel unit, P:252-265).  `views` is the array, a
+    ticket of the device pipeline (its download may still be in flight), or the exception that replaced them.
     Returns [(yaw_angle, future-or-exception)], to be drained with _drain_views."""
-    input_image_path = Path(input_image_path)
+    base_name = Path(input_image_path).stem
     output_dir = Path(output_dir)
-    base_name = input_image_path.stem
     yaw_angles = list(yaw_angles)
     try:
-        if device is None:
-            views = process_views(input_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg)
-        else:
-            views = process_views(input_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg,
-                                  device=device)
+        if isinstance(views, Exception):
+            raise views
+        if hasattr(views, "result"):
+            views = views.result()
     except Exception as e:  # the reference reports task failures per yaw and carries on (P:279-280)
         return [(yaw_angle, e) for yaw_angle in yaw_angles]
     return [(yaw_angle, executor.submit(_write_yaw, views[yi], yaw_angle, pitch_angles, base_name, output_width,
                                         output_height, output_format, output_dir))
             for yi, yaw_angle in enumerate(yaw_angles)]
+
+
+def _submit_views(executor, input_image, input_image_path, output_dir, yaw_angles, pitch_angles, output_width,
+                  output_height, output_format, fov_deg, device=None):
+    """One kernel launch for every yaw and pitch of the image, then one write task per yaw on `executor`."""
+    yaw_angles = list(yaw_angles)
+    try:
+        views = _views_of(input_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg, device)
+    except Exception as e:
+        views = e
+    return _submit_writes(executor, views, input_image_path, output_dir, yaw_angles, pitch_angles, output_width,
+                          output_height, output_format)
 
 
 def _drain_views(tasks):
@@ -311,34 +362,58 @@ def main(
 
         def run_share(image_files, device):
             # The reference walks the images one after the other (P:330-341) with the yaws of one image in
-            # parallel.  Same order of work here, as a pipeline: files are decoded a few ahead on helper threads,
-            # each image is one kernel launch, and its files are encoded by the shared writer pool while the
-            # next image is already being resampled; at most `depth` images are in flight.
+            # parallel.  Same order of work here, as a pipeline with every stage overlapped: files are decoded a
+            # few ahead on helper threads; the device keeps two images in flight (upload of image k+1 and download
+            # of image k-1 under the kernel of image k: _driver.DevicePipeline); the files of finished images are
+            # encoded by the shared writer pool, one task per yaw.
             from collections import deque
 
             depth = 3
             n_dec = max(1, min(depth, int(num_workers or 1)))
-            with ThreadPoolExecutor(max_workers=n_dec) as decoder, \
-                    ThreadPoolExecutor(max_workers=max(1, int(num_workers or 1))) as writers:
-                decoding = deque(decoder.submit(_imread_bgr, f) for f in image_files[:depth])
-                in_flight = deque()
-                for k, image_file in enumerate(image_files):
-                    decoded = decoding.popleft().result()
-                    if k + depth < len(image_files):
-                        decoding.append(decoder.submit(_imread_bgr, image_files[k + depth]))
-                    logging.info(f"Loading image: {image_file}")
-                    if decoded is None:
-                        logging.error(f"Failed to read image: {image_file}")
-                        continue
-                    in_flight.append(_submit_views(writers, decoded, image_file, output_dir, yaw_angles, pitch_angles,
-                                                   output_width, output_height, output_format, fov_deg, device))
-                    del decoded
-                    while len(in_flight) >= depth:
-                        _drain_views(in_flight.popleft())
-                while in_flight:
-                    _drain_views(in_flight.popleft())
+            yaws = [_angle(y, "yaw angle") for y in yaw_angles]
+            pitches = [_angle(p, "pitch angle") for p in pitch_angles]
+            pipe = _make_pipeline(device)
+            try:
+                with ThreadPoolExecutor(max_workers=n_dec) as decoder, \
+                        ThreadPoolExecutor(max_workers=max(1, int(num_workers or 1))) as writers:
+                    decoding = deque(decoder.submit(_imread_bgr, f) for f in image_files[:depth])
+                    on_device, writing = deque(), deque()
 
-        if _DEVICES and len(_DEVICES) > 1:
+                    def retire(n_keep):
+                        while len(on_device) > n_keep:
+                            ticket, image_file = on_device.popleft()
+                            writing.append(_submit_writes(writers, ticket, image_file, output_dir, yaw_angles,
+                                                          pitch_angles, output_width, output_height, output_format))
+                            while len(writing) >= depth:
+                                _drain_views(writing.popleft())
+
+                    for k, image_file in enumerate(image_files):
+                        decoded = decoding.popleft().result()
+                        if k + depth < len(image_files):
+                            decoding.append(decoder.submit(_imread_bgr, image_files[k + depth]))
+                        logging.info(f"Loading image: {image_file}")
+                        if decoded is None:
+                            logging.error(f"Failed to read image: {image_file}")
+                            continue
+                        try:
+                            ticket = pipe.submit(decoded, yaws, pitches, _angle(fov_deg, "FOV"), output_width, output_height)
+                        except Exception as e:
+                            ticket = e
+                        on_device.append((ticket, image_file))
+                        del decoded
+                        retire(len(pipe.slots) - 1)
+                    retire(0)
+                    while writing:
+                        _drain_views(writing.popleft())
+            finally:
+                pipe.close()
+
+        if _DEVICES and len(_DEVICES) > 1 and len(all_images) < len(_DEVICES):
+            # fewer images than GPUs: every image is drawn by all of them, its views dealt round-robin
+            logging.info(f"Dealing the views of each of {len(all_images)} images to devices {_DEVICES}")
+            for image_file in all_images:
+                process_single_image(input_image_path=image_file, **common)
+        elif _DEVICES and len(_DEVICES) > 1:
             # one host thread per GPU, images dealt round-robin, nothing exchanged between devices
             shares = [(all_images[i::len(_DEVICES)], d) for i, d in enumerate(_DEVICES)]
             shares = [(files, d) for files, d in shares if files]

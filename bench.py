@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on MI355X: Mpix/s remapped, 8K equirect -> 1080p x 36 views.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg1|cfg4|cfg5] [--maps fused|caller]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg1|cfg4|cfg5] [--scaling weak|strong]
 
 A "step" is one pass of the hot path over one batch of synthetic input: every (yaw, pitch) view of
 the rank's resident panorama(s), i.e. one launch of remap_views_kernel.  Inputs are resident in HBM
 before the timed region; outputs stay in HBM.  With N > 1 (launched by torch.distributed.run, one
-rank per GPU) every rank owns its own panorama(s) and view set -- the (image x yaw x pitch) batch is
-independent work, so there is NO data-path collective; torch.distributed (RCCL) is used only for the
-barrier and the max-over-ranks of the elapsed time.  value = pixels all ranks produced / that time.
+rank per GPU) the (image x yaw x pitch) batch is dealt to the ranks -- by default config 3's 64
+panoramas, 64 / N resident per GPU ("strong": the batch is fixed); --scaling strong on a
+single-panorama workload deals its views instead; --scaling weak gives every rank panoramas of its
+own.  It is independent work, so there is NO data-path collective; torch.distributed (RCCL) is used
+only for the barrier and the max-over-ranks of the elapsed time.  value = pixels of the whole job / that time.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     -- algorithmic bytes of one launch / mean launch duration (HIP events around every
@@ -39,6 +41,10 @@ WORKLOADS = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on
     "cfg2": dict(pw=8192, ph=4096, ow=1920, oh=1080, fov=90, yaws=list(range(0, 360, 30)), pitches=[60, 90, 120],
                  name="8192x4096 pano -> 1920x1080, FOV 90, 12 yaw x 3 pitch = 36 views"),
+    # BASELINE.json configs[2]: 64 panoramas x the config-2 view set, sharded over the ranks (64 / N resident per GPU)
+    "cfg3": dict(pw=8192, ph=4096, ow=1920, oh=1080, fov=90, yaws=list(range(0, 360, 30)), pitches=[60, 90, 120],
+                 n_panos_total=64,
+                 name="64 panos 8192x4096 -> 1920x1080 x 36 views each, panoramas dealt round-robin to the GPUs"),
     "cfg1": dict(pw=2048, ph=1024, ow=512, oh=512, fov=90, yaws=[0], pitches=[90],
                  name="2048x1024 pano -> one 512x512 view, FOV 90 yaw 0 pitch 90"),
     "cfg4": dict(pw=16384, ph=8192, ow=4096, oh=4096, fov=60, yaws=list(range(0, 360, 5)), pitches=[30, 60, 90, 120, 150],
@@ -106,8 +112,9 @@ class Dist:
 
 
 def shard_round_robin(n_items, world, rank):
-    """Items (panoramas, or views when there are fewer panoramas than GPUs) dealt round-robin."""
-    return list(range(rank, n_items, world))
+    """Items (panoramas, or views when there are fewer panoramas than GPUs) dealt round-robin -- the product's own
+    dealing function (360-to-planer-images_amd/_driver.py), which needs no GPU to import."""
+    return importlib.import_module(PKG + "._driver").shard_round_robin(n_items, world, rank)
 
 
 def run_timed(step, device_sync, dist, steps, warmup):
@@ -197,6 +204,7 @@ def measure_counters(args):
     kernel = "remap_views_kernel" if args.pixel_path == "u8" else "float_views_kernel"
     base = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2", "--no-preroll", "--no-cpu-baseline",
             "--counters", "none", "--workload", args.workload, "--panos-per-gpu", str(args.panos_per_gpu),
+            "--scaling", args.scaling,
             "--maps", args.maps, "--kind", args.kind, "--pixel-path", args.pixel_path]
     vals = {}
     tmp = tempfile.mkdtemp(prefix="p2p_pmc_")
@@ -256,8 +264,15 @@ def main():
     ap.add_argument("--steps", type=int, default=2000,
                     help="timed launches (default 2000 = 0.3 s of GPU time on config 2: long enough for the clock to settle)")
     ap.add_argument("--warmup", type=int, default=300)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--panos-per-gpu", type=int, default=1)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: cfg2 at --gpus 1 (the configuration the metric is quoted on); cfg3 at --gpus N > 1 "
+                         "(the 64-panorama batch, 64 / N panoramas resident per GPU: SURVEY 8(e) reads scaling there)")
+    ap.add_argument("--panos-per-gpu", type=int, default=None,
+                    help="panoramas resident per GPU (default 1; cfg3: its share of the 64)")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="weak: every rank gets --panos-per-gpu panoramas of its own (default for cfg2 / cfg4 / cfg5); "
+                         "strong: the workload's total is split -- cfg3's 64 panoramas dealt to the ranks (its default), "
+                         "or, for a single-panorama workload, its (yaw x pitch) views dealt round-robin, pitch-major")
     ap.add_argument("--maps", default="fused", choices=["fused", "caller"],
                     help="fused: coordinate maps computed in-kernel (default, the product path); "
                          "caller: float maps handed in (the bit-exact mode)")
@@ -282,6 +297,12 @@ def main():
     args = ap.parse_args()
     if args.no_preroll:
         args.preroll_s = 0.0
+    if args.workload is None:
+        args.workload = "cfg2" if args.gpus == 1 else "cfg3"
+    if args.scaling is None:
+        args.scaling = "strong" if "n_panos_total" in WORKLOADS[args.workload] else "weak"
+    if args.panos_per_gpu is None:
+        args.panos_per_gpu = 1
     counters = None
     mode = args.counters
     if mode == "auto":
@@ -305,20 +326,50 @@ def main():
     pkg = importlib.import_module(PKG)
     nat = pkg._native
     synth = importlib.import_module(PKG + ".synth")
+    drv = importlib.import_module(PKG + "._driver")
     w = WORKLOADS[args.workload]
-    npg = args.panos_per_gpu
-    views_per_rank = npg * len(w["yaws"]) * len(w["pitches"])
-
+    flags = (nat.FLAG_CACHE_COORDS if args.cache_coords else 0) | \
+        {"u8": 0, "f32": nat.FLAG_PIXELS_F32, "f16": nat.FLAG_PIXELS_F16}[args.pixel_path]
+    n_yaw, n_pitch = len(w["yaws"]), len(w["pitches"])
     ctx = nat.Context(dist.local_rank)
-    job = nat.Job(ctx, w["pw"], w["ph"], npg, w["yaws"], w["pitches"], w["fov"], w["ow"], w["oh"],
-                  flags=(nat.FLAG_CACHE_COORDS if args.cache_coords else 0) |
-                        {"u8": 0, "f32": nat.FLAG_PIXELS_F32, "f16": nat.FLAG_PIXELS_F16}[args.pixel_path])
-    for i in range(npg):
+    jobs = []          # what one step launches on this rank
+    sharding = None
+    if args.scaling == "strong" and "n_panos_total" in w:
+        # config 3: the batch's panoramas dealt round-robin to the ranks, each rank keeps its share resident
+        mine = shard_round_robin(w["n_panos_total"], dist.world, dist.rank)
+        npg, total_views = len(mine), w["n_panos_total"] * n_yaw * n_pitch
+        seeds = [1000 + i for i in mine]
+        sharding = "%d panoramas dealt round-robin, %d resident per GPU, no collective" % (w["n_panos_total"], npg)
+        if npg:
+            jobs.append(nat.Job(ctx, w["pw"], w["ph"], npg, w["yaws"], w["pitches"], w["fov"], w["ow"], w["oh"], flags=flags))
+        views_per_rank = npg * n_yaw * n_pitch
+    elif args.scaling == "strong":
+        # one panorama, its (yaw x pitch) views dealt round-robin, pitch-major (36 views on 8 GPUs
+        # = 4 or 5 each, a 7.2x cap); every rank uploads the panorama once, its groups share it
+        groups = drv.shard_views(n_yaw, n_pitch, dist.world, dist.rank)
+        npg, total_views, seeds = 1, n_yaw * n_pitch, [1000]
+        for pi, yis in sorted(groups.items()):
+            j = nat.Job(ctx, w["pw"], w["ph"], 1, [w["yaws"][y] for y in yis], [w["pitches"][pi]], w["fov"], w["ow"], w["oh"], flags=flags)
+            if jobs:
+                j.share_panos(jobs[0])
+            jobs.append(j)
+        views_per_rank = sum(len(v) for v in groups.values())
+        sharding = "views of one panorama dealt round-robin pitch-major, %d on this rank in %d launches, no collective" % (views_per_rank, len(jobs))
+    else:
+        npg = args.panos_per_gpu
+        total_views = npg * n_yaw * n_pitch * dist.world
         # weak scaling: panorama index = rank * panos_per_gpu + i, seed 1000 + index
-        job.set_pano(i, synth.synth_pano(w["pw"], w["ph"], 1000 + dist.rank * npg + i, args.kind))
+        seeds = [1000 + dist.rank * npg + i for i in range(npg)]
+        jobs.append(nat.Job(ctx, w["pw"], w["ph"], npg, w["yaws"], w["pitches"], w["fov"], w["ow"], w["oh"], flags=flags))
+        views_per_rank = npg * n_yaw * n_pitch
+        sharding = "independent panoramas per rank, no collective"
+    job = jobs[0] if jobs else None
+    for i, seed in enumerate(seeds if jobs else []):
+        jobs[0].set_pano(i, synth.synth_pano(w["pw"], w["ph"], seed, args.kind))
     if args.maps == "caller":
         import numpy as np  # float maps from the library's own device map builders, handed back in
 
+        assert len(jobs) == 1 and args.scaling != "strong", "--maps caller is a single-job mode"
         rows = np.stack([nat.build_yaw_row(w["pw"], float(np.radians(y)), dist.local_rank) for y in w["yaws"]])
         UV = [nat.build_pitch_map(w["ow"], w["oh"], float(np.radians(w["fov"])), float(np.radians(p)),
                                   w["pw"], w["ph"], dist.local_rank) for p in w["pitches"]]
@@ -333,13 +384,15 @@ def main():
     # ~2 us launch-to-launch boundary).  Per-launch event pairs -- two more event records per launch -- are
     # switched off inside the region and used afterwards on a short sample to report the spread.
     steps = args.steps
-    job.time_launches(False)
+    for j in jobs:
+        j.time_launches(False)
     state = {"n": 0}
 
     def step():
         if state["n"] == args.warmup:
             ctx.mark(0)
-        job.run()
+        for j in jobs:
+            j.run()
         state["n"] += 1
         if state["n"] == args.warmup + steps:
             ctx.mark(1)
@@ -350,18 +403,22 @@ def main():
     preroll_launches, t_pre = 0, time.perf_counter()
     while time.perf_counter() - t_pre < args.preroll_s:
         for _ in range(50):
-            job.run()
+            for j in jobs:
+                j.run()
         ctx.synchronize()
         preroll_launches += 50
     preroll_s = time.perf_counter() - t_pre if preroll_launches else 0.0
     elapsed = run_timed(step, device_sync, dist, steps, args.warmup)
     sclk_after = read_sclk_mhz()
-    k_avg_s = ctx.marked_ms() / steps / 1e3
-    job.time_launches(True)
+    k_avg_s = ctx.marked_ms() / steps / 1e3  # all of this rank's launches of one step
+    import numpy as np
     sample = min(32, steps)
-    for _ in range(sample):
-        job.run()
-    kms = job.kernel_ms_last(sample)
+    kms = np.zeros(sample, np.float32)
+    for j in jobs:
+        j.time_launches(True)
+        for _ in range(sample):
+            j.run()
+        kms = kms + j.kernel_ms_last(sample)
 
     # what a plain device-to-device copy reaches on this GPU right now (read + written bytes per second):
     # the practical ceiling next to the 8 TB/s specification peak
@@ -382,9 +439,10 @@ def main():
     except Exception:
         pass
 
-    pix_per_step = views_per_rank * w["ow"] * w["oh"] * dist.world
+    pix_per_step = total_views * w["ow"] * w["oh"]
     value = pix_per_step * steps / elapsed / 1e6
-    b_alg = algorithmic_bytes(w, npg)
+    # this rank's share: its resident panoramas read once, its views written once
+    b_alg = 3 * w["pw"] * w["ph"] * (npg if jobs else 0) + 3 * w["ow"] * w["oh"] * views_per_rank
     achieved = b_alg / k_avg_s / 1e9
     if mode == "measure":
         tr = traffic_from_counters(counters)
@@ -399,7 +457,6 @@ def main():
     if counters and "SQ_INSTS_VALU" in counters:
         px = views_per_rank * w["ow"] * w["oh"]
         # SQ counters on gfx950 sample a share of the waves (SQ_WAVES says how many): scale by launched / sampled
-        tiles = -(-w["ow"] // 64) * -(-w["oh"] // 16) * len(w["pitches"])
         waves = counters.get("SQ_WAVES")
         busy = counters.get("SQ_BUSY_CU_CYCLES")
         valu = {"SQ_INSTS_VALU": counters["SQ_INSTS_VALU"], "SQ_INSTS_SALU": counters.get("SQ_INSTS_SALU"),
@@ -414,10 +471,11 @@ def main():
         "metric": "Mpix/s remapped, 8K equirect->1080p x36 views" if args.workload == "cfg2"
                   else "Mpix/s remapped (%s)" % args.workload,
         "value": value, "unit": "Mpix/s", "n_gpus": dist.world, "steps": steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": args.pixel_path, "data": "synthetic",
         "config": {"workload": w["name"], "panos_per_gpu": npg, "views_per_gpu": views_per_rank,
-                   "maps": args.maps + ("+coordinate cache" if args.cache_coords else ""), "pano_kind": args.kind, "sharding": "independent panoramas per rank, no collective"},
+                   "maps": {"fused": "device plan (evaluated once per job geometry, like the reference's pitch_mapping_cache)",
+                            "caller": "caller float maps (plan built from them once)"}[args.maps], "pano_kind": args.kind, "sharding": sharding, "launches_per_step": len(jobs)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_how": traffic_how, "valu": valu,
                      "kernel": "remap_views_kernel" if args.pixel_path == "u8" else "float_views_kernel", "kernel_ms_avg": k_avg_s * 1e3,
@@ -433,7 +491,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(w)
     elif dist.rank == 0:
         out["cpu_baseline"] = None
-    job.close()
+    for j in reversed(jobs):
+        j.close()
     ctx.close()
     dist.close()
     if dist.rank == 0:

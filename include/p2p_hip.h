@@ -198,6 +198,16 @@ void p2p_job_destroy(p2p_job* job);
 /* H2D copy of panorama `index` (uint8 [ph][pw][3]) on the job's stream; returns once the host buffer may
    be reused or freed. */
 int p2p_job_set_pano(p2p_job* job, int index, const uint8_t* pano, int64_t row_stride);
+/* The same without waiting (cv2.imread of the NEXT image, P:244, overlaps the resampling of this one): the copy runs
+   on the context's upload stream behind the job's last kernel; `pano` must stay valid and unchanged until
+   p2p_job_wait / p2p_ctx_synchronize.  The job's next p2p_job_run waits for it on the device, not on the host.
+   A driver that keeps TWO jobs per device and alternates them gets upload k+1 and download k-1 under kernel k. */
+int p2p_job_set_pano_async(p2p_job* job, int index, const uint8_t* pano, int64_t row_stride);
+/* Let `job` read the device panoramas of `owner` (same context, panorama size and count) instead of holding a copy
+   of its own: the reference shares ONE pano_image among its per-yaw tasks (P:252-265); a device that draws several
+   (pitch, yaw subset) groups of one image -- the view-sharded multi-GPU path -- uploads it once.  `owner` must
+   outlive `job`; panoramas are set on the owner. */
+int p2p_job_share_panos(p2p_job* job, p2p_job* owner);
 /* Replace the job's yaw list (same count as at creation) and rebuild its column tables -- the key change
    the reference's yaw_mapping_cache sees between two process_yaw_and_pitchs calls on one image size
    (P:42-52: key (pano_width, pano_height, yaw_angle)); panoramas and pitch constants stay resident. */
@@ -210,6 +220,12 @@ int p2p_job_set_maps(p2p_job* job, const float* yaw_rows, const float* U, const 
 int p2p_job_run(p2p_job* job);
 /* Wait, then copy all views of panorama `index` to host: uint8 [n_yaw][n_pitch][oh][ow][3]. */
 int p2p_job_get_views(p2p_job* job, int index, uint8_t* out);
+/* The same without waiting (cv2.imwrite of image k, P:277, overlaps the resampling of image k+1): the copy runs on
+   the context's download stream behind the job's last run; `out` is complete after p2p_job_wait /
+   p2p_ctx_synchronize.  The job's next run waits for the copy on the device. */
+int p2p_job_get_views_async(p2p_job* job, int index, uint8_t* out);
+/* Wait for everything the job has in flight: uploads, its last run, downloads. */
+int p2p_job_wait(p2p_job* job);
 /* By default every p2p_job_run brackets its kernel with its own HIP event pair (p2p_job_kernel_ms*); on = 0
    turns that off (two event records less per launch), on = 1 back on.  Either call restarts the history. */
 int p2p_job_time_launches(p2p_job* job, int on);

@@ -234,3 +234,71 @@ def test_pinned_budget_falls_back_to_ordinary_arrays(gpu, synth, monkeypatch):
     assert np.array_equal(got, want)
     with pytest.raises(MemoryError):
         gpu.pinned_empty((1 << 20,))
+
+
+def test_view_sharded_path_two_contexts_on_one_device(gpu, pkg, synth):
+    """SURVEY 8(e) / P:252-265: with fewer images than GPUs the views of an image are dealt to the devices.  Two
+    contexts on device 0 stand in for two GPUs: the stitched result equals the single-device one byte for byte."""
+    import importlib
+    d = importlib.import_module("360-to-planer-images_amd._driver")
+    pano = synth.synth_pano(2048, 1024, 3100, "N")
+    yaws, pitches = list(range(0, 360, 30)), [60, 90, 120]
+    one = pkg.process_views(pano, yaws, pitches, 320, 180, 90)
+    for devices in ([0, 0], [0, 0, 0, 0, 0, 0, 0, 0], [0]):
+        got = d.process_views_sharded(pano, yaws, pitches, 320, 180, 90.0, devices)
+        assert np.array_equal(got, one), devices
+    # through the tool: a single image with --devices 0 0
+    m = pkg.panorama_to_plane_pitch
+    m.set_devices([0, 0])
+    try:
+        got = m._views_of(pano, yaws, pitches, 320, 180, 90)
+    finally:
+        m.set_devices(None)
+    assert np.array_equal(got, one)
+
+
+def test_asynchronous_copies_and_two_slot_pipeline(gpu, pkg, synth):
+    """p2p_job_set_pano_async / p2p_job_get_views_async: upload of image k+1 and download of image k-1 run on their
+    own streams around kernel k; the device-side ordering must give exactly the synchronous results."""
+    import importlib
+    d = importlib.import_module("360-to-planer-images_amd._driver")
+    yaws, pitches = [0, 30, 77], [60, 120]
+    panos = [synth.synth_pano(1024, 512, 3200 + i, "N") for i in range(7)]
+    want = [pkg.process_views(p, yaws, pitches, 200, 120, 90) for p in panos]
+    pipe = d.DevicePipeline(0)
+    tickets = [pipe.submit(p, yaws, pitches, 90.0, 200, 120) for p in panos]  # 7 images through 2 slots
+    for t, w in zip(tickets, want):
+        assert np.array_equal(t.result(), w)
+    # a geometry change re-creates the slot's job
+    t = pipe.submit(panos[0], [5], [90], 90.0, 64, 48)
+    assert np.array_equal(t.result(), pkg.process_views(panos[0], [5], [90], 64, 48, 90))
+    pipe.close()
+    # raw API: one job, asynchronous upload, run, asynchronous download, then the next image into the same job
+    ctx = gpu.Context(0)
+    job = gpu.Job(ctx, 1024, 512, 1, yaws, pitches, 90, 200, 120)
+    outs = []
+    for p in panos[:3]:
+        job.set_pano(0, p, wait=False)
+        job.run()
+        outs.append(job.get_views_async(0))
+    job.wait()
+    for o, w in zip(outs, want):
+        assert np.array_equal(o, w)
+    job.close()
+    ctx.close()
+
+
+def test_folder_walk_through_the_device_pipeline(gpu, pkg, synth, tmp_path):
+    from PIL import Image
+    m = pkg.panorama_to_plane_pitch
+    (tmp_path / "in").mkdir()
+    panos = [synth.synth_pano(512, 256, 3300 + i, "S") for i in range(5)]
+    for i, p in enumerate(panos):
+        Image.fromarray(np.ascontiguousarray(p[:, :, ::-1])).save(tmp_path / "in" / f"img{i}.png")
+    m.main(str(tmp_path / "in"), str(tmp_path / "out"), [0, 90], [60, 90], 96, 64, num_workers=4)
+    for i, p in enumerate(panos):
+        want = pkg.process_views(p, [0, 90], [60, 90], 96, 64, 90)
+        for yi, y in enumerate((0, 90)):
+            for pi, pt in enumerate((60, 90)):
+                got = np.asarray(Image.open(tmp_path / "out" / f"img{i}_96x64_yaw_{y}_pitch_{pt}.png"))[:, :, ::-1]
+                assert np.array_equal(got, want[yi, pi]), (i, y, pt)

@@ -1,6 +1,7 @@
 """Host-side logic that needs no GPU: the C ABI surface, the Python mirror of the reference's
 interface (names, defaults, validators, file naming, error swallowing) and loud failure without a device."""
 import argparse
+import importlib
 import inspect
 import logging
 import os
@@ -135,6 +136,7 @@ def test_file_naming_and_error_swallowing(pkg, tmp_path, monkeypatch, caplog):
         return np.zeros((len(yaws), len(pitches), oh, ow, 3), np.uint8)
 
     monkeypatch.setattr(m, "process_views", fake_views)
+    monkeypatch.setattr(m, "_make_pipeline", m._SyncPipeline)  # the folder walk without a device
     out = tmp_path / "out"
     with caplog.at_level(logging.INFO):
         m.main(str(tmp_path / "in"), str(out), [0, 90], [60, 120], 8, 6, num_workers=2, output_format="jpg", fov_deg=75)
@@ -201,6 +203,7 @@ def test_multi_device_round_robin_of_a_folder(pkg, tmp_path, monkeypatch):
         return np.zeros((len(yaws), len(pitches), oh, ow, 3), np.uint8)
 
     monkeypatch.setattr(m, "process_views", fake_views)
+    monkeypatch.setattr(m, "_make_pipeline", m._SyncPipeline)
     m.set_devices([0, 1, 2])
     try:
         m.main(str(tmp_path / "in"), str(tmp_path / "out"), [0], [90], 8, 8, num_workers=2)
@@ -214,3 +217,21 @@ def test_multi_device_round_robin_of_a_folder(pkg, tmp_path, monkeypatch):
     for d, lst in by_dev.items():
         assert len({tid for _, tid in lst}) == 1  # one host thread per device
     assert len(list((tmp_path / "out").iterdir())) == 7
+
+
+def test_view_sharding_pitch_major_round_robin(pkg):
+    """with fewer images than GPUs the (yaw x pitch) views of an image are dealt round-robin,
+    pitch-major; every view exactly once, shares differ by at most one view, few pitch groups per device."""
+    d = importlib.import_module("360-to-planer-images_amd._driver")
+    for n_yaw, n_pitch, world in ((12, 3, 8), (12, 3, 2), (4, 5, 8), (1, 1, 8), (360, 1, 8), (7, 3, 5)):
+        seen, sizes = set(), []
+        for r in range(world):
+            g = d.shard_views(n_yaw, n_pitch, world, r)
+            views = [(p, y) for p, ys in g.items() for y in ys]
+            assert not (seen & set(views))
+            seen |= set(views)
+            sizes.append(len(views))
+        assert seen == {(p, y) for p in range(n_pitch) for y in range(n_yaw)}
+        assert max(sizes) - min(sizes) <= 1
+    # config 2 on 8 GPUs: 36 views -> 4 or 5 per device; the 7.2x cap of SURVEY 8(e)
+    assert sorted(sum(len(v) for v in d.shard_views(12, 3, 8, r).values()) for r in range(8)) == [4] * 4 + [5] * 4
