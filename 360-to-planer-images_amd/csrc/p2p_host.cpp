@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -133,42 +134,101 @@ int use_device(int device)
 
 bool dims_ok(int w, int h) { return w >= 1 && h >= 1 && w < 32767 && h < 32767; }
 
-// one context per (thread, device) for the one-shot entry points, plus the job of the last one-shot
-// call on that device (the reference keeps its maps for the life of the process, P:17-18)
-struct ThreadCtxs {
-    std::map<int, p2p_ctx*> m;
-    std::map<int, p2p_job*> cached;
-    void drop_cached()
-    {
-        for (auto& kv : cached)
-            p2p_job_destroy(kv.second);
-        cached.clear();
-    }
-    ~ThreadCtxs()
-    {
-        drop_cached();
-        for (auto& kv : m)
-            p2p_ctx_destroy(kv.second);
-    }
+// The one-shot entry points run on a small pool of contexts per device (P2P_ONESHOT_SLOTS, default 4), not on
+// one per calling thread: the reference fans process_yaw_and_pitchs out to int(0.9 * cores) threads (P:252-265,
+// P:304-306) -- 230 on a 256-core host -- and one stream plus one cached job (a device copy of the panorama, the
+// views, the plan) per thread would be hundreds of streams and tens of GB.  A caller takes an idle slot
+// (preferring one whose cached job has its geometry: the reference keeps its maps for the life of the process,
+// P:17-18), waits if all are busy, and gives it back.  The pool is never torn down at exit: no HIP call runs
+// after the runtime's own shutdown, the OS reclaims the memory; p2p_release_cache() frees it on request.
+struct OneShotSlot {
+    int device = 0;
+    bool busy = false;
+    p2p_ctx* ctx = nullptr;
+    p2p_job* cached = nullptr;
 };
-thread_local ThreadCtxs g_tctx;
 
-int thread_ctx(int device, p2p_ctx** out)
+struct OneShotPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<OneShotSlot*> slots;
+};
+
+OneShotPool& pool()
 {
-    auto it = g_tctx.m.find(device);
-    if (it != g_tctx.m.end()) {
-        HIP_TRY(hipSetDevice(device));
-        *out = it->second;
-        return P2P_OK;
-    }
-    p2p_ctx* c = nullptr;
-    int rc = p2p_ctx_create(device, &c);
+    static OneShotPool* p = new OneShotPool();  // intentionally never destroyed (see above)
+    return *p;
+}
+
+// `wants(job)` says whether a slot's cached job can be re-used as is
+template <class F>
+int slot_acquire(int device, F wants, OneShotSlot** out)
+{
+    *out = nullptr;
+    int rc = use_device(device);
     if (rc != P2P_OK)
         return rc;
-    g_tctx.m[device] = c;
-    *out = c;
-    return P2P_OK;
+    const int max_slots = std::max(1, env_int("P2P_ONESHOT_SLOTS", 4));
+    OneShotPool& P = pool();
+    std::unique_lock<std::mutex> lk(P.mu);
+    for (;;) {
+        OneShotSlot* idle = nullptr;
+        int n_dev = 0;
+        for (OneShotSlot* s : P.slots) {
+            if (s->device != device)
+                continue;
+            ++n_dev;
+            if (s->busy)
+                continue;
+            if (s->cached && wants(s->cached)) {
+                idle = s;
+                break;
+            }
+            if (!idle || (idle->cached && !s->cached))
+                idle = s;  // otherwise prefer a slot that holds nothing
+        }
+        if (!idle && n_dev < max_slots) {
+            idle = new (std::nothrow) OneShotSlot();
+            if (!idle)
+                return fail(P2P_ERR_OOM, "host allocation failed");
+            idle->device = device;
+            P.slots.push_back(idle);
+        }
+        if (idle) {
+            idle->busy = true;
+            lk.unlock();
+            if (!idle->ctx) {
+                rc = p2p_ctx_create(device, &idle->ctx);
+                if (rc != P2P_OK) {
+                    lk.lock();
+                    idle->busy = false;
+                    P.cv.notify_one();
+                    return rc;
+                }
+            } else {
+                (void)hipSetDevice(device);
+            }
+            *out = idle;
+            return P2P_OK;
+        }
+        P.cv.wait(lk);
+    }
 }
+
+void slot_release(OneShotSlot* s)
+{
+    OneShotPool& P = pool();
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        s->busy = false;
+    }
+    P.cv.notify_one();
+}
+
+struct SlotGuard {  // gives the slot back on every return path
+    OneShotSlot* s = nullptr;
+    ~SlotGuard() { if (s) slot_release(s); }
+};
 
 int choose_pairs_per_block(const p2p_job_desc& d)
 {
@@ -881,7 +941,19 @@ int p2p_host_free(void* ptr)
 
 int p2p_release_cache(void)
 {
-    g_tctx.drop_cached();
+    // every idle slot's cached job (busy ones belong to calls in flight on other threads)
+    OneShotPool& P = pool();
+    std::vector<p2p_job*> victims;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        for (OneShotSlot* s : P.slots)
+            if (!s->busy && s->cached) {
+                victims.push_back(s->cached);
+                s->cached = nullptr;
+            }
+    }
+    for (p2p_job* j : victims)
+        p2p_job_destroy(j);
     return P2P_OK;
 }
 
@@ -906,10 +978,6 @@ static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride
         return fail(P2P_ERR_INVALID, "NULL image pointer");
     if (n_yaw == 0 || n_pitch == 0)
         return P2P_OK;
-    p2p_ctx* ctx = nullptr;
-    int rc = thread_ctx(device, &ctx);
-    if (rc != P2P_OK)
-        return rc;
     std::vector<double> dummy_yaw, dummy_pitch;
     if (!yaw_deg) {  // caller-supplied rows: degrees are irrelevant
         dummy_yaw.assign(n_yaw, 0.0);
@@ -925,29 +993,34 @@ static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride
     d.n_pitch = n_pitch; d.pitch_deg = pitch_deg;
     d.fov_deg = fov_deg; d.ow = ow; d.oh = oh; d.flags = flags;
 
-    // the job of the previous one-shot call on this thread and device, if its geometry matches
-    p2p_job* j = nullptr;
-    auto it = g_tctx.cached.find(device);
-    if (it != g_tctx.cached.end()) {
-        p2p_job* c = it->second;
+    // a slot of the one-shot pool, preferably one whose cached job has this call's geometry
+    auto same_geometry = [&](const p2p_job* c) {
         const p2p_job_desc& k = c->d;
-        const bool same = k.pw == pw && k.ph == ph && k.n_yaw == n_yaw && k.n_pitch == n_pitch &&
-                          c->fov == fov_deg && k.ow == ow && k.oh == oh && k.flags == flags &&
-                          c->border == border && c->host_maps == (U != nullptr) &&
-                          std::equal(c->pitch.begin(), c->pitch.end(), pitch_deg);
-        if (same) {
+        return k.pw == pw && k.ph == ph && k.n_yaw == n_yaw && k.n_pitch == n_pitch && c->fov == fov_deg &&
+               k.ow == ow && k.oh == oh && k.flags == flags && c->border == border && c->host_maps == (U != nullptr) &&
+               std::equal(c->pitch.begin(), c->pitch.end(), pitch_deg);
+    };
+    SlotGuard guard;
+    int rc = slot_acquire(device, same_geometry, &guard.s);
+    if (rc != P2P_OK)
+        return rc;
+    OneShotSlot* slot = guard.s;
+    p2p_job* j = nullptr;
+    if (slot->cached) {
+        p2p_job* c = slot->cached;
+        if (same_geometry(c)) {
             j = c;
             // caller rows replace the tables below; otherwise rebuild them only when the yaws changed
             if (!yaw_rows && (c->rows_from_host || !std::equal(c->yaw.begin(), c->yaw.end(), yaw_deg)))
                 rc = p2p_job_set_yaws_f64(c, yaw_deg);
         } else {
             p2p_job_destroy(c);
-            g_tctx.cached.erase(it);
+            slot->cached = nullptr;
         }
     }
     const bool fresh = (j == nullptr);
     if (fresh) {
-        rc = p2p_job_create_f64(ctx, &d, &j);
+        rc = p2p_job_create_f64(slot->ctx, &d, &j);
         if (rc != P2P_OK)
             return rc;
         j->border = border;
@@ -966,10 +1039,9 @@ static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride
     const bool keep = rc == P2P_OK && env_int("P2P_ONESHOT_CACHE", 1) != 0 &&
                       held <= (size_t)env_int("P2P_ONESHOT_CACHE_MAX_MB", 4096) * 1048576ull;
     if (keep) {
-        g_tctx.cached[device] = j;
+        slot->cached = j;
     } else {
-        if (!fresh)
-            g_tctx.cached.erase(device);
+        slot->cached = nullptr;
         p2p_job_destroy(j);
     }
     return rc;
@@ -1045,10 +1117,11 @@ int p2p_remap_maps_interp_u8(const uint8_t* src, int sw, int sh, int64_t row_str
         return views_oneshot(src, sw, sh, row_stride, &yaw0, 1, nullptr, 1, 90.0, ow, oh, out, device, 0,
                              nullptr, U, V, border_mode);
     }
-    p2p_ctx* ctx = nullptr;
-    int rc = thread_ctx(device, &ctx);
+    SlotGuard guard;
+    int rc = slot_acquire(device, [](const p2p_job*) { return false; }, &guard.s);
     if (rc != P2P_OK)
         return rc;
+    p2p_ctx* ctx = guard.s->ctx;
     const int pitch = (sw * cn + 15) & ~15;
     const size_t n_map = (size_t)ow * oh;
     uint8_t *d_src = nullptr, *d_dst = nullptr;
@@ -1093,10 +1166,11 @@ int p2p_build_pitch_map(int ow, int oh, double fov_rad, double pitch_rad, int pw
         return fail(P2P_ERR_INVALID, "NULL pointer");
     if (!dims_ok(ow, oh) || pw < 1 || ph < 1)
         return fail(P2P_ERR_INVALID, "bad sizes");
-    p2p_ctx* ctx = nullptr;
-    int rc = thread_ctx(device, &ctx);
+    SlotGuard guard;
+    int rc = slot_acquire(device, [](const p2p_job*) { return false; }, &guard.s);
     if (rc != P2P_OK)
         return rc;
+    p2p_ctx* ctx = guard.s->ctx;
     p2p::MapGeom g{};
     g.half_w = (float)(ow / 2.0);
     g.half_h = (float)(oh / 2.0);
@@ -1126,10 +1200,11 @@ int p2p_build_rot_map(int ow, int oh, double fov_rad, const float* R9, int pw, i
         return fail(P2P_ERR_INVALID, "NULL pointer");
     if (!dims_ok(ow, oh) || pw < 1 || ph < 1)
         return fail(P2P_ERR_INVALID, "bad sizes");
-    p2p_ctx* ctx = nullptr;
-    int rc = thread_ctx(device, &ctx);
+    SlotGuard guard;
+    int rc = slot_acquire(device, [](const p2p_job*) { return false; }, &guard.s);
     if (rc != P2P_OK)
         return rc;
+    p2p_ctx* ctx = guard.s->ctx;
     p2p::MapGeom g{};
     g.half_w = (float)(ow / 2.0);
     g.half_h = (float)(oh / 2.0);
@@ -1157,10 +1232,11 @@ int p2p_build_yaw_row(int pw, double yaw_rad, float* U_row, int device)
         return fail(P2P_ERR_INVALID, "NULL pointer");
     if (pw < 1 || pw >= 32767)
         return fail(P2P_ERR_INVALID, "bad panorama width %d", pw);
-    p2p_ctx* ctx = nullptr;
-    int rc = thread_ctx(device, &ctx);
+    SlotGuard guard;
+    int rc = slot_acquire(device, [](const p2p_job*) { return false; }, &guard.s);
     if (rc != P2P_OK)
         return rc;
+    p2p_ctx* ctx = guard.s->ctx;
     const double yr = yaw_rad;  // np.radians(yaw_angle), P:85
     double* d_yr = nullptr;
     float* d_row = nullptr;

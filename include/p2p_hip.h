@@ -14,9 +14,9 @@
  * the library owns device memory, streams and events; every function returns
  * P2P_OK (0) or a negative p2p_status and never throws; p2p_last_error() gives a
  * thread-local message for the last failure on the calling thread.  All entry
- * points are re-entrant; the one-shot functions keep one device context per
- * calling thread, so the reference's ThreadPoolExecutor fan-out (P:252-265) can
- * call them concurrently on one shared panorama.
+ * points are re-entrant; the one-shot functions share a small pool of device
+ * contexts, so the reference's ThreadPoolExecutor fan-out (P:252-265) can call
+ * them concurrently on one shared panorama.
  *
  * There is no CPU fallback in this library: without a usable HIP device every
  * compute entry point fails with P2P_ERR_NO_DEVICE.
@@ -247,11 +247,15 @@ int p2p_job_get_yaw_tables(p2p_job* job, uint32_t* packed);
  *
  * The reference keeps its maps for the life of the process (yaw_mapping_cache / pitch_mapping_cache,
  * P:17-18) and lets NumPy / cv2.imread allocate pageable arrays (P:244, the slices cv2.remap returns at
- * P:212-218).  Here the one-shot entry points keep, per calling thread and device, the device buffers and
- * tables of the last call's geometry (panorama size, yaw count, pitch list, FOV, output size): a second
- * call with the same geometry re-uploads only the panorama (and rebuilds the yaw tables if the yaw values
- * changed).  P2P_ONESHOT_CACHE=0 in the environment turns this off; P2P_ONESHOT_CACHE_MAX_MB (default 4096)
- * bounds what is kept.  p2p_release_cache frees what the calling thread holds.
+ * P:212-218).  Here the one-shot entry points run on a small pool of device contexts (P2P_ONESHOT_SLOTS per
+ * device, default 4) shared by all calling threads -- the reference's fan-out is int(0.9 * cores) threads
+ * (P:304-306), and a stream plus device buffers per THREAD would not scale.  Each slot keeps the device buffers,
+ * tables and plan of the last call it served: a later call with the same geometry (panorama size, yaw count,
+ * pitch list, FOV, output size) is handed that slot, re-uploads only the panorama and rebuilds the yaw tables if
+ * the yaw values changed.  Callers beyond the pool size wait their turn.  P2P_ONESHOT_CACHE=0 turns the keeping
+ * off; P2P_ONESHOT_CACHE_MAX_MB (default 4096) bounds what one slot keeps, so a device holds at most
+ * slots x that.  p2p_release_cache frees what idle slots hold.  Nothing is torn down at process exit (no HIP
+ * call after the runtime's own shutdown).
  *
  * p2p_host_alloc returns page-locked host memory: panoramas decoded into it and views copied back into it
  * move by DMA at PCIe rate instead of through the runtime's pageable staging.

@@ -302,3 +302,49 @@ def test_folder_walk_through_the_device_pipeline(gpu, pkg, synth, tmp_path):
             for pi, pt in enumerate((60, 90)):
                 got = np.asarray(Image.open(tmp_path / "out" / f"img{i}_96x64_yaw_{y}_pitch_{pt}.png"))[:, :, ::-1]
                 assert np.array_equal(got, want[yi, pi]), (i, y, pt)
+
+
+def test_one_shot_pool_is_bounded_and_survives_many_threads(gpu, pkg, synth, monkeypatch):
+    """The reference's default fan-out is int(0.9 * cores) threads (P:304-306).  The one-shot entry points serve them
+    from P2P_ONESHOT_SLOTS contexts per device: results identical, callers beyond the pool wait."""
+    monkeypatch.setenv("P2P_ONESHOT_SLOTS", "2")
+    pano = synth.synth_pano(1024, 512, 3400, "N")
+    yaws = list(range(0, 360, 10))
+    want = pkg.process_views(pano, yaws, [60, 120], 96, 64)
+    with ThreadPoolExecutor(max_workers=48) as ex:
+        got = list(ex.map(lambda y: pkg.process_yaw_and_pitchs(pano, y, [60, 120], 96, 64), yaws))
+    for yi in range(len(yaws)):
+        assert np.array_equal(got[yi][0], want[yi, 0]) and np.array_equal(got[yi][1], want[yi, 1])
+    gpu.release_cache()
+    assert np.array_equal(pkg.process_views(pano, yaws[:2], [60], 96, 64)[1, 0], want[1, 0])
+
+
+def test_process_exit_with_live_caches_from_pool_threads(gpu, tmp_path):
+    """Cached one-shot jobs, streams and page-locked blocks are alive when the interpreter exits -- from pool
+    threads that finished, from a daemon thread that never will, and on sys.exit from the main thread.  Nothing is
+    torn down through HIP after the runtime's own shutdown: the process exits 0 without a crash."""
+    import subprocess
+    import sys
+    root = str(__import__("pathlib").Path(__file__).resolve().parent.parent)
+    code = r'''
+import importlib, sys, threading, time
+from concurrent.futures import ThreadPoolExecutor
+sys.path.insert(0, %r)
+import numpy as np
+p = importlib.import_module("360-to-planer-images_amd")
+pano = np.random.default_rng(0).integers(0, 256, (256, 512, 3), dtype=np.uint8)
+ex = ThreadPoolExecutor(max_workers=6)
+list(ex.map(lambda y: p.process_yaw_and_pitchs(pano, y, [90], 64, 48), range(0, 360, 30)))
+def forever():
+    while True:
+        p.process_yaw_and_pitchs(pano, 7, [60], 64, 48)
+threading.Thread(target=forever, daemon=True).start()
+time.sleep(0.2)
+print("alive", flush=True)
+sys.exit(int(sys.argv[1]))
+''' % root
+    for rc in (0, 3):
+        r = subprocess.run([sys.executable, "-c", code, str(rc)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == rc, (r.returncode, r.stderr[-1500:])
+        assert "alive" in r.stdout
+        assert "Segmentation" not in r.stderr and "core dumped" not in r.stderr
