@@ -28,6 +28,7 @@ FLAG_PIXEL_CENTRES = 16  # float paths only: sample through pixel centres (not t
 ABI_SYMBOLS = (
     "p2p_version", "p2p_last_error", "p2p_device_count",
     "p2p_remap_views_u8", "p2p_remap_views_f64", "p2p_remap_views_maps_u8", "p2p_remap_maps_u8", "p2p_remap_maps_interp_u8",
+    "p2p_remap_maps_batch_u8",
     "p2p_build_pitch_map", "p2p_build_yaw_row", "p2p_build_rot_map",
     "p2p_ctx_create", "p2p_ctx_destroy", "p2p_ctx_synchronize", "p2p_ctx_mark", "p2p_ctx_marked_ms",
     "p2p_job_time_launches",
@@ -88,6 +89,8 @@ def lib():
     L.p2p_remap_maps_u8.restype = c_int
     L.p2p_remap_maps_u8.argtypes = [c_vp, c_int, c_int, c_i64, c_int, c_vp, c_vp, c_int, c_int, c_vp,
                                     c_int, c_vp, c_int]
+    L.p2p_remap_maps_batch_u8.restype = c_int
+    L.p2p_remap_maps_batch_u8.argtypes = [c_vp, c_int, c_int, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int]
     L.p2p_remap_maps_interp_u8.restype = c_int
     L.p2p_remap_maps_interp_u8.argtypes = [c_vp, c_int, c_int, c_i64, c_int, c_vp, c_vp, c_int, c_int, c_vp,
                                            c_int, c_int, c_vp, c_int]
@@ -385,6 +388,21 @@ def remap_maps(src, U, V, border=BORDER_CONSTANT, border_value=None, device=0, i
                                          ow, oh, out.ctypes.data, int(interpolation), int(border),
                                          None if bv is None else bv.ctypes.data, int(device)))
     return out[:, :, 0] if squeeze else out
+
+
+def remap_maps_batch(src, U, V, border=BORDER_CONSTANT, device=0):
+    """p2p_remap_maps_batch_u8: cv2.remap(src, U[k], V[k], INTER_LINEAR, borderMode=border) for every k, one launch."""
+    src = as_image(src, "src")
+    sh, sw = src.shape[:2]
+    U = np.ascontiguousarray(U, dtype=np.float32)
+    V = np.ascontiguousarray(V, dtype=np.float32)
+    if U.ndim != 3 or U.shape != V.shape:
+        raise ValueError("U and V must both be [n_maps][oh][ow]")
+    n, oh, ow = U.shape
+    out = np.empty((n, oh, ow, 3), dtype=np.uint8)
+    check(lib().p2p_remap_maps_batch_u8(src.ctypes.data, sw, sh, src.strides[0], U.ctypes.data, V.ctypes.data,
+                                        n, ow, oh, out.ctypes.data, int(border), int(device)))
+    return out
 
 
 def debug_stamps(reset=True):

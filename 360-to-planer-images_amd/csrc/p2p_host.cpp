@@ -1090,6 +1090,23 @@ int p2p_remap_maps_u8(const uint8_t* src, int sw, int sh, int64_t row_stride, in
                                     border_mode, border_value, device);
 }
 
+int p2p_remap_maps_batch_u8(const uint8_t* src, int sw, int sh, int64_t row_stride,
+                            const float* U, const float* V, int n_maps, int ow, int oh, uint8_t* out,
+                            int border_mode, int device)
+{
+    if (!src || !U || !V || !out)
+        return fail(P2P_ERR_INVALID, "NULL pointer");
+    if (n_maps < 0)
+        return fail(P2P_ERR_INVALID, "bad map count");
+    if (border_mode < P2P_BORDER_CONSTANT || border_mode > P2P_BORDER_REFLECT_101)
+        return fail(P2P_ERR_INVALID, "unsupported border mode %d", border_mode);
+    // the view kernel with an identity yaw stage and the n_maps caller maps as its "pitch" views: one upload of the
+    // image, one plan pass, one launch for all of them
+    const double yaw0 = 0.0;
+    return views_oneshot(src, sw, sh, row_stride, &yaw0, 1, nullptr, n_maps, 90.0, ow, oh, out, device, 0,
+                         nullptr, U, V, border_mode);
+}
+
 int p2p_remap_maps_interp_u8(const uint8_t* src, int sw, int sh, int64_t row_stride, int cn,
                              const float* U, const float* V, int ow, int oh, uint8_t* out,
                              int interpolation, int border_mode, const uint8_t* border_value, int device)

@@ -121,10 +121,19 @@ def process_image_batch(image_path: Path, args: argparse.Namespace, output_path:
             logging.error(f"Failed to read image {image_path}. Skipping.")
             return
         file_name = image_path.stem
-        for yaw in args.yaw_angles:
+        # every yaw of the image in ONE call: the image is uploaded once and all maps are drawn by one launch
+        # (the reference calls panorama_to_plane once per yaw, L:259-265; same pixels)
+        yaws = list(args.yaw_angles)
+        if pano_array.ndim == 3 and pano_array.shape[2] == 3 and yaws:
+            views = _native.remap_maps_batch(pano_array, np.stack([precomputed_mappings[y][0] for y in yaws]),
+                                             np.stack([precomputed_mappings[y][1] for y in yaws]),
+                                             border=_native.BORDER_REFLECT, device=_DEVICE)
+        else:
+            views = None
+        for k, yaw in enumerate(yaws):
             logging.debug(f"Processing {image_path} with yaw {yaw}°...")
             U, V = precomputed_mappings[yaw]
-            output_image_array = panorama_to_plane(pano_array, U, V)
+            output_image_array = views[k] if views is not None else panorama_to_plane(pano_array, U, V)
             output_format = args.output_format if args.output_format else image_path.suffix[1:]
             output_image_name = f"{file_name}_pitch{args.pitch}_yaw{yaw}_fov{args.FOV}.{output_format}"
             output_image_path = output_path / output_image_name

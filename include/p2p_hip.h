@@ -124,6 +124,16 @@ int p2p_remap_maps_u8(const uint8_t* src, int sw, int sh, int64_t row_stride, in
                       const float* U, const float* V, int ow, int oh, uint8_t* out,
                       int border_mode, const uint8_t* border_value, int device);
 
+/*
+ * The legacy tool's per-image loop, L:259-281: one image, one panorama_to_plane(pano, U_yaw, V_yaw) per yaw angle
+ * with maps precomputed up front (L:359-370).  All n_maps remaps of a 3-channel image in one call: the image is
+ * uploaded once and every map is drawn by the same launch.  U, V: float32 [n_maps][oh][ow]; out: uint8
+ * [n_maps][oh][ow][3]; INTER_LINEAR; border_mode as p2p_remap_maps_u8 with a zero constant border.
+ */
+int p2p_remap_maps_batch_u8(const uint8_t* src, int sw, int sh, int64_t row_stride,
+                            const float* U, const float* V, int n_maps, int ow, int oh, uint8_t* out,
+                            int border_mode, int device);
+
 /* interpolate_color(U, V, img, method) of the legacy tool, L:159-180: the same call with the method chosen,
    cv2.remap(img, U, V, interpolation, borderMode).  INTER_NEAREST rounds the coordinates half-even and copies;
    INTER_CUBIC uses OpenCV's 4x4 fixed-point kernel (A = -0.75, 1/32-pixel phases, 15-bit weights). */

@@ -1,0 +1,60 @@
+// Host-only stand-in for <hip/hip_runtime.h>, for tests/test_sanitizers.py ONLY: it lets the host side of the C ABI
+// (360-to-planer-images_amd/csrc/p2p_host.cpp: argument checking, job / plan / cache state, stream and event
+// bookkeeping) be compiled with g++ -fsanitize=address,undefined and driven without a GPU.  "Device" memory is host
+// memory, copies are memcpy, streams and events are counters; the kernels themselves are not part of this build
+// (tests/sanitize/launch_stubs.cpp).  GPU AddressSanitizer is not available on the target pool, so this is how
+// SURVEY section 5's "run the CPU-side code under ASan/UBSan" is met for the host shim.  Never shipped.
+#ifndef P2P_TEST_HIP_STUB_H
+#define P2P_TEST_HIP_STUB_H
+#include <stdint.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+typedef struct p2p_stub_stream* hipStream_t;
+typedef struct p2p_stub_event* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocPortable = 1 };
+struct int2 { int x, y; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+static inline int2 make_int2(int x, int y) { int2 r = {x, y}; return r; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r = {x, y}; return r; }
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+
+struct p2p_stub_stream { int alive; };
+struct p2p_stub_event { int recorded; };
+
+extern "C" int p2p_stub_device_count;  // tests flip this to exercise the no-device paths
+
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : (e == hipErrorOutOfMemory ? "out of memory" : "invalid value"); }
+static inline hipError_t hipGetLastError(void) { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = p2p_stub_device_count; return hipSuccess; }
+static inline hipError_t hipSetDevice(int d) { return d >= 0 && d < p2p_stub_device_count ? hipSuccess : hipErrorInvalidValue; }
+static inline hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t)
+{
+    for (size_t y = 0; y < h; ++y)
+        memcpy((char*)d + y * dp, (const char*)s + y * sp, w);
+    return hipSuccess;
+}
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)calloc(1, sizeof(p2p_stub_stream)); return *s ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipStreamSynchronize(hipStream_t s) { return s ? hipSuccess : hipErrorInvalidValue; }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) { return s && e ? hipSuccess : hipErrorInvalidValue; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)calloc(1, sizeof(p2p_stub_event)); return *e ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { if (!e || !s) return hipErrorInvalidValue; e->recorded = 1; return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t e) { return e ? hipSuccess : hipErrorInvalidValue; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { if (!a || !b) return hipErrorInvalidValue; *ms = 0.125f; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
+#endif

@@ -1,0 +1,120 @@
+// Drives the C ABI of include/p2p_hip.h through valid and invalid call sequences in the host-only build
+// (stub HIP runtime, stub launchers) under -fsanitize=address,undefined: every host-side allocation, copy size,
+// index computation and teardown path of 360-to-planer-images_amd/csrc/p2p_host.cpp, from several threads.
+#include "p2p_hip.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <thread>
+#include <vector>
+
+extern "C" int p2p_stub_device_count;
+extern "C" int p2p_stub_extras_wanted;
+
+#define CHECK(cond) do { if (!(cond)) { fprintf(stderr, "CHECK failed line %d: %s (%s)\n", __LINE__, #cond, p2p_last_error()); exit(1); } } while (0)
+
+static void one_shot_calls(int seed)
+{
+    const int pw = 64 + 4 * (seed % 3), ph = 32, ow = 70 + seed, oh = 33;
+    std::vector<uint8_t> pano((size_t)pw * ph * 3, (uint8_t)seed);
+    const int32_t yaws[3] = {0, 30, -400}, pitches[2] = {60, 120};
+    std::vector<uint8_t> out((size_t)3 * 2 * oh * ow * 3);
+    for (int rep = 0; rep < 3; ++rep)  // second and third call take the cached-job path, with changed yaws
+        CHECK(p2p_remap_views_u8(pano.data(), pw, ph, 3 * pw, yaws + (rep == 2), 3 - (rep == 2), pitches, 2, 90, ow, oh,
+                                 out.data(), 0, 0) == P2P_OK);
+    const double yd[2] = {30.5, 0.25}, pd[3] = {44.5, 0.0, 180.0};
+    std::vector<uint8_t> out2((size_t)2 * 3 * oh * ow * 3);
+    CHECK(p2p_remap_views_f64(pano.data(), pw, ph, 3 * pw, yd, 2, pd, 3, 72.5, ow, oh, out2.data(), 0, P2P_FLAG_PIXELS_F16) == P2P_OK);
+    std::vector<float> rows((size_t)pw, 1.0f), U((size_t)ow * oh, 2.0f), V((size_t)ow * oh, 3.0f);
+    std::vector<uint8_t> out3((size_t)oh * ow * 3);
+    CHECK(p2p_remap_views_maps_u8(pano.data(), pw, ph, 3 * pw, rows.data(), 1, U.data(), V.data(), 1, ow, oh, out3.data(), 0) == P2P_OK);
+    for (int cn : {1, 3, 4})
+        for (int inter : {P2P_INTER_NEAREST, P2P_INTER_LINEAR, P2P_INTER_CUBIC}) {
+            std::vector<uint8_t> src((size_t)pw * ph * cn, 7), dst((size_t)ow * oh * cn);
+            CHECK(p2p_remap_maps_interp_u8(src.data(), pw, ph, pw * cn, cn, U.data(), V.data(), ow, oh, dst.data(), inter,
+                                           P2P_BORDER_REFLECT, nullptr, 0) == P2P_OK);
+        }
+    std::vector<float> mu((size_t)ow * oh), mv((size_t)ow * oh), row(pw);
+    CHECK(p2p_build_pitch_map(ow, oh, 1.5, 1.0, pw, ph, mu.data(), mv.data(), 0) == P2P_OK);
+    const float R9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    CHECK(p2p_build_rot_map(ow, oh, 1.5, R9, pw, ph, mu.data(), mv.data(), 0) == P2P_OK);
+    CHECK(p2p_build_yaw_row(pw, 0.5, row.data(), 0) == P2P_OK);
+}
+
+int main()
+{
+    CHECK(p2p_device_count() == 1);
+    // ---- argument errors: every one must come back as a status, nothing may be touched ----
+    uint8_t px[48] = {0};
+    const int32_t y0[1] = {0}, p_bad[1] = {0}, p_ok[1] = {90};
+    CHECK(p2p_remap_views_u8(nullptr, 4, 4, 12, y0, 1, p_ok, 1, 90, 4, 4, px, 0, 0) == P2P_ERR_INVALID);
+    CHECK(p2p_remap_views_u8(px, 4, 4, 12, y0, 1, p_bad, 1, 90, 4, 4, px, 0, 0) == P2P_ERR_INVALID);
+    CHECK(p2p_remap_views_u8(px, 4, 4, 12, y0, 1, p_ok, 1, 90, 40000, 4, px, 0, 0) == P2P_ERR_INVALID);
+    CHECK(p2p_remap_views_u8(px, 4, 4, 12, y0, 1, p_ok, 1, 90, 4, 4, px, 7, 0) == P2P_ERR_NO_DEVICE);
+    CHECK(p2p_remap_views_u8(px, 4, 4, 12, y0, 0, p_ok, 1, 90, 4, 4, px, 0, 0) == P2P_OK);  // empty yaw list: nothing to do
+    CHECK(p2p_remap_views_u8(px, 4, 4, 8, y0, 1, p_ok, 1, 90, 4, 4, px, 0, 0) == P2P_ERR_INVALID);  // row stride < 3 * pw
+    p2p_ctx* ctx = nullptr;
+    CHECK(p2p_ctx_create(0, nullptr) == P2P_ERR_INVALID && p2p_ctx_create(3, &ctx) == P2P_ERR_NO_DEVICE);
+    CHECK(p2p_ctx_create(0, &ctx) == P2P_OK);
+    p2p_job* job = nullptr;
+    p2p_job_desc d = {64, 32, 2, 3, nullptr, 2, nullptr, 90, 70, 33, P2P_FLAG_KEEP_COORDS};
+    CHECK(p2p_job_create(ctx, &d, &job) == P2P_ERR_INVALID && job == nullptr);  // NULL angle lists
+    const int32_t yaws[3] = {0, 90, 14}, pitches[2] = {30, 150};
+    d.yaw_deg = yaws; d.pitch_deg = pitches;
+    CHECK(p2p_job_create(ctx, &d, &job) == P2P_OK);
+    std::vector<uint8_t> pano((size_t)64 * 32 * 3, 9), views((size_t)3 * 2 * 33 * 70 * 3);
+    CHECK(p2p_job_run(job) == P2P_ERR_STATE);                        // no panorama yet
+    CHECK(p2p_job_set_pano(job, 2, pano.data(), 192) == P2P_ERR_INVALID);
+    CHECK(p2p_job_set_pano(job, 0, pano.data(), 192) == P2P_OK);
+    CHECK(p2p_job_run(job) == P2P_ERR_STATE);                        // panorama 1 still missing
+    CHECK(p2p_job_get_views(job, 0, views.data()) == P2P_ERR_STATE);
+    CHECK(p2p_job_set_pano_async(job, 1, pano.data(), 192) == P2P_OK);
+    p2p_stub_extras_wanted = 100000;                                 // more pieces than the first pools: grow and re-plan
+    CHECK(p2p_job_run(job) == P2P_OK);
+    p2p_stub_extras_wanted = 0;
+    for (int i = 0; i < 300; ++i)                                    // past the ring of 256 event pairs
+        CHECK(p2p_job_run(job) == P2P_OK);
+    float ms[300];
+    CHECK(p2p_job_kernel_ms_last(job, ms, 256) == P2P_OK && p2p_job_kernel_ms_last(job, ms, 257) == P2P_ERR_STATE);
+    CHECK(p2p_job_get_views_async(job, 1, views.data()) == P2P_OK && p2p_job_wait(job) == P2P_OK);
+    std::vector<int32_t> coords((size_t)2 * 33 * 70 * 2);
+    CHECK(p2p_job_get_coords(job, coords.data()) == P2P_OK);
+    std::vector<uint32_t> tabs((size_t)3 * 64);
+    CHECK(p2p_job_get_yaw_tables(job, tabs.data()) == P2P_OK);
+    const int32_t yaws2[3] = {1, 2, 3};
+    CHECK(p2p_job_set_yaws(job, yaws2) == P2P_OK);
+    std::vector<float> rows((size_t)3 * 64, 5.0f), U((size_t)2 * 33 * 70, 1.0f), V((size_t)2 * 33 * 70, 1.0f);
+    rows[7] = 64.0f;                                                 // outside [0, pw - 1]
+    CHECK(p2p_job_set_maps(job, rows.data(), U.data(), V.data()) == P2P_ERR_INVALID);
+    rows[7] = 63.0f;
+    CHECK(p2p_job_set_maps(job, rows.data(), U.data(), V.data()) == P2P_OK && p2p_job_run(job) == P2P_OK);
+    // a second job borrowing the first one's panoramas
+    p2p_job* job2 = nullptr;
+    p2p_job_desc_f64 d2 = {64, 32, 2, 1, nullptr, 1, nullptr, 60.5, 16, 16, 0};
+    const double y2[1] = {12.5}, p2[1] = {77.25};
+    d2.yaw_deg = y2; d2.pitch_deg = p2;
+    CHECK(p2p_job_create_f64(ctx, &d2, &job2) == P2P_OK);
+    CHECK(p2p_job_share_panos(job2, job) == P2P_OK && p2p_job_set_pano(job2, 0, pano.data(), 192) == P2P_ERR_STATE);
+    CHECK(p2p_job_run(job2) == P2P_OK);
+    std::vector<uint8_t> v2((size_t)16 * 16 * 3);
+    CHECK(p2p_job_get_views(job2, 1, v2.data()) == P2P_OK);
+    p2p_job_destroy(job2);
+    p2p_job_destroy(job);
+    p2p_job_destroy(nullptr);
+    void* host = nullptr;
+    CHECK(p2p_host_alloc(1 << 20, &host) == P2P_OK && p2p_host_free(host) == P2P_OK && p2p_host_free(nullptr) == P2P_OK);
+    // ---- one-shot entry points from more threads than the pool has slots ----
+    std::vector<std::thread> th;
+    for (int i = 0; i < 12; ++i)
+        th.emplace_back(one_shot_calls, i);
+    for (auto& t : th)
+        t.join();
+    CHECK(p2p_release_cache() == P2P_OK);
+    one_shot_calls(99);  // the pool's contexts survive a release
+    CHECK(p2p_release_cache() == P2P_OK);
+    p2p_ctx_destroy(ctx);
+    p2p_stub_device_count = 0;
+    CHECK(p2p_device_count() == 0 && p2p_remap_views_u8(px, 4, 4, 12, y0, 1, p_ok, 1, 90, 4, 4, px, 0, 0) == P2P_ERR_NO_DEVICE);
+    printf("host sanitizer run OK\n");
+    return 0;
+}

@@ -1,0 +1,80 @@
+// Stand-ins for the kernel launchers of p2p_device.h in the host-only sanitizer build (tests/test_sanitizers.py):
+// they touch the buffers the host code reads back afterwards (piece headers, counters, yaw descriptors) with the
+// sizes the real kernels use, so that ASan sees every host-side allocation being addressed, and do no pixel work.
+#include "p2p_device.h"
+#include <string.h>
+extern "C" int p2p_stub_device_count = 1;
+extern "C" int p2p_stub_extras_wanted = 0;  // what the "plan pass" reports: exercises the grow-and-replan path
+
+namespace p2p {
+hipError_t launch_yaw_tables(uint32_t* packed, float* rows, int pw, int n_yaw, const double* yaw_rad, hipStream_t)
+{
+    for (int y = 0; y < n_yaw; ++y)
+        for (int c = 0; c < pw; ++c) {
+            if (packed) packed[(size_t)y * pw + c] = 3u * (uint32_t)c;
+            if (rows) rows[(size_t)y * pw + c] = (float)c + (float)(yaw_rad[y] * 0.0);
+        }
+    return hipSuccess;
+}
+hipError_t launch_yaw_pack(uint32_t* packed, const float* rows, size_t n, hipStream_t)
+{
+    for (size_t k = 0; k < n; ++k) packed[k] = 3u * (uint32_t)rows[k];
+    return hipSuccess;
+}
+hipError_t launch_yaw_desc(YawDesc* desc, uint32_t* f4tab, const uint32_t* packed, int pw, int n_yaw, hipStream_t)
+{
+    for (int y = 0; y < n_yaw; ++y) {
+        desc[y] = YawDesc{(int)(packed[(size_t)y * pw] / 3u), y % 3 == 2 ? 1 : 0, 0, -1};
+        memset(f4tab + (size_t)y * pw, 0, (size_t)pw * sizeof(uint32_t));
+    }
+    return hipSuccess;
+}
+hipError_t launch_rot_map(float* U, float* V, int ow, int oh, const MapGeom&, const float*, hipStream_t)
+{
+    memset(U, 0, (size_t)ow * oh * sizeof(float)); memset(V, 0, (size_t)ow * oh * sizeof(float));
+    return hipSuccess;
+}
+hipError_t launch_pitch_map(float* U, float* V, int ow, int oh, const MapGeom&, float, float, hipStream_t)
+{
+    memset(U, 0, (size_t)ow * oh * sizeof(float)); memset(V, 0, (size_t)ow * oh * sizeof(float));
+    return hipSuccess;
+}
+hipError_t launch_plan(const PlanParams& P, hipStream_t)
+{
+    const size_t tiles = (size_t)((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
+    for (size_t s = 0; s < tiles * P.n_pitch; ++s) {
+        P.hdr_main[s] = PieceHdr{0u, (uint32_t)TILE_W | 16u << 8, 2u, 0, 0, (uint32_t)s, (uint32_t)s, 0u};
+        P.px_main[s * 256 * VIEWS_PXT + 256 * VIEWS_PXT - 1] = 0u;
+        P.items_main[s * LDS_ITEMS_CAP + LDS_ITEMS_CAP - 1] = 0u;
+    }
+    memset(P.coords, 0, (size_t)P.n_pitch * P.oh * P.ow * sizeof(int2));
+    const uint32_t want = (uint32_t)p2p_stub_extras_wanted;
+    for (uint32_t e = 0; e < want && e < P.x_cap; ++e) {
+        P.hdr_x[e] = PieceHdr{0u, 16u | 8u << 8, 2u, 0, 0, e, e, 0u};
+        P.px_x[(size_t)e * 256 * XTRA_PXT + 256 * XTRA_PXT - 1] = 0u;
+        P.items_x[(size_t)e * LDS_ITEMS_CAP + LDS_ITEMS_CAP - 1] = 0u;
+    }
+    P.x_count[0] = want;
+    P.x_count[1] = (uint32_t)(tiles * P.n_pitch);
+    return hipSuccess;
+}
+hipError_t launch_remap_views(const ViewsParams& P, int, hipStream_t)
+{
+    const size_t n = (size_t)P.n_panos * P.n_yaw * P.n_pitch * P.oh * P.ow * 3;
+    P.out[0] = P.src[0];
+    P.out[n - 1] = P.src[(size_t)(P.n_panos - 1) * P.pano_stride + (size_t)(P.ph - 1) * P.src_pitch + 3 * P.pw - 1];
+    return hipSuccess;
+}
+hipError_t launch_remap_maps(const RemapParams& P, int cn, int, hipStream_t)
+{
+    memset(P.dst, 0, (size_t)P.ow * P.oh * cn);
+    return hipSuccess;
+}
+hipError_t launch_cubic_tab(short* tab, hipStream_t) { memset(tab, 0, 1024 * 16 * sizeof(short)); return hipSuccess; }
+hipError_t launch_float_views(const ViewsParams& P, const double*, bool, hipStream_t)
+{
+    P.out[(size_t)P.n_panos * P.n_yaw * P.n_pitch * P.oh * P.ow * 3 - 1] = 0;
+    return hipSuccess;
+}
+hipError_t read_stamps(unsigned long long* out16, bool) { memset(out16, 0, 16 * sizeof(*out16)); return hipSuccess; }
+}  // namespace p2p

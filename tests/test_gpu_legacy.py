@@ -98,3 +98,21 @@ def test_legacy_cli_files(gpu, legacy, synth, tmp_path):
     want = cpu_ref.remap(pano, U, V, cpu_ref.BORDER_REFLECT)
     assert got.shape == (150, 100, 3)
     assert np.abs(got.astype(int) - want.astype(int)).max() <= 1      # device map vs NumPy map: 1/32-px flips on a smooth image
+
+
+def test_batched_maps_remap_equals_one_call_per_map(gpu, synth):
+    """L:259-281: the legacy tool remaps one image through one precomputed map per yaw.  p2p_remap_maps_batch_u8
+    draws them all in one launch; same bytes as cv2.remap per map (oracle), incl. a NaN coordinate under
+    BORDER_REFLECT and an odd output size."""
+    from oracle import cpu_ref, maps
+    pano = synth.synth_pano(1024, 512, 4100, "N")
+    UV = [maps.pitch_map_deg(200, 120, p, 1024, 512, 90) for p in (5, 60, 90, 150)]
+    U, V = np.stack([u for u, _ in UV]), np.stack([v for _, v in UV])
+    got = gpu.remap_maps_batch(pano, U, V, border=gpu.BORDER_REFLECT)
+    for k in range(4):
+        assert np.array_equal(got[k], cpu_ref.remap(pano, U[k], V[k], cpu_ref.BORDER_REFLECT)), k
+        assert np.array_equal(got[k], gpu.remap_maps(pano, U[k], V[k], border=gpu.BORDER_REFLECT)), k
+    U2, V2 = U[:, :33, :77].copy(), V[:, :33, :77].copy()
+    got = gpu.remap_maps_batch(pano, U2, V2, border=gpu.BORDER_CONSTANT)
+    for k in range(4):
+        assert np.array_equal(got[k], cpu_ref.remap(pano, U2[k], V2[k], cpu_ref.BORDER_CONSTANT)), k

@@ -1,0 +1,43 @@
+"""the CPU-side code under AddressSanitizer + UndefinedBehaviorSanitizer (GPU ASan is not available
+on the target pool, and is not what is asked for).  Two host-only builds, made and run here with gcc:
+  * the host side of the C ABI (360-to-planer-images_amd/csrc/p2p_host.cpp) against a stand-in HIP runtime and
+    stand-in launchers (tests/sanitize/), driven through valid and invalid call sequences from 12 threads;
+  * oracle/cv_remap_oracle.c on maps full of NaN / infinities / out-of-range values.
+Any sanitizer report fails the test."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAN = os.path.join(ROOT, "tests", "sanitize")
+FLAGS = ["-g", "-O1", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+
+
+def _run(exe):
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=ENV)
+    report = r.stdout[-2000:] + r.stderr[-6000:]
+    assert r.returncode == 0 and "ERROR: AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr and \
+        "LeakSanitizer" not in r.stderr, report
+    return r.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_host_shim_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "host_san")
+    subprocess.check_call(["g++", "-std=c++17"] + FLAGS + [
+        "-I", os.path.join(SAN, "hip_stub"), "-I", os.path.join(ROOT, "include"),
+        "-I", os.path.join(ROOT, "360-to-planer-images_amd", "csrc"),
+        os.path.join(ROOT, "360-to-planer-images_amd", "csrc", "p2p_host.cpp"),
+        os.path.join(SAN, "launch_stubs.cpp"), os.path.join(SAN, "host_san_main.cpp"), "-o", exe, "-lpthread"])
+    assert "host sanitizer run OK" in _run(exe)
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
+def test_oracle_c_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "oracle_san")
+    subprocess.check_call(["gcc", "-std=c11", "-ffp-contract=off"] + FLAGS + [
+        os.path.join(ROOT, "oracle", "cv_remap_oracle.c"), os.path.join(SAN, "oracle_san_main.c"), "-o", exe, "-lm"])
+    assert "oracle sanitizer run OK" in _run(exe)
