@@ -102,6 +102,9 @@ struct ViewsParams {
     const PieceHdr* hdr_x;      // pieces of split tiles ("extras"), x_n of them
     const uint32_t* px_x;       // [x_n][256 * XTRA_PXT]
     const uint32_t* items_x;    // [x_n][LDS_ITEMS_CAP]
+    const uint32_t* px2_main;   // float pixel path: 16-bit coordinate fractions per pixel
+    const uint32_t* px2_x;
+    const double* yaw_rad;      // float pixel path: [n_yaw]
     int x_n;
     int plan_gx;             // extra workgroups per view row of the grid: 8 * ceil(x_n / n_pitch / 8)
     float centre;            // float pixel path only: 0 = the reference's sampling convention, 0.5 = pixel centres
@@ -120,6 +123,10 @@ struct PlanParams {
     PieceHdr* hdr_x;
     uint32_t* px_x;
     uint32_t* items_x;
+    int float_path;          // plan for the float pixel path: unclipped azimuth, 16-bit fractions in px2, spans one
+    float centre;            // column wider (the yaw's fractional shift may carry); centre: 0 or 0.5 (pixel centres)
+    uint32_t* px2_main;      // float path: [n_pitch][tiles][256 * VIEWS_PXT] frac(U) | frac(V) << 16, 1/65536 units
+    uint32_t* px2_x;
     uint32_t* x_count;       // [0] extras wanted (may exceed x_cap: the host then grows the pools and re-runs),
                              // [1] pieces marked for direct gathers
     uint32_t x_cap;
@@ -149,7 +156,7 @@ hipError_t launch_plan(const PlanParams& P, hipStream_t st);
 hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st);
 hipError_t launch_remap_maps(const RemapParams& P, int cn, int interpolation, hipStream_t st);
 hipError_t launch_cubic_tab(short* tab, hipStream_t st);
-hipError_t launch_float_views(const ViewsParams& P, const double* yaw_rad, bool half, hipStream_t st);
+hipError_t launch_float_views(const ViewsParams& P, bool half, int which, hipStream_t st);
 // diagnostic build only (-DP2P_STAMPS): per-phase s_memtime sums of remap_views_kernel's pair loop
 hipError_t read_stamps(unsigned long long* out16, bool reset);
 

@@ -1,62 +1,342 @@
-// p2p_float.hip -- opt-in float pixel path (not in the reference)
-//   not in the reference (opt-in): float_views_kernel, one float32 / float16 resample per view with wrap-around
+// p2p_float.hip -- opt-in float pixel path (not in the reference): float_views_kernel, float_views_rest_kernel
 // Reference behaviour (cited, never copied):
-//   P = /root/reference/app/panorama_to_plane-pitch.py, L = /root/reference/app/legacy/panorama_to_plane.py
-// The fixed-point arithmetic is OpenCV 4.10's (imgwarp.cpp remapBilinear, INTER_BITS = 5,
-// INTER_REMAP_COEF_BITS = 15); see DESIGN.md "Arithmetic contract".
-// Compiled with -ffp-contract=off: every float operation below rounds where NumPy rounds.
+//   P = /root/reference/app/panorama_to_plane-pitch.py
+// BASELINE config 5's "fp16 pixel path" and SURVEY 8(f)4's quality mode.  One resample instead of two: the pitch
+// map's float coordinate (P:114-175, evaluated by the plan pass with the azimuth left unclipped) is shifted by the
+// yaw's column offset yaw * pw / 360 (P:98-101 without the clip) with true wrap-around at the seam, nothing is
+// quantised to 1/32 pixel and no intermediate image is rounded to uint8; the 2x2 blend runs in float32 or in
+// packed float16 and is rounded to uint8 once (round-half-even, as np.rint).  Not bit-comparable with cv2.remap by
+// construction; tests bound it against a float32 NumPy evaluation of the same formula and against the exact path
+// on band-limited panoramas.
+//
+// Same machinery as the exact kernel (p2p_views.hip): per-job plan (piece headers, per-row footprint spans, LDS tap
+// offsets per pixel -- here of floor(U), floor(V) -- plus the coordinate fractions in 1/65536), source rows staged
+// through LDS as 16-byte pieces (stage 1 is a plain copy: the yaw's INTEGER column shift picks the pieces, its
+// fraction is added to the pixel's own per yaw and may carry the taps one column on), one barrier per yaw, the
+// pixels leave as 12-byte non-temporal buffer stores.  Without stage 1's blend and with one rounding the path is
+// cheaper than the exact one; the float blend itself is not (byte <-> float conversions cost what the packed
+// integer multiplies cost).  Pieces the plan marks for direct gathers (view seam, pole, widths not divisible by 4)
+// are drawn by float_views_rest_kernel, one thread per pixel from global memory.
 #include <hip/hip_fp16.h>
-#include "p2p_inline.h"
+#include <type_traits>
+#include "p2p_tile.h"
 
 namespace p2p {
 
-// ---------------------------------------------------------------------------------------------
-// Float pixel path (opt-in, BEYOND the reference: BASELINE config 5's "fp16 pixel path" and SURVEY 8(f)4's
-// quality mode).  One resample instead of two: the pitch map's float coordinate is shifted by the yaw's
-// column offset yaw * pw / 360 with true wrap-around at the seam, nothing is quantised to 1/32 pixel and no
-// intermediate image is rounded to uint8; the 2x2 blend runs in float32 or in packed float16.  The result
-// is rounded to uint8 once.  Not bit-comparable with cv2.remap by construction; tests bound it against a
-// float32 NumPy evaluation of the same formula and against the exact path on band-limited panoramas.
-// ---------------------------------------------------------------------------------------------
-template <bool HALF>
-__global__ __launch_bounds__(256) void float_views_kernel(ViewsParams P, const double* __restrict__ yaw_rad)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// yaw shift in source columns, [0, pw): P:98-101 without the clip at the seam
+__device__ __forceinline__ double yaw_shift(double yaw_rad, int pw)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int pitch_i = blockIdx.z;
-    if (x >= P.ow || y >= P.oh)
+    double sh = fmod(yaw_rad * (double)pw / 6.283185307179586, (double)pw);
+    if (sh < 0.0)
+        sh += (double)pw;
+    if (sh >= (double)pw)
+        sh = 0.0;
+    return sh;
+}
+
+// 2x2 blend of four BGRx taps, float32: per channel h0 = a + wx (b - a), h1 = c + wx (d - c), v = h0 + wy (h1 - h0),
+// rounded half-even and clamped by v_cvt_pk_u8_f32
+__device__ __forceinline__ uint32_t blend_f32(uint32_t a, uint32_t b, uint32_t c, uint32_t d, float wx, float wy)
+{
+    uint32_t r = 0u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float pa = (float)((a >> (8 * k)) & 0xFFu), pb = (float)((b >> (8 * k)) & 0xFFu);
+        const float pc = (float)((c >> (8 * k)) & 0xFFu), pd = (float)((d >> (8 * k)) & 0xFFu);
+        const float h0 = __builtin_fmaf(wx, pb - pa, pa);
+        const float h1 = __builtin_fmaf(wx, pd - pc, pc);
+        r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(wy, h1 - h0, h0), k, r);
+    }
+    return r;
+}
+
+// The float16 form.  A byte needs no conversion at all to be a half: the bit pattern 0x00vv IS the (subnormal)
+// float16 v * 2^-24.  v_perm_b32 puts the two horizontal neighbours of a channel into the two halves of a
+// register, v_dot2_f32_f16 blends them with the float16 weights ((1 - wx) 2^15, wx 2^15) and accumulates in
+// float32 (exact products: checked on the hardware, tools/ubench/cvt_probe.hip); the vertical blend of the two
+// row results is two float32 operations with the row weights pre-scaled by 2^9.  Per channel: 2 perm, 2 dot2,
+// 2 float ops, 1 convert -- what the exact path's packed-integer blend costs.  A pixel with no footprint has
+// both row weights 0 and comes out black.
+__device__ __forceinline__ uint32_t blend_f16(uint32_t a, uint32_t b, uint32_t c, uint32_t d, f16x2 wx2, float wy0s, float wy1s)
+{
+    uint32_t r = 0u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t sel = 0x0C040C00u + 0x00010001u * (uint32_t)k;  // byte k of two pixels as two u16
+        const f16x2 up = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(b, a, sel));
+        const f16x2 lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(d, c, sel));
+        const float hu = __builtin_amdgcn_fdot2(up, wx2, 0.0f, false);
+        const float hl = __builtin_amdgcn_fdot2(lo, wx2, 0.0f, false);
+        r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(hl, wy1s, hu * wy0s), k, r);
+    }
+    return r;
+}
+
+template <int PXT, bool HALF>
+__device__ __forceinline__ void draw_float(
+    const ViewsParams& P, const uint8_t* __restrict__ src, uint8_t* __restrict__ out, const PieceHdr h,
+    const uint32_t* __restrict__ pxw, const uint32_t* __restrict__ px2w, const uint32_t* __restrict__ itw,
+    uint4 (*tile4)[LDS_ITEMS_CAP], uint32_t* stage)
+{
+    const int t = threadIdx.x;
+    const PieceGeo G = piece_geo(h, t);
+    if (G.mode != 1 || (PXT == 4 ? G.w != 64 : (G.w != 32 && G.w != 16)))
+        return;  // the rest kernel's
+    const int pair0 = blockIdx.z * P.pairs_per_block;
+    int pair1 = pair0 + P.pairs_per_block;
+    if (pair1 > P.n_panos * P.n_yaw)
+        pair1 = P.n_panos * P.n_yaw;
+    const int npairs = pair1 - pair0;
+    if (npairs <= 0)
         return;
-    float U, V;
-    const PitchConst pc = P.pitch[pitch_i];
-    // P.centre = 0: the reference's convention (integer coordinates are sample points, P:122-131);
-    // 0.5 (P2P_FLAG_PIXEL_CENTRES): rays through output-pixel centres, panorama texel i centred at i + 0.5
-    pitch_map_eval((float)x + P.centre, (float)y + P.centre, P.geom, pc.c, pc.s, U, V);
-    const bool dead = !(U == U) || !(V == V);  // NaN next to a pole: black, as in the exact path
-    V -= P.centre;
-    if (V < 0.0f)
-        V = 0.0f;
-    const int y0 = dead ? 0 : (int)V;          // V in [0, ph - 1]
-    const float wy = dead ? 0.0f : V - (float)y0;
-    const int y1 = y0 + 1 < P.ph ? y0 + 1 : y0;
+
+    // ---- this thread's pixels ----
+    uint32_t tap_up[PXT], tap_lo[PXT];
+    float fu[PXT];
+    float wyf[PXT];          // float32 path: the row weight
+    float wy0s[PXT], wy1s[PXT];  // float16 path: both row weights, times 2^9 (the column weights carry 2^15)
+    bool live[PXT];
+#pragma unroll
+    for (int j = 0; j < PXT; ++j) {
+        const uint32_t wd = pxw[j * VIEWS_BLOCK + t], fr = px2w[j * VIEWS_BLOCK + t];
+        const uint32_t dl = (wd >> PXW_UP_BITS) & ((1u << PXW_DL_BITS) - 1u);
+        tap_up[j] = (wd & ((1u << PXW_UP_BITS) - 1u)) << 2;
+        tap_lo[j] = tap_up[j] + (dl << 2);
+        live[j] = dl != 0u;
+        fu[j] = (float)(fr & 0xFFFFu) * (1.0f / 65536.0f);
+        const float wy = (float)(fr >> 16) * (1.0f / 65536.0f);
+        wyf[j] = wy;
+        wy0s[j] = live[j] ? (1.0f - wy) * 512.0f : 0.0f;
+        wy1s[j] = live[j] ? wy * 512.0f : 0.0f;
+    }
+    uint32_t slot_off[VIEWS_SLOTS], slot_g[VIEWS_SLOTS];
+    decode_items(itw, t, G.n_items, P.src_pitch, slot_off, slot_g);
+    const uint32_t row_bytes = 3u * (uint32_t)P.pw;
     const size_t view_bytes = (size_t)P.oh * P.ow * 3;
-    const size_t px_off = ((size_t)y * P.ow + x) * 3;
-    for (int pano = 0; pano < P.n_panos; ++pano) {
-        const uint8_t* __restrict__ S = P.src + (size_t)pano * P.pano_stride;
-        const uint8_t* __restrict__ r0 = S + (size_t)y0 * P.src_pitch;
-        const uint8_t* __restrict__ r1 = S + (size_t)y1 * P.src_pitch;
-        for (int yi = 0; yi < P.n_yaw; ++yi) {
-            uint8_t* O = P.out + (((size_t)pano * P.n_yaw + yi) * P.n_pitch + pitch_i) * view_bytes + px_off;
+    const int ngroups = P.pw >> 2;
+
+    // ---- per-pair contexts in lane k: the yaw's integer column shift places the source pieces, its fraction is
+    // added to every pixel's own ----
+    uint32_t cw0 = 0, cw1 = 0;
+    float cwf = 0.0f;
+    int cw3 = 0;
+    {
+        const int k = t & 63;
+        if (k < npairs) {
+            cw3 = pano_of_pair(P, pair0 + k);
+            const int yi = pair0 + k - cw3 * P.n_yaw;
+            const double sh = yaw_shift(P.yaw_rad[yi], P.pw);
+            int si = (int)sh;
+            if (si >= P.pw)
+                si = P.pw - 1;
+            cwf = (float)(sh - (double)si);
+            int i_first = h.c0 + si;
+            if (i_first >= P.pw)
+                i_first -= P.pw;
+            const int g0 = i_first >> 2;
+            cw0 = 12u * (uint32_t)g0 | (uint32_t)(i_first & 3) << 20;
+            cw1 = (uint32_t)(ngroups - g0);
+        }
+    }
+
+    // the way out, as in the exact kernel: pixels -> LDS -> 4 adjacent pixels of one row per lane -> 12 bytes
+    const int wv = t >> 6, ln = t & 63;
+    uint32_t* const stg = stage + wv * (PXT * 64);
+    const int x4 = 4 * (ln & 15), sj = ln >> 4;
+    const int srow = ((wv * 64 + x4) >> G.lw) + sj * G.rstep, scol = x4 & (G.w - 1);
+    const bool s_ok = sj < PXT && srow < G.h && G.y0 + srow < P.oh && G.x0 + scol < P.ow;
+    const uint32_t out_off12 = s_ok ? (uint32_t)(((size_t)(G.y0 + srow) * P.ow + G.x0 + scol) * 3) : 0xFFFFFFFFu;
+    const uint32_t stg_rd = (uint32_t)(sj * 64 + x4);
+
+    const int wave_base = __builtin_amdgcn_readfirstlane(t & ~63);
+    int ns_wave = 0;
+#pragma unroll
+    for (int k = 0; k < VIEWS_SLOTS; ++k)
+        ns_wave += G.n_items > wave_base + k * VIEWS_BLOCK;
+
+    uint32_t buf_bytes = 0u;
+    Q16 qc[VIEWS_SLOTS], qn[VIEWS_SLOTS];
+    auto load_pieces = [&](auto ns_c, int k, Q16 (&qq)[VIEWS_SLOTS]) {
+        constexpr int NS = decltype(ns_c)::value;
+        const uint32_t goff = (uint32_t)__builtin_amdgcn_readlane((int)cw0, k) & 0xFFFFFu;
+        const uint32_t wrap_g = (uint32_t)__builtin_amdgcn_readlane((int)cw1, k);
+        const uint8_t* __restrict__ S = src + (size_t)__builtin_amdgcn_readlane(cw3, k) * P.pano_stride;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            uint32_t off = slot_off[sl] + goff;
+            off = slot_g[sl] >= wrap_g ? off - row_bytes : off;  // wrap-around: past the row's end, its start
+            qq[sl] = *reinterpret_cast<const Q16*>(S + off);
+        }
+    };
+    auto run_ns = [&](auto ns_c) {
+        constexpr int NS = decltype(ns_c)::value;
+        load_pieces(ns_c, 0, qc);
+        // one store that writes nothing, so that the loop is entered with the vmcnt shape it has inside
+        // (see draw_tight in p2p_views.hip)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_raw_buffer_store_b32(0u, __builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0x00020000), 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < npairs; ++k) {
+            uint4* tl4 = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(&tile4[0][0]) + buf_bytes);
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                // source pixels 0..3 of the piece (byte offsets 0, 3, 6, 9) as dwords
+                const uint32_t d0 = qc[sl].d[0], d1 = qc[sl].d[1], d2 = qc[sl].d[2], d3 = qc[sl].d[3];
+                uint4 o;
+                o.x = d0 & 0x00FFFFFFu;
+                o.y = __builtin_amdgcn_perm(d1, d0, 0x0C050403u);
+                o.z = __builtin_amdgcn_perm(d2, d1, 0x0C040302u);
+                o.w = __builtin_amdgcn_perm(d3, d2, 0x0C030201u);
+                tl4[t + sl * VIEWS_BLOCK] = o;
+            }
+            uint32_t soff = buf_bytes + 4u * (((uint32_t)__builtin_amdgcn_readlane((int)cw0, k) >> 20) & 3u);
+            asm volatile("" : "+s"(soff));
+            const float sf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cwf), k));
+            __syncthreads();
+            const unsigned char* tl = reinterpret_cast<const unsigned char*>(&tile4[0][0]);
+            uint32_t ta[PXT][4];
+            float wx[PXT];
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) {
+                // fraction of the pixel's own coordinate + fraction of the yaw shift; a carry moves the taps one column on
+                float xs = fu[j] + sf;
+                const bool carry = xs >= 1.0f;
+                wx[j] = carry ? xs - 1.0f : xs;
+                const uint32_t adv = soff + (carry ? 4u : 0u);
+                const uint32_t* up = reinterpret_cast<const uint32_t*>(tl + (tap_up[j] + adv));
+                const uint32_t* lo = reinterpret_cast<const uint32_t*>(tl + (tap_lo[j] + adv));
+                ta[j][0] = up[0];
+                ta[j][1] = up[1];
+                ta[j][2] = lo[0];
+                ta[j][3] = lo[1];
+            }
+            const int kn = k + 1 < npairs ? k + 1 : k;
+            load_pieces(ns_c, kn, qn);
+            uint32_t pix[PXT];
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) {
+                if (HALF) {
+                    const float w1 = wx[j] * 32768.0f;
+                    const f16x2 wx2 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(32768.0f - w1, w1));
+                    pix[j] = blend_f16(ta[j][0], ta[j][1], ta[j][2], ta[j][3], wx2, wy0s[j], wy1s[j]);
+                } else {
+                    const uint32_t v = blend_f32(ta[j][0], ta[j][1], ta[j][2], ta[j][3], wx[j], wyf[j]);
+                    pix[j] = live[j] ? v : 0u;
+                }
+            }
+            uint8_t* O = out + ((size_t)(pair0 + k) * P.n_pitch + G.pitch_i) * view_bytes;  // [pano][yaw][pitch][oh][ow][3]
+#pragma unroll
+            for (int j = 0; j < PXT; ++j)
+                stg[j * 64 + ln] = pix[j];
+            const uint4 v4 = *reinterpret_cast<const uint4*>(stg + stg_rd);
+            u32x3 o;
+            o.x = __builtin_amdgcn_perm(v4.y, v4.x, 0x04020100u);
+            o.y = __builtin_amdgcn_perm(v4.z, v4.y, 0x05040201u);
+            o.z = __builtin_amdgcn_perm(v4.w, v4.z, 0x06050402u);
+            __builtin_amdgcn_raw_buffer_store_b96(o, __builtin_amdgcn_make_buffer_rsrc(O, 0, (int)view_bytes, 0x00020000),
+                                                  (int)out_off12, 0, P2P_STORE_AUX);
+#pragma unroll
+            for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
+                qc[sl] = qn[sl];
+            buf_bytes ^= (uint32_t)sizeof(tile4[0]);
+        }
+    };
+    static_assert(VIEWS_SLOTS == 2 || VIEWS_SLOTS == 3, "dispatch below");
+    if (ns_wave == 0)
+        run_ns(std::integral_constant<int, 0>{});
+    else if (ns_wave == 1)
+        run_ns(std::integral_constant<int, 1>{});
+    else if (VIEWS_SLOTS == 2 || ns_wave == 2)
+        run_ns(std::integral_constant<int, 2>{});
+    else
+        run_ns(std::integral_constant<int, VIEWS_SLOTS>{});
+}
+
+template <bool HALF>
+__global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void float_views_kernel(
+    ViewsParams P, const uint8_t* __restrict__ src, uint8_t* __restrict__ out,
+    const PieceHdr* __restrict__ hdr_main, const uint32_t* __restrict__ px_main, const uint32_t* __restrict__ px2_main,
+    const uint32_t* __restrict__ items_main, const PieceHdr* __restrict__ hdr_x, const uint32_t* __restrict__ px_x,
+    const uint32_t* __restrict__ px2_x, const uint32_t* __restrict__ items_x)
+{
+    __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[(VIEWS_BLOCK / 64) * VIEWS_PXT * 64];
+    if ((int)blockIdx.x < P.plan_gx) {
+        const int ei = (int)blockIdx.y * P.plan_gx + (int)blockIdx.x;
+        if (ei >= P.x_n)
+            return;
+        const PieceHdr h = hdr_x[ei];
+        const size_t pb = (size_t)h.px_block * (VIEWS_BLOCK * XTRA_PXT);
+        draw_float<XTRA_PXT, HALF>(P, src, out, h, px_x + pb, px2_x + pb, items_x + (size_t)h.item_block * LDS_ITEMS_CAP, tile4, stage);
+        return;
+    }
+    const int bx = (int)blockIdx.x - P.plan_gx, gx = (int)gridDim.x - P.plan_gx;
+    const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
+    const int chunk = gx >> 3;
+    const int tile_id = (bx & 7) * chunk + (bx >> 3);
+    if (tile_id >= tiles)
+        return;
+    const int pitch_i = P.pitch_order[blockIdx.y];
+    const PieceHdr h = hdr_main[(size_t)pitch_i * tiles + tile_id];
+    const size_t pb = (size_t)h.px_block * (VIEWS_BLOCK * VIEWS_PXT);
+    draw_float<VIEWS_PXT, HALF>(P, src, out, h, px_main + pb, px2_main + pb, items_main + (size_t)h.item_block * LDS_ITEMS_CAP, tile4, stage);
+}
+
+// Pieces the plan marks for direct gathers: one thread per pixel, taps from global memory (the view's own seam,
+// where U jumps from pw - 1 to 0 between neighbouring pixels; a pole inside the piece; widths not divisible by 4).
+template <bool HALF>
+__global__ __launch_bounds__(VIEWS_BLOCK) void float_views_rest_kernel(
+    ViewsParams P, const uint8_t* __restrict__ src, uint8_t* __restrict__ out,
+    const PieceHdr* __restrict__ hdr_main, const PieceHdr* __restrict__ hdr_x)
+{
+    PieceHdr h;
+    if ((int)blockIdx.x < P.plan_gx) {
+        const int ei = (int)blockIdx.y * P.plan_gx + (int)blockIdx.x;
+        if (ei >= P.x_n)
+            return;
+        h = hdr_x[ei];
+    } else {
+        const int bx = (int)blockIdx.x - P.plan_gx, gx = (int)gridDim.x - P.plan_gx;
+        const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
+        const int tile_id = (bx & 7) * (gx >> 3) + (bx >> 3);
+        if (tile_id >= tiles)
+            return;
+        h = hdr_main[(size_t)P.pitch_order[blockIdx.y] * tiles + tile_id];
+    }
+    const int t = threadIdx.x;
+    const PieceGeo G = piece_geo(h, t);
+    if (G.mode != 2)
+        return;
+    const int pair0 = blockIdx.z * P.pairs_per_block;
+    int pair1 = pair0 + P.pairs_per_block;
+    if (pair1 > P.n_panos * P.n_yaw)
+        pair1 = P.n_panos * P.n_yaw;
+    const size_t view_bytes = (size_t)P.oh * P.ow * 3;
+    const int px = G.x0 + G.col;
+    for (int j = 0; j < VIEWS_PXT; ++j) {
+        const int row = G.row0 + j * G.rstep, py = G.y0 + row;
+        if (row >= G.h || px >= P.ow || py >= P.oh)
+            continue;
+        const int2 cc = P.coords[((size_t)G.pitch_i * P.oh + py) * P.ow + px];
+        const float U = __int_as_float(cc.x), V = __int_as_float(cc.y);
+        const bool dead = !(U == U);
+        const int y0 = dead ? 0 : (int)V;  // V in [0, ph - 1]
+        const float wy = dead ? 0.0f : V - (float)y0;
+        const int y1 = y0 + 1 < P.ph ? y0 + 1 : y0;
+        const size_t px_off = ((size_t)py * P.ow + px) * 3;
+        for (int pair = pair0; pair < pair1; ++pair) {
+            const int pano = pano_of_pair(P, pair), yi = pair - pano * P.n_yaw;
+            uint8_t* O = out + ((size_t)pair * P.n_pitch + G.pitch_i) * view_bytes + px_off;
             if (dead) {
                 O[0] = O[1] = O[2] = 0;
                 continue;
             }
-            // source column = U + yaw * pw / 2 pi (mod pw): P:98-101 without the clip at the seam
-            double sh = fmod(yaw_rad[yi] * (double)P.pw / 6.283185307179586, (double)P.pw);
-            if (sh < 0.0)
-                sh += (double)P.pw;
-            float xs = U + (float)sh - P.centre;
-            if (xs < 0.0f)
-                xs += (float)P.pw;
+            const uint8_t* __restrict__ S = src + (size_t)pano * P.pano_stride;
+            const uint8_t* __restrict__ r0 = S + (size_t)y0 * P.src_pitch;
+            const uint8_t* __restrict__ r1 = S + (size_t)y1 * P.src_pitch;
+            float xs = U + (float)yaw_shift(P.yaw_rad[yi], P.pw);
             if (xs >= (float)P.pw)
                 xs -= (float)P.pw;
             int x0 = (int)xs;
@@ -64,51 +344,18 @@ __global__ __launch_bounds__(256) void float_views_kernel(ViewsParams P, const d
                 x0 = P.pw - 1;
             const float wx = xs - (float)x0;
             const int x1 = x0 + 1 < P.pw ? x0 + 1 : 0;  // wrap-around
-            uint32_t a, b, c, d;
-            {
-                uint2 q0, q1;
-                __builtin_memcpy(&q0, r0 + 3 * x0, 8);
-                __builtin_memcpy(&q1, r1 + 3 * x0, 8);
-                a = q0.x;
-                c = q1.x;
-                b = __builtin_amdgcn_alignbyte(q0.y, q0.x, 3);
-                d = __builtin_amdgcn_alignbyte(q1.y, q1.x, 3);
-                if (x1 == 0) {
-                    __builtin_memcpy(&b, r0, 4);
-                    __builtin_memcpy(&d, r1, 4);
-                }
-            }
-            uint32_t res = 0;
+            uint32_t a = 0, b = 0, c = 0, d = 0;
+            __builtin_memcpy(&a, r0 + 3 * x0, 3);
+            __builtin_memcpy(&b, r0 + 3 * x1, 3);
+            __builtin_memcpy(&c, r1 + 3 * x0, 3);
+            __builtin_memcpy(&d, r1 + 3 * x1, 3);
+            uint32_t res;
             if (HALF) {
-                const __half2 hx = __float2half2_rn(wx), hy = __float2half2_rn(wy);
-                auto pair = [](uint32_t p, int s0, int s1) {
-                    return __halves2half2(__ushort2half_rn((unsigned short)((p >> s0) & 0xFFu)),
-                                          __ushort2half_rn((unsigned short)((p >> s1) & 0xFFu)));
-                };
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {  // (B, G) then (R, R)
-                    const int s0 = k ? 16 : 0, s1 = k ? 16 : 8;
-                    const __half2 pa = pair(a, s0, s1), pb = pair(b, s0, s1), pc2 = pair(c, s0, s1), pd = pair(d, s0, s1);
-                    const __half2 h0 = __hfma2(hx, __hsub2(pb, pa), pa);
-                    const __half2 h1 = __hfma2(hx, __hsub2(pd, pc2), pc2);
-                    const __half2 v = __hfma2(hy, __hsub2(h1, h0), h0);
-                    int lo = __half2int_rn(__low2half(v)), hi = __half2int_rn(__high2half(v));
-                    lo = lo < 0 ? 0 : (lo > 255 ? 255 : lo);
-                    hi = hi < 0 ? 0 : (hi > 255 ? 255 : hi);
-                    res |= k ? (uint32_t)lo << 16 : ((uint32_t)lo | (uint32_t)hi << 8);
-                }
+                const float w1 = wx * 32768.0f;
+                res = blend_f16(a, b, c, d, __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(32768.0f - w1, w1)),
+                                (1.0f - wy) * 512.0f, wy * 512.0f);
             } else {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float pa = (float)((a >> (8 * k)) & 0xFFu), pb = (float)((b >> (8 * k)) & 0xFFu);
-                    const float pc2 = (float)((c >> (8 * k)) & 0xFFu), pd = (float)((d >> (8 * k)) & 0xFFu);
-                    const float h0 = __builtin_fmaf(wx, pb - pa, pa);
-                    const float h1 = __builtin_fmaf(wx, pd - pc2, pc2);
-                    const float v = __builtin_fmaf(wy, h1 - h0, h0);
-                    int r = (int)__builtin_rintf(v);
-                    r = r < 0 ? 0 : (r > 255 ? 255 : r);
-                    res |= (uint32_t)r << (8 * k);
-                }
+                res = blend_f32(a, b, c, d, wx, wy);
             }
             O[0] = (uint8_t)res;
             O[1] = (uint8_t)(res >> 8);
@@ -117,13 +364,26 @@ __global__ __launch_bounds__(256) void float_views_kernel(ViewsParams P, const d
     }
 }
 
-hipError_t launch_float_views(const ViewsParams& P, const double* yaw_rad, bool half, hipStream_t st)
+// which = 0: the tile kernel, 1: the direct-gather pieces
+hipError_t launch_float_views(const ViewsParams& P, bool half, int which, hipStream_t st)
 {
-    dim3 grid((P.ow + 63) / 64, (P.oh + 3) / 4, P.n_pitch);
-    if (half)
-        hipLaunchKernelGGL(float_views_kernel<true>, grid, dim3(256), 0, st, P, yaw_rad);
-    else
-        hipLaunchKernelGGL(float_views_kernel<false>, grid, dim3(256), 0, st, P, yaw_rad);
+    const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
+    const int n_pairs = P.n_panos * P.n_yaw;
+    const int zblocks = (n_pairs + P.pairs_per_block - 1) / P.pairs_per_block;
+    const dim3 grid(P.plan_gx + 8 * ((tiles + 7) / 8), P.n_pitch, zblocks);
+    if (which == 0) {
+        if (half)
+            hipLaunchKernelGGL(float_views_kernel<true>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.out, P.hdr_main, P.px_main,
+                               P.px2_main, P.items_main, P.hdr_x, P.px_x, P.px2_x, P.items_x);
+        else
+            hipLaunchKernelGGL(float_views_kernel<false>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.out, P.hdr_main, P.px_main,
+                               P.px2_main, P.items_main, P.hdr_x, P.px_x, P.px2_x, P.items_x);
+    } else {
+        if (half)
+            hipLaunchKernelGGL(float_views_rest_kernel<true>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.out, P.hdr_main, P.hdr_x);
+        else
+            hipLaunchKernelGGL(float_views_rest_kernel<false>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.out, P.hdr_main, P.hdr_x);
+    }
     return hipGetLastError();
 }
 

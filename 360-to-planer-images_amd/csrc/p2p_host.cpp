@@ -97,6 +97,8 @@ struct p2p_job {
     p2p::PieceHdr* d_hdr_x = nullptr;    // pieces of split tiles
     uint32_t* d_px_x = nullptr;
     uint32_t* d_items_x = nullptr;
+    uint32_t* d_px2_main = nullptr;      // float pixel path only: 16-bit coordinate fractions
+    uint32_t* d_px2_x = nullptr;
     uint32_t* d_x_count = nullptr;
     uint32_t x_cap = 0;
     int x_n = -1;                        // -1: the plan has not been built for the current maps
@@ -355,6 +357,8 @@ void p2p_job_destroy(p2p_job* j)
     (void)hipFree(j->d_hdr_x);
     (void)hipFree(j->d_px_x);
     (void)hipFree(j->d_items_x);
+    (void)hipFree(j->d_px2_main);
+    (void)hipFree(j->d_px2_x);
     (void)hipFree(j->d_x_count);
     (void)hipFree(j->d_pitch_order);
     for (hipEvent_t e : j->ev_ring)
@@ -447,8 +451,10 @@ static int job_create_core(p2p_ctx* ctx, const p2p_job_desc& d, const double* ya
     if (e == hipSuccess) e = hipMalloc((void**)&j->d_pitch, (size_t)d.n_pitch * sizeof(p2p::PitchConst));
     const bool float_path = (d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)) != 0;
     j->n_tiles = (size_t)((d.ow + p2p::TILE_W - 1) / p2p::TILE_W) * ((d.oh + p2p::TILE_H - 1) / p2p::TILE_H);
-    if (!float_path) {
+    {
         const size_t slots = j->n_tiles * d.n_pitch;
+        if (float_path && e == hipSuccess)
+            e = hipMalloc((void**)&j->d_px2_main, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void**)&j->d_coords, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2));
         if (e == hipSuccess) e = hipMalloc((void**)&j->d_hdr_main, slots * sizeof(p2p::PieceHdr));
         if (e == hipSuccess) e = hipMalloc((void**)&j->d_px_main, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t));
@@ -642,6 +648,9 @@ static int job_build_plan(p2p_job* j)
     Q.px_main = j->d_px_main;
     Q.items_main = j->d_items_main;
     Q.x_count = j->d_x_count;
+    Q.float_path = (d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)) != 0;
+    Q.centre = (d.flags & P2P_FLAG_PIXEL_CENTRES) ? 0.5f : 0.0f;
+    Q.px2_main = j->d_px2_main;
     const size_t slots = j->n_tiles * d.n_pitch;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (!j->d_hdr_x) {
@@ -651,7 +660,10 @@ static int job_build_plan(p2p_job* j)
             HIP_TRY(hipMalloc((void**)&j->d_hdr_x, (size_t)j->x_cap * sizeof(p2p::PieceHdr)));
             HIP_TRY(hipMalloc((void**)&j->d_px_x, (size_t)j->x_cap * 256 * p2p::XTRA_PXT * sizeof(uint32_t)));
             HIP_TRY(hipMalloc((void**)&j->d_items_x, (size_t)j->x_cap * p2p::LDS_ITEMS_CAP * sizeof(uint32_t)));
+            if (Q.float_path)
+                HIP_TRY(hipMalloc((void**)&j->d_px2_x, (size_t)j->x_cap * 256 * p2p::XTRA_PXT * sizeof(uint32_t)));
         }
+        Q.px2_x = j->d_px2_x;
         Q.hdr_x = j->d_hdr_x;
         Q.px_x = j->d_px_x;
         Q.items_x = j->d_items_x;
@@ -676,6 +688,7 @@ static int job_build_plan(p2p_job* j)
         (void)hipFree(j->d_hdr_x); j->d_hdr_x = nullptr;
         (void)hipFree(j->d_px_x); j->d_px_x = nullptr;
         (void)hipFree(j->d_items_x); j->d_items_x = nullptr;
+        (void)hipFree(j->d_px2_x); j->d_px2_x = nullptr;
         j->x_cap = n;
     }
     return fail(P2P_ERR_HIP, "the plan pass did not converge");
@@ -726,22 +739,9 @@ int p2p_job_run(p2p_job* j)
     }
     const int slot = (int)(j->runs % kEvRing);
     const bool timed = j->time_launches;
-    if (j->d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)) {
-        // opt-in float pixel path (beyond the reference): one float resample per view, see float_views_kernel
-        if (j->host_maps)
-            return fail(P2P_ERR_STATE, "the float pixel path evaluates its own maps; caller maps are not supported");
-        P.centre = (j->d.flags & P2P_FLAG_PIXEL_CENTRES) ? 0.5f : 0.0f;
-        if (timed)
-            HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
-        HIP_TRY(p2p::launch_float_views(P, j->d_yaw_rad, (j->d.flags & P2P_FLAG_PIXELS_F16) != 0, j->ctx->stream));
-        if (timed)
-            HIP_TRY(hipEventRecord(j->ev_ring[2 * slot + 1], j->ctx->stream));
-        HIP_TRY(hipEventRecord(j->ev_run, j->ctx->stream));
-        j->ev_run_recorded = true;
-        j->runs++;
-        j->ran = true;
-        return P2P_OK;
-    }
+    const bool float_path = (j->d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)) != 0;
+    if (float_path && j->host_maps)
+        return fail(P2P_ERR_STATE, "the float pixel path evaluates its own maps; caller maps are not supported");
     if (j->x_n < 0) {
         int rc = job_build_plan(j);
         if (rc != P2P_OK)
@@ -757,6 +757,29 @@ int p2p_job_run(p2p_job* j)
     P.items_x = j->d_items_x;
     P.x_n = j->x_n;
     P.plan_gx = 8 * ((((P.x_n + j->d.n_pitch - 1) / j->d.n_pitch) + 7) / 8);
+    if (float_path) {
+        // opt-in float pixel path (beyond the reference): one float resample per view, see p2p_float.hip
+        P.px2_main = j->d_px2_main;
+        P.px2_x = j->d_px2_x;
+        P.yaw_rad = j->d_yaw_rad;
+        const bool half = (j->d.flags & P2P_FLAG_PIXELS_F16) != 0;
+        if (timed)
+            HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
+        if (j->n_direct > 0)
+            HIP_TRY(p2p::launch_float_views(P, half, 1, j->ctx->stream));
+        HIP_TRY(p2p::launch_float_views(P, half, 0, j->ctx->stream));
+        if (timed)
+            HIP_TRY(hipEventRecord(j->ev_ring[2 * slot + 1], j->ctx->stream));
+        HIP_TRY(hipEventRecord(j->ev_run, j->ctx->stream));
+        j->ev_run_recorded = true;
+        if (!j->owns_src) {
+            HIP_TRY(hipEventRecord(j->src_owner->ev_run, j->ctx->stream));
+            j->src_owner->ev_run_recorded = true;
+        }
+        j->runs++;
+        j->ran = true;
+        return P2P_OK;
+    }
     if (timed)
         HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
     // The main kernel draws every LDS-scheme piece for every yaw that is a plain shift -- on the reference's own

@@ -35,8 +35,10 @@ __device__ __forceinline__ float clip_keep_nan(float v, float lo, float hi)
 //   x**2 + y**2 + z**2 left to right, IEEE sqrt and divide, the 3x3 float32 sgemm as the
 //   sequential-FMA accumulation OpenBLAS performs (acc = fma(R[i][k], v[k], acc), k = 0..2),
 //   arccos / arctan2 % 2pi, scale, clip.
+// clip_u = false (float pixel path only): U stays the unclipped azimuth in [0, pw) -- that path wraps around the
+// seam instead of collapsing (pw - 1, pw) onto column pw - 1 as P:172 does.
 __device__ __forceinline__ void pitch_map_eval(float u, float v, const MapGeom& g, float c, float s,
-                                               float& U, float& V)
+                                               float& U, float& V, bool clip_u = true)
 {
     const float TWO_PI_F = 6.283185307179586f;  // float32(2*np.pi), the "weak" Python scalar
     const float PI_F = 3.141592653589793f;
@@ -67,7 +69,10 @@ __device__ __forceinline__ void pitch_map_eval(float u, float v, const MapGeom& 
     V = tv * R_PI;
     U = __builtin_fmaf(__builtin_fmaf(-U, TWO_PI_F, tu), R_TWO_PI, U);
     V = __builtin_fmaf(__builtin_fmaf(-V, PI_F, tv), R_PI, V);
-    U = clip_keep_nan(U, 0.0f, g.pw_f - 1.0f);  // P:172
+    if (clip_u)
+        U = clip_keep_nan(U, 0.0f, g.pw_f - 1.0f);  // P:172
+    else if (U >= g.pw_f)
+        U -= g.pw_f;
     V = clip_keep_nan(V, 0.0f, g.ph_f - 1.0f);  // P:173
 }
 

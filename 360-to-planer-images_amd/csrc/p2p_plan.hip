@@ -93,12 +93,54 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
 
     // ---- the pitch-stage coordinate of every pixel of the tile, quantised as cv::remap does ----
     int ix[PXT], iy[PXT];
-    uint32_t fx[PXT], fy[PXT];
+    uint32_t fx[PXT], fy[PXT], frac16[PXT];
     bool inside[PXT], inrange[PXT];
 #pragma unroll
     for (int j = 0; j < PXT; ++j) {
         const int py = y0 + ty0 + j * ROWSTEP;
         inside[j] = px < P.ow && py < P.oh;
+        frac16[j] = 0u;
+        if (P.float_path) {
+            // Float pixel path (not in the reference): one float resample at (U + yaw shift, V), true wrap-around in
+            // U.  The plan keeps floor(U), floor(V) (as tap offsets) and the fractions in 1/65536; the yaw's
+            // fractional shift is added per yaw by the kernel and may carry into the next column, so the row spans
+            // are one column wider.  The bottom row is folded onto (ph - 2, fraction 1) so that the lower tap exists.
+            ix[j] = iy[j] = -32768;
+            fx[j] = fy[j] = 0u;
+            inrange[j] = false;
+            if (inside[j]) {
+                const size_t k = ((size_t)pitch_i * P.oh + py) * P.ow + px;
+                const PitchConst pc = P.pitch[pitch_i];
+                float U, V;
+                pitch_map_eval((float)px + P.centre, (float)py + P.centre, P.geom, pc.c, pc.s, U, V, false);
+                float uc = U - P.centre, vc = V - P.centre;
+                if (uc < 0.0f)
+                    uc += P.geom.pw_f;
+                if (vc < 0.0f)
+                    vc = 0.0f;
+                const bool dead = !(U == U) || !(V == V);  // NaN next to a pole: black, as in the exact path
+                P.coords[k] = make_int2(__float_as_int(dead ? __int_as_float(0x7FC00000) : uc), __float_as_int(vc));
+                if (!dead && P.ph >= 2) {
+                    int xi = (int)uc;
+                    if (xi >= P.pw)
+                        xi = P.pw - 1;
+                    float fu = uc - (float)xi, fv;
+                    int yi = (int)vc;
+                    if (yi >= P.ph - 1) {
+                        yi = P.ph - 2;
+                        fv = 1.0f;
+                    } else {
+                        fv = vc - (float)yi;
+                    }
+                    const uint32_t fu16 = min(65535u, (uint32_t)(fu * 65536.0f)), fv16 = min(65535u, (uint32_t)(fv * 65536.0f));
+                    frac16[j] = fu16 | fv16 << 16;
+                    ix[j] = xi;
+                    iy[j] = yi;
+                    inrange[j] = true;
+                }
+            }
+            continue;
+        }
         int sx = INT32_MIN, sy = INT32_MIN;
         if (inside[j]) {
             const size_t k = ((size_t)pitch_i * P.oh + py) * P.ow + px;
@@ -163,8 +205,9 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
             const int nrow = any_live ? r1 - r0 + 2 : 0;
             // The LDS scheme needs the whole footprint strictly inside the panorama (no tap is a border tap) and a
             // panorama width divisible by 4 (12-byte items never straddle a row end).
-            bool ok = any_live && !stray && (P.pw & 3) == 0 && c0 >= 0 && r0 >= 0 && c1 + 1 < P.pw && r1 + 1 < P.ph &&
-                      nrow <= PLAN_MAX_ROWS;
+            // (float path: taps reach one column further, and its stores need view rows of whole dwords)
+            bool ok = any_live && !stray && (P.pw & 3) == 0 && c0 >= 0 && r0 >= 0 && c1 + 1 + P.float_path < P.pw &&
+                      r1 + 1 < P.ph && nrow <= PLAN_MAX_ROWS && !(P.float_path && (P.ow & 3) != 0);
             uint32_t n_items = 0;
             if (ok) {
                 // ---- per rot row: the span of columns the taps read ----
@@ -177,8 +220,8 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
                 for (int j = 0; j < PXT; ++j)
                     if (member[j] && inrange[j]) {
                         const int r = iy[j] - r0;
-                        atomicMin(&s_rmin[r], ix[j]);     atomicMax(&s_rmax[r], ix[j] + 1);
-                        atomicMin(&s_rmin[r + 1], ix[j]); atomicMax(&s_rmax[r + 1], ix[j] + 1);
+                        atomicMin(&s_rmin[r], ix[j]);     atomicMax(&s_rmax[r], ix[j] + 1 + P.float_path);
+                        atomicMin(&s_rmin[r + 1], ix[j]); atomicMax(&s_rmax[r + 1], ix[j] + 1 + P.float_path);
                     }
                 __syncthreads();
                 // a row's LDS span starts at a column congruent to c0 mod 4 (so that one per-yaw alignment serves
@@ -225,12 +268,15 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
             uint32_t blk;
             PieceHdr* hdr;
             uint32_t* pxw;
+            uint32_t* px2w = nullptr;
             uint32_t* itw;
             bool store = true;
             if (level == 0) {
                 blk = (uint32_t)slot_main;
                 hdr = P.hdr_main + blk;
                 pxw = P.px_main + (size_t)blk * (256 * VIEWS_PXT);
+                if (P.float_path)
+                    px2w = P.px2_main + (size_t)blk * (256 * VIEWS_PXT);
                 itw = P.items_main + (size_t)blk * LDS_ITEMS_CAP;
             } else {
                 if (t == 0)
@@ -240,6 +286,8 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
                 store = blk < P.x_cap;  // beyond the pools: counted only, the host grows them and runs again
                 hdr = P.hdr_x + blk;
                 pxw = P.px_x + (size_t)blk * (256 * XTRA_PXT);
+                if (P.float_path)
+                    px2w = P.px2_x + (size_t)blk * (256 * XTRA_PXT);
                 itw = P.items_x + (size_t)blk * LDS_ITEMS_CAP;
             }
             if (!store)
@@ -262,6 +310,8 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
                             word = up | (lo - up) << PXW_UP_BITS | fx[j] << 22 | fy[j] << 27;
                         }
                         pxw[jp * VIEWS_BLOCK + tp] = word;
+                        if (px2w)
+                            px2w[jp * VIEWS_BLOCK + tp] = frac16[j];
                     }
                 if (t < nrow) {
                     const uint32_t g0 = (uint32_t)((s_rmin[t] - c0) >> 2);

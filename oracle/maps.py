@@ -46,8 +46,10 @@ def yaw_map(pano_width, pano_height, yaw_angle):
     return U, V
 
 
-def pitch_map(W, H, FOV_rad, pitch_radian, pano_width, pano_height):
-    """(U, V) of P:114-175, each (H, W) float32.  Arguments as P:114."""
+def pitch_map(W, H, FOV_rad, pitch_radian, pano_width, pano_height, clip_u=True):
+    """(U, V) of P:114-175, each (H, W) float32.  Arguments as P:114.
+    clip_u=False is NOT the reference: it leaves the azimuth unclipped in [0, pano_width), which is what the
+    build's opt-in float pixel path (true wrap-around at the seam) resamples at; tests of that path use it."""
     focal = (0.5 * W) / np.tan(FOV_rad / 2)  # P:119 (float64 scalar)
     u, v = np.meshgrid(
         np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing="xy"
@@ -65,12 +67,15 @@ def pitch_map(W, H, FOV_rad, pitch_radian, pano_width, pano_height):
     phi = (np.arctan2(y_rot, x_rot) % TWO_PI).astype(np.float32)  # P:164
     U = (phi * pano_width) / TWO_PI  # P:167
     V = (theta * pano_height) / np.pi  # P:169
-    U = np.clip(U, 0, pano_width - 1).astype(np.float32)  # P:172
+    if clip_u:
+        U = np.clip(U, 0, pano_width - 1).astype(np.float32)  # P:172
+    else:
+        U = np.where(U >= pano_width, U - pano_width, U).astype(np.float32)
     V = np.clip(V, 0, pano_height - 1).astype(np.float32)  # P:173 (NaN stays NaN)
     return U, V
 
 
-def pitch_map_deg(output_width, output_height, pitch_angle, pano_width, pano_height, fov_deg=90):
+def pitch_map_deg(output_width, output_height, pitch_angle, pano_width, pano_height, fov_deg=90, clip_u=True):
     """get_pitch_mapping()'s argument convention (P:55-73): degrees in, np.radians() applied."""
     return pitch_map(
         output_width,
@@ -79,6 +84,7 @@ def pitch_map_deg(output_width, output_height, pitch_angle, pano_width, pano_hei
         np.radians(pitch_angle),
         pano_width,
         pano_height,
+        clip_u=clip_u,
     )
 
 

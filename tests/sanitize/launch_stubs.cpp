@@ -71,7 +71,7 @@ hipError_t launch_remap_maps(const RemapParams& P, int cn, int, hipStream_t)
     return hipSuccess;
 }
 hipError_t launch_cubic_tab(short* tab, hipStream_t) { memset(tab, 0, 1024 * 16 * sizeof(short)); return hipSuccess; }
-hipError_t launch_float_views(const ViewsParams& P, const double*, bool, hipStream_t)
+hipError_t launch_float_views(const ViewsParams& P, bool, int, hipStream_t)
 {
     P.out[(size_t)P.n_panos * P.n_yaw * P.n_pitch * P.oh * P.ow * 3 - 1] = 0;
     return hipSuccess;

@@ -19,7 +19,7 @@ def numpy_float_views(pano, yaws, pitches, ow, oh, fov=90):
     P = pano.astype(np.float32)
     out = np.zeros((len(yaws), len(pitches), oh, ow, 3), np.uint8)
     for pi, pitch in enumerate(pitches):
-        U, V = maps.pitch_map_deg(ow, oh, pitch, pw, ph, fov)
+        U, V = maps.pitch_map_deg(ow, oh, pitch, pw, ph, fov, clip_u=False)  # the float path wraps, it does not clip
         dead = np.isnan(U) | np.isnan(V)
         U, V = np.nan_to_num(U), np.nan_to_num(V)
         y0 = V.astype(np.int32)
@@ -103,6 +103,23 @@ def test_float_path_wraps_at_the_seam_where_the_exact_path_clips(gpu):
     assert wrap.shape == exact.shape
 
 
+def test_float_path_blends_across_the_seam_of_the_map_itself(gpu):
+    """The pitch map's own azimuth in (pw - 1, pw) -- which P:172 clips onto column pw - 1 -- is resampled between
+    column pw - 1 and column 0 by the float path (it used to inherit the clip and repeat a texel)."""
+    pw, ph, ow, oh, pitch, fov = 256, 128, 320, 200, 25, 120   # the pole is in view: every azimuth occurs
+    pano = np.zeros((ph, pw, 3), np.uint8)
+    pano[:, 0] = 200     # first column bright, last column dark: a blend shows up as intermediate values
+    pano[:, pw - 1] = 40
+    U, V = maps.pitch_map_deg(ow, oh, pitch, pw, ph, fov, clip_u=False)
+    band = (U > pw - 1) & (U < pw) & ~np.isnan(V)
+    assert band.sum() > 0
+    got = gpu.remap_views(pano, [0], [pitch], fov, ow, oh, flags=gpu.FLAG_PIXELS_F32)[0, 0]
+    want = numpy_float_views(pano, [0], [pitch], ow, oh, fov)[0, 0]
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+    vals = got[band][:, 0]
+    assert ((vals > 45) & (vals < 195)).any()  # genuinely between the two columns
+
+
 def test_float_path_rejects_caller_maps(gpu, synth):
     ctx = gpu.Context(0)
     job = gpu.Job(ctx, 256, 128, 1, [0], [90], 90, 64, 48, flags=gpu.FLAG_PIXELS_F16)
@@ -130,7 +147,7 @@ def test_pixel_centre_convention(gpu, synth):
     yr, zr = c * y - s * z, s * y + c * z
     U = (np.arctan2(yr, x) % np.float32(2 * np.pi)) * np.float32(pw) / np.float32(2 * np.pi)
     V = np.arccos(zr) * np.float32(ph) / np.float32(np.pi)
-    U, V = np.clip(U, 0, pw - 1), np.clip(V, 0, ph - 1)
+    V = np.clip(V, 0, ph - 1)  # the float path wraps U instead of clipping it
     xs = (U + np.float32(yaw * pw / 360.0) - np.float32(0.5)) % np.float32(pw)
     ys = np.maximum(V - np.float32(0.5), 0)
     x0 = np.minimum(xs.astype(np.int32), pw - 1); wx = (xs - x0)[..., None]
