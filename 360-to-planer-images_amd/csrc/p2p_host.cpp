@@ -75,7 +75,8 @@ struct p2p_job {
     hipEvent_t ev_run = nullptr;     // last run                                -> uploads and downloads wait for it
     hipEvent_t ev_down = nullptr;    // last asynchronous download from d_out   -> the next run waits for it
     bool up_pending = false, down_pending = false;
-    bool ev_run_recorded = false;    // some run (of this job or of one that borrows its panoramas) has been enqueued
+    bool ev_run_recorded = false;    // ev_run has been recorded at least once
+    bool run_unmarked = false;       // a run (of this job or of one that borrows its panoramas) was enqueued after it
     size_t pano_stride = 0;
     int src_pitch = 0;
     uint8_t* d_out = nullptr;
@@ -521,6 +522,18 @@ int p2p_job_create_f64(p2p_ctx* ctx, const p2p_job_desc_f64* desc, p2p_job** out
     return job_create_core(ctx, d, desc->yaw_deg, desc->pitch_deg, desc->fov_deg, out);
 }
 
+// ev_run := "everything enqueued on the kernel stream so far", which covers the job's last run; recorded lazily,
+// when a copy needs the ordering, so that back-to-back launches pay nothing for it
+static int mark_run(p2p_job* j)
+{
+    if (j->run_unmarked) {
+        HIP_TRY(hipEventRecord(j->ev_run, j->ctx->stream));
+        j->ev_run_recorded = true;
+        j->run_unmarked = false;
+    }
+    return P2P_OK;
+}
+
 int p2p_job_set_pano_async(p2p_job* j, int index, const uint8_t* pano, int64_t row_stride)
 {
     if (!j || !pano)
@@ -534,6 +547,8 @@ int p2p_job_set_pano_async(p2p_job* j, int index, const uint8_t* pano, int64_t r
     HIP_TRY(hipSetDevice(j->ctx->device));
     // on the upload stream, behind the last kernel that reads this job's panoramas: the copy overlaps whatever
     // other jobs of the context are running (the driver keeps two jobs per device and alternates)
+    if (int rc = mark_run(j))
+        return rc;
     if (j->ev_run_recorded)
         HIP_TRY(hipStreamWaitEvent(j->ctx->stream_up, j->ev_run, 0));
     HIP_TRY(hipMemcpy2DAsync(j->d_src + (size_t)index * j->pano_stride, (size_t)j->src_pitch, pano,
@@ -704,10 +719,16 @@ int p2p_job_run(p2p_job* j)
             return fail(P2P_ERR_STATE, "panorama %d was never set", i);
     HIP_TRY(hipSetDevice(j->ctx->device));
     // behind the uploads into the panoramas it reads and the downloads of the views it is about to overwrite
-    if (so->up_pending)
-        HIP_TRY(hipStreamWaitEvent(j->ctx->stream, so->ev_up, 0));
+    // (a finished copy needs no wait any more: one hipEventQuery instead of a barrier packet per launch)
+    if (so->up_pending) {
+        if (hipEventQuery(so->ev_up) == hipSuccess)
+            const_cast<p2p_job*>(so)->up_pending = false;
+        else
+            HIP_TRY(hipStreamWaitEvent(j->ctx->stream, so->ev_up, 0));
+    }
     if (j->down_pending) {
-        HIP_TRY(hipStreamWaitEvent(j->ctx->stream, j->ev_down, 0));
+        if (hipEventQuery(j->ev_down) != hipSuccess)
+            HIP_TRY(hipStreamWaitEvent(j->ctx->stream, j->ev_down, 0));
         j->down_pending = false;
     }
     p2p::ViewsParams P{};
@@ -770,12 +791,9 @@ int p2p_job_run(p2p_job* j)
         HIP_TRY(p2p::launch_float_views(P, half, 0, j->ctx->stream));
         if (timed)
             HIP_TRY(hipEventRecord(j->ev_ring[2 * slot + 1], j->ctx->stream));
-        HIP_TRY(hipEventRecord(j->ev_run, j->ctx->stream));
-        j->ev_run_recorded = true;
-        if (!j->owns_src) {
-            HIP_TRY(hipEventRecord(j->src_owner->ev_run, j->ctx->stream));
-            j->src_owner->ev_run_recorded = true;
-        }
+        j->run_unmarked = true;
+        if (!j->owns_src)
+            j->src_owner->run_unmarked = true;
         j->runs++;
         j->ran = true;
         return P2P_OK;
@@ -792,12 +810,10 @@ int p2p_job_run(p2p_job* j)
         HIP_TRY(p2p::launch_remap_views(P, 0, j->ctx->stream));
     if (timed)
         HIP_TRY(hipEventRecord(j->ev_ring[2 * slot + 1], j->ctx->stream));
-    HIP_TRY(hipEventRecord(j->ev_run, j->ctx->stream));
-    j->ev_run_recorded = true;
-    if (!j->owns_src) {
-        HIP_TRY(hipEventRecord(j->src_owner->ev_run, j->ctx->stream));  // uploads into the shared panoramas wait for this run too
-        j->src_owner->ev_run_recorded = true;
-    }
+    // (the event that orders copies behind this run is recorded when a copy asks for it: mark_run)
+    j->run_unmarked = true;
+    if (!j->owns_src)
+        j->src_owner->run_unmarked = true;  // uploads into the shared panoramas wait for this run too
     j->runs++;
     j->ran = true;
     return P2P_OK;
@@ -870,6 +886,8 @@ int p2p_job_get_views_async(p2p_job* j, int index, uint8_t* out)
     HIP_TRY(hipSetDevice(j->ctx->device));
     const size_t per = j->out_bytes / j->d.n_panos;
     // on the download stream, behind the job's last run: the copy overlaps other jobs' kernels and uploads
+    if (int rc = mark_run(j))
+        return rc;
     HIP_TRY(hipStreamWaitEvent(j->ctx->stream_down, j->ev_run, 0));
     HIP_TRY(hipMemcpyAsync(out, j->d_out + per * index, per, hipMemcpyDeviceToHost, j->ctx->stream_down));
     HIP_TRY(hipEventRecord(j->ev_down, j->ctx->stream_down));
@@ -884,6 +902,8 @@ int p2p_job_wait(p2p_job* j)
     HIP_TRY(hipSetDevice(j->ctx->device));
     if (j->up_pending)
         HIP_TRY(hipEventSynchronize(j->ev_up));
+    if (int rc = mark_run(j))
+        return rc;
     if (j->ev_run_recorded)
         HIP_TRY(hipEventSynchronize(j->ev_run));
     if (j->down_pending)

@@ -166,16 +166,17 @@ __device__ __forceinline__ bool tight_piece(const PieceGeo& g, const ViewsParams
 
 // ---- per-pair contexts: lane k of every wave works out pair pair0 + k once; the loops read them back with
 // v_readlane, so no descriptor load sits on the per-pair critical path.  Sorted by class across the lanes:
-//   0  whole-column shift: stage 1 is a copy                      } tight loops
-//   1  one blend weight for the whole piece                       }
-//   2  the same, but the piece holds the column P:105 clips to    }  (one rot pixel is a copy instead)
-//      pw - 1
-//   3  per-column weights (a shift fraction within float noise of a rounding tie: 6 of the 360 one-degree
+//   0  whole-column shift (stage 1 is a copy), footprint inside one pass of the source row     } tight loops
+//   1  whole-column shift, footprint across the source row's end (items wrap to its start)      }
+//   2  one blend weight for the whole piece, footprint inside one pass of the row               }
+//   3  one blend weight, footprint across the row's end -- where the column P:105 clips to      }
+//      pw - 1 lives: that one rot pixel is a copy instead
+//   4  per-column weights (a shift fraction within float noise of a rounding tie: 6 of the 360 one-degree
 //      yaws on 8192 columns) or a caller row that is not a shift -> general loop of the rest kernel
 struct PairCtxs {
     uint32_t cw0, cw1;
     int cw2, cw3;
-    int n0, n1, n2;  // pairs of class 0, of classes 0..1, of classes 0..2
+    int n0, n1, n2, n3;  // pairs of class 0, of classes 0..1, 0..2, 0..3
     int npairs, pair0;
 };
 
@@ -190,7 +191,7 @@ __device__ __forceinline__ PairCtxs pair_contexts(const ViewsParams& P, const Ya
     X.npairs = pair1 - X.pair0;
     const int ngroups = P.pw >> 2;
     uint32_t cw0 = 0, cw1 = 0;
-    int cw2 = 0, cw3 = 0, cls = 3;
+    int cw2 = 0, cw3 = 0, cls = 4;
     const int k = t & 63;
     if (k < X.npairs) {
         cw3 = pano_of_pair(P, X.pair0 + k);
@@ -208,20 +209,27 @@ __device__ __forceinline__ PairCtxs pair_contexts(const ViewsParams& P, const Ya
         cw1 = (uint32_t)(ngroups - g0) | (uint32_t)yi << 16;
         cw2 = 4 * g0 - yd.s;
         cw3 |= k << 26;  // n_panos < 2^26 (host check): the chunk-local pair index rides along
-        cls = yd.mode != 0 ? 3 : (clamp_in ? 2 : (yd.f == 0 ? 0 : 1));
+        // items reach group ((c1 + 1 - c0) + 3) >> 2 past the first; beyond the row's last group they wrap
+        // (telling the two apart at compile time would save 3 instructions per item, but the prefetch of the NEXT
+        // pair crosses class boundaries: not done, only the clipped column makes a class of its own)
+        const bool wraps = clamp_in;
+        cls = yd.mode != 0 ? 4 : (yd.f == 0 ? (wraps ? 1 : 0) : (wraps ? 3 : 2));
     }
     const bool valid = k < X.npairs;
-    const unsigned long long m0 = __ballot(valid && cls == 0), m1 = __ballot(valid && cls == 1);
-    const unsigned long long m2 = __ballot(valid && cls == 2), m3 = __ballot(valid && cls == 3);
-    X.n0 = __popcll(m0);
-    X.n1 = X.n0 + __popcll(m1);
-    X.n2 = X.n1 + __popcll(m2);
     const unsigned long long below = (1ull << k) - 1ull;
-    int r = k;
-    if (valid)
-        r = cls == 0 ? __popcll(m0 & below)
-                     : (cls == 1 ? X.n0 + __popcll(m1 & below)
-                                 : (cls == 2 ? X.n1 + __popcll(m2 & below) : X.n2 + __popcll(m3 & below)));
+    int r = k, base = 0, cum[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const unsigned long long m = __ballot(valid && cls == c);
+        if (valid && cls == c)
+            r = base + __popcll(m & below);
+        base += __popcll(m);
+        cum[c] = base;
+    }
+    X.n0 = cum[0];
+    X.n1 = cum[1];
+    X.n2 = cum[2];
+    X.n3 = cum[3];
     X.cw0 = (uint32_t)__builtin_amdgcn_ds_permute(4 * r, (int)cw0);
     X.cw1 = (uint32_t)__builtin_amdgcn_ds_permute(4 * r, (int)cw1);
     X.cw2 = __builtin_amdgcn_ds_permute(4 * r, cw2);
@@ -266,7 +274,7 @@ __device__ __forceinline__ void draw_tight(
     if (!tight_piece<PXT>(G, P))
         return;  // the rest kernel's
     const PairCtxs X = pair_contexts(P, ydesc, h.c0, h.c1, t);
-    const int nplain = X.n2;
+    const int nplain = X.n3;
     if (nplain == 0)
         return;
     uint32_t tap_up[PXT], tap_lo[PXT];
@@ -355,10 +363,11 @@ __device__ __forceinline__ void draw_tight(
             tl4[t + sl * VIEWS_BLOCK] = o;
         }
     };
-    auto tight = [&](auto ns_c, auto mode_c, int kbeg, int kend) {
-        for (int k = kbeg; k < kend; ++k) {
+    // one pair: `cur` holds its source pieces, the next pair's are requested into `nxt`
+    auto one_pair = [&](auto ns_c, auto mode_c, int k, const Q16 (&cur)[VIEWS_SLOTS], Q16 (&nxt)[VIEWS_SLOTS]) {
+        {
             uint4* tl4 = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(&tile4[0][0]) + buf_bytes);
-            stage1(ns_c, mode_c, k, qc, tl4);
+            stage1(ns_c, mode_c, k, cur, tl4);
             // LDS position of rot column c0 within its row's first item: 0..3, from the yaw's shift
             uint32_t soff = buf_bytes + 4u * (((uint32_t)__builtin_amdgcn_readlane((int)X.cw0, k) >> 20) & 3u);
             asm volatile("" : "+s"(soff));  // one scalar: keeps the buffer base out of separate vector adds
@@ -379,12 +388,12 @@ __device__ __forceinline__ void draw_tight(
             // the next pair's pieces (the last pair asks for its own again: no branch on the memory path)
             const int kn = k + 1 < nplain ? k + 1 : k;
 #ifndef P2P_ABLATE_LOADS
-            load_pieces(ns_c, kn, qn);
+            load_pieces(ns_c, kn, nxt);
 #else
             (void)kn;
 #pragma unroll
             for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
-                qn[sl] = qc[sl];
+                nxt[sl] = cur[sl];
 #endif
             uint32_t pix[PXT];
 #pragma unroll
@@ -413,10 +422,21 @@ __device__ __forceinline__ void draw_tight(
                 __builtin_amdgcn_raw_buffer_store_b96(o, __builtin_amdgcn_make_buffer_rsrc(O, 0, (int)view_bytes, 0x00020000),
                                                       (int)out_off12, 0, P2P_STORE_AUX);
             }
+            buf_bytes ^= (uint32_t)sizeof(tile4[0]);
+        }
+    };
+    // the pieces ping-pong between two register sets (pairs two at a time), so nothing is copied per pair
+    auto tight = [&](auto ns_c, auto mode_c, int kbeg, int kend) {
+        int k = kbeg;
+        for (; k + 1 < kend; k += 2) {
+            one_pair(ns_c, mode_c, k, qc, qn);
+            one_pair(ns_c, mode_c, k + 1, qn, qc);
+        }
+        if (k < kend) {
+            one_pair(ns_c, mode_c, k, qc, qn);
 #pragma unroll
             for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
                 qc[sl] = qn[sl];
-            buf_bytes ^= (uint32_t)sizeof(tile4[0]);
         }
     };
     auto run_ns = [&](auto ns_c) {
@@ -428,9 +448,9 @@ __device__ __forceinline__ void draw_tight(
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_raw_buffer_store_b32(0u, __builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0x00020000), 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        tight(ns_c, std::integral_constant<int, 0>{}, 0, X.n0);
-        tight(ns_c, std::integral_constant<int, 1>{}, X.n0, X.n1);
-        tight(ns_c, std::integral_constant<int, 2>{}, X.n1, X.n2);
+        tight(ns_c, std::integral_constant<int, 0>{}, 0, X.n1);
+        tight(ns_c, std::integral_constant<int, 1>{}, X.n1, X.n2);
+        tight(ns_c, std::integral_constant<int, 2>{}, X.n2, X.n3);
     };
     static_assert(VIEWS_SLOTS == 2 || VIEWS_SLOTS == 3, "dispatch below");
     if (ns_wave == 0)
@@ -581,7 +601,7 @@ __device__ __forceinline__ void draw_rest(
 
     // ---- LDS scheme, general loop ----
     const PairCtxs X = pair_contexts(P, ydesc, h.c0, h.c1, t);
-    const int kfirst = main_draws_plain ? X.n2 : 0;  // the main kernel has classes 0..2 of its pieces
+    const int kfirst = main_draws_plain ? X.n3 : 0;  // the main kernel has classes 0..3 of its pieces
     if (kfirst >= X.npairs)
         return;
     uint32_t tap_up[PXT], tap_lo[PXT];

@@ -54,6 +54,7 @@ static inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigne
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)calloc(1, sizeof(p2p_stub_event)); return *e ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { if (!e || !s) return hipErrorInvalidValue; e->recorded = 1; return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t e) { return e ? hipSuccess : hipErrorInvalidValue; }
 static inline hipError_t hipEventSynchronize(hipEvent_t e) { return e ? hipSuccess : hipErrorInvalidValue; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { if (!a || !b) return hipErrorInvalidValue; *ms = 0.125f; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }

@@ -12,7 +12,7 @@ vals = defaultdict(list)
 for f in sorted(glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), recursive=True)):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if kernel_key not in row.get("Kernel_Name", ""):
+            if kernel_key not in row.get("Kernel_Name", "") or "rest_kernel" in row.get("Kernel_Name", ""):
                 continue
             vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(vals):

@@ -5,21 +5,24 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/trace.log
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline --counters none > $OUT/bench_under_trace.json 2> $OUT/trace.log
+# the driver's own command line, under the trace too (20 timed launches after the disclosed pre-roll)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_driver -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --counters none > $OUT/bench_driver_under_trace.json 2> $OUT/trace_driver.log
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 120 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$c.log
+  timeout 120 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-preroll --counters none > /dev/null 2> $OUT/pmc_$c.log
   timeout 120 rocprofv3 --pmc $c --output-format csv -d $OUT/calib_$c -- $ROOT/tools/ubench/fetch_calib > /dev/null 2> $OUT/calib_$c.log
 done
-timeout 120 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $OUT/pmc_ea -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/pmc_ea.log
-timeout 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum --output-format csv -d $OUT/pmc_tcc -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/pmc_tcc.log
+timeout 120 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $OUT/pmc_ea -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-preroll --counters none > /dev/null 2> $OUT/pmc_ea.log
+timeout 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum --output-format csv -d $OUT/pmc_tcc -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-preroll --counters none > /dev/null 2> $OUT/pmc_tcc.log
 cd $ROOT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err
 python3 - <<PY
 import csv, glob, json, os, re
 out = "$OUT"
 def counters(d, key):
-    # key "remap_views_kernel" = the drawing instance <MAPSRC 0, MODE 0> only (the plan pass <0, 1> runs once per job)
-    pat = re.compile(r"remap_views_kernel<0,\s*0>") if key == "remap_views_kernel" else re.compile(re.escape(key))
+    # key "remap_views_kernel" = the main kernel only (remap_views_rest_kernel and plan_kernel are others)
+    pat = re.compile(r"remap_views_kernel\(") if key == "remap_views_kernel" else re.compile(re.escape(key))
     vals = {}
     for f in glob.glob(os.path.join(out, d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
@@ -36,5 +39,6 @@ res["views"].update(counters("pmc_tcc", "remap_views_kernel"))
 json.dump(res, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
-cat $(find $OUT/trace -name "*kernel_stats.csv" | head -1)
+cat $(find $OUT/trace -name "*kernel_stats.csv" | head -1) | cut -c1-160
+cat $(find $OUT/trace_driver -name "*kernel_stats.csv" | head -1) | cut -c1-160
 cat $OUT/bench.json

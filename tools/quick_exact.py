@@ -1,0 +1,11 @@
+import importlib, sys, os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
+import numpy as np
+pkg = importlib.import_module("360-to-planer-images_amd"); synth = importlib.import_module("360-to-planer-images_amd.synth")
+from _util import oracle_maps, oracle_views
+pano = synth.synth_pano(2048, 1024, 1, "N")
+yaws, pitches = [0, 30, 77], [60, 90]
+rows, U, V = oracle_maps(yaws, pitches, 480, 270, 2048, 1024, 90)
+got = pkg._native.remap_views_maps(pano, rows, U, V)
+want = oracle_views(pano, yaws, pitches, 480, 270, 90)
+print("exact:", np.array_equal(got, want), int((got != want).sum()))
