@@ -50,17 +50,18 @@ enum { P2P_INTER_NEAREST = 0, P2P_INTER_LINEAR = 1, P2P_INTER_CUBIC = 2 };
 /* p2p_job_desc.flags / p2p_remap_views_u8 flags */
 enum {
     P2P_FLAG_DEFAULT = 0,
-    P2P_FLAG_KEEP_COORDS = 1,  /* keep the quantised pitch-stage coordinates the kernel used
-                                  (readable with p2p_job_get_coords); for parity tests */
-    P2P_FLAG_CACHE_COORDS = 2, /* jobs only: the first p2p_job_run evaluates the pitch maps in-kernel and
-                                  stores the quantised coordinates; later runs of the job load them
-                                  instead of re-evaluating -- the reference's pitch_mapping_cache (P:17-18,
-                                  P:62-73), which it keeps across yaws AND images.  Off by default. */
+    P2P_FLAG_KEEP_COORDS = 1,  /* accepted for compatibility: the quantised pitch-stage coordinates are part of every
+                                  job's plan now and p2p_job_get_coords always works (parity tests use it) */
+    P2P_FLAG_CACHE_COORDS = 2, /* accepted for compatibility: every job evaluates its pitch maps ONCE, in the plan pass
+                                  of its first p2p_job_run, and later runs start from the stored tables -- the
+                                  reference's pitch_mapping_cache (P:17-18, P:62-73), which it keeps across yaws AND
+                                  images.  p2p_job_set_maps replaces the maps and with them the plan. */
     /* Float pixel path, opt-in and BEYOND the reference (BASELINE config 5's "fp16 pixel path"):
-       one float resample per view instead of two fixed-point ones -- the pitch map's coordinate shifted by
-       yaw * pw / 360 with true wrap-around at the seam, no 1/32-pixel quantisation, no uint8 intermediate;
-       the 2x2 blend in float32 or packed float16, rounded to uint8 once.  Not comparable bit for bit with
-       cv2.remap; within 1-2 levels of the exact path on band-limited panoramas. */
+       one float resample per view instead of two fixed-point ones -- the pitch map's coordinate (azimuth left
+       unclipped) shifted by yaw * pw / 360 with true wrap-around at the seam, no 1/32-pixel quantisation, no uint8
+       intermediate; the 2x2 blend in float32, or with float16 taps and weights accumulated in float32; rounded to
+       uint8 once (half-even).  Not comparable bit for bit with cv2.remap; within 1-2 levels of the exact path on
+       band-limited panoramas. */
     P2P_FLAG_PIXELS_F32 = 4,
     P2P_FLAG_PIXELS_F16 = 8,
     /* With a float pixel path only: rays through the centres of the output pixels and panorama texels centred at
@@ -246,8 +247,9 @@ int p2p_job_kernel_ms(p2p_job* job, float* ms);
 int p2p_job_kernel_ms_last(p2p_job* job, float* ms, int n);
 /* Device address / byte size of the output block [n_panos][n_yaw][n_pitch][oh][ow][3]. */
 void* p2p_job_device_out(p2p_job* job, int64_t* bytes);
-/* With P2P_FLAG_KEEP_COORDS: the pitch-stage coordinates in 1/32 px the last run used,
-   int32 [n_pitch][oh][ow][2] = (sx, sy); INT32_MIN marks a NaN coordinate (black pixel). */
+/* The pitch-stage coordinates in 1/32 px the job's plan holds (after the first p2p_job_run),
+   int32 [n_pitch][oh][ow][2] = (sx, sy); INT32_MIN marks a NaN coordinate (black pixel).  Jobs of the float
+   pixel path hold float coordinates there instead (U - centre, V - centre as float32 bits). */
 int p2p_job_get_coords(p2p_job* job, int32_t* sxsy);
 /* The packed per-column yaw tables in use, uint32 [n_yaw][pw] = 3*ix | fx << 20. */
 int p2p_job_get_yaw_tables(p2p_job* job, uint32_t* packed);
