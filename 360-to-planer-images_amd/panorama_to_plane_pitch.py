@@ -193,8 +193,21 @@ def _imwrite_bgr(path, image):
     return True
 
 
+# throughput summary of a main() run (keep the reference's log format, add one Mpix/s + GB/s line)
+_stats_lock = __import__("threading").Lock()
+_stats = {"views": 0, "pixels": 0, "src_bytes": 0}
+
+
+def _count(views=0, pixels=0, src_bytes=0):
+    with _stats_lock:
+        _stats["views"] += views
+        _stats["pixels"] += pixels
+        _stats["src_bytes"] += src_bytes
+
+
 def _write_yaw(views_y, yaw_angle, pitch_angles, base_name, output_width, output_height, output_format, output_dir):
     """Encode and write every pitch view of one yaw (one task of the writer pool)."""
+    _count(views=len(pitch_angles), pixels=len(pitch_angles) * int(output_width) * int(output_height))
     for pi, pitch_angle in enumerate(pitch_angles):
         out_filename = f"{base_name}_{output_width}x{output_height}_yaw_{yaw_angle}_pitch_{pitch_angle}.{output_format}"
         output_file = output_dir / out_filename
@@ -286,6 +299,7 @@ def _submit_views(executor, input_image, input_image_path, output_dir, yaw_angle
                   output_height, output_format, fov_deg, device=None):
     """One kernel launch for every yaw and pitch of the image, then one write task per yaw on `executor`."""
     yaw_angles = list(yaw_angles)
+    _count(src_bytes=int(getattr(input_image, "nbytes", 0)))
     try:
         views = _views_of(input_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg, device)
     except Exception as e:
@@ -329,6 +343,11 @@ def main(
     enable_file_logging=False,
 ):
     """Drop-in for P:286-356: one image or every .jpg/.jpeg/.png under a directory (recursive)."""
+    import time as _time
+
+    t_start = _time.perf_counter()
+    with _stats_lock:
+        _stats.update(views=0, pixels=0, src_bytes=0)
     if num_workers is None:
         cpu_cores = os.cpu_count() or 1
         num_workers = max(1, int(cpu_cores * 0.9))
@@ -395,6 +414,7 @@ def main(
                         if decoded is None:
                             logging.error(f"Failed to read image: {image_file}")
                             continue
+                        _count(src_bytes=int(decoded.nbytes))
                         try:
                             ticket = pipe.submit(decoded, yaws, pitches, _angle(fov_deg, "FOV"), output_width, output_height)
                         except Exception as e:
@@ -427,6 +447,12 @@ def main(
         process_single_image(input_image_path=input_path_obj, **common)
 
     logging.info("All processing completed.")
+    dt = max(_time.perf_counter() - t_start, 1e-9)
+    with _stats_lock:
+        n_views, n_px, n_src = _stats["views"], _stats["pixels"], _stats["src_bytes"]
+    if n_views:
+        logging.info(f"{n_views} views, {n_px / 1e6:.1f} Mpix in {dt:.2f} s: {n_px / 1e6 / dt:.1f} Mpix/s end to end "
+                     f"(decode and encode included), {(n_src + 3 * n_px) / 1e9 / dt:.2f} GB/s of pixels through the GPU")
 
 
 def check_pitch(value: str) -> int:

@@ -364,8 +364,14 @@ def main():
         views_per_rank = npg * n_yaw * n_pitch
         sharding = "independent panoramas per rank, no collective"
     job = jobs[0] if jobs else None
-    for i, seed in enumerate(seeds if jobs else []):
-        jobs[0].set_pano(i, synth.synth_pano(w["pw"], w["ph"], seed, args.kind))
+    if jobs:
+        # synthetic panoramas, seed 1000 + index; generated on a few host threads (NumPy releases the
+        # GIL): config 3's share is up to 64 of them
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=max(1, min(8, len(seeds), (os.cpu_count() or 1) // max(1, dist.world)))) as ex:
+            for i, pano in enumerate(ex.map(lambda sd: synth.synth_pano(w["pw"], w["ph"], sd, args.kind), seeds)):
+                jobs[0].set_pano(i, pano)
     if args.maps == "caller":
         import numpy as np  # float maps from the library's own device map builders, handed back in
 
