@@ -32,7 +32,7 @@ static_assert(LDS_ITEMS_CAP <= VIEWS_SLOTS * VIEWS_BLOCK && LDS_ITEMS_CAP > (VIE
 constexpr int PXW_UP_BITS = 12;     // per-pixel word: bits of the upper tap's LDS offset (dwords; 4 * LDS_ITEMS_CAP <= 4096)
 constexpr int PXW_DL_BITS = 10;     //                 bits of (lower tap - upper tap)
 static_assert(4 * LDS_ITEMS_CAP <= (1 << PXW_UP_BITS), "tap offsets must fit the per-pixel word");
-constexpr int VIEWS_WAVES_PER_SIMD = P2P_WAVES;  // __launch_bounds__ of the view kernel: 128 VGPRs
+constexpr int VIEWS_WAVES_PER_SIMD = P2P_WAVES;  // __launch_bounds__ of the main view kernel: 80 VGPRs, and 6 x 26.5 KB of LDS
 constexpr int PLAN_MAX_ROWS = 256;  // rot rows a piece's footprint may span (one plan thread per row)
 constexpr int PLAN_MIN_W = 16;      // tiles whose footprint outgrows the LDS buffers are halved in width down to
 constexpr int PLAN_MIN_H = 8;       // PLAN_MIN_W, then once in height; what still does not fit gathers directly

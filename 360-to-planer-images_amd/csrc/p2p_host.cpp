@@ -60,6 +60,10 @@ struct p2p_ctx {
     hipStream_t stream_down = nullptr; // asynchronous view downloads (p2p_job_get_views_async)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     short* d_ctab = nullptr;  // INTER_CUBIC weight table, built on first use
+    // grow-only scratch of the generic remap entry point (source image, output, two maps): kept with the context
+    // instead of four hipMalloc / hipFree per call
+    void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[4] = {0, 0, 0, 0};
 };
 
 struct p2p_job {
@@ -312,6 +316,8 @@ void p2p_ctx_destroy(p2p_ctx* c)
             (void)hipStreamDestroy(*st);
         }
     (void)hipFree(c->d_ctab);
+    for (void* p : c->scratch)
+        (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -990,9 +996,19 @@ int p2p_release_cache(void)
     {
         std::lock_guard<std::mutex> lk(P.mu);
         for (OneShotSlot* s : P.slots)
-            if (!s->busy && s->cached) {
-                victims.push_back(s->cached);
-                s->cached = nullptr;
+            if (!s->busy) {
+                if (s->cached) {
+                    victims.push_back(s->cached);
+                    s->cached = nullptr;
+                }
+                if (s->ctx) {
+                    (void)hipSetDevice(s->device);
+                    for (int i = 0; i < 4; ++i) {
+                        (void)hipFree(s->ctx->scratch[i]);
+                        s->ctx->scratch[i] = nullptr;
+                        s->ctx->scratch_bytes[i] = 0;
+                    }
+                }
             }
     }
     for (p2p_job* j : victims)
@@ -1184,20 +1200,26 @@ int p2p_remap_maps_interp_u8(const uint8_t* src, int sw, int sh, int64_t row_str
     p2p_ctx* ctx = guard.s->ctx;
     const int pitch = (sw * cn + 15) & ~15;
     const size_t n_map = (size_t)ow * oh;
-    uint8_t *d_src = nullptr, *d_dst = nullptr;
-    float *d_U = nullptr, *d_V = nullptr;
-    auto cleanup = [&]() {
-        (void)hipFree(d_src); (void)hipFree(d_dst); (void)hipFree(d_U); (void)hipFree(d_V);
-    };
     hipError_t e = hipSuccess;
+    auto scratch = [&](int i, size_t bytes) -> void* {
+        if (e == hipSuccess && ctx->scratch_bytes[i] < bytes) {
+            (void)hipFree(ctx->scratch[i]);
+            ctx->scratch[i] = nullptr;
+            ctx->scratch_bytes[i] = 0;
+            e = hipMalloc(&ctx->scratch[i], bytes);
+            if (e == hipSuccess)
+                ctx->scratch_bytes[i] = bytes;
+        }
+        return ctx->scratch[i];
+    };
     if (interpolation == P2P_INTER_CUBIC && !ctx->d_ctab) {
         e = hipMalloc((void**)&ctx->d_ctab, 1024 * 16 * sizeof(short));
         if (e == hipSuccess) e = p2p::launch_cubic_tab(ctx->d_ctab, ctx->stream);
     }
-    if (e == hipSuccess) e = hipMalloc((void**)&d_src, (size_t)pitch * sh + kSlack);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_dst, n_map * cn);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_U, n_map * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_V, n_map * sizeof(float));
+    uint8_t* d_src = (uint8_t*)scratch(0, (size_t)pitch * sh + kSlack);
+    uint8_t* d_dst = (uint8_t*)scratch(1, n_map * cn);
+    float* d_U = (float*)scratch(2, n_map * sizeof(float));
+    float* d_V = (float*)scratch(3, n_map * sizeof(float));
     if (e == hipSuccess)
         e = hipMemcpy2DAsync(d_src, pitch, src, (size_t)row_stride, (size_t)sw * cn, sh, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_U, U, n_map * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
@@ -1213,7 +1235,6 @@ int p2p_remap_maps_interp_u8(const uint8_t* src, int sw, int sh, int64_t row_str
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_dst, n_map * cn, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    cleanup();
     if (e != hipSuccess)
         return fail(e == hipErrorOutOfMemory ? P2P_ERR_OOM : P2P_ERR_HIP, "p2p_remap_maps_u8: %s", hipGetErrorString(e));
     return P2P_OK;
