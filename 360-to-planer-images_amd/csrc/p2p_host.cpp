@@ -253,9 +253,10 @@ int choose_pairs_per_block(const p2p_job_desc& d)
     if (z < 1) z = 1;
     if (z > n_pairs) z = n_pairs;
     int ppb = (int)((n_pairs + z - 1) / z);
-    // measured: 16 pairs per workgroup is the sweet spot (longer loops do not run faster per pair), except
-    // for very large view sets (config 4: 164 k tile-views), where halving the chunk count still pays
-    int cap = env_int("P2P_MAX_PAIRS_PER_BLOCK", base >= 16 * target ? 40 : 16);
+    // measured on the plan-driven kernel (config 5, 360 yaws): 16 pairs per workgroup 0.885 ms, 30: 0.843, 45: 0.835,
+    // 60: 0.832 -- the per-workgroup set-up is small now.  Chunks that run across several panoramas are another
+    // matter (8 resident panoramas: 16 pairs 0.843 ms, 48 pairs 0.894): their sources compete for the caches
+    int cap = env_int("P2P_MAX_PAIRS_PER_BLOCK", d.n_panos > 1 ? 16 : 48);
     if (cap > 64) cap = 64;
     if (cap < 1) cap = 1;
     if (ppb > cap) {
