@@ -280,6 +280,14 @@ __device__ __forceinline__ void draw_tight(
     uint32_t tap_up[PXT], tap_lo[PXT];
     TapWeights tw[PXT];
     decode_px<PXT>(pxw, t, tap_up, tap_lo, tw);
+#ifdef P2P_ABLATE_CONFLICTS
+    // timing experiment only (wrong pixels): every lane reads its own two dwords -- tap reads without bank conflicts
+#pragma unroll
+    for (int j = 0; j < PXT; ++j) {
+        tap_up[j] = (uint32_t)(t & 63) * 8u + (uint32_t)j * 512u;
+        tap_lo[j] = tap_up[j] + 2048u;
+    }
+#endif
     uint32_t slot_off[VIEWS_SLOTS], slot_g[VIEWS_SLOTS];
     decode_items(itw, t, G.n_items, P.src_pitch, slot_off, slot_g);
     const uint32_t row_bytes = 3u * (uint32_t)P.pw;
