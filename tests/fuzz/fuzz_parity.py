@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off fuzz of the integer path: random jobs (sizes, FOVs, yaw / pitch lists, several panoramas, odd widths)
 through p2p_job_* with the oracle's float maps, every byte compared with the CPU restatement.
-Usage: python tests/fuzz/fuzz_parity.py [n_cases] [seed] [only_case | -1] [big]
+Usage: python tests/fuzz/fuzz_parity.py [n_cases] [seed] [only_case | -1] [big | real]
 With "big": large panoramas, views towards the poles, wide FOVs -- footprints that outgrow the LDS buffers
 (plan pass, sub-tiles, compacted item lists, direct gathers)."""
 import importlib, os, sys, time
@@ -15,6 +15,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2026
 only = int(sys.argv[3]) if len(sys.argv) > 3 and int(sys.argv[3]) >= 0 else None      # re-run one case, checking every yaw
 big = len(sys.argv) > 4 and sys.argv[4] == "big"
+real = len(sys.argv) > 4 and sys.argv[4] == "real"   # real-valued yaw / pitch / FOV, pitch anywhere in [0, 180]
 ctx = nat.Context(0)
 t0 = time.time(); bad = 0
 for case in range(n_cases):
@@ -38,6 +39,10 @@ for case in range(n_cases):
         n_yaw = int(rng.integers(1, 5)); yaws = [int(v) for v in rng.integers(0, 360, size=n_yaw)]
         pitches = [int(v) for v in rng.choice([3, 10, 20, 30, 45, 60, 120, 150, 170, 177], size=int(rng.integers(1, 3)))]
         n_panos = int(rng.integers(1, 3))
+    if real:
+        yaws = [float(v) for v in rng.uniform(-400, 800, size=n_yaw)]
+        pitches = [float(v) for v in rng.uniform(0, 180, size=len(pitches))]
+        fov = float(rng.uniform(15, 160))
     panos = [synth.synth_pano(pw, ph, 9000 + 7 * case + i, "N") for i in range(n_panos)]
     rows, U, V = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
     job = nat.Job(ctx, pw, ph, n_panos, yaws, pitches, fov, ow, oh)
