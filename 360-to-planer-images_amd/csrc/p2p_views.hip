@@ -51,21 +51,12 @@ __device__ __forceinline__ uint32_t rot_blend8(uint32_t a_br, uint32_t a_g, uint
 // constants are therefore handed in as VGPRs.
 __device__ __forceinline__ uint32_t vmad24(uint32_t s_w, uint32_t v, uint32_t c)
 {
+#ifdef P2P_NO_ASM_MAD
+    return umad24(s_w, v, c);
+#else
     uint32_t r;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "s"(s_w), "v"(v), "v"(c));
     return r;
-}
-
-__device__ __forceinline__ uint32_t rot_blend8_mad(uint32_t a_br, uint32_t a_g, uint32_t b_br, uint32_t b_g,
-                                                   uint32_t f8, uint32_t g8, uint32_t bias_br, uint32_t bias_g)
-{
-#ifdef P2P_NO_ASM_MAD
-    (void)bias_br; (void)bias_g;
-    return rot_blend8(a_br, a_g, b_br, b_g, f8, g8);
-#else
-    const uint32_t br = vmad24(f8, b_br, vmad24(g8, a_br, bias_br));
-    const uint32_t gg = vmad24(f8, b_g, vmad24(g8, a_g, bias_g));
-    return __builtin_amdgcn_perm(br, gg, 0x0C070205u);
 #endif
 }
 
@@ -96,34 +87,42 @@ __device__ __forceinline__ uint32_t blend4(uint32_t a, uint32_t b, uint32_t c, u
 }
 
 
-// per-pixel stage-2 weights, constant across (panorama, yaw) pairs
+// per-pixel stage-2 weights, constant across (panorama, yaw) pairs: cv::remap's four tap weights
+// (32-fx)(32-fy), fx(32-fy), (32-fx)fy, fx*fy (sum 1024), scaled by 64 so that the rounded result
+// (sum + 512) >> 10 is byte 2 of the scaled sum.  The one weight that does not fit 16 bits, 1024 * 64 (fx = fy = 0:
+// the other three are 0), is stored as 65535: a * 65535 + 32768 = a * 65536 + (32768 - a) has the same byte 2.
 struct TapWeights {
-    uint32_t gx2, fx2;  // [32-fx, 32-fx], [fx, fx] as two u16
-    uint32_t wy;        // 64 * [32-fy, fy] as two u16 (0 for a pixel with no footprint)
+    uint32_t w_up;  // [w_a, w_b] as two u16 (0 for a pixel with no footprint)
+    uint32_t w_lo;  // [w_c, w_d]
 };
 
-// Stage 2 with packed 16-bit maths: per channel, the two rows ride in the two halves of a dword:
-//   H = [a.c, c.c] * [gx, gx] + [b.c, d.c] * [fx, fx]   (v_pk_mul_lo_u16, v_pk_mad_u16; <= 8160)
-//   V = H.lo * gy + H.hi * fy + 512                      (v_dot2_u32_u16)
-// identical in value to blend4().
+__device__ __forceinline__ TapWeights tap_weights(uint32_t fx, uint32_t fy, bool live)
+{
+    const uint32_t gx = 32u - fx, gy = 32u - fy;
+    const uint32_t wa = min(64u * gx * gy, 65535u);
+    TapWeights w;
+    w.w_up = live ? wa | ((64u * fx * gy) << 16) : 0u;
+    w.w_lo = live ? (64u * gx * fy) | ((64u * fx * fy) << 16) : 0u;
+    return w;
+}
+
+// Stage 2 as two 2-tap dot products per channel: v_perm_b32 widens one channel of two horizontal neighbours to two
+// u16, v_dot2_u32_u16 multiplies by the row's two weights and accumulates (exact in 32 bits: <= 255 * 65536 + 32768).
+// 14 instructions per pixel; identical in value to blend4().
 __device__ __forceinline__ uint32_t blend4_packed(uint32_t a, uint32_t b, uint32_t c, uint32_t d,
                                                   const TapWeights& w)
 {
-    const u16x2 gx = as_u16x2(w.gx2), fx = as_u16x2(w.fx2), wy = as_u16x2(w.wy);
+    const u16x2 wu = as_u16x2(w.w_up), wl = as_u16x2(w.w_lo);
     // v_perm_b32(S0, S1, sel): selector bytes 0-3 pick S1's bytes, 4-7 pick S0's, 0x0c is zero
-    const u16x2 b_ac = as_u16x2(__builtin_amdgcn_perm(c, a, 0x0C040C00u));
-    const u16x2 b_bd = as_u16x2(__builtin_amdgcn_perm(d, b, 0x0C040C00u));
-    const u16x2 g_ac = as_u16x2(__builtin_amdgcn_perm(c, a, 0x0C050C01u));
-    const u16x2 g_bd = as_u16x2(__builtin_amdgcn_perm(d, b, 0x0C050C01u));
-    const u16x2 r_ac = as_u16x2(__builtin_amdgcn_perm(c, a, 0x0C060C02u));
-    const u16x2 r_bd = as_u16x2(__builtin_amdgcn_perm(d, b, 0x0C060C02u));
-    const u16x2 hb = b_ac * gx + b_bd * fx;
-    const u16x2 hg = g_ac * gx + g_bd * fx;
-    const u16x2 hr = r_ac * gx + r_bd * fx;
-    // wy holds 64*[32-fy, fy]: the sums come out scaled by 64, so (sum + 512) >> 10 is byte 2 of each
-    const uint32_t vb = __builtin_amdgcn_udot2(hb, wy, 32768u, false);
-    const uint32_t vg = __builtin_amdgcn_udot2(hg, wy, 32768u, false);
-    const uint32_t vr = __builtin_amdgcn_udot2(hr, wy, 32768u, false);
+    const u16x2 b_ab = as_u16x2(__builtin_amdgcn_perm(b, a, 0x0C040C00u));
+    const u16x2 b_cd = as_u16x2(__builtin_amdgcn_perm(d, c, 0x0C040C00u));
+    const u16x2 g_ab = as_u16x2(__builtin_amdgcn_perm(b, a, 0x0C050C01u));
+    const u16x2 g_cd = as_u16x2(__builtin_amdgcn_perm(d, c, 0x0C050C01u));
+    const u16x2 r_ab = as_u16x2(__builtin_amdgcn_perm(b, a, 0x0C060C02u));
+    const u16x2 r_cd = as_u16x2(__builtin_amdgcn_perm(d, c, 0x0C060C02u));
+    const uint32_t vb = __builtin_amdgcn_udot2(b_cd, wl, __builtin_amdgcn_udot2(b_ab, wu, 32768u, false), false);
+    const uint32_t vg = __builtin_amdgcn_udot2(g_cd, wl, __builtin_amdgcn_udot2(g_ab, wu, 32768u, false), false);
+    const uint32_t vr = __builtin_amdgcn_udot2(r_cd, wl, __builtin_amdgcn_udot2(r_ab, wu, 32768u, false), false);
     const uint32_t bg = __builtin_amdgcn_perm(vg, vb, 0x0C0C0602u);  // B | G << 8
     return __builtin_amdgcn_perm(vr, bg, 0x0C060100u);               // | R << 16
 }
@@ -249,12 +248,9 @@ __device__ __forceinline__ void decode_px(const uint32_t* __restrict__ pxw, int 
         tap_up[j] = (wd & ((1u << PXW_UP_BITS) - 1u)) << 2;
         tap_lo[j] = tap_up[j] + (dl << 2);
         const uint32_t fx = (wd >> 22) & 31u, fy = wd >> 27;
-        const uint32_t gx = 32u - fx, gy = 32u - fy;
-        tw[j].gx2 = gx | (gx << 16);
-        tw[j].fx2 = fx | (fx << 16);
         // a pixel with no footprint in the panorama (NaN coordinate) gets weight 0 everywhere:
         // (0 + 512) >> 10 == 0, the BORDER_CONSTANT value
-        tw[j].wy = dl ? 64u * (gy | (fy << 16)) : 0u;
+        tw[j] = tap_weights(fx, fy, dl != 0);
     }
 }
 
@@ -298,12 +294,30 @@ __device__ __forceinline__ void draw_tight(
     // the piece or the view, four-pixel groups the piece does not have) get an offset beyond it and the hardware
     // drops them.  No lane is masked off: a masked store brings a branch, and with it vmcnt(0).
     const int wv = t >> 6, ln = t & 63;
+#ifndef P2P_DPP_STORES
     uint32_t* const stg = stage + wv * (PXT * 64);
     const int x4 = 4 * (ln & 15), sj = ln >> 4;    // the group's first pixel as a lane of this wave; which of the thread's pixels
     const int srow = ((wv * 64 + x4) >> G.lw) + sj * G.rstep, scol = x4 & (G.w - 1);
     const bool s_ok = sj < PXT && srow < G.h && G.y0 + srow < P.oh && G.x0 + scol < P.ow;
     const uint32_t out_off12 = s_ok ? (uint32_t)(((size_t)(G.y0 + srow) * P.ow + G.x0 + scol) * 3) : 0xFFFFFFFFu;
     const uint32_t stg_rd = (uint32_t)(sj * 64 + x4);
+#else
+    // Four adjacent pixels of a row are 12 bytes = 3 dwords: lane 4m + r (r = 0, 1, 2) makes dword r of its group
+    // from its own pixel and its right neighbour's (one DPP row shift, one v_perm_b32), lane 4m + 3 stores nothing.
+    (void)stage; (void)wv;
+    const int r4 = ln & 3;
+    const uint32_t out_sel = r4 == 0 ? 0x04020100u : r4 == 1 ? 0x05040201u : 0x06050402u;
+    uint32_t out_off[PXT];
+#pragma unroll
+    for (int j = 0; j < PXT; ++j) {
+        const int row = G.row0 + j * G.rstep;
+        const bool ok = r4 != 3 && row < G.h && G.y0 + row < P.oh && G.x0 + G.col < P.ow;
+        out_off[j] = ok ? (uint32_t)(((size_t)(G.y0 + row) * P.ow + G.x0 + G.col) * 3) + (uint32_t)r4 : 0xFFFFFFFFu;
+#ifdef P2P_ABLATE_STORES3
+        out_off[j] = 0xFFFFFFFFu;  // timing experiment: every store issued, every store dropped by the range check
+#endif
+    }
+#endif
 
     const int wave_base = __builtin_amdgcn_readfirstlane(t & ~63);
     int ns_wave = 0;  // items this wave produces per pair (wave-uniform)
@@ -311,8 +325,8 @@ __device__ __forceinline__ void draw_tight(
     for (int k = 0; k < VIEWS_SLOTS; ++k)
         ns_wave += G.n_items > wave_base + k * VIEWS_BLOCK;
 
-    uint32_t bias_br = 0x00800080u, bias_g = 0x00008000u;
-    asm volatile("" : "+v"(bias_br), "+v"(bias_g));
+    uint32_t bias_br = 0x00800080u;  // rounding of both 16-bit fields, kept in a VGPR (see vmad24)
+    asm volatile("" : "+v"(bias_br));
 
     uint32_t buf_bytes = 0u;
     Q16 qc[VIEWS_SLOTS], qn[VIEWS_SLOTS];
@@ -326,6 +340,9 @@ __device__ __forceinline__ void draw_tight(
         for (int sl = 0; sl < NS; ++sl) {
             uint32_t off = slot_off[sl] + goff;
             off = slot_g[sl] >= wrap_g ? off - row_bytes : off;  // items past the end of the row continue at its start
+#ifdef P2P_ABLATE_LOADS2
+            off &= 0x3FFFu;  // timing experiment (wrong pixels): every load issued, all of them hits in 16 KB
+#endif
             qq[sl] = *reinterpret_cast<const Q16*>(S + off);
         }
     };
@@ -344,18 +361,29 @@ __device__ __forceinline__ void draw_tight(
             uint4 o;
             if (MODE != 0) {
                 const uint32_t f8 = 8u * f, g8 = 256u - f8;
-                const uint32_t m0 = d0 & 0x00FF00FFu, n0 = d0 & 0x0000FF00u;                    // bytes 0,1,2
-                const uint32_t m1 = __builtin_amdgcn_perm(d1, d0, 0x0C050C03u);                  // 3,(4),5
-                const uint32_t n1 = __builtin_amdgcn_perm(d1, d0, 0x0C0C040Cu);
-                const uint32_t m2 = __builtin_amdgcn_perm(d2, d1, 0x0C040C02u);                  // 6,(7),8
-                const uint32_t n2 = __builtin_amdgcn_perm(d2, d1, 0x0C0C030Cu);
-                const uint32_t m3 = __builtin_amdgcn_perm(d3, d2, 0x0C030C01u);                  // 9,(10),11
-                const uint32_t n3 = __builtin_amdgcn_perm(d3, d2, 0x0C0C020Cu);
-                const uint32_t m4 = d3 & 0x00FF00FFu, n4 = d3 & 0x0000FF00u;                    // 12,13,14
-                o.x = rot_blend8_mad(m0, n0, m1, n1, f8, g8, bias_br, bias_g);
-                o.y = rot_blend8_mad(m1, n1, m2, n2, f8, g8, bias_br, bias_g);
-                o.z = rot_blend8_mad(m2, n2, m3, n3, f8, g8, bias_br, bias_g);
-                o.w = rot_blend8_mad(m3, n3, m4, n4, f8, g8, bias_br, bias_g);
+                // B and R of a pixel share one multiply-add pair (fields at bits 0 and 16), and so do the G of two
+                // neighbouring pixels: 12 v_mad_u32_u24 per item instead of 16.  Source byte 3i + c is channel c of
+                // source pixel i; the piece's dwords hold bytes 0-3, 4-7, 8-11, 12-15.
+                const uint32_t m0 = d0 & 0x00FF00FFu;                                // B0 R0  (bytes 0, 2)
+                const uint32_t m1 = __builtin_amdgcn_perm(d1, d0, 0x0C050C03u);      // B1 R1  (3, 5)
+                const uint32_t m2 = __builtin_amdgcn_perm(d2, d1, 0x0C040C02u);      // B2 R2  (6, 8)
+                const uint32_t m3 = __builtin_amdgcn_perm(d3, d2, 0x0C030C01u);      // B3 R3  (9, 11)
+                const uint32_t m4 = d3 & 0x00FF00FFu;                                // B4 R4  (12, 14)
+                const uint32_t n01 = __builtin_amdgcn_perm(d1, d0, 0x0C040C01u);     // G0 G1  (1, 4)
+                const uint32_t n12 = __builtin_amdgcn_perm(d1, d1, 0x0C030C00u);     // G1 G2  (4, 7)
+                const uint32_t n23 = __builtin_amdgcn_perm(d2, d1, 0x0C060C03u);     // G2 G3  (7, 10)
+                const uint32_t n34 = __builtin_amdgcn_perm(d3, d2, 0x0C050C02u);     // G3 G4  (10, 13)
+                const uint32_t br0 = vmad24(f8, m1, vmad24(g8, m0, bias_br));
+                const uint32_t br1 = vmad24(f8, m2, vmad24(g8, m1, bias_br));
+                const uint32_t br2 = vmad24(f8, m3, vmad24(g8, m2, bias_br));
+                const uint32_t br3 = vmad24(f8, m4, vmad24(g8, m3, bias_br));
+                const uint32_t g01 = vmad24(f8, n12, vmad24(g8, n01, bias_br));
+                const uint32_t g23 = vmad24(f8, n34, vmad24(g8, n23, bias_br));
+                // every 16-bit field holds 256 * blend + rounding: the wanted byte is the field's high byte
+                o.x = __builtin_amdgcn_perm(br0, g01, 0x0C070105u);
+                o.y = __builtin_amdgcn_perm(br1, g01, 0x0C070305u);
+                o.z = __builtin_amdgcn_perm(br2, g23, 0x0C070105u);
+                o.w = __builtin_amdgcn_perm(br3, g23, 0x0C070305u);
                 if (MODE == 2) {
                     // source column pw - 1 is pixel 3 of the row's last item; its right neighbour is not a pixel
                     // of this row, and the clipped map gives it weight 0 anyway
@@ -414,6 +442,9 @@ __device__ __forceinline__ void draw_tight(
 #endif
             {
                 uint8_t* O = out + ((size_t)pair * P.n_pitch + G.pitch_i) * view_bytes;  // [pano][yaw][pitch][oh][ow][3]
+                // aux 2 = nt: the views are written once and not read by this kernel, they should not displace
+                // the panorama from the caches
+#ifndef P2P_DPP_STORES
 #pragma unroll
                 for (int j = 0; j < PXT; ++j)
                     stg[j * 64 + ln] = pix[j];
@@ -426,10 +457,21 @@ __device__ __forceinline__ void draw_tight(
 #ifdef P2P_ABLATE_STORES2
                 if (o.x == 0x12345678u && o.z == 0x9ABCDEF0u)
 #endif
-                // aux 2 = nt: the views are written once and not read by this kernel, they should not displace
-                // the panorama from the caches
                 __builtin_amdgcn_raw_buffer_store_b96(o, __builtin_amdgcn_make_buffer_rsrc(O, 0, (int)view_bytes, 0x00020000),
                                                       (int)out_off12, 0, P2P_STORE_AUX);
+#else
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(O, 0, (int)view_bytes, 0x00020000);
+#pragma unroll
+                for (int j = 0; j < PXT; ++j) {
+                    // row_shl:1 -- every lane gets its right neighbour's pixel (lane 15 of a row: unused)
+                    const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)pix[j], 0x101, 0xF, 0xF, true);
+                    const uint32_t dw = __builtin_amdgcn_perm(nb, pix[j], out_sel);
+#ifdef P2P_ABLATE_STORES2
+                    if (dw == 0x12345678u)
+#endif
+                    __builtin_amdgcn_raw_buffer_store_b32(dw, rsrc, (int)out_off[j], 0, P2P_STORE_AUX);
+                }
+#endif
             }
             buf_bytes ^= (uint32_t)sizeof(tile4[0]);
         }
@@ -455,7 +497,13 @@ __device__ __forceinline__ void draw_tight(
         // vmcnt(0) for both paths.  One store that writes nothing (a buffer store through a descriptor of zero
         // records: counted like any store, dropped by the hardware) gives both paths the same shape.
         __builtin_amdgcn_sched_barrier(0);
+#ifndef P2P_DPP_STORES
         __builtin_amdgcn_raw_buffer_store_b32(0u, __builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0x00020000), 0, 0, 0);
+#else
+#pragma unroll
+        for (int j = 0; j < PXT; ++j)  // as many as a pair issues
+            __builtin_amdgcn_raw_buffer_store_b32(0u, __builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0x00020000), 0, 0, 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         tight(ns_c, std::integral_constant<int, 0>{}, 0, X.n1);
         tight(ns_c, std::integral_constant<int, 1>{}, X.n1, X.n2);
