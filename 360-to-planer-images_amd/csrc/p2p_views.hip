@@ -90,7 +90,7 @@ __device__ __forceinline__ uint32_t blend4(uint32_t a, uint32_t b, uint32_t c, u
 // per-pixel stage-2 weights, constant across (panorama, yaw) pairs: cv::remap's four tap weights
 // (32-fx)(32-fy), fx(32-fy), (32-fx)fy, fx*fy (sum 1024), scaled by 64 so that the rounded result
 // (sum + 512) >> 10 is byte 2 of the scaled sum.  The one weight that does not fit 16 bits, 1024 * 64 (fx = fy = 0:
-// the other three are 0), is stored as 65535: a * 65535 + 32768 = a * 65536 + (32768 - a) has the same byte 2.
+// the other three are 0), is stored as 65504 (tap_weights below): byte 2 comes out the same.
 struct TapWeights {
     uint32_t w_up;  // [w_a, w_b] as two u16 (0 for a pixel with no footprint)
     uint32_t w_lo;  // [w_c, w_d]
@@ -98,11 +98,14 @@ struct TapWeights {
 
 __device__ __forceinline__ TapWeights tap_weights(uint32_t fx, uint32_t fy, bool live)
 {
-    const uint32_t gx = 32u - fx, gy = 32u - fy;
-    const uint32_t wa = min(64u * gx * gy, 65535u);
+    // [32-fx, fx] as two u16 times 64 (32-fy) and times 64 fy, one packed multiply each; for fx = fy = 0 the row
+    // factor is 2047 instead of 2048: a * 32 * 2047 + 32768 = a * 65536 + (32768 - 32 a) keeps byte 2 = a, where
+    // 32 * 2048 would not fit the u16
+    const u16x2 wx = as_u16x2((32u - fx) | (fx << 16));
+    const uint32_t up = 2048u - 64u * fy - ((fx | fy) == 0u ? 1u : 0u), lo = 64u * fy;
     TapWeights w;
-    w.w_up = live ? wa | ((64u * fx * gy) << 16) : 0u;
-    w.w_lo = live ? (64u * gx * fy) | ((64u * fx * fy) << 16) : 0u;
+    w.w_up = live ? __builtin_bit_cast(uint32_t, wx * as_u16x2(up | (up << 16))) : 0u;
+    w.w_lo = live ? __builtin_bit_cast(uint32_t, wx * as_u16x2(lo | (lo << 16))) : 0u;
     return w;
 }
 
