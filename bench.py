@@ -472,7 +472,9 @@ def main():
                 "active_inst_valu_over_busy_cu_cycles": (counters.get("SQ_ACTIVE_INST_VALU", 0.0) / busy) if busy else None,
                 "issue_ceiling_of_that_ratio": {"slow_class_only": 0.97, "fast_class_only": 1.80,
                                                 "source": "profiles/r01_valu_counter_calibration.txt"},
-                "note": "secondary ceiling: the exact two-stage fixed-point emulation is VALU-issue bound, not HBM bound"}
+                "note": "secondary ceilings: the exact two-stage fixed-point emulation keeps the VALU issue ports about "
+                        "0.8 busy and moves traffic_rate_GBs through the L2 fabric at the same time (a plain copy "
+                        "reaches measured_copy_GBs): co-limited, DESIGN.md 5.2"}
     out = {
         "metric": "Mpix/s remapped, 8K equirect->1080p x36 views" if args.workload == "cfg2"
                   else "Mpix/s remapped (%s)" % args.workload,
@@ -488,6 +490,7 @@ def main():
                      "kernel_ms_sample": {"n": int(sample), "mean": float(kms.mean()), "min": float(kms.min()),
                                           "max": float(kms.max()), "how": "own HIP event pair per launch, after the timed region"},
                      "algorithmic_bytes_per_launch": b_alg,
+                     "traffic_rate_GBs": (traffic / k_avg_s / 1e9) if (traffic and k_avg_s) else None,
                      "measured_copy_GBs": copy_gbs,
                      "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None},
         "preroll_s": preroll_s, "preroll_launches": preroll_launches,
