@@ -13,9 +13,10 @@
 // offsets per pixel -- here of floor(U), floor(V) -- plus the coordinate fractions in 1/65536), source rows staged
 // through LDS as 16-byte pieces (stage 1 is a plain copy: the yaw's INTEGER column shift picks the pieces, its
 // fraction is added to the pixel's own per yaw and may carry the taps one column on), one barrier per yaw, the
-// pixels leave as 12-byte non-temporal buffer stores.  Without stage 1's blend and with one rounding the path is
-// cheaper than the exact one; the float blend itself is not (byte <-> float conversions cost what the packed
-// integer multiplies cost).  Pieces the plan marks for direct gathers (view seam, pole, widths not divisible by 4)
+// pixels leave as 12-byte non-temporal buffer stores.  Stage 1 is cheaper than the exact path's (a copy), the
+// per-pixel part is not: the float blend, the per-yaw weights and the carry come to about 100 issue cycles per pixel
+// against 64 (byte <-> float conversions and dot products issue at the same rate as the packed integer multiplies),
+// so the two paths run at the same speed.  Pieces the plan marks for direct gathers (view seam, pole, widths not divisible by 4)
 // are drawn by float_views_rest_kernel, one thread per pixel from global memory.
 #include <hip/hip_fp16.h>
 #include <type_traits>

@@ -149,13 +149,14 @@ __device__ __forceinline__ uint32_t blend4_packed(uint32_t a, uint32_t b, uint32
 //
 // Two kernels share this scheme:
 //   remap_views_kernel       whole interior pieces x yaws that are plain shifts -- nothing but three branch-free
-//                            loops (copy / blend / blend with the clipped column patched), 66 VGPRs, no spills;
+//                            loops (copy / blend / blend with the clipped column patched), 78 VGPRs, no spills;
 //   remap_views_rest_kernel  everything else, with all the case distinctions: pieces at the image border, pieces
 //                            the plan marks for direct gathers (a pole inside the piece: the footprint spans every
 //                            column; footprints touching the panorama border; widths not divisible by 4; general
 //                            caller maps with border taps), yaws with per-column weights, yaw rows that are not a shift.
 // Kept in one kernel, the rare paths set the register allocation (96 VGPRs + spills) and tripled the ISA; the
-// common path ran at 110 us instead of 75 on config 2.  The two kernels write disjoint pixels and run on two streams.
+// common path ran at 110 us instead of 75 on config 2.  The two kernels write disjoint pixels; the rest kernel is
+// launched (same stream, after the main one) only when the plan or the yaw tables have something for it.
 // Blocks map to tiles XCD-aware: each of the 8 XCDs owns a contiguous run of the tile raster, so neighbouring
 // tiles (shared source halo and output lines) meet in one L2.
 // ---------------------------------------------------------------------------------------------
@@ -866,7 +867,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_rest_kernel(
                          items_main + (size_t)h.item_block * LDS_ITEMS_CAP, tile4);
 }
 
-// which = 0: the main kernel, 1: the rest (they write disjoint pixels: the host runs them on two streams)
+// which = 0: the main kernel, 1: the rest (they write disjoint pixels; the host launches the rest only when needed)
 hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
 {
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
