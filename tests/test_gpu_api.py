@@ -348,3 +348,15 @@ sys.exit(int(sys.argv[1]))
         assert r.returncode == rc, (r.returncode, r.stderr[-1500:])
         assert "alive" in r.stdout
         assert "Segmentation" not in r.stderr and "core dumped" not in r.stderr
+
+
+def test_no_device_or_host_memory_drift_over_many_images(gpu):
+    """tools/soak_leak.py: one-shot calls from several threads, the two-slot pipeline, the view-sharded driver and
+    the float path over changing geometries, round after round -- free device memory and the resident set stay put
+    once the caches have filled."""
+    import subprocess
+    import sys
+    root = __import__("pathlib").Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "soak_leak.py"), "12"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "drift after round" in r.stdout
