@@ -107,6 +107,9 @@ struct ViewsParams {
     const double* yaw_rad;      // float pixel path: [n_yaw]
     int x_n;
     int plan_gx;             // extra workgroups per view row of the grid: 8 * ceil(x_n / n_pitch / 8)
+    const uint32_t* direct_list;  // the plan's direct-gather pieces (PlanParams::direct_list) and how many
+    int n_direct;
+    int direct_ppb;          // (panorama, yaw) pairs per workgroup of remap_views_direct_kernel
     float centre;            // float pixel path only: 0 = the reference's sampling convention, 0.5 = pixel centres
 };
 
@@ -130,6 +133,8 @@ struct PlanParams {
     uint32_t* x_count;       // [0] extras wanted (may exceed x_cap: the host then grows the pools and re-runs),
                              // [1] pieces marked for direct gathers
     uint32_t x_cap;
+    uint32_t* direct_list;   // [n_pitch * tiles + x_cap] the pieces marked for direct gathers, in no particular order:
+                             // index into hdr_main, or 0x80000000 | index into hdr_x
 };
 
 struct RemapParams {

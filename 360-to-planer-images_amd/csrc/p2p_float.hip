@@ -292,26 +292,15 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void float_views_rest_kernel(
     ViewsParams P, const uint8_t* __restrict__ src, uint8_t* __restrict__ out,
     const PieceHdr* __restrict__ hdr_main, const PieceHdr* __restrict__ hdr_x)
 {
-    PieceHdr h;
-    if ((int)blockIdx.x < P.plan_gx) {
-        const int ei = (int)blockIdx.y * P.plan_gx + (int)blockIdx.x;
-        if (ei >= P.x_n)
-            return;
-        h = hdr_x[ei];
-    } else {
-        const int bx = (int)blockIdx.x - P.plan_gx, gx = (int)gridDim.x - P.plan_gx;
-        const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
-        const int tile_id = (bx & 7) * (gx >> 3) + (bx >> 3);
-        if (tile_id >= tiles)
-            return;
-        h = hdr_main[(size_t)P.pitch_order[blockIdx.y] * tiles + tile_id];
-    }
+    // one workgroup per (piece of the plan's direct-gather list, chunk of pairs)
+    const uint32_t id = P.direct_list[blockIdx.x];
+    const PieceHdr h = (id & 0x80000000u) ? hdr_x[id & 0x7FFFFFFFu] : hdr_main[id];
     const int t = threadIdx.x;
     const PieceGeo G = piece_geo(h, t);
     if (G.mode != 2)
         return;
-    const int pair0 = blockIdx.z * P.pairs_per_block;
-    int pair1 = pair0 + P.pairs_per_block;
+    const int pair0 = blockIdx.z * P.direct_ppb;
+    int pair1 = pair0 + P.direct_ppb;
     if (pair1 > P.n_panos * P.n_yaw)
         pair1 = P.n_panos * P.n_yaw;
     const size_t view_bytes = (size_t)P.oh * P.ow * 3;
@@ -380,10 +369,11 @@ hipError_t launch_float_views(const ViewsParams& P, bool half, int which, hipStr
             hipLaunchKernelGGL(float_views_kernel<false>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.out, P.hdr_main, P.px_main,
                                P.px2_main, P.items_main, P.hdr_x, P.px_x, P.px2_x, P.items_x);
     } else {
+        const dim3 dgrid(P.n_direct, 1, (n_pairs + P.direct_ppb - 1) / P.direct_ppb);
         if (half)
-            hipLaunchKernelGGL(float_views_rest_kernel<true>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.out, P.hdr_main, P.hdr_x);
+            hipLaunchKernelGGL(float_views_rest_kernel<true>, dgrid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.out, P.hdr_main, P.hdr_x);
         else
-            hipLaunchKernelGGL(float_views_rest_kernel<false>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.out, P.hdr_main, P.hdr_x);
+            hipLaunchKernelGGL(float_views_rest_kernel<false>, dgrid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.out, P.hdr_main, P.hdr_x);
     }
     return hipGetLastError();
 }

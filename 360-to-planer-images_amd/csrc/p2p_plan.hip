@@ -320,8 +320,8 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
                 }
             }
             if (t == 0) {
-                if (!ok)
-                    atomicAdd(P.x_count + 1, 1u);  // pieces for the direct-gather path (the rest kernel's work)
+                if (!ok)  // pieces for the direct-gather path, listed for remap_views_direct_kernel
+                    P.direct_list[atomicAdd(P.x_count + 1, 1u)] = level == 0 ? blk : (0x80000000u | blk);
                 PieceHdr h;
                 h.xy = (uint32_t)(x0 + rc.x) | (uint32_t)(y0 + rc.y) << 16;
                 h.geom = (uint32_t)rc.w | (uint32_t)rc.h << 8 | (uint32_t)pitch_i << 16;

@@ -540,7 +540,9 @@ struct PairCtx {      // uniform per (piece, pair)
     int korig;        // pair index inside the chunk (its output slot is pair0 + korig)
 };
 
-template <int PXT>
+// DIRECT = true: the body of remap_views_direct_kernel -- a piece the plan marks for direct gathers, a few pairs
+// per workgroup; false: remap_views_rest_kernel -- the general loop over the LDS-scheme pieces.
+template <int PXT, bool DIRECT>
 __device__ __forceinline__ void draw_rest(
     const ViewsParams& P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab,
     const YawDesc* __restrict__ ydesc, const uint32_t* __restrict__ f4tab, uint8_t* __restrict__ out,
@@ -639,11 +641,13 @@ __device__ __forceinline__ void draw_rest(
         }
     };
 
-    if (G.mode != 1) {
+    if constexpr (DIRECT) {
+        if (G.mode == 1)
+            return;
         DirectPx d;
         load_direct(d);
-        const int pair0 = blockIdx.z * P.pairs_per_block;
-        int pair1 = pair0 + P.pairs_per_block;
+        const int pair0 = blockIdx.z * P.direct_ppb;
+        int pair1 = pair0 + P.direct_ppb;
         if (pair1 > P.n_panos * P.n_yaw)
             pair1 = P.n_panos * P.n_yaw;
         int pano_i = pano_of_pair(P, pair0);
@@ -659,6 +663,8 @@ __device__ __forceinline__ void draw_rest(
         }
         return;
     }
+    if (G.mode != 1)
+        return;  // remap_views_direct_kernel's
 
     // ---- LDS scheme, general loop ----
     const PairCtxs X = pair_contexts(P, ydesc, h.c0, h.c1, t);
@@ -849,7 +855,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_rest_kernel(
         if (ei >= P.x_n)
             return;
         const PieceHdr h = hdr_x[ei];
-        draw_rest<XTRA_PXT>(P, src, ytab, ydesc, f4tab, out, h, px_x + (size_t)h.px_block * (VIEWS_BLOCK * XTRA_PXT),
+        draw_rest<XTRA_PXT, false>(P, src, ytab, ydesc, f4tab, out, h, px_x + (size_t)h.px_block * (VIEWS_BLOCK * XTRA_PXT),
                             items_x + (size_t)h.item_block * LDS_ITEMS_CAP, tile4);
         return;
     }
@@ -863,13 +869,38 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_rest_kernel(
     const PieceHdr h = hdr_main[(size_t)pitch_i * tiles + tile_id];
     if ((h.mode_items & 3u) == 0u)
         return;  // a split tile: drawn by its pieces
-    draw_rest<VIEWS_PXT>(P, src, ytab, ydesc, f4tab, out, h, px_main + (size_t)h.px_block * (VIEWS_BLOCK * VIEWS_PXT),
+    draw_rest<VIEWS_PXT, false>(P, src, ytab, ydesc, f4tab, out, h, px_main + (size_t)h.px_block * (VIEWS_BLOCK * VIEWS_PXT),
                          items_main + (size_t)h.item_block * LDS_ITEMS_CAP, tile4);
 }
 
-// which = 0: the main kernel, 1: the rest (they write disjoint pixels; the host launches the rest only when needed)
+// One workgroup per (direct-gather piece of the plan's list, chunk of pairs): the few pieces with a pole or the
+// panorama's border inside.  Launched over the whole grid (as part of the rest kernel, round 2's first version)
+// the thousands of workgroups with nothing to do cost more than the gathers.
+#ifndef P2P_DIRECT_WAVES
+#define P2P_DIRECT_WAVES 6  // measured 2 / 4 / 5 / 6 / 8 on the reference CLI's default view set: 108 / 104 / 102 / 101 / 110 us
+#endif
+__global__ __launch_bounds__(VIEWS_BLOCK, P2P_DIRECT_WAVES) void remap_views_direct_kernel(
+    ViewsParams P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab, uint8_t* __restrict__ out,
+    const PieceHdr* __restrict__ hdr_main, const PieceHdr* __restrict__ hdr_x, const uint32_t* __restrict__ direct_list)
+{
+    const uint32_t id = direct_list[blockIdx.x];
+    if (id & 0x80000000u)
+        draw_rest<XTRA_PXT, true>(P, src, ytab, nullptr, nullptr, out, hdr_x[id & 0x7FFFFFFFu], nullptr, nullptr, nullptr);
+    else
+        draw_rest<VIEWS_PXT, true>(P, src, ytab, nullptr, nullptr, out, hdr_main[id], nullptr, nullptr, nullptr);
+}
+
+// which = 0: the main kernel, 1: the rest, 2: the direct-gather pieces (the three write disjoint pixels; the host
+// launches the last two only when the plan or the yaw tables have something for them)
 hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
 {
+    if (which == 2) {
+        const int np = P.n_panos * P.n_yaw;
+        const dim3 grid(P.n_direct, 1, (np + P.direct_ppb - 1) / P.direct_ppb);
+        hipLaunchKernelGGL(remap_views_direct_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.out, P.hdr_main,
+                           P.hdr_x, P.direct_list);
+        return hipGetLastError();
+    }
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
     const int n_pairs = P.n_panos * P.n_yaw;
     const int zblocks = (n_pairs + P.pairs_per_block - 1) / P.pairs_per_block;
