@@ -153,3 +153,22 @@ def test_cfg5_yaw_sweep_at_8k(gpu, pkg, pano8k):
         worst = max(worst, int(np.abs(res[0].astype(np.int16) - res[1].astype(np.int16)).max()))
     assert worst <= 1, worst
     ctx.close()
+
+
+def test_reference_cli_default_view_set_on_an_8k_noise_panorama(gpu, pkg, synth):
+    """The reference CLI's defaults (P:412-437): 800 x 800, FOV 90, yaw 0 / 90 / 180 / 270, pitch 30 / 60 / 90 / 120
+    / 150 -- 2.56 source pixels per output pixel (every tile splits into small pieces) and a pole inside the
+    pitch 30 / 150 views (the direct-gather kernel draws its surroundings).  All 20 views byte for byte."""
+    pw, ph, ow, oh, fov = 8192, 4096, 800, 800, 90
+    yaws, pitches = [0, 90, 180, 270], [30, 60, 90, 120, 150]
+    pano = synth.synth_pano(pw, ph, 4242, "N")
+    want = oracle_views_threaded(pano, yaws, pitches, ow, oh, fov)
+    rows, U, V = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
+    exact = gpu.remap_views_maps(pano, rows, U, V)
+    bad = np.argwhere(exact != want)
+    assert bad.size == 0, (len(bad), bad[:4].tolist())
+    smooth = synth.synth_pano(pw, ph, 4243, "S")
+    fused = pkg.process_views(smooth, yaws, pitches, ow, oh, fov)
+    mx, gt1, anyd = diff_stats(fused, oracle_views_threaded(smooth, yaws, pitches, ow, oh, fov))
+    print("CLI default view set, fused vs oracle: max %d, >1: %.3g, any: %.3g" % (mx, gt1, anyd))
+    assert mx <= 1
