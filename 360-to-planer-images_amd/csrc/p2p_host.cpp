@@ -238,10 +238,12 @@ struct SlotGuard {  // gives the slot back on every return path
     ~SlotGuard() { if (s) slot_release(s); }
 };
 
-int choose_pairs_per_block(const p2p_job_desc& d)
+int choose_pairs_per_block(const p2p_job_desc& d, int x_n)
 {
     const int tiles = ((d.ow + p2p::TILE_W - 1) / p2p::TILE_W) * ((d.oh + p2p::TILE_H - 1) / p2p::TILE_H);
-    const long long base = (long long)tiles * d.n_pitch;
+    // workgroups per pair chunk: the tiles and the pieces of split tiles (a strongly minifying job -- the reference
+    // CLI's default 800 x 800 views of an 8K panorama -- has four pieces per tile)
+    const long long base = (long long)tiles * d.n_pitch + (x_n > 0 ? x_n : 0);
     const int n_pairs = d.n_panos * d.n_yaw;
     int forced = env_int("P2P_PAIRS_PER_BLOCK", 0);
     if (forced > 64)
@@ -755,7 +757,6 @@ int p2p_job_run(p2p_job* j)
     P.n_yaw = j->d.n_yaw;
     P.n_pitch = j->d.n_pitch;
     P.n_panos = j->d.n_panos;
-    P.pairs_per_block = choose_pairs_per_block(j->d);
     P.n_yaw_magic = (uint32_t)(((1ull << 32) + (uint64_t)j->d.n_yaw - 1) / (uint64_t)j->d.n_yaw);
     P.pitch = j->d_pitch;
     P.mapU = j->d_mapU;
@@ -780,6 +781,7 @@ int p2p_job_run(p2p_job* j)
         if (rc != P2P_OK)
             return rc;
     }
+    P.pairs_per_block = choose_pairs_per_block(j->d, j->x_n);
     P.pitch_order = j->d_pitch_order;
     P.coords = j->d_coords;
     P.hdr_main = j->d_hdr_main;
