@@ -107,6 +107,9 @@ struct ViewsParams {
     const double* yaw_rad;      // float pixel path: [n_yaw]
     int x_n;
     int plan_gx;             // extra workgroups per view row of the grid: 8 * ceil(x_n / n_pitch / 8)
+    const uint32_t* rest_pairs;   // the rest kernel's own pair list (pano * n_yaw + yaw) when it draws only the yaws the
+    int n_rest_pairs;             // main kernel leaves to it (0: every pair of the job, in pairs_per_block chunks)
+    int rest_ppb;
     const uint32_t* direct_list;  // the plan's direct-gather pieces (PlanParams::direct_list) and how many
     int n_direct;
     int direct_ppb;          // (panorama, yaw) pairs per workgroup of remap_views_direct_kernel

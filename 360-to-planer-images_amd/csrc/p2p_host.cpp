@@ -106,6 +106,8 @@ struct p2p_job {
     uint32_t* d_px2_x = nullptr;
     uint32_t* d_x_count = nullptr;
     uint32_t* d_direct_list = nullptr;   // pieces the plan marks for direct gathers
+    uint32_t* d_rest_pairs = nullptr;    // (panorama, yaw) pairs whose yaw the main kernel leaves to the rest kernel
+    int n_rest_pairs = 0;
     uint32_t x_cap = 0;
     int x_n = -1;                        // -1: the plan has not been built for the current maps
     int n_direct = 0;                    // pieces the plan marks for direct gathers
@@ -372,6 +374,7 @@ void p2p_job_destroy(p2p_job* j)
     (void)hipFree(j->d_px2_x);
     (void)hipFree(j->d_x_count);
     (void)hipFree(j->d_direct_list);
+    (void)hipFree(j->d_rest_pairs);
     (void)hipFree(j->d_pitch_order);
     for (hipEvent_t e : j->ev_ring)
         (void)hipEventDestroy(e);
@@ -387,6 +390,20 @@ static int count_odd_yaws(p2p_job* j)
     j->n_odd_yaws = 0;
     for (const auto& d : yd)
         j->n_odd_yaws += d.mode != 0;
+    // the rest kernel's pair list: every panorama x the yaws with per-column weights or rows that are not a shift
+    (void)hipFree(j->d_rest_pairs);
+    j->d_rest_pairs = nullptr;
+    j->n_rest_pairs = 0;
+    if (j->n_odd_yaws > 0) {
+        std::vector<uint32_t> pairs;
+        for (int p = 0; p < j->d.n_panos; ++p)
+            for (int y = 0; y < j->d.n_yaw; ++y)
+                if (yd[y].mode != 0)
+                    pairs.push_back((uint32_t)p * (uint32_t)j->d.n_yaw + (uint32_t)y);
+        HIP_TRY(hipMalloc((void**)&j->d_rest_pairs, pairs.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(j->d_rest_pairs, pairs.data(), pairs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        j->n_rest_pairs = (int)pairs.size();
+    }
     return P2P_OK;
 }
 
@@ -794,6 +811,12 @@ int p2p_job_run(p2p_job* j)
     P.plan_gx = 8 * ((((P.x_n + j->d.n_pitch - 1) / j->d.n_pitch) + 7) / 8);
     P.direct_list = j->d_direct_list;
     P.n_direct = j->n_direct;
+    // with view rows of whole dwords the main kernel draws every plain-shift yaw of every LDS-scheme piece, and the
+    // rest kernel only the listed pairs (up to 16 per workgroup: one set-up for all of them); otherwise it draws all
+    const bool rest_listed = (j->d.ow & 3) == 0 && j->n_rest_pairs > 0 && env_int("P2P_FORCE_REST", 0) == 0;
+    P.rest_pairs = rest_listed ? j->d_rest_pairs : nullptr;
+    P.n_rest_pairs = rest_listed ? j->n_rest_pairs : 0;
+    P.rest_ppb = std::min(16, std::max(1, j->n_rest_pairs));
     {
         // pairs per workgroup of the direct-gather kernel: about 4096 workgroups in all, at most 16 pairs each
         // (the piece's coordinates are loaded once per workgroup)

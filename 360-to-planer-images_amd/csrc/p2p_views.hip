@@ -183,12 +183,16 @@ struct PairCtxs {
     int npairs, pair0;
 };
 
+// LIST: the chunk's pairs come from P.rest_pairs (the rest kernel drawing only the yaws left to it) instead of being
+// the contiguous run blockIdx.z * pairs_per_block ...
+template <bool LIST = false>
 __device__ __forceinline__ PairCtxs pair_contexts(const ViewsParams& P, const YawDesc* __restrict__ ydesc, int c0, int c1, int t)
 {
     PairCtxs X;
-    X.pair0 = blockIdx.z * P.pairs_per_block;
-    int pair1 = X.pair0 + P.pairs_per_block;
-    const int n_pairs = P.n_panos * P.n_yaw;
+    const int ppb = LIST ? P.rest_ppb : P.pairs_per_block;
+    X.pair0 = blockIdx.z * ppb;
+    int pair1 = X.pair0 + ppb;
+    const int n_pairs = LIST ? P.n_rest_pairs : P.n_panos * P.n_yaw;
     if (pair1 > n_pairs)
         pair1 = n_pairs;
     X.npairs = pair1 - X.pair0;
@@ -197,8 +201,9 @@ __device__ __forceinline__ PairCtxs pair_contexts(const ViewsParams& P, const Ya
     int cw2 = 0, cw3 = 0, cls = 4;
     const int k = t & 63;
     if (k < X.npairs) {
-        cw3 = pano_of_pair(P, X.pair0 + k);
-        const int yi = X.pair0 + k - cw3 * P.n_yaw;
+        const int pair = LIST ? (int)P.rest_pairs[X.pair0 + k] : X.pair0 + k;
+        cw3 = pano_of_pair(P, pair);
+        const int yi = pair - cw3 * P.n_yaw;
         const YawDesc yd = ydesc[yi];
         int i_first = c0 + yd.s;
         if (i_first >= P.pw)
@@ -667,7 +672,8 @@ __device__ __forceinline__ void draw_rest(
         return;  // remap_views_direct_kernel's
 
     // ---- LDS scheme, general loop ----
-    const PairCtxs X = pair_contexts(P, ydesc, h.c0, h.c1, t);
+    const bool listed = P.n_rest_pairs > 0;
+    const PairCtxs X = listed ? pair_contexts<true>(P, ydesc, h.c0, h.c1, t) : pair_contexts<false>(P, ydesc, h.c0, h.c1, t);
     const int kfirst = main_draws_plain ? X.n3 : 0;  // the main kernel has classes 0..3 of its pieces
     if (kfirst >= X.npairs)
         return;
@@ -728,7 +734,7 @@ __device__ __forceinline__ void draw_rest(
     for (int ki = kfirst; ki < X.npairs; ++ki) {
         const uint8_t* __restrict__ S = src + (size_t)pc.pano * P.pano_stride;
         const int cur_yaw = pc.yaw_i;
-        const int pair = X.pair0 + pc.korig;
+        const int pair = listed ? pc.pano * P.n_yaw + pc.yaw_i : X.pair0 + pc.korig;
         const bool has_next = ki + 1 < X.npairs;
         uint32_t pix[PXT];
 
@@ -903,7 +909,9 @@ hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
     }
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
     const int n_pairs = P.n_panos * P.n_yaw;
-    const int zblocks = (n_pairs + P.pairs_per_block - 1) / P.pairs_per_block;
+    int zblocks = (n_pairs + P.pairs_per_block - 1) / P.pairs_per_block;
+    if (which == 1 && P.n_rest_pairs > 0)
+        zblocks = (P.n_rest_pairs + P.rest_ppb - 1) / P.rest_ppb;
     // 8 XCDs, each a contiguous run of tiles; P.plan_gx is a multiple of 8 too
     const dim3 grid(P.plan_gx + 8 * ((tiles + 7) / 8), P.n_pitch, zblocks);
     if (which == 0)
