@@ -1,8 +1,8 @@
 // p2p_views.hip -- the hot kernel: both cv2.remap stages of every (panorama, yaw, pitch) view in one launch
-//   cv2.remap x2       P:192-199, P:212-218 -> remap_views_kernel (both stages fused, fixed point) and
-//                                            remap_views_rest_kernel (the odd cases), driven by the tables of the
-//                                            plan pass (p2p_plan.hip); 3-channel single remaps of the legacy tool
-//                                            (L:179) too
+//   cv2.remap x2       P:192-199, P:212-218 -> remap_views_kernel (both stages fused, fixed point),
+//                                            remap_views_rest_kernel and remap_views_direct_kernel (the odd
+//                                            cases), driven by the tables of the plan pass (p2p_plan.hip);
+//                                            3-channel single remaps of the legacy tool (L:179) too
 // Reference behaviour (cited, never copied):
 //   P = /root/reference/app/panorama_to_plane-pitch.py, L = /root/reference/app/legacy/panorama_to_plane.py
 // The fixed-point arithmetic is OpenCV 4.10's (imgwarp.cpp remapBilinear, INTER_BITS = 5,
@@ -147,16 +147,19 @@ __device__ __forceinline__ uint32_t blend4_packed(uint32_t a, uint32_t b, uint32
 // The footprint is kept as per-row spans (each rot row only as wide as the taps of that row need), not as the
 // bounding rectangle: 1.4 .. 1.7 rot pixels per output pixel instead of 1.7 .. 2.3 on config 2.
 //
-// Two kernels share this scheme:
-//   remap_views_kernel       whole interior pieces x yaws that are plain shifts -- nothing but three branch-free
-//                            loops (copy / blend / blend with the clipped column patched), 78 VGPRs, no spills;
-//   remap_views_rest_kernel  everything else, with all the case distinctions: pieces at the image border, pieces
-//                            the plan marks for direct gathers (a pole inside the piece: the footprint spans every
-//                            column; footprints touching the panorama border; widths not divisible by 4; general
-//                            caller maps with border taps), yaws with per-column weights, yaw rows that are not a shift.
+// Three kernels share this arithmetic:
+//   remap_views_kernel         whole interior pieces x yaws that are plain shifts -- nothing but three branch-free
+//                              loops (copy / blend / blend with the clipped column patched), 78 VGPRs, no spills;
+//   remap_views_rest_kernel    the general LDS loop with its case distinctions: yaws with per-column weights, yaw
+//                              rows that are not a shift (gathered per pixel), byte stores for view widths not
+//                              divisible by 4.  With view rows of whole dwords only the pairs of the job's
+//                              rest_pairs list, several per workgroup;
+//   remap_views_direct_kernel  the pieces the plan marks for direct gathers (a pole inside the piece: the footprint
+//                              spans every column; footprints touching the panorama border; general caller maps
+//                              with border taps), one workgroup per (piece of the plan's list, chunk of pairs).
 // Kept in one kernel, the rare paths set the register allocation (96 VGPRs + spills) and tripled the ISA; the
-// common path ran at 110 us instead of 75 on config 2.  The two kernels write disjoint pixels; the rest kernel is
-// launched (same stream, after the main one) only when the plan or the yaw tables have something for it.
+// common path ran at 110 us instead of 75 on config 2.  The kernels write disjoint pixels; the last two are
+// launched (same stream, before the main one) only when the plan or the yaw tables have something for them.
 // Blocks map to tiles XCD-aware: each of the 8 XCDs owns a contiguous run of the tile raster, so neighbouring
 // tiles (shared source halo and output lines) meet in one L2.
 // ---------------------------------------------------------------------------------------------
