@@ -14,7 +14,7 @@ synth = importlib.import_module("360-to-planer-images_amd.synth")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 77
 t0 = time.time(); bad = 0; worst16 = 0; worst32 = 0
-for case in range(n_cases):
+for case in range(int(os.environ.get("FUZZ_FIRST", "0")), n_cases):  # FUZZ_FIRST: resume a long run
     rng = np.random.default_rng(seed * 7919 + case)
     pw = int(rng.choice([256, 512, 1000, 1024, 2048, 4096])); ph = max(16, pw // 2)
     ow, oh = int(rng.integers(8, 500)), int(rng.integers(8, 300))

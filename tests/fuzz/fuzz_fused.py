@@ -12,7 +12,7 @@ synth = importlib.import_module("360-to-planer-images_amd.synth")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 worst = 0; over = 0; t0 = time.time()
-for case in range(n_cases):
+for case in range(int(os.environ.get("FUZZ_FIRST", "0")), n_cases):  # FUZZ_FIRST: resume a long run
     rng = np.random.default_rng(seed * 100003 + case)
     pw = int(rng.choice([512, 1024, 2048, 4096])); ph = pw // 2
     ow, oh = int(rng.integers(16, 500)), int(rng.integers(16, 400))

@@ -18,7 +18,7 @@ big = len(sys.argv) > 4 and sys.argv[4] == "big"
 real = len(sys.argv) > 4 and sys.argv[4] == "real"   # real-valued yaw / pitch / FOV, pitch anywhere in [0, 180]
 ctx = nat.Context(0)
 t0 = time.time(); bad = 0
-for case in range(n_cases):
+for case in range(int(os.environ.get("FUZZ_FIRST", "0")), n_cases):  # FUZZ_FIRST: resume a long run
     if only is not None and case != only:
         continue
     rng = np.random.default_rng(seed * 100003 + case)

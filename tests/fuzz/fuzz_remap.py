@@ -13,8 +13,9 @@ pkg = importlib.import_module("360-to-planer-images_amd"); nat = pkg._native
 synth = importlib.import_module("360-to-planer-images_amd.synth")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+part = os.environ.get("FUZZ_REMAP_PART", "both")  # remap | job | both: which half runs (hunting a rare fault)
 bad = 0; t0 = time.time()
-for case in range(n_cases):
+for case in range(int(os.environ.get("FUZZ_FIRST", "0")), n_cases):  # FUZZ_FIRST: resume a long run
     rng = np.random.default_rng(seed * 100003 + case)
     cn = int(rng.choice([1, 3, 3, 4])); interp = int(rng.choice([0, 1, 1, 2])); mode = int(rng.integers(0, 5))
     sh, sw = int(rng.integers(1, 300)), int(rng.integers(1, 400))
@@ -35,13 +36,16 @@ for case in range(n_cases):
         U[rng.integers(0, oh), rng.integers(0, ow)] = rng.choice([np.nan, np.inf, -np.inf, 1e9, -1e9, 40000.0])
         V[rng.integers(0, oh), rng.integers(0, ow)] = rng.choice([np.nan, np.inf, -np.inf, 1e9, -1e9, -40000.0])
     cval = rng.integers(0, 256, size=4, dtype=np.uint8) if rng.random() < 0.7 else None
-    got = nat.remap_maps(img, U, V, border=mode, border_value=cval, interpolation=interp)
-    want = cpu_ref.remap(img, U, V, mode, cval, interpolation=interp)
+    if part != "job":
+        got = nat.remap_maps(img, U, V, border=mode, border_value=cval, interpolation=interp)
+        want = cpu_ref.remap(img, U, V, mode, cval, interpolation=interp)
+    else:
+        got = want = np.zeros(1)
     if not np.array_equal(got, want):
         bad += 1
         print("MISMATCH remap", dict(case=case, cn=cn, interp=interp, mode=mode, sh=sh, sw=sw, oh=oh, ow=ow, kind=float(kind),
                                      n=int((got != want).sum())), flush=True)
-    if case % 5 == 0:   # fused self-consistency on a random small job
+    if case % 5 == 0 and part != "remap":   # fused self-consistency on a random small job
         pw = int(rng.choice([256, 512, 1024, 2048])); ph = pw // 2
         vw, vh = int(rng.integers(16, 300)), int(rng.integers(16, 200))
         yaws = [int(v) for v in rng.integers(0, 360, size=int(rng.integers(1, 14)))]
