@@ -252,3 +252,23 @@ def test_single_yaw_jobs_with_several_panoramas(gpu, synth):
             assert np.array_equal(job.get_views(i), oracle_views(p, yaws, [60, 107], 169, 81, 90)), (yaws, i)
         job.close()
         ctx.close()
+
+
+def test_rest_pair_list_runs_over_several_chunks_and_panoramas(gpu, synth):
+    # 3 panoramas x the 6 flickering yaws of an 8192-wide panorama (14 + 45 k: per-column weights) = 18 pairs for
+    # the rest kernel's own pair list, i.e. two chunks of it (16 pairs per workgroup), next to plain yaws that the
+    # main kernel draws
+    pw, ph, ow, oh = 8192, 512, 256, 144
+    yaws, pitches = [14, 0, 59, 104, 30, 149, 194, 239], [80, 100]
+    ctx = gpu.Context(0)
+    job = gpu.Job(ctx, pw, ph, 3, yaws, pitches, 90, ow, oh)
+    rows, U, V = oracle_maps(yaws, pitches, ow, oh, pw, ph, 90)
+    job.set_maps(rows, U, V)
+    panos = [synth.synth_pano(pw, ph, 1030 + i, "N") for i in range(3)]
+    for i, p in enumerate(panos):
+        job.set_pano(i, p)
+    job.run()
+    for i, p in enumerate(panos):
+        assert np.array_equal(job.get_views(i), oracle_views(p, yaws, pitches, ow, oh, 90)), i
+    job.close()
+    ctx.close()
