@@ -7,8 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libp2p_hip.so")
 SOURCES = [os.path.join(CSRC, f) for f in ("p2p_views.hip", "p2p_plan.hip", "p2p_maps.hip", "p2p_remap.hip", "p2p_float.hip", "p2p_host.cpp")]
-DEPS = SOURCES + [os.path.join(CSRC, "p2p_device.h"), os.path.join(CSRC, "p2p_inline.h"),
-                  os.path.join(HERE, "..", "include", "p2p_hip.h")]
+DEPS = SOURCES + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
+    [os.path.join(HERE, "..", "include", "p2p_hip.h")]
 # -ffp-contract=off: the coordinate maths must round exactly where NumPy rounds (no fused a*b+c
 # unless written as fmaf).  IEEE divide / sqrt are hipcc's default for fp32.
 # -amdgpu-atomic-optimizer-strategy=DPP: the default (iterative) strategy turns every LDS atomicMin/Max

@@ -18,8 +18,6 @@ P2P_OK = 0
 P2P_ERR_INVALID, P2P_ERR_NO_DEVICE, P2P_ERR_HIP, P2P_ERR_OOM, P2P_ERR_STATE = -1, -2, -3, -4, -5
 BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_101 = 0, 1, 2, 3, 4
 INTER_NEAREST, INTER_LINEAR, INTER_CUBIC = 0, 1, 2
-FLAG_KEEP_COORDS = 1
-FLAG_CACHE_COORDS = 2
 FLAG_PIXELS_F32 = 4   # opt-in float pixel path (beyond the reference): one float32 resample per view
 FLAG_PIXELS_F16 = 8   # the same with the 2x2 blend in packed float16
 FLAG_PIXEL_CENTRES = 16  # float paths only: sample through pixel centres (not the reference's convention)
@@ -36,7 +34,6 @@ ABI_SYMBOLS = (
     "p2p_job_set_pano_async", "p2p_job_share_panos", "p2p_job_get_views_async", "p2p_job_wait", "p2p_job_set_maps", "p2p_job_run",
     "p2p_job_get_views", "p2p_job_kernel_ms", "p2p_job_kernel_ms_last", "p2p_job_device_out", "p2p_job_get_coords",
     "p2p_job_get_yaw_tables", "p2p_job_set_yaws", "p2p_host_alloc", "p2p_host_free", "p2p_release_cache",
-    "p2p_debug_stamps",
 )
 
 
@@ -146,8 +143,6 @@ def lib():
     L.p2p_job_get_coords.argtypes = [c_vp, c_vp]
     L.p2p_job_get_yaw_tables.restype = c_int
     L.p2p_job_get_yaw_tables.argtypes = [c_vp, c_vp]
-    L.p2p_debug_stamps.restype = c_int
-    L.p2p_debug_stamps.argtypes = [c_vp, c_int]
     L.p2p_job_set_yaws.restype = c_int
     L.p2p_job_set_yaws.argtypes = [c_vp, c_vp]
     L.p2p_host_alloc.restype = c_int
@@ -402,12 +397,6 @@ def remap_maps_batch(src, U, V, border=BORDER_CONSTANT, device=0):
     out = np.empty((n, oh, ow, 3), dtype=np.uint8)
     check(lib().p2p_remap_maps_batch_u8(src.ctypes.data, sw, sh, src.strides[0], U.ctypes.data, V.ctypes.data,
                                         n, ow, oh, out.ctypes.data, int(border), int(device)))
-    return out
-
-
-def debug_stamps(reset=True):
-    out = np.zeros(16, dtype=np.uint64)
-    check(lib().p2p_debug_stamps(out.ctypes.data, int(bool(reset))))
     return out
 
 

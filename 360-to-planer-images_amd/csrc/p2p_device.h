@@ -165,8 +165,6 @@ hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st);
 hipError_t launch_remap_maps(const RemapParams& P, int cn, int interpolation, hipStream_t st);
 hipError_t launch_cubic_tab(short* tab, hipStream_t st);
 hipError_t launch_float_views(const ViewsParams& P, bool half, int which, hipStream_t st);
-// diagnostic build only (-DP2P_STAMPS): per-phase s_memtime sums of remap_views_kernel's pair loop
-hipError_t read_stamps(unsigned long long* out16, bool reset);
 
 }  // namespace p2p
 #endif

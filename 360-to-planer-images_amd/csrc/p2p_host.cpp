@@ -212,7 +212,7 @@ int slot_acquire(int device, F wants, OneShotSlot** out)
                 if (rc != P2P_OK) {
                     lk.lock();
                     idle->busy = false;
-                    P.cv.notify_one();
+                    P.cv.notify_all();
                     return rc;
                 }
             } else {
@@ -232,7 +232,7 @@ void slot_release(OneShotSlot* s)
         std::lock_guard<std::mutex> lk(P.mu);
         s->busy = false;
     }
-    P.cv.notify_one();
+    P.cv.notify_all();  // one condition variable, waiters for several devices: the right one must wake
 }
 
 struct SlotGuard {  // gives the slot back on every return path
@@ -651,16 +651,21 @@ int p2p_job_set_maps(p2p_job* j, const float* yaw_rows, const float* U, const fl
     const p2p_job_desc& d = j->d;
     HIP_TRY(hipSetDevice(j->ctx->device));
     const size_t n_map = (size_t)d.n_pitch * d.oh * d.ow;
+    if (yaw_rows) {
+        // the yaw stage's taps must stay inside the row, as P:105's clip guarantees (checked before anything is
+        // enqueued: an error return leaves no copy from the caller's buffers in flight and the job as it was)
+        const size_t n = (size_t)d.n_yaw * d.pw;
+        for (size_t k = 0; k < n; ++k)
+            if (!(yaw_rows[k] >= 0.0f && yaw_rows[k] <= (float)(d.pw - 1)))
+                return fail(P2P_ERR_INVALID, "yaw_rows[%zu] = %g outside [0, pw-1] (P:105 clips it)", k, (double)yaw_rows[k]);
+    }
     if (!j->d_mapU) HIP_TRY(hipMalloc((void**)&j->d_mapU, n_map * sizeof(float)));
     if (!j->d_mapV) HIP_TRY(hipMalloc((void**)&j->d_mapV, n_map * sizeof(float)));
+    j->x_n = -1;  // the plan follows the maps (also when a later step of this call fails)
     HIP_TRY(hipMemcpyAsync(j->d_mapU, U, n_map * sizeof(float), hipMemcpyHostToDevice, j->ctx->stream));
     HIP_TRY(hipMemcpyAsync(j->d_mapV, V, n_map * sizeof(float), hipMemcpyHostToDevice, j->ctx->stream));
     if (yaw_rows) {
         const size_t n = (size_t)d.n_yaw * d.pw;
-        // the yaw stage's taps must stay inside the row, as P:105's clip guarantees
-        for (size_t k = 0; k < n; ++k)
-            if (!(yaw_rows[k] >= 0.0f && yaw_rows[k] <= (float)(d.pw - 1)))
-                return fail(P2P_ERR_INVALID, "yaw_rows[%zu] = %g outside [0, pw-1] (P:105 clips it)", k, (double)yaw_rows[k]);
         if (!j->d_rows) HIP_TRY(hipMalloc((void**)&j->d_rows, n * sizeof(float)));
         HIP_TRY(hipMemcpyAsync(j->d_rows, yaw_rows, n * sizeof(float), hipMemcpyHostToDevice, j->ctx->stream));
         HIP_TRY(p2p::launch_yaw_pack(j->d_ytab, j->d_rows, n, j->ctx->stream));
@@ -1062,15 +1067,6 @@ int p2p_release_cache(void)
     return P2P_OK;
 }
 
-int p2p_debug_stamps(uint64_t* out16, int reset)
-{
-    if (!out16)
-        return fail(P2P_ERR_INVALID, "NULL pointer");
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(p2p::read_stamps(reinterpret_cast<unsigned long long*>(out16), reset != 0));
-    return P2P_OK;
-}
-
 // ------------------------------------------------------------------------------------------
 // one-shot entry points
 // ------------------------------------------------------------------------------------------
@@ -1159,7 +1155,7 @@ int p2p_remap_views_f64(const uint8_t* pano, int pw, int ph, int64_t row_stride,
     if (n_yaw < 0 || n_pitch < 0 || (n_yaw > 0 && !yaw_deg) || (n_pitch > 0 && !pitch_deg))
         return fail(P2P_ERR_INVALID, "bad yaw/pitch list");
     return views_oneshot(pano, pw, ph, row_stride, yaw_deg, n_yaw, pitch_deg, n_pitch, fov_deg, ow, oh,
-                         out, device, flags & ~(P2P_FLAG_KEEP_COORDS | P2P_FLAG_CACHE_COORDS), nullptr, nullptr, nullptr);
+                         out, device, flags, nullptr, nullptr, nullptr);
 }
 
 int p2p_remap_views_u8(const uint8_t* pano, int pw, int ph, int64_t row_stride,

@@ -926,12 +926,4 @@ hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t read_stamps(unsigned long long* out16, bool reset)
-{
-    (void)reset;
-    for (int i = 0; i < 16; ++i)
-        out16[i] = 0;
-    return hipSuccess;
-}
-
 }  // namespace p2p

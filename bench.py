@@ -197,10 +197,35 @@ PMC_PASSES = (  # one rocprofv3 run each: FETCH_SIZE takes 3 of the 4 TCC slots,
 )
 
 
+_PROFILER_ENV_PREFIXES = ("ROCP", "ROCPROF", "ROCTRACER", "ROCTX", "HSA_TOOLS", "ROCM_TOOLS")
+
+
+def under_profiler():
+    """True when THIS process was started by a profiler (rocprofv3 preloads its tool library and exports its own
+    variables): then no counter children are spawned -- a rocprofv3 launcher inheriting that environment would
+    initialise the GPU and exec its target, the hop this pool forbids."""
+    env = os.environ
+    if any("rocprof" in env.get(k, "").lower() or "roctracer" in env.get(k, "").lower()
+           for k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES")):
+        return True
+    return any(k.startswith(_PROFILER_ENV_PREFIXES) for k in env)
+
+
+def clean_child_env(tmp):
+    """Environment for the rocprofv3 children: this one minus anything a profiler may have put there."""
+    env = {k: v for k, v in os.environ.items() if not k.startswith(_PROFILER_ENV_PREFIXES)}
+    if "rocprof" in env.get("LD_PRELOAD", "").lower() or "roctracer" in env.get("LD_PRELOAD", "").lower():
+        del env["LD_PRELOAD"]
+    env["TMPDIR"] = tmp
+    return env
+
+
 def measure_counters(args):
     """HBM-side bytes and VALU instruction counts of the hot kernel of THIS build, per launch: this script re-run
     under `rocprofv3 --pmc` (counters only: no tracing in the same run), a few launches, one pass per counter
     group.  Returns {counter: mean per launch} or None when the profiler is not usable."""
+    if under_profiler():
+        return None
     kernel = "remap_views_kernel" if args.pixel_path == "u8" else "float_views_kernel"
     base = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2", "--no-preroll", "--no-cpu-baseline",
             "--counters", "none", "--workload", args.workload, "--panos-per-gpu", str(args.panos_per_gpu),
@@ -213,8 +238,8 @@ def measure_counters(args):
             d = os.path.join(tmp, "p%d" % i)
             try:
                 subprocess.run(["rocprofv3", "--pmc"] + group + ["--output-format", "csv", "-d", d, "--"] + base,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, cwd=tmp,
-                               env=dict(os.environ, TMPDIR=tmp))
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, cwd=tmp,
+                               env=clean_child_env(tmp))
             except (OSError, subprocess.SubprocessError):
                 continue
             acc = {}
@@ -277,10 +302,6 @@ def main():
                     help="fused: coordinate maps computed in-kernel (default, the product path); "
                          "caller: float maps handed in (the bit-exact mode)")
     ap.add_argument("--kind", default="S", choices=["S", "N"], help="synthetic panorama distribution")
-    ap.add_argument("--cache-coords", action="store_true",
-                    help="opt-in coordinate cache (P2P_FLAG_CACHE_COORDS): the first launch evaluates the pitch "
-                         "maps, later launches load the stored coordinates, as the reference's "
-                         "pitch_mapping_cache does across yaws and images; default off = maps evaluated in every launch")
     ap.add_argument("--pixel-path", default="u8", choices=["u8", "f32", "f16"],
                     help="u8: the reference's two fixed-point remap stages (default; the parity path). "
                          "f32 / f16: the opt-in single float resample, which the reference does not have")
@@ -293,7 +314,8 @@ def main():
     ap.add_argument("--counters", default="auto", choices=["auto", "measure", "file", "none"],
                     help="roofline.traffic / roofline.valu: measure = rocprofv3 --pmc child runs of this script (one pass "
                          "per counter group, before this process touches the GPU); file = profiles/traffic.json; "
-                         "auto = measure at --gpus 1 when rocprofv3 is on PATH, else file")
+                         "auto = measure at --gpus 1 when rocprofv3 is on PATH and this process is not itself running "
+                         "under a profiler, else file")
     args = ap.parse_args()
     if args.no_preroll:
         args.preroll_s = 0.0
@@ -306,7 +328,8 @@ def main():
     counters = None
     mode = args.counters
     if mode == "auto":
-        mode = "measure" if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and shutil.which("rocprofv3")) else "file"
+        mode = "measure" if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and shutil.which("rocprofv3")
+                             and not under_profiler()) else "file"
     if mode == "measure":
         counters = measure_counters(args)  # child processes; nothing in THIS process has touched the GPU yet
 
@@ -328,8 +351,7 @@ def main():
     synth = importlib.import_module(PKG + ".synth")
     drv = importlib.import_module(PKG + "._driver")
     w = WORKLOADS[args.workload]
-    flags = (nat.FLAG_CACHE_COORDS if args.cache_coords else 0) | \
-        {"u8": 0, "f32": nat.FLAG_PIXELS_F32, "f16": nat.FLAG_PIXELS_F16}[args.pixel_path]
+    flags = {"u8": 0, "f32": nat.FLAG_PIXELS_F32, "f16": nat.FLAG_PIXELS_F16}[args.pixel_path]
     n_yaw, n_pitch = len(w["yaws"]), len(w["pitches"])
     ctx = nat.Context(dist.local_rank)
     jobs = []          # what one step launches on this rank
@@ -462,13 +484,13 @@ def main():
     valu = None
     if counters and "SQ_INSTS_VALU" in counters:
         px = views_per_rank * w["ow"] * w["oh"]
-        # SQ counters on gfx950 sample a share of the waves (SQ_WAVES says how many): scale by launched / sampled
+        # SQ_WAVES counts every wave of the launch (config 2: 24 480): the figures below are per launch, unscaled
         waves = counters.get("SQ_WAVES")
         busy = counters.get("SQ_BUSY_CU_CYCLES")
         valu = {"SQ_INSTS_VALU": counters["SQ_INSTS_VALU"], "SQ_INSTS_SALU": counters.get("SQ_INSTS_SALU"),
                 "SQ_WAVES": waves,
                 "valu_wave_insts_per_wave": counters["SQ_INSTS_VALU"] / waves if waves else None,
-                "valu_lane_insts_per_output_px_sampled": (counters["SQ_INSTS_VALU"] * 64.0 / px) if px else None,
+                "valu_lane_insts_per_output_px": (counters["SQ_INSTS_VALU"] * 64.0 / px) if px else None,
                 "active_inst_valu_over_busy_cu_cycles": (counters.get("SQ_ACTIVE_INST_VALU", 0.0) / busy) if busy else None,
                 "issue_ceiling_of_that_ratio": {"slow_class_only": 0.97, "fast_class_only": 1.80,
                                                 "source": "profiles/r01_valu_counter_calibration.txt"},

@@ -50,12 +50,9 @@ enum { P2P_INTER_NEAREST = 0, P2P_INTER_LINEAR = 1, P2P_INTER_CUBIC = 2 };
 /* p2p_job_desc.flags / p2p_remap_views_u8 flags */
 enum {
     P2P_FLAG_DEFAULT = 0,
-    P2P_FLAG_KEEP_COORDS = 1,  /* accepted for compatibility: the quantised pitch-stage coordinates are part of every
-                                  job's plan now and p2p_job_get_coords always works (parity tests use it) */
-    P2P_FLAG_CACHE_COORDS = 2, /* accepted for compatibility: every job evaluates its pitch maps ONCE, in the plan pass
-                                  of its first p2p_job_run, and later runs start from the stored tables -- the
-                                  reference's pitch_mapping_cache (P:17-18, P:62-73), which it keeps across yaws AND
-                                  images.  p2p_job_set_maps replaces the maps and with them the plan. */
+    /* (bits 1 and 2 are unused: every job keeps its quantised pitch-stage coordinates -- p2p_job_get_coords -- and
+       evaluates its pitch maps once, in the plan pass of its first p2p_job_run, as the reference's
+       pitch_mapping_cache does, P:17-18, P:62-73) */
     /* Float pixel path, opt-in and BEYOND the reference (BASELINE config 5's "fp16 pixel path"):
        one float resample per view instead of two fixed-point ones -- the pitch map's coordinate (azimuth left
        unclipped) shifted by yaw * pw / 360 with true wrap-around at the seam, no 1/32-pixel quantisation, no uint8
@@ -276,11 +273,6 @@ int p2p_job_get_yaw_tables(p2p_job* job, uint32_t* packed);
 int p2p_host_alloc(size_t bytes, void** out);
 int p2p_host_free(void* ptr);
 int p2p_release_cache(void);
-
-/* Diagnostic: with a -DP2P_STAMPS build of the library, the summed s_memtime ticks the view
-   kernel's waves spent per phase of the pair loop ([0..5] phases, [6] waves, [7] pair iterations);
-   all zeros in the shipped build. */
-int p2p_debug_stamps(uint64_t* out16, int reset);
 
 #ifdef __cplusplus
 }

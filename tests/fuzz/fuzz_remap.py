@@ -53,7 +53,7 @@ for case in range(int(os.environ.get("FUZZ_FIRST", "0")), n_cases):  # FUZZ_FIRS
         fov = int(rng.choice([60, 90, 120]))
         n_panos = int(rng.integers(1, 3))
         ctx = nat.Context(0)
-        job = nat.Job(ctx, pw, ph, n_panos, yaws, pitches, fov, vw, vh, flags=nat.FLAG_KEEP_COORDS)
+        job = nat.Job(ctx, pw, ph, n_panos, yaws, pitches, fov, vw, vh)
         panos = [synth.synth_pano(pw, ph, 100 + case + i, "N") for i in range(n_panos)]
         for i, p in enumerate(panos):
             job.set_pano(i, p)

@@ -57,7 +57,7 @@ int main()
     CHECK(p2p_ctx_create(0, nullptr) == P2P_ERR_INVALID && p2p_ctx_create(3, &ctx) == P2P_ERR_NO_DEVICE);
     CHECK(p2p_ctx_create(0, &ctx) == P2P_OK);
     p2p_job* job = nullptr;
-    p2p_job_desc d = {64, 32, 2, 3, nullptr, 2, nullptr, 90, 70, 33, P2P_FLAG_KEEP_COORDS};
+    p2p_job_desc d = {64, 32, 2, 3, nullptr, 2, nullptr, 90, 70, 33, P2P_FLAG_DEFAULT};
     CHECK(p2p_job_create(ctx, &d, &job) == P2P_ERR_INVALID && job == nullptr);  // NULL angle lists
     const int32_t yaws[3] = {0, 90, 14}, pitches[2] = {30, 150};
     d.yaw_deg = yaws; d.pitch_deg = pitches;

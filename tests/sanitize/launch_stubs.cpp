@@ -76,5 +76,4 @@ hipError_t launch_float_views(const ViewsParams& P, bool, int, hipStream_t)
     P.out[(size_t)P.n_panos * P.n_yaw * P.n_pitch * P.oh * P.ow * 3 - 1] = 0;
     return hipSuccess;
 }
-hipError_t read_stamps(unsigned long long* out16, bool) { memset(out16, 0, 16 * sizeof(*out16)); return hipSuccess; }
 }  // namespace p2p

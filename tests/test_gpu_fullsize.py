@@ -51,7 +51,7 @@ def test_cfg2_all_36_views_self_consistent(gpu, pkg, pano8k):
     c = CFG2
     yaws = list(range(0, 360, 30))
     ctx = gpu.Context(0)
-    job = gpu.Job(ctx, c["pw"], c["ph"], 1, yaws, c["pitches"], c["fov"], c["ow"], c["oh"], flags=gpu.FLAG_KEEP_COORDS)
+    job = gpu.Job(ctx, c["pw"], c["ph"], 1, yaws, c["pitches"], c["fov"], c["ow"], c["oh"])
     job.set_pano(0, pano8k)
     job.run()
     fused, coords = job.get_views(0), job.get_coords()
@@ -79,7 +79,7 @@ def test_cfg3_one_gpu_share_of_the_64_panorama_batch(gpu, synth):
     panos = [synth.synth_pano(c["pw"], c["ph"], 1000 + i, "N") for i in range(n)]
     rows, U, V = oracle_maps(yaws, c["pitches"], c["ow"], c["oh"], c["pw"], c["ph"], c["fov"])
     ctx = gpu.Context(0)
-    fused = gpu.Job(ctx, c["pw"], c["ph"], n, yaws, c["pitches"], c["fov"], c["ow"], c["oh"], flags=gpu.FLAG_KEEP_COORDS)
+    fused = gpu.Job(ctx, c["pw"], c["ph"], n, yaws, c["pitches"], c["fov"], c["ow"], c["oh"])
     exact = gpu.Job(ctx, c["pw"], c["ph"], n, yaws, c["pitches"], c["fov"], c["ow"], c["oh"])
     for i, p in enumerate(panos):
         fused.set_pano(i, p)

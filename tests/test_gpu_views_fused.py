@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def _fused_with_coords(gpu, pano, yaws, pitches, ow, oh, fov):
     ph, pw = pano.shape[:2]
     ctx = gpu.Context(0)
-    job = gpu.Job(ctx, pw, ph, 1, yaws, pitches, fov, ow, oh, flags=gpu.FLAG_KEEP_COORDS)
+    job = gpu.Job(ctx, pw, ph, 1, yaws, pitches, fov, ow, oh)
     job.set_pano(0, pano)
     job.run()
     views, coords, tabs = job.get_views(0), job.get_coords(), job.get_yaw_tables()
