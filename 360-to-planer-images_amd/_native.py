@@ -426,6 +426,12 @@ def build_yaw_row(pw, yaw_rad, device=0):
     return row
 
 
+def _finalizing():
+    import sys
+
+    return sys is None or sys.is_finalizing()
+
+
 class Context:
     """p2p_ctx: one device, one HIP stream."""
 
@@ -452,7 +458,8 @@ class Context:
 
     def __del__(self):
         try:
-            self.close()
+            if not _finalizing():  # no HIP call once the interpreter (and with it the runtime) is going down
+                self.close()
         except Exception:
             pass
 
@@ -585,6 +592,7 @@ class Job:
 
     def __del__(self):
         try:
-            self.close()
+            if not _finalizing():
+                self.close()
         except Exception:
             pass

@@ -15,11 +15,10 @@ namespace p2p {
 #ifndef P2P_WAVES
 #define P2P_WAVES 6
 #endif
-constexpr int TILE_W = P2P_TILE_W;  // output tile of one workgroup (main pass)
+constexpr int TILE_W = P2P_TILE_W;  // output tile of one workgroup
 constexpr int TILE_H = 16;
 constexpr int VIEWS_BLOCK = 256;
 constexpr int VIEWS_PXT = TILE_W * TILE_H / VIEWS_BLOCK;  // output pixels per thread (rows ROWSTEP apart)
-constexpr int XTRA_PXT = VIEWS_PXT > 1 ? VIEWS_PXT / 2 : 1;  // pieces of split tiles: at most half a tile
 #ifndef P2P_SLOTS
 #define P2P_SLOTS 3
 #endif
@@ -33,25 +32,26 @@ constexpr int PXW_UP_BITS = 12;     // per-pixel word: bits of the upper tap's L
 constexpr int PXW_DL_BITS = 10;     //                 bits of (lower tap - upper tap)
 static_assert(4 * LDS_ITEMS_CAP <= (1 << PXW_UP_BITS), "tap offsets must fit the per-pixel word");
 constexpr int VIEWS_WAVES_PER_SIMD = P2P_WAVES;  // __launch_bounds__ of the main view kernel: 80 VGPRs, and 6 x 26.5 KB of LDS
-constexpr int PLAN_MAX_ROWS = 256;  // rot rows a piece's footprint may span (one plan thread per row)
-constexpr int PLAN_MIN_W = 16;      // tiles whose footprint outgrows the LDS buffers are halved in width down to
-constexpr int PLAN_MIN_H = 8;       // PLAN_MIN_W, then once in height; what still does not fit gathers directly
+constexpr int PLAN_MAX_ROWS = 256;  // rot rows a tile's footprint may span (one plan thread per row)
+// Every device panorama row is followed by a copy of the row's first PANO_PAD pixels: the source pixels of two
+// neighbouring rot columns are then three contiguous pixels also where the yaw shift runs across the row's end
+// (the gather kernel loads them with one 12-byte load).
+constexpr int PANO_PAD = 8;
+constexpr int AUDIT_WORDS = 8;  // the audit build's violation record: hit, site, block x, y, z, thread, value, limit (p2p_audit.h)
 
-// One piece of work of the view kernel: a w x h rectangle of output pixels of one pitch view (a whole tile, or a
-// part of a tile that had to be split), with everything that depends on the maps only worked out once by the plan
-// pass: its footprint in the yaw-resampled panorama as a list of 4-pixel items (per-row spans) and, per pixel,
-// the LDS offsets of its taps and its two 5-bit weights.  32 bytes, read with scalar loads.
+// One tile of TILE_W x TILE_H output pixels of one pitch view, with everything that depends on the maps only worked
+// out once by the plan pass.  mode 1 (LDS scheme): its footprint in the yaw-resampled panorama as a list of 4-pixel
+// items (per-row spans) and, per pixel, the LDS offsets of its taps and its two 5-bit weights.  mode 2 (gathers): a
+// footprint that does not fit the LDS buffers (strong minification, a pole inside the tile) or touches the
+// panorama's border; the gather kernel draws it from the plan's quantised coordinates.  16 bytes, read with one
+// scalar load; the tile's position and its pitch view come from the workgroup's index, never from memory.
 struct PieceHdr {
-    uint32_t xy;          // x0 | y0 << 16
-    uint32_t geom;        // w | h << 8 | pitch index << 16
-    uint32_t mode_items;  // mode (0: nothing to draw here, 1: LDS scheme, 2: direct gathers) | n_items << 8
-    int32_t c0, c1;       // rot columns of the footprint (mode 1): LDS position 0 of every row is a column
-                          // congruent to c0 mod 4; c1 + 1 is the last column any tap reads
-    uint32_t px_block;    // index of the piece's block of per-pixel words (blocks of 256 * PXT dwords)
-    uint32_t item_block;  // index of its item list (blocks of LDS_ITEMS_CAP dwords)
+    uint32_t mode_items;  // mode (1: LDS scheme, 2: gathers) | n_items << 8
+    int32_t c0, c1;       // rot columns the taps of the tile's live pixels read: c0 .. c1 + 1 (c1 < c0: no live pixel).
+                          // mode 1: LDS position 0 of every row is a column congruent to c0 mod 4
     uint32_t pad;
 };
-static_assert(sizeof(PieceHdr) == 32, "PieceHdr is read as one s_load_dwordx8");
+static_assert(sizeof(PieceHdr) == 16, "PieceHdr is read as one s_load_dwordx4");
 // per-pixel word: tap_up (dwords into an LDS buffer, PXW_UP_BITS) | (tap_lo - tap_up) << 12 (PXW_DL_BITS, 0 = the
 // pixel has no footprint: NaN coordinate) | fx << 22 | fy << 27
 // item word: rot row << 16 | 4-pixel group relative to the group of column c0
@@ -77,9 +77,9 @@ struct PitchConst {
 };
 
 struct ViewsParams {
-    const uint8_t* src;      // [n_panos] panoramas, each ph rows of src_pitch bytes (BGR interleaved)
-    size_t pano_stride;      // bytes between panoramas
-    int src_pitch;           // bytes between rows (>= 3 * pw)
+    const uint8_t* src;      // [n_panos] panoramas, each ph rows of src_pitch bytes (BGR interleaved, PANO_PAD wrap pixels)
+    size_t pano_stride;      // bytes between panoramas (< 2^32: one buffer descriptor spans a panorama)
+    int src_pitch;           // bytes between rows (>= 3 * (pw + PANO_PAD))
     int pw, ph;
     const uint32_t* ytab;    // [n_yaw][pw] packed yaw-table entries: 3*ix | fx << 20
     const YawDesc* ydesc;    // [n_yaw]
@@ -88,32 +88,27 @@ struct ViewsParams {
     int pairs_per_block;     // (panorama, yaw) pairs looped over by one workgroup
     uint32_t n_yaw_magic;    // ceil(2^32 / n_yaw): pair / n_yaw == umulhi(pair, magic) while pair * n_yaw < 2^32
     const PitchConst* pitch; // [n_pitch]
-    const float* mapU;       // [n_pitch][oh][ow] caller maps (HOST_MAPS) or nullptr
-    const float* mapV;
     MapGeom geom;
     int ow, oh;
     uint8_t* out;            // [n_panos][n_yaw][n_pitch][oh][ow][3]
     int border;              // stage-2 border mode (0 = BORDER_CONSTANT 0, the reference's current tool)
     const uint16_t* pitch_order;  // [n_pitch] blockIdx.y -> pitch index, heaviest view first
     const int2* coords;      // [n_pitch][oh][ow] quantised pitch-stage coordinates (sx, sy), written by the plan pass
-    const PieceHdr* hdr_main;   // [n_pitch][tiles]
-    const uint32_t* px_main;    // [n_pitch][tiles][256 * VIEWS_PXT]
-    const uint32_t* items_main; // [n_pitch][tiles][LDS_ITEMS_CAP]
-    const PieceHdr* hdr_x;      // pieces of split tiles ("extras"), x_n of them
-    const uint32_t* px_x;       // [x_n][256 * XTRA_PXT]
-    const uint32_t* items_x;    // [x_n][LDS_ITEMS_CAP]
-    const uint32_t* px2_main;   // float pixel path: 16-bit coordinate fractions per pixel
-    const uint32_t* px2_x;
-    const double* yaw_rad;      // float pixel path: [n_yaw]
-    int x_n;
-    int plan_gx;             // extra workgroups per view row of the grid: 8 * ceil(x_n / n_pitch / 8)
-    const uint32_t* rest_pairs;   // the rest kernel's own pair list (pano * n_yaw + yaw) when it draws only the yaws the
-    int n_rest_pairs;             // main kernel leaves to it (0: every pair of the job, in pairs_per_block chunks)
+    const PieceHdr* hdr;     // [n_pitch][tiles]
+    const uint32_t* px;      // [n_pitch][tiles][256 * VIEWS_PXT]
+    const uint32_t* items;   // [n_pitch][tiles][LDS_ITEMS_CAP]
+    const uint32_t* px2;     // float pixel path: 16-bit coordinate fractions per pixel
+    const double* yaw_rad;   // float pixel path: [n_yaw]
+    const uint32_t* odd_pairs;    // the (panorama, yaw) pairs (pano * n_yaw + yaw) whose yaw is not a plain shift with one
+    int n_odd_pairs;              // weight: the rest kernel's and the table kernel's pair list (see use_pair_list)
+    int use_pair_list;            // 1: those two kernels draw only the listed pairs; 0: every pair of the job
     int rest_ppb;
-    const uint32_t* direct_list;  // the plan's direct-gather pieces (PlanParams::direct_list) and how many
-    int n_direct;
-    int direct_ppb;          // (panorama, yaw) pairs per workgroup of remap_views_direct_kernel
+    const uint32_t* gather_list;  // the plan's mode-2 tiles (pitch * tiles + tile), in no particular order, and how many
+    int n_gather;
+    int gather_ppb;          // (panorama, yaw) pairs per workgroup of the gather / table kernels
+    int gather_all;          // 1: the gather kernel draws EVERY tile (few of the job's tiles fit the LDS scheme: one launch less)
     float centre;            // float pixel path only: 0 = the reference's sampling convention, 0.5 = pixel centres
+    uint32_t* audit;         // -DP2P_AUDIT builds: the context's violation record (see p2p_audit.h); else nullptr
 };
 
 struct PlanParams {
@@ -123,21 +118,14 @@ struct PlanParams {
     const float* mapU;       // caller maps [n_pitch][oh][ow] or nullptr (then pitch_map_eval)
     const float* mapV;
     int2* coords;
-    PieceHdr* hdr_main;
-    uint32_t* px_main;
-    uint32_t* items_main;
-    PieceHdr* hdr_x;
-    uint32_t* px_x;
-    uint32_t* items_x;
+    PieceHdr* hdr;
+    uint32_t* px;
+    uint32_t* items;
     int float_path;          // plan for the float pixel path: unclipped azimuth, 16-bit fractions in px2, spans one
     float centre;            // column wider (the yaw's fractional shift may carry); centre: 0 or 0.5 (pixel centres)
-    uint32_t* px2_main;      // float path: [n_pitch][tiles][256 * VIEWS_PXT] frac(U) | frac(V) << 16, 1/65536 units
-    uint32_t* px2_x;
-    uint32_t* x_count;       // [0] extras wanted (may exceed x_cap: the host then grows the pools and re-runs),
-                             // [1] pieces marked for direct gathers
-    uint32_t x_cap;
-    uint32_t* direct_list;   // [n_pitch * tiles + x_cap] the pieces marked for direct gathers, in no particular order:
-                             // index into hdr_main, or 0x80000000 | index into hdr_x
+    uint32_t* px2;           // float path: [n_pitch][tiles][256 * VIEWS_PXT] frac(U) | frac(V) << 16, 1/65536 units
+    uint32_t* n_gather;      // [0] tiles marked for gathers
+    uint32_t* gather_list;   // [n_pitch * tiles] the tiles marked for gathers (pitch * tiles + tile), in no particular order
 };
 
 struct RemapParams {

@@ -16,7 +16,7 @@
 // pixels leave as 12-byte non-temporal buffer stores.  Stage 1 is cheaper than the exact path's (a copy), the
 // per-pixel part is not: the float blend, the per-yaw weights and the carry come to about 100 issue cycles per pixel
 // against 64 (byte <-> float conversions and dot products issue at the same rate as the packed integer multiplies),
-// so the two paths run at the same speed.  Pieces the plan marks for direct gathers (view seam, pole, widths not divisible by 4)
+// so the two paths run at the same speed.  Tiles the plan marks for gathers (view seam, pole, widths not divisible by 4)
 // are drawn by float_views_rest_kernel, one thread per pixel from global memory.
 #include <hip/hip_fp16.h>
 #include <type_traits>
@@ -75,16 +75,17 @@ __device__ __forceinline__ uint32_t blend_f16(uint32_t a, uint32_t b, uint32_t c
     return r;
 }
 
-template <int PXT, bool HALF>
+template <bool HALF>
 __device__ __forceinline__ void draw_float(
-    const ViewsParams& P, const uint8_t* __restrict__ src, uint8_t* __restrict__ out, const PieceHdr h,
+    const ViewsParams& P, const uint8_t* __restrict__ src, uint8_t* __restrict__ out, const TileGeo& G,
     const uint32_t* __restrict__ pxw, const uint32_t* __restrict__ px2w, const uint32_t* __restrict__ itw,
     uint4 (*tile4)[LDS_ITEMS_CAP], uint32_t* stage)
 {
+    constexpr int PXT = VIEWS_PXT;
     const int t = threadIdx.x;
-    const PieceGeo G = piece_geo(h, t);
-    if (G.mode != 1 || (PXT == 4 ? G.w != 64 : (G.w != 32 && G.w != 16)))
+    if (G.mode != 1)
         return;  // the rest kernel's
+    P2P_AUD_LT(P.audit, AUD_FLOAT_HDR, G.n_items, LDS_ITEMS_CAP + 1);
     const int pair0 = blockIdx.z * P.pairs_per_block;
     int pair1 = pair0 + P.pairs_per_block;
     if (pair1 > P.n_panos * P.n_yaw)
@@ -133,7 +134,7 @@ __device__ __forceinline__ void draw_float(
             if (si >= P.pw)
                 si = P.pw - 1;
             cwf = (float)(sh - (double)si);
-            int i_first = h.c0 + si;
+            int i_first = G.c0 + si;
             if (i_first >= P.pw)
                 i_first -= P.pw;
             const int g0 = i_first >> 2;
@@ -146,8 +147,8 @@ __device__ __forceinline__ void draw_float(
     const int wv = t >> 6, ln = t & 63;
     uint32_t* const stg = stage + wv * (PXT * 64);
     const int x4 = 4 * (ln & 15), sj = ln >> 4;
-    const int srow = ((wv * 64 + x4) >> G.lw) + sj * G.rstep, scol = x4 & (G.w - 1);
-    const bool s_ok = sj < PXT && srow < G.h && G.y0 + srow < P.oh && G.x0 + scol < P.ow;
+    const int srow = ((wv * 64 + x4) >> TILE_LW) + sj * TILE_ROWSTEP, scol = x4 & (TILE_W - 1);
+    const bool s_ok = sj < PXT && srow < TILE_H && G.y0 + srow < P.oh && G.x0 + scol < P.ow;
     const uint32_t out_off12 = s_ok ? (uint32_t)(((size_t)(G.y0 + srow) * P.ow + G.x0 + scol) * 3) : 0xFFFFFFFFu;
     const uint32_t stg_rd = (uint32_t)(sj * 64 + x4);
 
@@ -163,12 +164,14 @@ __device__ __forceinline__ void draw_float(
         constexpr int NS = decltype(ns_c)::value;
         const uint32_t goff = (uint32_t)__builtin_amdgcn_readlane((int)cw0, k) & 0xFFFFFu;
         const uint32_t wrap_g = (uint32_t)__builtin_amdgcn_readlane((int)cw1, k);
-        const uint8_t* __restrict__ S = src + (size_t)__builtin_amdgcn_readlane(cw3, k) * P.pano_stride;
+        const auto S = make_buf(src + (size_t)__builtin_amdgcn_readlane(cw3, k) * P.pano_stride, (uint32_t)P.pano_stride);
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
             uint32_t off = slot_off[sl] + goff;
             off = slot_g[sl] >= wrap_g ? off - row_bytes : off;  // wrap-around: past the row's end, its start
-            qq[sl] = *reinterpret_cast<const Q16*>(S + off);
+            P2P_AUD_RANGE(P.audit, AUD_FLOAT_SRC, off, 16u, P.pano_stride);
+            const bu32x4 q = __builtin_amdgcn_raw_buffer_load_b128(S, (int)off, 0, 0);
+            qq[sl].d[0] = q.x; qq[sl].d[1] = q.y; qq[sl].d[2] = q.z; qq[sl].d[3] = q.w;
         }
     };
     auto run_ns = [&](auto ns_c) {
@@ -258,61 +261,55 @@ __device__ __forceinline__ void draw_float(
 template <bool HALF>
 __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void float_views_kernel(
     ViewsParams P, const uint8_t* __restrict__ src, uint8_t* __restrict__ out,
-    const PieceHdr* __restrict__ hdr_main, const uint32_t* __restrict__ px_main, const uint32_t* __restrict__ px2_main,
-    const uint32_t* __restrict__ items_main, const PieceHdr* __restrict__ hdr_x, const uint32_t* __restrict__ px_x,
-    const uint32_t* __restrict__ px2_x, const uint32_t* __restrict__ items_x)
+    const PieceHdr* __restrict__ hdr, const uint32_t* __restrict__ px, const uint32_t* __restrict__ px2,
+    const uint32_t* __restrict__ items)
 {
     __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
     __shared__ __attribute__((aligned(16))) uint32_t stage[(VIEWS_BLOCK / 64) * VIEWS_PXT * 64];
-    if ((int)blockIdx.x < P.plan_gx) {
-        const int ei = (int)blockIdx.y * P.plan_gx + (int)blockIdx.x;
-        if (ei >= P.x_n)
-            return;
-        const PieceHdr h = hdr_x[ei];
-        const size_t pb = (size_t)h.px_block * (VIEWS_BLOCK * XTRA_PXT);
-        draw_float<XTRA_PXT, HALF>(P, src, out, h, px_x + pb, px2_x + pb, items_x + (size_t)h.item_block * LDS_ITEMS_CAP, tile4, stage);
+    const int tile_id = tile_of_block(P, (int)blockIdx.x, (int)gridDim.x);
+    if (tile_id < 0)
         return;
-    }
-    const int bx = (int)blockIdx.x - P.plan_gx, gx = (int)gridDim.x - P.plan_gx;
+    const int pitch_i = pitch_of_block(P, (int)blockIdx.y);
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
-    const int chunk = gx >> 3;
-    const int tile_id = (bx & 7) * chunk + (bx >> 3);
-    if (tile_id >= tiles)
-        return;
-    const int pitch_i = P.pitch_order[blockIdx.y];
-    const PieceHdr h = hdr_main[(size_t)pitch_i * tiles + tile_id];
-    const size_t pb = (size_t)h.px_block * (VIEWS_BLOCK * VIEWS_PXT);
-    draw_float<VIEWS_PXT, HALF>(P, src, out, h, px_main + pb, px2_main + pb, items_main + (size_t)h.item_block * LDS_ITEMS_CAP, tile4, stage);
+    const PieceHdr h = hdr[(size_t)pitch_i * tiles + tile_id];
+    const TileGeo G = tile_geo(P, h, pitch_i, tile_id, (int)threadIdx.x);
+    const size_t pb = (size_t)G.slot * (VIEWS_BLOCK * VIEWS_PXT);
+    draw_float<HALF>(P, src, out, G, px + pb, px2 + pb, items + (size_t)G.slot * LDS_ITEMS_CAP, tile4, stage);
 }
 
-// Pieces the plan marks for direct gathers: one thread per pixel, taps from global memory (the view's own seam,
-// where U jumps from pw - 1 to 0 between neighbouring pixels; a pole inside the piece; widths not divisible by 4).
+// Tiles the plan marks for gathers: one thread per pixel, taps from global memory (the view's own seam,
+// where U jumps from pw - 1 to 0 between neighbouring pixels; a pole inside the tile; widths not divisible by 4).
 template <bool HALF>
 __global__ __launch_bounds__(VIEWS_BLOCK) void float_views_rest_kernel(
-    ViewsParams P, const uint8_t* __restrict__ src, uint8_t* __restrict__ out,
-    const PieceHdr* __restrict__ hdr_main, const PieceHdr* __restrict__ hdr_x)
+    ViewsParams P, const uint8_t* __restrict__ src, uint8_t* __restrict__ out, const PieceHdr* __restrict__ hdr)
 {
-    // one workgroup per (piece of the plan's direct-gather list, chunk of pairs)
-    const uint32_t id = P.direct_list[blockIdx.x];
-    const PieceHdr h = (id & 0x80000000u) ? hdr_x[id & 0x7FFFFFFFu] : hdr_main[id];
+    // one workgroup per (tile of the plan's gather list, chunk of pairs)
+    const uint32_t tiles = (uint32_t)(((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H));
+    uint32_t slot = P.gather_list[blockIdx.x];
+    P2P_AUD_LT(P.audit, AUD_FLOAT_LIST, slot, tiles * (uint32_t)P.n_pitch);
+    if (slot >= tiles * (uint32_t)P.n_pitch)
+        slot = 0u;
+    const int pitch_i = (int)(slot / tiles), tile_id = (int)(slot - (uint32_t)pitch_i * tiles);
+    const PieceHdr h = hdr[slot];
     const int t = threadIdx.x;
-    const PieceGeo G = piece_geo(h, t);
+    const TileGeo G = tile_geo(P, h, pitch_i, tile_id, t);
     if (G.mode != 2)
         return;
-    const int pair0 = blockIdx.z * P.direct_ppb;
-    int pair1 = pair0 + P.direct_ppb;
+    const int pair0 = blockIdx.z * P.gather_ppb;
+    int pair1 = pair0 + P.gather_ppb;
     if (pair1 > P.n_panos * P.n_yaw)
         pair1 = P.n_panos * P.n_yaw;
     const size_t view_bytes = (size_t)P.oh * P.ow * 3;
     const int px = G.x0 + G.col;
     for (int j = 0; j < VIEWS_PXT; ++j) {
-        const int row = G.row0 + j * G.rstep, py = G.y0 + row;
-        if (row >= G.h || px >= P.ow || py >= P.oh)
+        const int row = G.row0 + j * TILE_ROWSTEP, py = G.y0 + row;
+        if (row >= TILE_H || px >= P.ow || py >= P.oh)
             continue;
         const int2 cc = P.coords[((size_t)G.pitch_i * P.oh + py) * P.ow + px];
         const float U = __int_as_float(cc.x), V = __int_as_float(cc.y);
         const bool dead = !(U == U);
-        const int y0 = dead ? 0 : (int)V;  // V in [0, ph - 1]
+        int y0 = dead ? 0 : (int)V;  // V in [0, ph - 1]
+        y0 = y0 < 0 ? 0 : (y0 > P.ph - 1 ? P.ph - 1 : y0);
         const float wy = dead ? 0.0f : V - (float)y0;
         const int y1 = y0 + 1 < P.ph ? y0 + 1 : y0;
         const size_t px_off = ((size_t)py * P.ow + px) * 3;
@@ -330,8 +327,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void float_views_rest_kernel(
             if (xs >= (float)P.pw)
                 xs -= (float)P.pw;
             int x0 = (int)xs;
-            if (x0 >= P.pw)
-                x0 = P.pw - 1;
+            x0 = x0 < 0 ? 0 : (x0 >= P.pw ? P.pw - 1 : x0);
             const float wx = xs - (float)x0;
             const int x1 = x0 + 1 < P.pw ? x0 + 1 : 0;  // wrap-around
             uint32_t a = 0, b = 0, c = 0, d = 0;
@@ -354,26 +350,24 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void float_views_rest_kernel(
     }
 }
 
-// which = 0: the tile kernel, 1: the direct-gather pieces
+// which = 0: the tile kernel, 1: the gather tiles
 hipError_t launch_float_views(const ViewsParams& P, bool half, int which, hipStream_t st)
 {
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
     const int n_pairs = P.n_panos * P.n_yaw;
     const int zblocks = (n_pairs + P.pairs_per_block - 1) / P.pairs_per_block;
-    const dim3 grid(P.plan_gx + 8 * ((tiles + 7) / 8), P.n_pitch, zblocks);
+    const dim3 grid(8 * ((tiles + 7) / 8), P.n_pitch, zblocks);
     if (which == 0) {
         if (half)
-            hipLaunchKernelGGL(float_views_kernel<true>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.out, P.hdr_main, P.px_main,
-                               P.px2_main, P.items_main, P.hdr_x, P.px_x, P.px2_x, P.items_x);
+            hipLaunchKernelGGL(float_views_kernel<true>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.out, P.hdr, P.px, P.px2, P.items);
         else
-            hipLaunchKernelGGL(float_views_kernel<false>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.out, P.hdr_main, P.px_main,
-                               P.px2_main, P.items_main, P.hdr_x, P.px_x, P.px2_x, P.items_x);
+            hipLaunchKernelGGL(float_views_kernel<false>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.out, P.hdr, P.px, P.px2, P.items);
     } else {
-        const dim3 dgrid(P.n_direct, 1, (n_pairs + P.direct_ppb - 1) / P.direct_ppb);
+        const dim3 dgrid(P.n_gather, 1, (n_pairs + P.gather_ppb - 1) / P.gather_ppb);
         if (half)
-            hipLaunchKernelGGL(float_views_rest_kernel<true>, dgrid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.out, P.hdr_main, P.hdr_x);
+            hipLaunchKernelGGL(float_views_rest_kernel<true>, dgrid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.out, P.hdr);
         else
-            hipLaunchKernelGGL(float_views_rest_kernel<false>, dgrid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.out, P.hdr_main, P.hdr_x);
+            hipLaunchKernelGGL(float_views_rest_kernel<false>, dgrid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.out, P.hdr);
     }
     return hipGetLastError();
 }

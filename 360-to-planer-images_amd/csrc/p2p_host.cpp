@@ -64,6 +64,7 @@ struct p2p_ctx {
     // instead of four hipMalloc / hipFree per call
     void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[4] = {0, 0, 0, 0};
+    uint32_t* d_audit = nullptr;  // -DP2P_AUDIT builds: the kernels' violation record (p2p_audit.h)
 };
 
 struct p2p_job {
@@ -96,21 +97,16 @@ struct p2p_job {
     // the plan (p2p_plan.hip): what depends on the maps only, built once per job geometry like the reference's
     // pitch_mapping_cache (P:17-18, P:55-73)
     int2* d_coords = nullptr;            // [n_pitch][oh][ow] quantised coordinates
-    p2p::PieceHdr* d_hdr_main = nullptr; // [n_pitch][tiles]
-    uint32_t* d_px_main = nullptr;       // [n_pitch][tiles][256 * VIEWS_PXT]
-    uint32_t* d_items_main = nullptr;    // [n_pitch][tiles][LDS_ITEMS_CAP]
-    p2p::PieceHdr* d_hdr_x = nullptr;    // pieces of split tiles
-    uint32_t* d_px_x = nullptr;
-    uint32_t* d_items_x = nullptr;
-    uint32_t* d_px2_main = nullptr;      // float pixel path only: 16-bit coordinate fractions
-    uint32_t* d_px2_x = nullptr;
-    uint32_t* d_x_count = nullptr;
-    uint32_t* d_direct_list = nullptr;   // pieces the plan marks for direct gathers
-    uint32_t* d_rest_pairs = nullptr;    // (panorama, yaw) pairs whose yaw the main kernel leaves to the rest kernel
-    int n_rest_pairs = 0;
-    uint32_t x_cap = 0;
-    int x_n = -1;                        // -1: the plan has not been built for the current maps
-    int n_direct = 0;                    // pieces the plan marks for direct gathers
+    p2p::PieceHdr* d_hdr = nullptr;      // [n_pitch][tiles]
+    uint32_t* d_px = nullptr;            // [n_pitch][tiles][256 * VIEWS_PXT]
+    uint32_t* d_items = nullptr;         // [n_pitch][tiles][LDS_ITEMS_CAP]
+    uint32_t* d_px2 = nullptr;           // float pixel path only: 16-bit coordinate fractions
+    uint32_t* d_n_gather = nullptr;
+    uint32_t* d_gather_list = nullptr;   // [n_pitch * tiles] tiles the plan marks for gathers
+    uint32_t* d_odd_pairs = nullptr;     // (panorama, yaw) pairs whose yaw is not a plain shift with one weight
+    int n_odd_pairs = 0;
+    bool planned = false;                // the plan has been built for the current maps
+    int n_gather = 0;                    // tiles the plan marks for gathers
     int n_odd_yaws = 0;                  // yaws that are not a plain shift with one weight (YawDesc.mode != 0)
     uint16_t* d_pitch_order = nullptr;   // [n_pitch] heaviest view first
     size_t n_tiles = 0;
@@ -240,12 +236,10 @@ struct SlotGuard {  // gives the slot back on every return path
     ~SlotGuard() { if (s) slot_release(s); }
 };
 
-int choose_pairs_per_block(const p2p_job_desc& d, int x_n)
+int choose_pairs_per_block(const p2p_job_desc& d)
 {
     const int tiles = ((d.ow + p2p::TILE_W - 1) / p2p::TILE_W) * ((d.oh + p2p::TILE_H - 1) / p2p::TILE_H);
-    // workgroups per pair chunk: the tiles and the pieces of split tiles (a strongly minifying job -- the reference
-    // CLI's default 800 x 800 views of an 8K panorama -- has four pieces per tile)
-    const long long base = (long long)tiles * d.n_pitch + (x_n > 0 ? x_n : 0);
+    const long long base = (long long)tiles * d.n_pitch;  // workgroups per pair chunk
     const int n_pairs = d.n_panos * d.n_yaw;
     int forced = env_int("P2P_PAIRS_PER_BLOCK", 0);
     if (forced > 64)
@@ -303,6 +297,10 @@ int p2p_ctx_create(int device, p2p_ctx** out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_down, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+#ifdef P2P_AUDIT
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_audit, p2p::AUDIT_WORDS * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(c->d_audit, 0, p2p::AUDIT_WORDS * sizeof(uint32_t));
+#endif
     if (e != hipSuccess) {
         p2p_ctx_destroy(c);
         return fail(P2P_ERR_HIP, "stream/event creation: %s", hipGetErrorString(e));
@@ -322,6 +320,7 @@ void p2p_ctx_destroy(p2p_ctx* c)
             (void)hipStreamDestroy(*st);
         }
     (void)hipFree(c->d_ctab);
+    (void)hipFree(c->d_audit);
     for (void* p : c->scratch)
         (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -364,17 +363,13 @@ void p2p_job_destroy(p2p_job* j)
     (void)hipFree(j->d_mapV);
     (void)hipFree(j->d_rows);
     (void)hipFree(j->d_coords);
-    (void)hipFree(j->d_hdr_main);
-    (void)hipFree(j->d_px_main);
-    (void)hipFree(j->d_items_main);
-    (void)hipFree(j->d_hdr_x);
-    (void)hipFree(j->d_px_x);
-    (void)hipFree(j->d_items_x);
-    (void)hipFree(j->d_px2_main);
-    (void)hipFree(j->d_px2_x);
-    (void)hipFree(j->d_x_count);
-    (void)hipFree(j->d_direct_list);
-    (void)hipFree(j->d_rest_pairs);
+    (void)hipFree(j->d_hdr);
+    (void)hipFree(j->d_px);
+    (void)hipFree(j->d_items);
+    (void)hipFree(j->d_px2);
+    (void)hipFree(j->d_n_gather);
+    (void)hipFree(j->d_gather_list);
+    (void)hipFree(j->d_odd_pairs);
     (void)hipFree(j->d_pitch_order);
     for (hipEvent_t e : j->ev_ring)
         (void)hipEventDestroy(e);
@@ -390,19 +385,20 @@ static int count_odd_yaws(p2p_job* j)
     j->n_odd_yaws = 0;
     for (const auto& d : yd)
         j->n_odd_yaws += d.mode != 0;
-    // the rest kernel's pair list: every panorama x the yaws with per-column weights or rows that are not a shift
-    (void)hipFree(j->d_rest_pairs);
-    j->d_rest_pairs = nullptr;
-    j->n_rest_pairs = 0;
+    // the odd-pair list: every panorama x the yaws with per-column weights or rows that are not a shift
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream));  // nothing in flight reads the old list
+    (void)hipFree(j->d_odd_pairs);
+    j->d_odd_pairs = nullptr;
+    j->n_odd_pairs = 0;
     if (j->n_odd_yaws > 0) {
         std::vector<uint32_t> pairs;
         for (int p = 0; p < j->d.n_panos; ++p)
             for (int y = 0; y < j->d.n_yaw; ++y)
                 if (yd[y].mode != 0)
                     pairs.push_back((uint32_t)p * (uint32_t)j->d.n_yaw + (uint32_t)y);
-        HIP_TRY(hipMalloc((void**)&j->d_rest_pairs, pairs.size() * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpy(j->d_rest_pairs, pairs.data(), pairs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        j->n_rest_pairs = (int)pairs.size();
+        HIP_TRY(hipMalloc((void**)&j->d_odd_pairs, pairs.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(j->d_odd_pairs, pairs.data(), pairs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        j->n_odd_pairs = (int)pairs.size();
     }
     return P2P_OK;
 }
@@ -447,7 +443,7 @@ static int job_create_core(p2p_ctx* ctx, const p2p_job_desc& d, const double* ya
     j->fov = fov_deg;
     j->pano_set.assign(d.n_panos, 0);
 
-    j->src_pitch = (3 * d.pw + 15) & ~15;
+    j->src_pitch = (3 * (d.pw + p2p::PANO_PAD) + 15) & ~15;  // every row is followed by a copy of its first pixels
     j->pano_stride = (((size_t)j->src_pitch * d.ph + kSlack) + 255) & ~(size_t)255;
     j->out_bytes = (size_t)d.n_panos * d.n_yaw * d.n_pitch * d.oh * d.ow * 3;
 
@@ -482,13 +478,18 @@ static int job_create_core(p2p_ctx* ctx, const p2p_job_desc& d, const double* ya
     j->n_tiles = (size_t)((d.ow + p2p::TILE_W - 1) / p2p::TILE_W) * ((d.oh + p2p::TILE_H - 1) / p2p::TILE_H);
     {
         const size_t slots = j->n_tiles * d.n_pitch;
+        if (slots >= 0x7FFFFFFFull) {
+            p2p_job_destroy(j);
+            return fail(P2P_ERR_INVALID, "too many tiles (%zu): fewer pitch angles or smaller views per job", slots);
+        }
         if (float_path && e == hipSuccess)
-            e = hipMalloc((void**)&j->d_px2_main, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t));
+            e = hipMalloc((void**)&j->d_px2, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void**)&j->d_coords, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2));
-        if (e == hipSuccess) e = hipMalloc((void**)&j->d_hdr_main, slots * sizeof(p2p::PieceHdr));
-        if (e == hipSuccess) e = hipMalloc((void**)&j->d_px_main, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&j->d_items_main, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&j->d_x_count, 2 * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&j->d_hdr, slots * sizeof(p2p::PieceHdr));
+        if (e == hipSuccess) e = hipMalloc((void**)&j->d_px, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&j->d_items, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&j->d_n_gather, sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&j->d_gather_list, slots * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void**)&j->d_pitch_order, (size_t)d.n_pitch * sizeof(uint16_t));
         // views looking further from the horizon have larger source footprints: launch them first
         std::vector<uint16_t> ord(d.n_pitch);
@@ -579,8 +580,13 @@ int p2p_job_set_pano_async(p2p_job* j, int index, const uint8_t* pano, int64_t r
         return rc;
     if (j->ev_run_recorded)
         HIP_TRY(hipStreamWaitEvent(j->ctx->stream_up, j->ev_run, 0));
-    HIP_TRY(hipMemcpy2DAsync(j->d_src + (size_t)index * j->pano_stride, (size_t)j->src_pitch, pano,
-                             (size_t)row_stride, (size_t)3 * j->d.pw, (size_t)j->d.ph,
+    uint8_t* dst = j->d_src + (size_t)index * j->pano_stride;
+    HIP_TRY(hipMemcpy2DAsync(dst, (size_t)j->src_pitch, pano, (size_t)row_stride, (size_t)3 * j->d.pw, (size_t)j->d.ph,
+                             hipMemcpyHostToDevice, j->ctx->stream_up));
+    // behind every row a copy of its first pixels (PANO_PAD of them, or the whole row if it is shorter): the
+    // gather kernel reads the pixels under a yaw shift that runs across the row's end as one contiguous run
+    HIP_TRY(hipMemcpy2DAsync(dst + (size_t)3 * j->d.pw, (size_t)j->src_pitch, pano, (size_t)row_stride,
+                             (size_t)3 * std::min(j->d.pw, p2p::PANO_PAD), (size_t)j->d.ph,
                              hipMemcpyHostToDevice, j->ctx->stream_up));
     HIP_TRY(hipEventRecord(j->ev_up, j->ctx->stream_up));
     j->up_pending = true;
@@ -661,7 +667,7 @@ int p2p_job_set_maps(p2p_job* j, const float* yaw_rows, const float* U, const fl
     }
     if (!j->d_mapU) HIP_TRY(hipMalloc((void**)&j->d_mapU, n_map * sizeof(float)));
     if (!j->d_mapV) HIP_TRY(hipMalloc((void**)&j->d_mapV, n_map * sizeof(float)));
-    j->x_n = -1;  // the plan follows the maps (also when a later step of this call fails)
+    j->planned = false;  // the plan follows the maps (also when a later step of this call fails)
     HIP_TRY(hipMemcpyAsync(j->d_mapU, U, n_map * sizeof(float), hipMemcpyHostToDevice, j->ctx->stream));
     HIP_TRY(hipMemcpyAsync(j->d_mapV, V, n_map * sizeof(float), hipMemcpyHostToDevice, j->ctx->stream));
     if (yaw_rows) {
@@ -674,7 +680,6 @@ int p2p_job_set_maps(p2p_job* j, const float* yaw_rows, const float* U, const fl
     }
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));
     j->host_maps = true;
-    j->x_n = -1;  // the plan follows the maps
     return yaw_rows ? count_odd_yaws(j) : P2P_OK;
 }
 
@@ -692,58 +697,57 @@ static int job_build_plan(p2p_job* j)
     Q.mapU = j->host_maps ? j->d_mapU : nullptr;
     Q.mapV = j->host_maps ? j->d_mapV : nullptr;
     Q.coords = j->d_coords;
-    Q.hdr_main = j->d_hdr_main;
-    Q.px_main = j->d_px_main;
-    Q.items_main = j->d_items_main;
-    Q.x_count = j->d_x_count;
+    Q.hdr = j->d_hdr;
+    Q.px = j->d_px;
+    Q.items = j->d_items;
+    Q.n_gather = j->d_n_gather;
+    Q.gather_list = j->d_gather_list;
     Q.float_path = (d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)) != 0;
     Q.centre = (d.flags & P2P_FLAG_PIXEL_CENTRES) ? 0.5f : 0.0f;
-    Q.px2_main = j->d_px2_main;
-    const size_t slots = j->n_tiles * d.n_pitch;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        if (!j->d_hdr_x) {
-            // first guess: one tile in eight is split in two (grown below if the plan wants more)
-            if (j->x_cap == 0)
-                j->x_cap = (uint32_t)std::min<size_t>(slots / 4 + 64, 0x7FFFFFFFu);
-            HIP_TRY(hipMalloc((void**)&j->d_hdr_x, (size_t)j->x_cap * sizeof(p2p::PieceHdr)));
-            HIP_TRY(hipMalloc((void**)&j->d_px_x, (size_t)j->x_cap * 256 * p2p::XTRA_PXT * sizeof(uint32_t)));
-            HIP_TRY(hipMalloc((void**)&j->d_items_x, (size_t)j->x_cap * p2p::LDS_ITEMS_CAP * sizeof(uint32_t)));
-            if (Q.float_path)
-                HIP_TRY(hipMalloc((void**)&j->d_px2_x, (size_t)j->x_cap * 256 * p2p::XTRA_PXT * sizeof(uint32_t)));
-            HIP_TRY(hipMalloc((void**)&j->d_direct_list, (slots + j->x_cap) * sizeof(uint32_t)));
-        }
-        Q.direct_list = j->d_direct_list;
-        Q.px2_x = j->d_px2_x;
-        Q.hdr_x = j->d_hdr_x;
-        Q.px_x = j->d_px_x;
-        Q.items_x = j->d_items_x;
-        Q.x_cap = j->x_cap;
-        HIP_TRY(hipMemsetAsync(j->d_x_count, 0, 2 * sizeof(uint32_t), st));
-        // pixels outside the view (partial tiles) and unused item slots read as zero
-        HIP_TRY(hipMemsetAsync(j->d_px_main, 0, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(j->d_items_main, 0, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(j->d_px_x, 0, (size_t)j->x_cap * 256 * p2p::XTRA_PXT * sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(j->d_items_x, 0, (size_t)j->x_cap * p2p::LDS_ITEMS_CAP * sizeof(uint32_t), st));
-        HIP_TRY(p2p::launch_plan(Q, st));
-        uint32_t cnt[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(cnt, j->d_x_count, sizeof(cnt), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        const uint32_t n = cnt[0];
-        if (n <= j->x_cap) {
-            j->x_n = (int)n;
-            j->n_direct = (int)cnt[1];
-            return P2P_OK;
-        }
-        // more pieces than the pools hold (views full of poles): size them exactly and plan again
-        (void)hipFree(j->d_hdr_x); j->d_hdr_x = nullptr;
-        (void)hipFree(j->d_px_x); j->d_px_x = nullptr;
-        (void)hipFree(j->d_items_x); j->d_items_x = nullptr;
-        (void)hipFree(j->d_px2_x); j->d_px2_x = nullptr;
-        (void)hipFree(j->d_direct_list); j->d_direct_list = nullptr;
-        j->x_cap = n;
+    Q.px2 = j->d_px2;
+#ifdef P2P_AUDIT
+    {
+        // every pool poisoned: a kernel that reads a slot the plan pass did not write gets 0xFF.. and the audit sees it
+        const size_t slots = j->n_tiles * d.n_pitch;
+        HIP_TRY(hipMemsetAsync(j->d_hdr, 0xFF, slots * sizeof(p2p::PieceHdr), st));
+        HIP_TRY(hipMemsetAsync(j->d_px, 0xFF, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(j->d_items, 0xFF, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(j->d_gather_list, 0xFF, slots * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(j->d_coords, 0xFF, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2), st));
+        if (j->d_px2)
+            HIP_TRY(hipMemsetAsync(j->d_px2, 0xFF, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t), st));
     }
-    return fail(P2P_ERR_HIP, "the plan pass did not converge");
+#endif
+    // (the plan pass writes every header, every per-pixel word and every item slot of every tile: nothing to clear)
+    HIP_TRY(hipMemsetAsync(j->d_n_gather, 0, sizeof(uint32_t), st));
+    HIP_TRY(p2p::launch_plan(Q, st));
+    uint32_t cnt = 0;
+    HIP_TRY(hipMemcpyAsync(&cnt, j->d_n_gather, sizeof(cnt), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if ((size_t)cnt > j->n_tiles * d.n_pitch)
+        return fail(P2P_ERR_HIP, "the plan pass listed %u gather tiles of %zu", cnt, j->n_tiles * d.n_pitch);
+    j->n_gather = (int)cnt;
+    j->planned = true;
+    if (env_int("P2P_VERBOSE", 0))
+        fprintf(stderr, "p2p plan: %u of %zu tiles gather (%dx%d views, %d pitches)\n", cnt, j->n_tiles * d.n_pitch, d.ow, d.oh, d.n_pitch);
+    return P2P_OK;
 }
+
+#ifdef P2P_AUDIT
+// audit build: wait for the launch and read the kernels' violation record
+static int audit_check(p2p_ctx* ctx, const char* what)
+{
+    uint32_t rec[p2p::AUDIT_WORDS] = {0};
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(rec, ctx->d_audit, sizeof(rec), hipMemcpyDeviceToHost));
+    if (rec[0]) {
+        HIP_TRY(hipMemset(ctx->d_audit, 0, sizeof(rec)));
+        return fail(P2P_ERR_HIP, "AUDIT %s: site 0x%x block (%u, %u, %u) thread %u value %u limit %u", what, rec[1], rec[2],
+                    rec[3], rec[4], rec[5], rec[6], rec[7]);
+    }
+    return P2P_OK;
+}
+#endif
 
 int p2p_job_run(p2p_job* j)
 {
@@ -781,9 +785,8 @@ int p2p_job_run(p2p_job* j)
     P.n_panos = j->d.n_panos;
     P.n_yaw_magic = (uint32_t)(((1ull << 32) + (uint64_t)j->d.n_yaw - 1) / (uint64_t)j->d.n_yaw);
     P.pitch = j->d_pitch;
-    P.mapU = j->d_mapU;
-    P.mapV = j->d_mapV;
     P.geom = j->geom;
+    P.audit = j->ctx->d_audit;
     P.ow = j->d.ow;
     P.oh = j->d.oh;
     P.out = j->d_out;
@@ -798,50 +801,50 @@ int p2p_job_run(p2p_job* j)
     const bool float_path = (j->d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)) != 0;
     if (float_path && j->host_maps)
         return fail(P2P_ERR_STATE, "the float pixel path evaluates its own maps; caller maps are not supported");
-    if (j->x_n < 0) {
+    if (!j->planned) {
         int rc = job_build_plan(j);
         if (rc != P2P_OK)
             return rc;
     }
-    P.pairs_per_block = choose_pairs_per_block(j->d, j->x_n);
+    P.pairs_per_block = choose_pairs_per_block(j->d);
     P.pitch_order = j->d_pitch_order;
     P.coords = j->d_coords;
-    P.hdr_main = j->d_hdr_main;
-    P.px_main = j->d_px_main;
-    P.items_main = j->d_items_main;
-    P.hdr_x = j->d_hdr_x;
-    P.px_x = j->d_px_x;
-    P.items_x = j->d_items_x;
-    P.x_n = j->x_n;
-    P.plan_gx = 8 * ((((P.x_n + j->d.n_pitch - 1) / j->d.n_pitch) + 7) / 8);
-    P.direct_list = j->d_direct_list;
-    P.n_direct = j->n_direct;
-    // with view rows of whole dwords the main kernel draws every plain-shift yaw of every LDS-scheme piece, and the
-    // rest kernel only the listed pairs (up to 16 per workgroup: one set-up for all of them); otherwise it draws all
-    const bool rest_listed = (j->d.ow & 3) == 0 && j->n_rest_pairs > 0 && env_int("P2P_FORCE_REST", 0) == 0;
-    P.rest_pairs = rest_listed ? j->d_rest_pairs : nullptr;
-    P.n_rest_pairs = rest_listed ? j->n_rest_pairs : 0;
-    P.rest_ppb = std::min(16, std::max(1, j->n_rest_pairs));
+    P.hdr = j->d_hdr;
+    P.px = j->d_px;
+    P.items = j->d_items;
+    P.gather_list = j->d_gather_list;
+    P.n_gather = j->n_gather;
+    // With view rows of whole dwords the main and the gather kernel draw every plain-shift yaw, and the rest / table
+    // kernels only the listed odd pairs (up to 16 per workgroup: one set-up for all of them); otherwise those two draw all
+    const bool fast_width = (j->d.ow & 3) == 0 && env_int("P2P_FORCE_REST", 0) == 0;
+    const bool gather_ok = fast_width && j->border == 0;  // the gather kernel: BORDER_CONSTANT 0, 12-byte stores
+    P.odd_pairs = j->d_odd_pairs;
+    P.n_odd_pairs = j->n_odd_pairs;
+    P.rest_ppb = std::min(16, std::max(1, j->n_odd_pairs));
     {
-        // pairs per workgroup of the direct-gather kernel: about 4096 workgroups in all, at most 16 pairs each
-        // (the piece's coordinates are loaded once per workgroup)
+        // pairs per workgroup of the gather / table kernels: about 4096 workgroups in all, at most 16 pairs each
+        // (the tile's coordinates and weights are set up once per workgroup)
         const long long np = (long long)j->d.n_panos * j->d.n_yaw;
-        long long ppb = (np * std::max(1, j->n_direct) + 4095) / 4096;
-        P.direct_ppb = (int)std::min<long long>(std::max<long long>(ppb, 1), std::min<long long>(np, 16));
+        long long ppb = (np * std::max(1, j->n_gather) + 2047) / 2048;
+        const long long cap = env_int("P2P_GATHER_PPB", 16);
+        P.gather_ppb = (int)std::min<long long>(std::max<long long>(ppb, 1), std::min<long long>(np, std::min<long long>(cap, 64)));
     }
     if (float_path) {
         // opt-in float pixel path (beyond the reference): one float resample per view, see p2p_float.hip
-        P.px2_main = j->d_px2_main;
-        P.px2_x = j->d_px2_x;
+        P.px2 = j->d_px2;
         P.yaw_rad = j->d_yaw_rad;
         const bool half = (j->d.flags & P2P_FLAG_PIXELS_F16) != 0;
         if (timed)
             HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
-        if (j->n_direct > 0)
+        if (j->n_gather > 0)
             HIP_TRY(p2p::launch_float_views(P, half, 1, j->ctx->stream));
         HIP_TRY(p2p::launch_float_views(P, half, 0, j->ctx->stream));
         if (timed)
             HIP_TRY(hipEventRecord(j->ev_ring[2 * slot + 1], j->ctx->stream));
+#ifdef P2P_AUDIT
+        if (int rc = audit_check(j->ctx, "float views"))
+            return rc;
+#endif
         j->run_unmarked = true;
         if (!j->owns_src)
             j->src_owner->run_unmarked = true;
@@ -851,22 +854,48 @@ int p2p_job_run(p2p_job* j)
     }
     if (timed)
         HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
-    // The main kernel draws every LDS-scheme piece for every yaw that is a plain shift -- on the reference's own
-    // workloads that is everything but the pieces with a pole inside.  The other two kernels are launched only when
-    // the plan or the yaw tables call for them; the three write disjoint pixels.
-    // The rest kernel runs the general loop (yaws with per-column weights or rows that are not a shift, view widths
-    // not divisible by 4) over the whole grid; the direct-gather pieces have a kernel and a grid of their own.
-    const bool need_rest = j->n_odd_yaws > 0 || (j->d.ow & 3) != 0 || env_int("P2P_FORCE_REST", 0) != 0;
-    // (the direct-gather kernel on a side stream, forked and joined by events, measured slower: 106.6 vs 101.6 us
-    // on the reference CLI's default view set, -0.8 % on config 4's pitch 30)
-    if (j->n_direct > 0)
-        HIP_TRY(p2p::launch_remap_views(P, 2, j->ctx->stream));
-    if (need_rest)
+    // The main kernel draws every LDS-scheme tile for every yaw that is a plain shift, the gather kernel every other
+    // tile for those yaws -- on the reference's own workloads that is everything.  The other two kernels are launched
+    // only when the yaw tables or the job's shape call for them; the four write disjoint pixels.
+    const size_t slots = j->n_tiles * (size_t)j->d.n_pitch;
+    const bool any_lds = (size_t)j->n_gather < slots;  // a tile the LDS-scheme kernels draw
+    const bool need_rest = any_lds && (j->n_odd_yaws > 0 || !fast_width);
+    // Few tiles left for the LDS scheme (the edge tiles of a strongly minifying view set): the gather kernel, which
+    // needs nothing but the coordinates, draws those too, and the main kernel's launch (6 us for a handful of
+    // tiles) is saved.  The odd pairs of those tiles stay the rest kernel's.
+    P.gather_all = (gather_ok && j->n_gather > 0 && (slots - (size_t)j->n_gather) * 4 <= slots &&
+                    env_int("P2P_GATHER_ALL", 1) != 0) ? 1 : 0;
+    // (the gather kernel of a big job on a side stream, forked and joined by events, so that its cache waits overlap
+    // the main kernel's arithmetic: config 4's pitch 30 1647 vs 1621 us, all five pitches 8021 vs 7988 -- the two
+    // kernels do not interleave, not kept)
+    if (j->n_gather > 0) {
+        if (gather_ok) {
+            P.use_pair_list = 0;
+            if (P.gather_all) {
+                const long long np = (long long)j->d.n_panos * j->d.n_yaw;
+                const long long ppb = (np * (long long)slots + 2047) / 2048;
+                P.gather_ppb = (int)std::min<long long>(std::max<long long>(ppb, 1), std::min<long long>(np, 16));
+            }
+            HIP_TRY(p2p::launch_remap_views(P, 3, j->ctx->stream));
+        }
+        // the table kernel: every pair where the gather kernel does not apply, else the odd pairs
+        P.use_pair_list = gather_ok ? 1 : 0;
+        if (!gather_ok || j->n_odd_pairs > 0)
+            HIP_TRY(p2p::launch_remap_views(P, 2, j->ctx->stream));
+    }
+    if (need_rest) {
+        P.use_pair_list = (fast_width && j->n_odd_pairs > 0) ? 1 : 0;
         HIP_TRY(p2p::launch_remap_views(P, 1, j->ctx->stream));
-    if ((j->d.ow & 3) == 0)
+    }
+    P.use_pair_list = 0;
+    if (fast_width && any_lds && !P.gather_all)
         HIP_TRY(p2p::launch_remap_views(P, 0, j->ctx->stream));
     if (timed)
         HIP_TRY(hipEventRecord(j->ev_ring[2 * slot + 1], j->ctx->stream));
+#ifdef P2P_AUDIT
+    if (int rc = audit_check(j->ctx, "views"))
+        return rc;
+#endif
     // (the event that orders copies behind this run is recorded when a copy asks for it: mark_run)
     j->run_unmarked = true;
     if (!j->owns_src)

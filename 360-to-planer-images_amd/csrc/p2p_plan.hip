@@ -9,8 +9,8 @@
 //   * the quantised coordinates (sx, sy), for the direct-gather path and for p2p_job_get_coords;
 //   * per tile: the footprint of the tile in the yaw-resampled panorama as per-row spans of 4-pixel items, and
 //     per pixel the LDS offsets of its 2x2 taps inside that footprint plus its two 5-bit weights (one dword);
-//   * for tiles whose footprint does not fit the LDS buffers: the same for halves / quarters ... of the tile
-//     ("extras"), down to 16x8 pieces; what still does not fit is marked for direct gathers.
+//   * tiles whose footprint does not fit the LDS buffers (strong minification, a pole inside) or touches the
+//     panorama's border are marked for the gather kernel and entered in a list.
 // No pixel data is touched here.  The view kernel (p2p_views.hip) then starts every launch from these tables.
 // Compiled with -ffp-contract=off: every float operation rounds where NumPy rounds.
 #include "p2p_inline.h"
@@ -18,34 +18,6 @@
 namespace p2p {
 
 namespace {
-
-constexpr int LOG2_TILE_W = TILE_W == 64 ? 6 : (TILE_W == 32 ? 5 : 4);
-static_assert((1 << LOG2_TILE_W) == TILE_W, "TILE_W must be 16, 32 or 64");
-constexpr int N_WSPLIT = LOG2_TILE_W - 4;          // width halvings down to PLAN_MIN_W = 16
-constexpr int N_LEVELS = N_WSPLIT + 2;             // whole tile, width halvings, one height halving
-static_assert(TILE_H == 2 * PLAN_MIN_H && PLAN_MIN_W == 16, "piece geometry below assumes 16-row tiles");
-static_assert((TILE_W >> 1) * TILE_H <= 256 * XTRA_PXT, "a half tile must fit an extra piece");
-
-struct Rect {
-    int x, y, w, h;  // relative to the tile origin
-};
-
-__device__ __forceinline__ Rect piece_rect(int level, int idx)
-{
-    Rect r;
-    if (level <= N_WSPLIT) {
-        r.w = TILE_W >> level;
-        r.h = TILE_H;
-        r.x = idx * r.w;
-        r.y = 0;
-    } else {
-        r.w = PLAN_MIN_W;
-        r.h = PLAN_MIN_H;
-        r.x = (idx >> 1) * PLAN_MIN_W;
-        r.y = (idx & 1) * PLAN_MIN_H;
-    }
-    return r;
-}
 
 // block-wide exclusive scan of one value per thread (256 threads); returns the exclusive prefix, total in *total
 __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* s_scan, uint32_t* total)
@@ -58,7 +30,6 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* s_scan
         if ((t & 63) >= d)
             incl += up;
     }
-    __syncthreads();  // s_scan may still be read from the previous use
     if ((t & 63) == 63)
         s_scan[t >> 6] = incl;
     __syncthreads();
@@ -74,12 +45,11 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* s_scan
 template <bool CALLER_MAPS>
 __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
 {
-    __shared__ int s_box[4];    // min ix, max ix, min iy, max iy of the piece's live pixels
+    __shared__ int s_box[4];    // min ix, max ix, min iy, max iy of the tile's live pixels
     __shared__ int s_flags[2];  // any live pixel, any pixel outside the panorama under a non-constant border
     __shared__ int s_rmin[PLAN_MAX_ROWS], s_rmax[PLAN_MAX_ROWS];
     __shared__ uint32_t s_rbase[PLAN_MAX_ROWS + 1];
     __shared__ uint32_t s_scan[4];
-    __shared__ uint32_t s_slot;
 
     constexpr int PXT = VIEWS_PXT;
     constexpr int ROWSTEP = VIEWS_BLOCK / TILE_W;
@@ -90,6 +60,11 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
     const int x0 = (tile_id % tiles_x) * TILE_W, y0 = (tile_id / tiles_x) * TILE_H;
     const int tx = t % TILE_W, ty0 = t / TILE_W;
     const int px = x0 + tx;
+    const uint32_t slot = (uint32_t)(pitch_i * tiles_x * tiles_y + tile_id);
+    if (t == 0) {
+        s_box[0] = INT32_MAX; s_box[1] = INT32_MIN; s_box[2] = INT32_MAX; s_box[3] = INT32_MIN;
+        s_flags[0] = 0; s_flags[1] = 0;
+    }
 
     // ---- the pitch-stage coordinate of every pixel of the tile, quantised as cv::remap does ----
     int ix[PXT], iy[PXT];
@@ -166,177 +141,108 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
         inrange[j] = inside[j] && ix[j] >= -1 && iy[j] >= -1 && ix[j] < P.pw && iy[j] < P.ph;
     }
 
-    const int slot_main = pitch_i * tiles_x * tiles_y + tile_id;
-    uint32_t pending = 1u;  // pieces of the current level still to be placed, one bit per index
-    for (int level = 0; level < N_LEVELS; ++level) {
-        uint32_t next = 0u;
-        for (int idx = 0; idx < (1 << level); ++idx) {
-            if (!((pending >> idx) & 1u))
-                continue;
-            const Rect rc = piece_rect(level, idx);
-            if (x0 + rc.x >= P.ow || y0 + rc.y >= P.oh)
-                continue;  // no pixel of the view in this piece
-            bool member[PXT];
+    // ---- bounding box of the live pixels' coordinates ----
+    __syncthreads();
 #pragma unroll
-            for (int j = 0; j < PXT; ++j) {
-                const int ry = ty0 + j * ROWSTEP;
-                member[j] = inside[j] && tx >= rc.x && tx < rc.x + rc.w && ry >= rc.y && ry < rc.y + rc.h;
-            }
-            // ---- bounding box of the live pixels' coordinates ----
-            __syncthreads();
-            if (t == 0) {
-                s_box[0] = INT32_MAX; s_box[1] = INT32_MIN; s_box[2] = INT32_MAX; s_box[3] = INT32_MIN;
-                s_flags[0] = 0; s_flags[1] = 0;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < PXT; ++j) {
-                if (member[j] && inrange[j]) {
-                    atomicMin(&s_box[0], ix[j]); atomicMax(&s_box[1], ix[j]);
-                    atomicMin(&s_box[2], iy[j]); atomicMax(&s_box[3], iy[j]);
-                    s_flags[0] = 1;
-                } else if (member[j] && P.border != 0) {
-                    s_flags[1] = 1;  // reads reflected / wrapped / replicated pixels: cv::borderInterpolate, direct path
-                }
-            }
-            __syncthreads();
-            const int c0 = s_box[0], c1 = s_box[1], r0 = s_box[2], r1 = s_box[3];
-            const bool any_live = s_flags[0] != 0, stray = s_flags[1] != 0;
-            const int nrow = any_live ? r1 - r0 + 2 : 0;
-            // The LDS scheme needs the whole footprint strictly inside the panorama (no tap is a border tap) and a
-            // panorama width divisible by 4 (12-byte items never straddle a row end).
-            // (float path: taps reach one column further, and its stores need view rows of whole dwords)
-            bool ok = any_live && !stray && (P.pw & 3) == 0 && c0 >= 0 && r0 >= 0 && c1 + 1 + P.float_path < P.pw &&
-                      r1 + 1 < P.ph && nrow <= PLAN_MAX_ROWS && !(P.float_path && (P.ow & 3) != 0);
-            uint32_t n_items = 0;
-            if (ok) {
-                // ---- per rot row: the span of columns the taps read ----
-                if (t < nrow) {
-                    s_rmin[t] = INT32_MAX;
-                    s_rmax[t] = -1;
-                }
-                __syncthreads();
-#pragma unroll
-                for (int j = 0; j < PXT; ++j)
-                    if (member[j] && inrange[j]) {
-                        const int r = iy[j] - r0;
-                        atomicMin(&s_rmin[r], ix[j]);     atomicMax(&s_rmax[r], ix[j] + 1 + P.float_path);
-                        atomicMin(&s_rmin[r + 1], ix[j]); atomicMax(&s_rmax[r + 1], ix[j] + 1 + P.float_path);
-                    }
-                __syncthreads();
-                // a row's LDS span starts at a column congruent to c0 mod 4 (so that one per-yaw alignment serves
-                // every row) and leaves room for the yaw's alignment 0..3 within the first item
-                int o = 0;
-                uint32_t width = 0;
-                if (t < nrow && s_rmax[t] >= 0) {
-                    o = s_rmin[t] - ((s_rmin[t] - c0) & 3);
-                    width = (uint32_t)(((3 + s_rmax[t] - o) >> 2) + 1);
-                }
-                const uint32_t base = block_scan_excl(width, s_scan, &n_items);
-                ok = n_items <= (uint32_t)LDS_ITEMS_CAP;
-                if (ok && t < nrow) {
-                    s_rmin[t] = o;
-                    s_rbase[t] = base;
-                    s_rmax[t] = (int)width;
-                }
-                __syncthreads();
-                if (ok) {
-                    // the per-pixel word keeps (lower tap - upper tap) in PXW_DL_BITS bits: the distance between the
-                    // same column in two consecutive rows (about one row's width) -- a piece with a longer row is split
-                    bool far = false;
-#pragma unroll
-                    for (int j = 0; j < PXT; ++j)
-                        if (member[j] && inrange[j]) {
-                            const int r = iy[j] - r0;
-                            const uint32_t up = 4u * s_rbase[r] + (uint32_t)(ix[j] - s_rmin[r]);
-                            const uint32_t lo = 4u * s_rbase[r + 1] + (uint32_t)(ix[j] - s_rmin[r + 1]);
-                            far |= lo - up >= (1u << PXW_DL_BITS);
-                        }
-                    ok = __syncthreads_or(far) == 0;
-                }
-            }
-            const bool deepest = level + 1 == N_LEVELS;
-            // splitting helps only where a smaller piece can fit: not when no pixel has a footprint at all, and not
-            // when the panorama width rules the LDS scheme out
-            if (!ok && !deepest && (P.pw & 3) == 0 && (any_live || stray)) {
-                next |= 3u << (2 * idx);
-                if (level == 0 && t == 0)
-                    P.hdr_main[slot_main] = PieceHdr{0u, 0u, 0u, 0, 0, 0u, 0u, 0u};  // drawn by its pieces
-                continue;
-            }
-            // ---- place the piece: the tile's own slot at level 0, an extras slot otherwise ----
-            uint32_t blk;
-            PieceHdr* hdr;
-            uint32_t* pxw;
-            uint32_t* px2w = nullptr;
-            uint32_t* itw;
-            bool store = true;
-            if (level == 0) {
-                blk = (uint32_t)slot_main;
-                hdr = P.hdr_main + blk;
-                pxw = P.px_main + (size_t)blk * (256 * VIEWS_PXT);
-                if (P.float_path)
-                    px2w = P.px2_main + (size_t)blk * (256 * VIEWS_PXT);
-                itw = P.items_main + (size_t)blk * LDS_ITEMS_CAP;
-            } else {
-                if (t == 0)
-                    s_slot = atomicAdd(P.x_count, 1u);
-                __syncthreads();
-                blk = s_slot;
-                store = blk < P.x_cap;  // beyond the pools: counted only, the host grows them and runs again
-                hdr = P.hdr_x + blk;
-                pxw = P.px_x + (size_t)blk * (256 * XTRA_PXT);
-                if (P.float_path)
-                    px2w = P.px2_x + (size_t)blk * (256 * XTRA_PXT);
-                itw = P.items_x + (size_t)blk * LDS_ITEMS_CAP;
-            }
-            if (!store)
-                continue;
-            if (ok) {
-                // per-pixel words, in the piece's own thread order: thread t' = (row % rows_per_j) * w + col
-                // draws pixel j' = row / rows_per_j (rows_per_j = 256 / w)
-                const int lw = 31 - __clz(rc.w);
-                const int rows_per_j = VIEWS_BLOCK >> lw;
-#pragma unroll
-                for (int j = 0; j < PXT; ++j)
-                    if (member[j]) {
-                        const int col = tx - rc.x, row = ty0 + j * ROWSTEP - rc.y;
-                        const int jp = row / rows_per_j, tp = (row - jp * rows_per_j) * rc.w + col;
-                        uint32_t word = 0u;
-                        if (inrange[j]) {
-                            const int r = iy[j] - r0;
-                            const uint32_t up = 4u * s_rbase[r] + (uint32_t)(ix[j] - s_rmin[r]);
-                            const uint32_t lo = 4u * s_rbase[r + 1] + (uint32_t)(ix[j] - s_rmin[r + 1]);
-                            word = up | (lo - up) << PXW_UP_BITS | fx[j] << 22 | fy[j] << 27;
-                        }
-                        pxw[jp * VIEWS_BLOCK + tp] = word;
-                        if (px2w)
-                            px2w[jp * VIEWS_BLOCK + tp] = frac16[j];
-                    }
-                if (t < nrow) {
-                    const uint32_t g0 = (uint32_t)((s_rmin[t] - c0) >> 2);
-                    for (int g = 0; g < s_rmax[t]; ++g)
-                        itw[s_rbase[t] + g] = (uint32_t)(r0 + t) << 16 | (g0 + (uint32_t)g);
-                }
-            }
-            if (t == 0) {
-                if (!ok)  // pieces for the direct-gather path, listed for remap_views_direct_kernel
-                    P.direct_list[atomicAdd(P.x_count + 1, 1u)] = level == 0 ? blk : (0x80000000u | blk);
-                PieceHdr h;
-                h.xy = (uint32_t)(x0 + rc.x) | (uint32_t)(y0 + rc.y) << 16;
-                h.geom = (uint32_t)rc.w | (uint32_t)rc.h << 8 | (uint32_t)pitch_i << 16;
-                h.mode_items = ok ? (1u | n_items << 8) : 2u;
-                h.c0 = ok ? c0 : 0;
-                h.c1 = ok ? c1 : 0;
-                h.px_block = blk;
-                h.item_block = blk;
-                h.pad = 0u;
-                *hdr = h;
-            }
+    for (int j = 0; j < PXT; ++j) {
+        if (inrange[j]) {
+            atomicMin(&s_box[0], ix[j]); atomicMax(&s_box[1], ix[j]);
+            atomicMin(&s_box[2], iy[j]); atomicMax(&s_box[3], iy[j]);
+            s_flags[0] = 1;
+        } else if (inside[j] && P.border != 0) {
+            s_flags[1] = 1;  // reads reflected / wrapped / replicated pixels: cv::borderInterpolate, table path
         }
-        pending = next;
-        if (!pending)
-            break;
+    }
+    __syncthreads();
+    const int c0 = s_box[0], c1 = s_box[1], r0 = s_box[2], r1 = s_box[3];
+    const bool any_live = s_flags[0] != 0, stray = s_flags[1] != 0;
+    const int nrow = any_live ? r1 - r0 + 2 : 0;
+    // The LDS scheme needs the whole footprint strictly inside the panorama (no tap is a border tap) and a
+    // panorama width divisible by 4 (12-byte items never straddle a row end).
+    // (float path: taps reach one column further, and its stores need view rows of whole dwords)
+    bool ok = any_live && !stray && (P.pw & 3) == 0 && c0 >= 0 && r0 >= 0 && c1 + 1 + P.float_path < P.pw &&
+              r1 + 1 < P.ph && nrow <= PLAN_MAX_ROWS && !(P.float_path && (P.ow & 3) != 0);
+    uint32_t n_items = 0;
+    if (ok) {
+        // ---- per rot row: the span of columns the taps read ----
+        if (t < nrow) {
+            s_rmin[t] = INT32_MAX;
+            s_rmax[t] = -1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PXT; ++j)
+            if (inrange[j]) {
+                const int r = iy[j] - r0;
+                atomicMin(&s_rmin[r], ix[j]);     atomicMax(&s_rmax[r], ix[j] + 1 + P.float_path);
+                atomicMin(&s_rmin[r + 1], ix[j]); atomicMax(&s_rmax[r + 1], ix[j] + 1 + P.float_path);
+            }
+        __syncthreads();
+        // a row's LDS span starts at a column congruent to c0 mod 4 (so that one per-yaw alignment serves
+        // every row) and leaves room for the yaw's alignment 0..3 within the first item
+        int o = 0;
+        uint32_t width = 0;
+        if (t < nrow && s_rmax[t] >= 0) {
+            o = s_rmin[t] - ((s_rmin[t] - c0) & 3);
+            width = (uint32_t)(((3 + s_rmax[t] - o) >> 2) + 1);
+        }
+        const uint32_t base = block_scan_excl(width, s_scan, &n_items);
+        ok = n_items <= (uint32_t)LDS_ITEMS_CAP;
+        if (ok && t < nrow) {
+            s_rmin[t] = o;
+            s_rbase[t] = base;
+            s_rmax[t] = (int)width;
+        }
+        __syncthreads();
+        if (ok) {
+            // the per-pixel word keeps (lower tap - upper tap) in PXW_DL_BITS bits: the distance between the
+            // same column in two consecutive rows (about one row's width) -- a tile with a longer row gathers
+            bool far = false;
+#pragma unroll
+            for (int j = 0; j < PXT; ++j)
+                if (inrange[j]) {
+                    const int r = iy[j] - r0;
+                    const uint32_t up = 4u * s_rbase[r] + (uint32_t)(ix[j] - s_rmin[r]);
+                    const uint32_t lo = 4u * s_rbase[r + 1] + (uint32_t)(ix[j] - s_rmin[r + 1]);
+                    far |= lo - up >= (1u << PXW_DL_BITS);
+                }
+            ok = __syncthreads_or(far) == 0;
+        }
+    }
+    uint32_t* pxw = P.px + (size_t)slot * (VIEWS_BLOCK * PXT);
+    uint32_t* px2w = P.float_path ? P.px2 + (size_t)slot * (VIEWS_BLOCK * PXT) : nullptr;
+    uint32_t* itw = P.items + (size_t)slot * LDS_ITEMS_CAP;
+    // per-pixel words in the tile's thread order (thread t draws pixels j = 0..PXT-1, rows ROWSTEP apart); pixels
+    // outside the view, pixels without a footprint and the pixels of a gather tile read as zero; so do unused items
+#pragma unroll
+    for (int j = 0; j < PXT; ++j) {
+        uint32_t word = 0u;
+        if (ok && inrange[j]) {
+            const int r = iy[j] - r0;
+            const uint32_t up = 4u * s_rbase[r] + (uint32_t)(ix[j] - s_rmin[r]);
+            const uint32_t lo = 4u * s_rbase[r + 1] + (uint32_t)(ix[j] - s_rmin[r + 1]);
+            word = up | (lo - up) << PXW_UP_BITS | fx[j] << 22 | fy[j] << 27;
+        }
+        pxw[j * VIEWS_BLOCK + t] = word;
+        if (px2w)
+            px2w[j * VIEWS_BLOCK + t] = ok ? frac16[j] : 0u;
+    }
+    if (ok && t < nrow) {
+        const uint32_t g0 = (uint32_t)((s_rmin[t] - c0) >> 2);
+        for (int g = 0; g < s_rmax[t]; ++g)
+            itw[s_rbase[t] + g] = (uint32_t)(r0 + t) << 16 | (g0 + (uint32_t)g);
+    }
+    for (uint32_t k = (ok ? n_items : 0u) + (uint32_t)t; k < (uint32_t)LDS_ITEMS_CAP; k += VIEWS_BLOCK)
+        itw[k] = 0u;
+    if (t == 0) {
+        if (!ok)  // tiles for the gather kernels, listed
+            P.gather_list[atomicAdd(P.n_gather, 1u)] = slot;
+        PieceHdr h;
+        h.mode_items = ok ? (1u | n_items << 8) : 2u;
+        h.c0 = any_live ? c0 : 0;
+        h.c1 = any_live ? c1 : -1;
+        h.pad = 0u;
+        P.hdr[slot] = h;
     }
 }
 

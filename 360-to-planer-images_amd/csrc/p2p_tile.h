@@ -1,14 +1,14 @@
 // p2p_tile.h -- what the tile-based view kernels share (p2p_views.hip: the reference's fixed-point arithmetic;
-// p2p_float.hip: the opt-in float pixel path): piece geometry, the plan's item words, small types.
+// p2p_float.hip: the opt-in float pixel path): tile geometry, the plan's item words, small types.
 #ifndef P2P_TILE_H
 #define P2P_TILE_H
 
 #include "p2p_inline.h"
+#include "p2p_audit.h"
 
 namespace p2p {
 
 struct __attribute__((aligned(4))) Q16 { uint32_t d[4]; };
-
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
@@ -17,26 +17,34 @@ __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cas
 #define P2P_STORE_AUX 2  // cache policy of the view stores: 2 = nt
 #endif
 
+constexpr int TILE_LW = TILE_W == 64 ? 6 : (TILE_W == 32 ? 5 : 4);
+static_assert((1 << TILE_LW) == TILE_W, "TILE_W must be 16, 32 or 64");
+constexpr int TILE_ROWSTEP = VIEWS_BLOCK / TILE_W;  // rows between a thread's pixels
 
-struct PieceGeo {
-    int x0, y0, w, h, pitch_i, mode, n_items, lw;
-    int col, row0, rstep;  // this thread's column and first row inside the piece; rows between its pixels
+// A tile's place in its view follows from the workgroup's index alone (never from memory); the plan's header adds
+// how it is drawn (mode), the size of its footprint and its rot columns.
+struct TileGeo {
+    int x0, y0, pitch_i, mode, n_items;
+    int c0, c1;
+    int col, row0;  // this thread's column and first row inside the tile
+    uint32_t slot;  // pitch_i * tiles + tile: index of the tile's header, per-pixel words and item list
 };
 
-__device__ __forceinline__ PieceGeo piece_geo(const PieceHdr& h, int t)
+__device__ __forceinline__ TileGeo tile_geo(const ViewsParams& P, const PieceHdr& h, int pitch_i, int tile_id, int t)
 {
-    PieceGeo g;
-    g.x0 = (int)(h.xy & 0xFFFFu);
-    g.y0 = (int)(h.xy >> 16);
-    g.w = (int)(h.geom & 0xFFu);
-    g.h = (int)((h.geom >> 8) & 0xFFu);
-    g.pitch_i = (int)(h.geom >> 16);
+    const int tiles_x = (P.ow + TILE_W - 1) / TILE_W;
+    const int tiles = tiles_x * ((P.oh + TILE_H - 1) / TILE_H);
+    TileGeo g;
+    g.x0 = (tile_id % tiles_x) * TILE_W;
+    g.y0 = (tile_id / tiles_x) * TILE_H;
+    g.pitch_i = pitch_i;
     g.mode = (int)(h.mode_items & 3u);
     g.n_items = (int)(h.mode_items >> 8);
-    g.lw = __builtin_ctz((unsigned)g.w);
-    g.col = t & (g.w - 1);
-    g.row0 = t >> g.lw;
-    g.rstep = VIEWS_BLOCK >> g.lw;
+    g.c0 = h.c0;
+    g.c1 = h.c1;
+    g.col = t & (TILE_W - 1);
+    g.row0 = t >> TILE_LW;
+    g.slot = (uint32_t)pitch_i * (uint32_t)tiles + (uint32_t)tile_id;
     return g;
 }
 
@@ -47,6 +55,23 @@ __device__ __forceinline__ int pano_of_pair(const ViewsParams& P, int pair)
     return P.n_yaw == 1 ? pair : (int)__umulhi((uint32_t)pair, P.n_yaw_magic);
 }
 
+// blockIdx.y -> pitch view, heaviest first; the table is the host's, its values are clamped all the same
+__device__ __forceinline__ int pitch_of_block(const ViewsParams& P, int by)
+{
+    int p = P.pitch_order[by];
+    P2P_AUD_LT(P.audit, AUD_MAIN_PITCH, p, P.n_pitch);
+    return p < P.n_pitch ? p : P.n_pitch - 1;
+}
+
+// blockIdx.x -> tile, XCD-aware: the 8 XCDs each own a contiguous run of the tile raster, so neighbouring tiles
+// (shared source halo and output lines) meet in one L2.  gridDim.x == 8 * ceil(tiles / 8); -1: no tile.
+__device__ __forceinline__ int tile_of_block(const ViewsParams& P, int bx, int gx)
+{
+    const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
+    const int chunk = gx >> 3;
+    const int tile_id = (bx & 7) * chunk + (bx >> 3);
+    return tile_id < tiles ? tile_id : -1;
+}
 
 __device__ __forceinline__ void decode_items(const uint32_t* __restrict__ itw, int t, int n_items, int src_pitch,
                                              uint32_t (&slot_off)[VIEWS_SLOTS], uint32_t (&slot_g)[VIEWS_SLOTS])
@@ -54,10 +79,28 @@ __device__ __forceinline__ void decode_items(const uint32_t* __restrict__ itw, i
 #pragma unroll
     for (int k = 0; k < VIEWS_SLOTS; ++k) {
         const int item = t + k * VIEWS_BLOCK;
-        const uint32_t iw = itw[item < n_items ? item : 0];  // surplus lanes redo item 0 into LDS space nobody reads
+        const uint32_t iw = itw[item < n_items && item < LDS_ITEMS_CAP ? item : 0];  // surplus lanes redo item 0 into LDS space nobody reads
         slot_g[k] = iw & 0xFFFFu;
         slot_off[k] = (iw >> 16) * (uint32_t)src_pitch + 12u * slot_g[k];  // rot row * src_pitch + 12 * g
     }
+}
+
+// Lanes 0..n-1 of a wave each hold one (panorama, yaw) pair's context and a class 0..NCLS-1; returns the lane every
+// context has to move to so that the classes sit in ascending runs, and the run ends (pairs of classes 0..c) in cum[].
+template <int NCLS>
+__device__ __forceinline__ int sort_lanes_by_class(int k, bool valid, int cls, int (&cum)[NCLS])
+{
+    const unsigned long long below = (1ull << k) - 1ull;
+    int r = k, base = 0;
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) {
+        const unsigned long long m = __ballot(valid && cls == c);
+        if (valid && cls == c)
+            r = base + __popcll(m & below);
+        base += __popcll(m);
+        cum[c] = base;
+    }
+    return r;
 }
 
 }  // namespace p2p

@@ -131,11 +131,13 @@ __device__ __forceinline__ uint32_t blend4_packed(uint32_t a, uint32_t b, uint32
 }
 
 // ---------------------------------------------------------------------------------------------
-// The view kernels.  One workgroup = one piece of the plan (p2p_plan.hip): a tile of TILE_W x TILE_H output
-// pixels of one pitch view (VIEWS_PXT pixels per thread), or a part of a tile whose footprint did not fit.  The
-// plan pass has already worked out everything that depends on the maps only, so a workgroup starts with a handful
-// of loads: the piece header (scalar), one dword per pixel (LDS offsets of its 2x2 taps + the two 5-bit weights)
-// and one dword per footprint item (rot row, 4-pixel group).  Then, per (panorama, yaw) pair of its chunk:
+// The view kernels.  One workgroup = one tile of TILE_W x TILE_H output pixels of one pitch view (VIEWS_PXT pixels
+// per thread).  The plan pass (p2p_plan.hip) has already worked out everything that depends on the maps only, so a
+// workgroup starts with a handful of loads.  Two schemes:
+//
+// LDS scheme (mode 1 tiles: the tile's footprint in the yaw-resampled panorama fits an LDS buffer).  Set-up: the
+// tile header (scalar), one dword per pixel (LDS offsets of its 2x2 taps + the two 5-bit weights) and one dword per
+// footprint item (rot row, 4-pixel group).  Then, per (panorama, yaw) pair of its chunk:
 //   stage 1  the yaw map is a circular column shift (YawDesc), so a footprint row is one contiguous run of
 //            source bytes: each thread loads one 4-byte-aligned 16-byte piece (5 1/3 source pixels: fully
 //            coalesced, no per-pixel table lookup), blends 4 rot pixels in registers with the exact uint8
@@ -147,34 +149,42 @@ __device__ __forceinline__ uint32_t blend4_packed(uint32_t a, uint32_t b, uint32
 // The footprint is kept as per-row spans (each rot row only as wide as the taps of that row need), not as the
 // bounding rectangle: 1.4 .. 1.7 rot pixels per output pixel instead of 1.7 .. 2.3 on config 2.
 //
-// Three kernels share this arithmetic:
-//   remap_views_kernel         whole interior pieces x yaws that are plain shifts -- nothing but three branch-free
-//                              loops (copy / blend / blend with the clipped column patched), 78 VGPRs, no spills;
-//   remap_views_rest_kernel    the general LDS loop with its case distinctions: yaws with per-column weights, yaw
-//                              rows that are not a shift (gathered per pixel), byte stores for view widths not
-//                              divisible by 4.  With view rows of whole dwords only the pairs of the job's
-//                              rest_pairs list, several per workgroup;
-//   remap_views_direct_kernel  the pieces the plan marks for direct gathers (a pole inside the piece: the footprint
-//                              spans every column; footprints touching the panorama border; general caller maps
-//                              with border taps), one workgroup per (piece of the plan's list, chunk of pairs).
-// Kept in one kernel, the rare paths set the register allocation (96 VGPRs + spills) and tripled the ISA; the
-// common path ran at 110 us instead of 75 on config 2.  The kernels write disjoint pixels; the last two are
-// launched (same stream, before the main one) only when the plan or the yaw tables have something for them.
-// Blocks map to tiles XCD-aware: each of the 8 XCDs owns a contiguous run of the tile raster, so neighbouring
-// tiles (shared source halo and output lines) meet in one L2.
+// Gather scheme (mode 2 tiles: strong minification -- the reference CLI's default 800 x 800 views of an 8K panorama
+// read 2.6 source pixels per output pixel --, a pole inside the tile, taps on the panorama's border).  No LDS tile,
+// no barrier: per pixel and pair two 12-byte loads fetch the three source pixels under the two rot taps of the upper
+// and of the lower row, stage 1 blends just those four rot pixels in registers, stage 2 as above.  The cost per
+// output pixel does not depend on the footprint.
+//
+// Four kernels share this arithmetic:
+//   remap_views_kernel         mode 1 tiles x yaws that are plain shifts -- nothing but three branch-free loops
+//                              (copy / blend / blend with the clipped column patched), no spills;
+//   remap_views_gather_kernel  mode 2 tiles x yaws that are plain shifts, BORDER_CONSTANT, view rows of whole dwords
+//                              -- three branch-free loops again (copy / blend / seam inside the tile);
+//   remap_views_rest_kernel    mode 1 tiles, the general LDS loop with its case distinctions: yaws with per-column
+//                              weights, yaw rows that are not a shift (gathered per pixel), byte stores for view
+//                              widths not divisible by 4.  With view rows of whole dwords only the job's odd pairs;
+//   remap_views_table_kernel   mode 2 tiles through the packed yaw table and cv::borderInterpolate: every pair when
+//                              the gather kernel does not apply (other border modes, odd widths), else the odd pairs.
+// The kernels write disjoint pixels; all but the first are launched (same stream, before it) only when the plan or
+// the yaw tables have something for them.
+//
+// Addressing: a tile's position, its pitch view and its table slots follow from the workgroup index.  Every offset
+// that comes out of a table (source offsets from items, coordinates and yaw tables; pair lists; tile lists) is either
+// clamped or goes through a buffer descriptor with the exact extent, so no content of the tables can take a load or
+// a store outside its buffer (p2p_audit.h; the -DP2P_AUDIT build records every such event).
 // ---------------------------------------------------------------------------------------------
-// the pieces the main kernel draws: LDS scheme, view rows of whole dwords (its stores are 12 bytes = 4 pixels)
-template <int PXT>
-__device__ __forceinline__ bool tight_piece(const PieceGeo& g, const ViewsParams& P)
+
+// the tiles the main kernel draws: LDS scheme, view rows of whole dwords (its stores are 12 bytes = 4 pixels)
+__device__ __forceinline__ bool tight_tile(const TileGeo& g, const ViewsParams& P)
 {
-    return g.mode == 1 && (P.ow & 3) == 0 && (PXT == 4 ? g.w == 64 : (g.w == 32 || g.w == 16));
+    return g.mode == 1 && (P.ow & 3) == 0;
 }
 
 // ---- per-pair contexts: lane k of every wave works out pair pair0 + k once; the loops read them back with
 // v_readlane, so no descriptor load sits on the per-pair critical path.  Sorted by class across the lanes:
 //   0  whole-column shift (stage 1 is a copy), footprint inside one pass of the source row     } tight loops
 //   1  whole-column shift, footprint across the source row's end (items wrap to its start)      }
-//   2  one blend weight for the whole piece, footprint inside one pass of the row               }
+//   2  one blend weight for the whole tile, footprint inside one pass of the row                }
 //   3  one blend weight, footprint across the row's end -- where the column P:105 clips to      }
 //      pw - 1 lives: that one rot pixel is a copy instead
 //   4  per-column weights (a shift fraction within float noise of a rounding tie: 6 of the 360 one-degree
@@ -186,25 +196,44 @@ struct PairCtxs {
     int npairs, pair0;
 };
 
-// LIST: the chunk's pairs come from P.rest_pairs (the rest kernel drawing only the yaws left to it) instead of being
+// the chunk of pairs a workgroup loops over: blockIdx.z * ppb ..., of all the job's pairs or of its odd-pair list
+__device__ __forceinline__ void pair_chunk(const ViewsParams& P, bool list, int ppb, int& first, int& count)
+{
+    const int n_pairs = list ? P.n_odd_pairs : P.n_panos * P.n_yaw;
+    first = (int)blockIdx.z * ppb;
+    int last = first + ppb;
+    if (last > n_pairs)
+        last = n_pairs;
+    count = last > first ? last - first : 0;
+    if (count > 64)
+        count = 64;  // one context per lane of a wave (the host never asks for more)
+}
+
+__device__ __forceinline__ int pair_of_lane(const ViewsParams& P, bool list, int first, int k, uint32_t site)
+{
+    int pair = first + k;
+    if (list) {
+        pair = (int)P.odd_pairs[first + k];
+        P2P_AUD_LT(P.audit, site, pair, P.n_panos * P.n_yaw);
+        const int last = P.n_panos * P.n_yaw - 1;
+        pair = (unsigned)pair <= (unsigned)last ? pair : last;
+    }
+    return pair;
+}
+
+// LIST: the chunk's pairs come from P.odd_pairs (the rest kernel drawing only the yaws left to it) instead of being
 // the contiguous run blockIdx.z * pairs_per_block ...
 template <bool LIST = false>
 __device__ __forceinline__ PairCtxs pair_contexts(const ViewsParams& P, const YawDesc* __restrict__ ydesc, int c0, int c1, int t)
 {
     PairCtxs X;
-    const int ppb = LIST ? P.rest_ppb : P.pairs_per_block;
-    X.pair0 = blockIdx.z * ppb;
-    int pair1 = X.pair0 + ppb;
-    const int n_pairs = LIST ? P.n_rest_pairs : P.n_panos * P.n_yaw;
-    if (pair1 > n_pairs)
-        pair1 = n_pairs;
-    X.npairs = pair1 - X.pair0;
+    pair_chunk(P, LIST, LIST ? P.rest_ppb : P.pairs_per_block, X.pair0, X.npairs);
     const int ngroups = P.pw >> 2;
     uint32_t cw0 = 0, cw1 = 0;
     int cw2 = 0, cw3 = 0, cls = 4;
     const int k = t & 63;
     if (k < X.npairs) {
-        const int pair = LIST ? (int)P.rest_pairs[X.pair0 + k] : X.pair0 + k;
+        const int pair = pair_of_lane(P, LIST, X.pair0, k, AUD_REST_PAIR);
         cw3 = pano_of_pair(P, pair);
         const int yi = pair - cw3 * P.n_yaw;
         const YawDesc yd = ydesc[yi];
@@ -213,7 +242,7 @@ __device__ __forceinline__ PairCtxs pair_contexts(const ViewsParams& P, const Ya
             i_first -= P.pw;
         const int g0 = i_first >> 2;
         const bool clamp_in = yd.c_clamp >= c0 && yd.c_clamp <= c1 + 1;
-        // uniform weight unless this yaw flickers or the piece holds the column clipped to pw-1
+        // uniform weight unless this yaw flickers or the tile holds the column clipped to pw-1
         const bool per_column = yd.mode == 1 || clamp_in;
         cw0 = 12u * (uint32_t)g0 | (uint32_t)(i_first & 3) << 20 | (uint32_t)(yd.mode != 2) << 22 |
               (uint32_t)per_column << 23 | (uint32_t)yd.f << 24;
@@ -226,17 +255,8 @@ __device__ __forceinline__ PairCtxs pair_contexts(const ViewsParams& P, const Ya
         const bool wraps = clamp_in;
         cls = yd.mode != 0 ? 4 : (yd.f == 0 ? (wraps ? 1 : 0) : (wraps ? 3 : 2));
     }
-    const bool valid = k < X.npairs;
-    const unsigned long long below = (1ull << k) - 1ull;
-    int r = k, base = 0, cum[5];
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-        const unsigned long long m = __ballot(valid && cls == c);
-        if (valid && cls == c)
-            r = base + __popcll(m & below);
-        base += __popcll(m);
-        cum[c] = base;
-    }
+    int cum[5];
+    const int r = sort_lanes_by_class<5>(k, k < X.npairs, cls, cum);
     X.n0 = cum[0];
     X.n1 = cum[1];
     X.n2 = cum[2];
@@ -266,28 +286,77 @@ __device__ __forceinline__ void decode_px(const uint32_t* __restrict__ pxw, int 
     }
 }
 
+// The way out of the tight kernels: a wave's pixels -> LDS (a dword per pixel) -> 4 adjacent pixels of one row per
+// lane -> 12 bytes, written with a buffer store whose descriptor covers exactly this view: lanes with nothing to
+// store (rows past the view, four-pixel groups past its right edge) get an offset beyond it and the hardware
+// drops them.  No lane is masked off: a masked store brings a branch, and with it vmcnt(0).
+struct StoreCtx {
+    uint32_t* stg;       // this wave's staging dwords
+    uint32_t stg_rd;     // where this lane reads its four pixels back
+    uint32_t out_off12;  // byte offset of those 12 bytes inside a view (0xFFFFFFFF: nothing to store)
+    int ln;
+};
+
+__device__ __forceinline__ StoreCtx store_ctx(const ViewsParams& P, const TileGeo& G, uint32_t* stage, int t)
+{
+    StoreCtx s;
+    const int wv = t >> 6;
+    s.ln = t & 63;
+    s.stg = stage + wv * (VIEWS_PXT * 64);
+    const int x4 = 4 * (s.ln & 15), sj = s.ln >> 4;  // the group's first pixel as a lane of this wave; which of the thread's pixels
+    const int srow = ((wv * 64 + x4) >> TILE_LW) + sj * TILE_ROWSTEP, scol = x4 & (TILE_W - 1);
+    const bool s_ok = sj < VIEWS_PXT && srow < TILE_H && G.y0 + srow < P.oh && G.x0 + scol < P.ow;
+    s.out_off12 = s_ok ? (uint32_t)(((size_t)(G.y0 + srow) * P.ow + G.x0 + scol) * 3) : 0xFFFFFFFFu;
+    s.stg_rd = (uint32_t)(sj * 64 + x4);
+    return s;
+}
+
+__device__ __forceinline__ void store_wave_pixels(const StoreCtx& s, const uint32_t (&pix)[VIEWS_PXT], uint8_t* O, size_t view_bytes)
+{
+#pragma unroll
+    for (int j = 0; j < VIEWS_PXT; ++j)
+        s.stg[j * 64 + s.ln] = pix[j];
+    // DS operations of one wave execute in order: the read below sees the writes above
+    const uint4 v = *reinterpret_cast<const uint4*>(s.stg + s.stg_rd);
+    u32x3 o;
+    o.x = __builtin_amdgcn_perm(v.y, v.x, 0x04020100u);  // B0 G0 R0 B1
+    o.y = __builtin_amdgcn_perm(v.z, v.y, 0x05040201u);  // G1 R1 B2 G2
+    o.z = __builtin_amdgcn_perm(v.w, v.z, 0x06050402u);  // R2 B3 G3 R3
+#ifdef P2P_ABLATE_STORES2
+    if (o.x == 0x12345678u && o.z == 0x9ABCDEF0u)
+#endif
+    // aux 2 = nt: the views are written once and not read by this kernel, they should not displace the panorama
+    __builtin_amdgcn_raw_buffer_store_b96(o, __builtin_amdgcn_make_buffer_rsrc(O, 0, (int)view_bytes, 0x00020000),
+                                          (int)s.out_off12, 0, P2P_STORE_AUX);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Main kernel body: the three tight loops.  Free of branches on the vector-memory path, so that the compiler's
 // s_waitcnt vmcnt stay counted (with a conditional load or store in the loop it falls back to vmcnt(0), and every
 // pair then waits for the previous pair's stores to be acknowledged: loads and stores retire in issue order).
 // ---------------------------------------------------------------------------------------------
-template <int PXT>
 __device__ __forceinline__ void draw_tight(
     const ViewsParams& P, const uint8_t* __restrict__ src, const YawDesc* __restrict__ ydesc,
-    uint8_t* __restrict__ out, const PieceHdr h, const uint32_t* __restrict__ pxw, const uint32_t* __restrict__ itw,
+    uint8_t* __restrict__ out, const TileGeo& G, const uint32_t* __restrict__ pxw, const uint32_t* __restrict__ itw,
     uint4 (*tile4)[LDS_ITEMS_CAP], uint32_t* stage)
 {
+    constexpr int PXT = VIEWS_PXT;
     const int t = threadIdx.x;
-    const PieceGeo G = piece_geo(h, t);
-    if (!tight_piece<PXT>(G, P))
-        return;  // the rest kernel's
-    const PairCtxs X = pair_contexts(P, ydesc, h.c0, h.c1, t);
+    if (!tight_tile(G, P))
+        return;  // the other kernels'
+    P2P_AUD_LT(P.audit, AUD_MAIN_HDR, G.n_items, LDS_ITEMS_CAP + 1);
+    const PairCtxs X = pair_contexts(P, ydesc, G.c0, G.c1, t);
     const int nplain = X.n3;
     if (nplain == 0)
         return;
     uint32_t tap_up[PXT], tap_lo[PXT];
     TapWeights tw[PXT];
     decode_px<PXT>(pxw, t, tap_up, tap_lo, tw);
+#ifdef P2P_AUDIT
+#pragma unroll
+    for (int j = 0; j < PXT; ++j)
+        P2P_AUD_RANGE(P.audit, AUD_MAIN_TAP, tap_lo[j] + 12u, 8u, sizeof(tile4[0]));
+#endif
 #ifdef P2P_ABLATE_CONFLICTS
     // timing experiment only (wrong pixels): every lane reads its own two dwords -- tap reads without bank conflicts
 #pragma unroll
@@ -300,36 +369,7 @@ __device__ __forceinline__ void draw_tight(
     decode_items(itw, t, G.n_items, P.src_pitch, slot_off, slot_g);
     const uint32_t row_bytes = 3u * (uint32_t)P.pw;
     const size_t view_bytes = (size_t)P.oh * P.ow * 3;
-
-    // the way out: a wave's pixels -> LDS (a dword per pixel) -> 4 adjacent pixels of one row per lane -> 12 bytes,
-    // written with a buffer store whose descriptor covers exactly this view: lanes with nothing to store (rows past
-    // the piece or the view, four-pixel groups the piece does not have) get an offset beyond it and the hardware
-    // drops them.  No lane is masked off: a masked store brings a branch, and with it vmcnt(0).
-    const int wv = t >> 6, ln = t & 63;
-#ifndef P2P_DPP_STORES
-    uint32_t* const stg = stage + wv * (PXT * 64);
-    const int x4 = 4 * (ln & 15), sj = ln >> 4;    // the group's first pixel as a lane of this wave; which of the thread's pixels
-    const int srow = ((wv * 64 + x4) >> G.lw) + sj * G.rstep, scol = x4 & (G.w - 1);
-    const bool s_ok = sj < PXT && srow < G.h && G.y0 + srow < P.oh && G.x0 + scol < P.ow;
-    const uint32_t out_off12 = s_ok ? (uint32_t)(((size_t)(G.y0 + srow) * P.ow + G.x0 + scol) * 3) : 0xFFFFFFFFu;
-    const uint32_t stg_rd = (uint32_t)(sj * 64 + x4);
-#else
-    // Four adjacent pixels of a row are 12 bytes = 3 dwords: lane 4m + r (r = 0, 1, 2) makes dword r of its group
-    // from its own pixel and its right neighbour's (one DPP row shift, one v_perm_b32), lane 4m + 3 stores nothing.
-    (void)stage; (void)wv;
-    const int r4 = ln & 3;
-    const uint32_t out_sel = r4 == 0 ? 0x04020100u : r4 == 1 ? 0x05040201u : 0x06050402u;
-    uint32_t out_off[PXT];
-#pragma unroll
-    for (int j = 0; j < PXT; ++j) {
-        const int row = G.row0 + j * G.rstep;
-        const bool ok = r4 != 3 && row < G.h && G.y0 + row < P.oh && G.x0 + G.col < P.ow;
-        out_off[j] = ok ? (uint32_t)(((size_t)(G.y0 + row) * P.ow + G.x0 + G.col) * 3) + (uint32_t)r4 : 0xFFFFFFFFu;
-#ifdef P2P_ABLATE_STORES3
-        out_off[j] = 0xFFFFFFFFu;  // timing experiment: every store issued, every store dropped by the range check
-#endif
-    }
-#endif
+    const StoreCtx SC = store_ctx(P, G, stage, t);
 
     const int wave_base = __builtin_amdgcn_readfirstlane(t & ~63);
     int ns_wave = 0;  // items this wave produces per pair (wave-uniform)
@@ -346,7 +386,9 @@ __device__ __forceinline__ void draw_tight(
         constexpr int NS = decltype(ns_c)::value;
         const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)X.cw0, k);
         const uint32_t wrap_g = (uint32_t)__builtin_amdgcn_readlane((int)X.cw1, k) & 0xFFFFu;
-        const uint8_t* __restrict__ S = src + (size_t)(__builtin_amdgcn_readlane(X.cw3, k) & 0x3FFFFFF) * P.pano_stride;
+        // one descriptor per panorama: an item word that points outside it loads zeros instead of faulting
+        const auto S = make_buf(src + (size_t)(__builtin_amdgcn_readlane(X.cw3, k) & 0x3FFFFFF) * P.pano_stride,
+                                (uint32_t)P.pano_stride);
         const uint32_t goff = w0 & 0xFFFFFu;
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
@@ -355,7 +397,9 @@ __device__ __forceinline__ void draw_tight(
 #ifdef P2P_ABLATE_LOADS2
             off &= 0x3FFFu;  // timing experiment (wrong pixels): every load issued, all of them hits in 16 KB
 #endif
-            qq[sl] = *reinterpret_cast<const Q16*>(S + off);
+            P2P_AUD_RANGE(P.audit, AUD_MAIN_SRC, off, 16u, P.pano_stride);
+            const bu32x4 q = __builtin_amdgcn_raw_buffer_load_b128(S, (int)off, 0, 0);
+            qq[sl].d[0] = q.x; qq[sl].d[1] = q.y; qq[sl].d[2] = q.z; qq[sl].d[3] = q.w;
         }
     };
     // MODE 0: copy, 1: blend, 2: blend, and the rot pixel whose source column is pw - 1 (P:105's clip) is a copy
@@ -452,39 +496,7 @@ __device__ __forceinline__ void draw_tight(
 #ifdef P2P_ABLATE_STORES
             if (pix[0] == 0x12345678u && pix[PXT - 1] == 0x9ABCDEF0u)
 #endif
-            {
-                uint8_t* O = out + ((size_t)pair * P.n_pitch + G.pitch_i) * view_bytes;  // [pano][yaw][pitch][oh][ow][3]
-                // aux 2 = nt: the views are written once and not read by this kernel, they should not displace
-                // the panorama from the caches
-#ifndef P2P_DPP_STORES
-#pragma unroll
-                for (int j = 0; j < PXT; ++j)
-                    stg[j * 64 + ln] = pix[j];
-                // DS operations of one wave execute in order: the read below sees the writes above
-                const uint4 v = *reinterpret_cast<const uint4*>(stg + stg_rd);
-                u32x3 o;
-                o.x = __builtin_amdgcn_perm(v.y, v.x, 0x04020100u);  // B0 G0 R0 B1
-                o.y = __builtin_amdgcn_perm(v.z, v.y, 0x05040201u);  // G1 R1 B2 G2
-                o.z = __builtin_amdgcn_perm(v.w, v.z, 0x06050402u);  // R2 B3 G3 R3
-#ifdef P2P_ABLATE_STORES2
-                if (o.x == 0x12345678u && o.z == 0x9ABCDEF0u)
-#endif
-                __builtin_amdgcn_raw_buffer_store_b96(o, __builtin_amdgcn_make_buffer_rsrc(O, 0, (int)view_bytes, 0x00020000),
-                                                      (int)out_off12, 0, P2P_STORE_AUX);
-#else
-                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(O, 0, (int)view_bytes, 0x00020000);
-#pragma unroll
-                for (int j = 0; j < PXT; ++j) {
-                    // row_shl:1 -- every lane gets its right neighbour's pixel (lane 15 of a row: unused)
-                    const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)pix[j], 0x101, 0xF, 0xF, true);
-                    const uint32_t dw = __builtin_amdgcn_perm(nb, pix[j], out_sel);
-#ifdef P2P_ABLATE_STORES2
-                    if (dw == 0x12345678u)
-#endif
-                    __builtin_amdgcn_raw_buffer_store_b32(dw, rsrc, (int)out_off[j], 0, P2P_STORE_AUX);
-                }
-#endif
-            }
+            store_wave_pixels(SC, pix, out + ((size_t)pair * P.n_pitch + G.pitch_i) * view_bytes, view_bytes);  // [pano][yaw][pitch][oh][ow][3]
             buf_bytes ^= (uint32_t)sizeof(tile4[0]);
         }
     };
@@ -509,13 +521,7 @@ __device__ __forceinline__ void draw_tight(
         // vmcnt(0) for both paths.  One store that writes nothing (a buffer store through a descriptor of zero
         // records: counted like any store, dropped by the hardware) gives both paths the same shape.
         __builtin_amdgcn_sched_barrier(0);
-#ifndef P2P_DPP_STORES
         __builtin_amdgcn_raw_buffer_store_b32(0u, __builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0x00020000), 0, 0, 0);
-#else
-#pragma unroll
-        for (int j = 0; j < PXT; ++j)  // as many as a pair issues
-            __builtin_amdgcn_raw_buffer_store_b32(0u, __builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0x00020000), 0, 0, 0);
-#endif
         __builtin_amdgcn_sched_barrier(0);
         tight(ns_c, std::integral_constant<int, 0>{}, 0, X.n1);
         tight(ns_c, std::integral_constant<int, 1>{}, X.n1, X.n2);
@@ -533,9 +539,215 @@ __device__ __forceinline__ void draw_tight(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Rest kernel body: same arithmetic, every case distinction.
+// Gather kernel body (mode 2 tiles x plain-shift yaws, BORDER_CONSTANT 0, view rows of whole dwords).
+//
+// Rot column r of a yaw with shift s blends source columns (r + s) mod pw and the next one with the yaw's weight f
+// (YawDesc), except the one column whose left source is pw - 1: P:105 clips it there, it is a copy.  A pixel's two
+// rot taps r, r + 1 therefore read THREE contiguous source pixels -- also across the row's end, where the device rows
+// carry a copy of their first pixels (PANO_PAD): one 12-byte load per row.  Per (tile, yaw) one of three loops:
+//   0  whole-column shift and no pixel of the tile at the seam: a, b are the first two pixels of the load (copy)
+//   1  blend, no pixel at the seam: the shift (s, or s - pw when every pixel is past the seam) is one constant per pair
+//   2  the seam or the clipped column inside the tile's columns (always so next to a pole): wrap test per pixel,
+//      the two rot taps patched to copies where their left source is pw - 1
+// Per pixel and pair: 2 aligned 12-byte loads; 3 re-alignments and 12 blend instructions per row (class 1) + the 14 of
+// stage 2 -- about 50 instructions whatever the footprint, against 16 + 7 per rot pixel of the footprint in the LDS scheme.
 // ---------------------------------------------------------------------------------------------
-struct PairCtx {      // uniform per (piece, pair)
+__device__ __forceinline__ void draw_gather(
+    const ViewsParams& P, const uint8_t* __restrict__ src, const YawDesc* __restrict__ ydesc, uint8_t* __restrict__ out,
+    const TileGeo& G, uint32_t* stage)
+{
+    constexpr int PXT = VIEWS_PXT;
+    const int t = threadIdx.x;
+    // the pixels' quantised coordinates first: their address follows from the tile's position alone, the loads fly
+    // while the header and the yaw descriptors arrive
+    const int px = G.x0 + G.col;
+    int2 cxy[PXT];
+#pragma unroll
+    for (int j = 0; j < PXT; ++j) {
+        const int py = G.y0 + G.row0 + j * TILE_ROWSTEP;
+        cxy[j] = make_int2(INT32_MIN, INT32_MIN);
+        if (px < P.ow && py < P.oh)
+            cxy[j] = P.coords[((size_t)G.pitch_i * P.oh + py) * P.ow + px];
+    }
+    // the rot columns this tile taps, as the plan's header has them -- validated: everything below stays inside a
+    // panorama for any header
+    const int last_col = P.pw - 1;
+    P2P_AUD_LT(P.audit, AUD_GATHER_BOX, G.c1 < G.c0 ? 0 : G.c0, P.pw);
+    P2P_AUD_LT(P.audit, AUD_GATHER_BOX, G.c1 < G.c0 ? 0 : G.c1, P.pw);
+    const int c0v = G.c0 < 0 ? 0 : (G.c0 > last_col ? last_col : G.c0);
+    const int c1v = G.c1 < c0v ? c0v : (G.c1 > last_col ? last_col : G.c1);
+
+    // ---- pair contexts (lane k), sorted by class ----
+    int pair0, npairs;
+    pair_chunk(P, false, P.gather_ppb, pair0, npairs);
+    int cwA = 0, cwB = 0, cwC = 0, cw3 = 0, cls = 3;
+    const int k = t & 63;
+    if (k < npairs) {
+        const int pair = pair0 + k;
+        cw3 = pano_of_pair(P, pair);
+        const int yi = pair - cw3 * P.n_yaw;
+        const YawDesc yd = ydesc[yi];
+        cw3 |= k << 26;
+        if (yd.mode == 0 && (unsigned)yd.s < (unsigned)P.pw && (unsigned)yd.f <= 32u) {
+            const bool nowrap = c1v + 1 + yd.s <= P.pw - 2, allwrap = c0v + yd.s >= P.pw;
+            // (a whole-column shift has no clipped column; the seam itself still needs the wrap test)
+            cls = (nowrap || allwrap) ? (yd.f == 0 ? 0 : 1) : 2;
+            cwA = 3 * (allwrap ? yd.s - P.pw : yd.s);
+            cwB = yd.f | (yd.c_clamp + 1) << 8;
+            cwC = P.pw - yd.s;  // rot columns from here on read past the row's end
+        }
+    }
+    int cum[4];
+    const int r = sort_lanes_by_class<4>(k, k < npairs, cls, cum);
+    if (cum[2] == 0)
+        return;  // every yaw of the chunk is the table kernel's
+    cwA = __builtin_amdgcn_ds_permute(4 * r, cwA);
+    cwB = __builtin_amdgcn_ds_permute(4 * r, cwB);
+    cwC = __builtin_amdgcn_ds_permute(4 * r, cwC);
+    cw3 = __builtin_amdgcn_ds_permute(4 * r, cw3);
+
+    // ---- this thread's pixels: tap weights, the two row offsets of its left rot tap ----
+    uint32_t off_up[PXT], d_lo[PXT];  // byte offset of the upper row's left source pixel at shift 0; lower row - upper row
+    int rx[PXT];
+    TapWeights tw[PXT];
+#pragma unroll
+    for (int j = 0; j < PXT; ++j) {
+        const int py = G.y0 + G.row0 + j * TILE_ROWSTEP;
+        const bool inside = px < P.ow && py < P.oh;
+        const int2 c = cxy[j];
+        const int ix = sat_short(c.x >> 5), iy = sat_short(c.y >> 5);
+        // cv::remap, BORDER_CONSTANT 0: a pixel whose 2x2 footprint misses the panorama is black, a tap outside it
+        // reads 0 -- weight 0 here, and an address that stays inside
+        const bool live = inside && ix >= -1 && iy >= -1 && ix < P.pw && iy < P.ph;
+        TapWeights w = tap_weights((uint32_t)c.x & 31u, (uint32_t)c.y & 31u, live);
+        int x = ix;
+        if (ix + 1 > last_col) {  // right taps outside
+            w.w_up &= 0xFFFFu;
+            w.w_lo &= 0xFFFFu;
+        }
+        if (ix < 0) {             // left taps outside: the right tap (rot column 0) moves to the left slot
+            w.w_up >>= 16;
+            w.w_lo >>= 16;
+            x = 0;
+        }
+        if (iy < 0)
+            w.w_up = 0u;
+        if (iy + 1 > P.ph - 1)
+            w.w_lo = 0u;
+        tw[j] = w;
+#ifdef P2P_AUDIT
+        if (live)
+            P2P_AUD_LT(P.audit, AUD_GATHER_COORD, x - c0v, c1v - c0v + 1);
+#endif
+        x = (!live || x < c0v) ? c0v : (x > c1v ? c1v : x);
+        const int yu = iy < 0 ? 0 : (iy > P.ph - 1 ? P.ph - 1 : iy);
+        const int yl = iy + 1 < 0 ? 0 : (iy + 1 > P.ph - 1 ? P.ph - 1 : iy + 1);
+        rx[j] = x;
+        off_up[j] = (uint32_t)yu * (uint32_t)P.src_pitch + 3u * (uint32_t)x;
+        d_lo[j] = (uint32_t)(yl - yu) * (uint32_t)P.src_pitch;
+    }
+    const size_t view_bytes = (size_t)P.oh * P.ow * 3;
+    const StoreCtx SC = store_ctx(P, G, stage, t);
+    const uint32_t row_bytes = 3u * (uint32_t)P.pw;
+    uint32_t bias_br = 0x00800080u;
+    asm volatile("" : "+v"(bias_br));
+
+    // Loads are 12 bytes from a 4-byte-aligned address (a vector load from an odd address is served byte by byte:
+    // 240 cycles per wave instead of 12); the three pixels start at byte 0..3 of the load, v_alignbyte_b32 brings
+    // them to byte 0.  The rows of a panorama are 16 bytes apart modulo 16, so both rows share the alignment.
+    struct TapRegs {
+        bu32x3 U[PXT], L[PXT];
+        uint32_t al[PXT];
+    };
+    TapRegs ta, tb;  // the loads of pair k + 1 are in flight while pair k is blended: two sets, used alternately
+    // MODE as the classes above
+    auto load_taps = [&](auto mode_c, int kk, TapRegs& R) {
+        constexpr int MODE = decltype(mode_c)::value;
+        const auto S = make_buf(src + (size_t)(__builtin_amdgcn_readlane(cw3, kk) & 0x3FFFFFF) * P.pano_stride, (uint32_t)P.pano_stride);
+        const uint32_t shift3 = (uint32_t)__builtin_amdgcn_readlane(cwA, kk);
+        const int seam = __builtin_amdgcn_readlane(cwC, kk);
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) {
+            uint32_t a = off_up[j] + shift3;
+            if (MODE == 2)
+                a = rx[j] >= seam ? a - row_bytes : a;
+            R.al[j] = a;  // its two low bits are the alignment
+            a &= ~3u;
+            P2P_AUD_RANGE(P.audit, AUD_GATHER_SRC, a + d_lo[j], 12u, P.pano_stride);
+            R.U[j] = __builtin_amdgcn_raw_buffer_load_b96(S, (int)a, 0, 0);
+            R.L[j] = __builtin_amdgcn_raw_buffer_load_b96(S, (int)(a + d_lo[j]), 0, 0);
+        }
+    };
+    // the two rot taps of one row from its three source pixels (bytes o .. o + 8 of the load)
+    auto rot_pair = [&](auto mode_c, const bu32x3& q, uint32_t o, uint32_t f8, uint32_t g8, bool a_clip, bool b_clip, uint32_t& a, uint32_t& b) {
+        constexpr int MODE = decltype(mode_c)::value;
+        const uint32_t u0 = __builtin_amdgcn_alignbyte(q.y, q.x, o), u1 = __builtin_amdgcn_alignbyte(q.z, q.y, o);
+        const uint32_t a_cp = u0 & 0x00FFFFFFu, b_cp = __builtin_amdgcn_perm(u1, u0, 0x0C050403u);
+        if (MODE == 0) {
+            a = a_cp;
+            b = b_cp;
+            return;
+        }
+        const uint32_t u2 = __builtin_amdgcn_alignbyte(q.z, q.z, o);        // byte 8 of the run in its byte 0
+        const uint32_t m0 = u0 & 0x00FF00FFu;                               // B0 R0  (bytes 0, 2)
+        const uint32_t m1 = __builtin_amdgcn_perm(u1, u0, 0x0C050C03u);     // B1 R1  (3, 5)
+        const uint32_t m2 = __builtin_amdgcn_perm(u2, u1, 0x0C040C02u);     // B2 R2  (6, 8)
+        const uint32_t n01 = __builtin_amdgcn_perm(u1, u0, 0x0C040C01u);    // G0 G1  (1, 4)
+        const uint32_t n12 = __builtin_amdgcn_perm(u1, u1, 0x0C030C00u);    // G1 G2  (4, 7)
+        const uint32_t br0 = vmad24(f8, m1, vmad24(g8, m0, bias_br));
+        const uint32_t br1 = vmad24(f8, m2, vmad24(g8, m1, bias_br));
+        const uint32_t g01 = vmad24(f8, n12, vmad24(g8, n01, bias_br));
+        a = __builtin_amdgcn_perm(br0, g01, 0x0C070105u);
+        b = __builtin_amdgcn_perm(br1, g01, 0x0C070305u);
+        if (MODE == 2) {
+            a = a_clip ? a_cp : a;
+            b = b_clip ? b_cp : b;
+        }
+    };
+    auto one_pair = [&](auto mode_c, int kk, int kend, const TapRegs& cur, TapRegs& nxt) {
+        // the next pair's taps go out first (the last pair asks for its own again: no branch on the memory path);
+        // "this pair's taps landed" is then a counted vmcnt: the previous pair's store and these loads may be pending
+        load_taps(mode_c, kk + 1 < kend ? kk + 1 : kk, nxt);
+        const uint32_t wB = (uint32_t)__builtin_amdgcn_readlane(cwB, kk);
+        const uint32_t f8 = 8u * (wB & 0xFFu), g8 = 256u - f8;
+        const int cc = (int)(wB >> 8) - 1;  // the rot column clipped to source column pw - 1, or -1
+        uint32_t pix[PXT];
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) {
+            const bool a_clip = rx[j] == cc, b_clip = rx[j] + 1 == cc;
+            uint32_t a, b, c, d;
+            rot_pair(mode_c, cur.U[j], cur.al[j], f8, g8, a_clip, b_clip, a, b);
+            rot_pair(mode_c, cur.L[j], cur.al[j], f8, g8, a_clip, b_clip, c, d);
+            pix[j] = blend4_packed(a, b, c, d, tw[j]);
+        }
+        const int pair = pair0 + (int)((uint32_t)__builtin_amdgcn_readlane(cw3, kk) >> 26);
+        store_wave_pixels(SC, pix, out + ((size_t)pair * P.n_pitch + G.pitch_i) * view_bytes, view_bytes);
+    };
+    auto run = [&](auto mode_c, int kbeg, int kend) {
+        if (kbeg >= kend)
+            return;
+        load_taps(mode_c, kbeg, ta);
+        // one store that writes nothing: the loop is entered with the vmcnt shape it has inside (see draw_tight)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_raw_buffer_store_b32(0u, __builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0x00020000), 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        int kk = kbeg;
+        for (; kk + 1 < kend; kk += 2) {
+            one_pair(mode_c, kk, kend, ta, tb);
+            one_pair(mode_c, kk + 1, kend, tb, ta);
+        }
+        if (kk < kend)
+            one_pair(mode_c, kk, kend, ta, tb);
+    };
+    run(std::integral_constant<int, 0>{}, 0, cum[0]);
+    run(std::integral_constant<int, 1>{}, cum[0], cum[1]);
+    run(std::integral_constant<int, 2>{}, cum[1], cum[2]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rest / table kernel body: same arithmetic, every case distinction.
+// ---------------------------------------------------------------------------------------------
+struct PairCtx {      // uniform per (tile, pair)
     bool fast;        // LDS scheme applies (the yaw row is a circular shift)
     bool per_column;  // per-column weights (f4tab) instead of one f
     int joff;         // LDS position of rot column c0 within its row's first item
@@ -548,30 +760,40 @@ struct PairCtx {      // uniform per (piece, pair)
     int korig;        // pair index inside the chunk (its output slot is pair0 + korig)
 };
 
-// DIRECT = true: the body of remap_views_direct_kernel -- a piece the plan marks for direct gathers, a few pairs
-// per workgroup; false: remap_views_rest_kernel -- the general loop over the LDS-scheme pieces.
-template <int PXT, bool DIRECT>
+// table path: (3*i | f << 20) table entry, 8-byte load of pixels i and i+1 through the panorama's descriptor
+__device__ __forceinline__ uint32_t rot_pixel_buf(const ViewsParams& P, __amdgpu_buffer_rsrc_t S, uint32_t row_off, uint32_t te, uint32_t site)
+{
+    const uint32_t off = row_off + (te & 0xFFFFFu);
+    P2P_AUD_RANGE(P.audit, site, off, 8u, P.pano_stride);
+    const bu32x2 q = __builtin_amdgcn_raw_buffer_load_b64(S, (int)off, 0, 0);
+    const uint32_t f = te >> 20;
+    return rot_blend2(q.x, __builtin_amdgcn_alignbyte(q.y, q.x, 3), f, 32u - f);
+}
+
+// TABLE = true: the body of remap_views_table_kernel -- a mode 2 tile, a few pairs per workgroup; false:
+// remap_views_rest_kernel -- the general loop over the mode 1 tiles.
+template <bool TABLE>
 __device__ __forceinline__ void draw_rest(
     const ViewsParams& P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab,
     const YawDesc* __restrict__ ydesc, const uint32_t* __restrict__ f4tab, uint8_t* __restrict__ out,
-    const PieceHdr h, const uint32_t* __restrict__ pxw, const uint32_t* __restrict__ itw,
+    const TileGeo& G, const uint32_t* __restrict__ pxw, const uint32_t* __restrict__ itw,
     uint4 (*tile4)[LDS_ITEMS_CAP])
 {
+    constexpr int PXT = VIEWS_PXT;
     const int t = threadIdx.x;
-    const PieceGeo G = piece_geo(h, t);
-    const bool main_draws_plain = tight_piece<PXT>(G, P);
+    const bool main_draws_plain = tight_tile(G, P);
     const int px = G.x0 + G.col, py0 = G.y0 + G.row0;
     bool inside[PXT];
 #pragma unroll
     for (int j = 0; j < PXT; ++j)
-        inside[j] = G.row0 + j * G.rstep < G.h && px < P.ow && py0 + j * G.rstep < P.oh;
+        inside[j] = G.row0 + j * TILE_ROWSTEP < TILE_H && px < P.ow && py0 + j * TILE_ROWSTEP < P.oh;
 
     // output addressing: 4 horizontally adjacent pixels = 12 bytes = 3 aligned dwords
     const int lane4 = t & 3;
     const bool fast_store = (P.ow & 3) == 0;
     const size_t view_bytes = (size_t)P.oh * P.ow * 3;
     const uint32_t pix_off = (uint32_t)(((size_t)py0 * P.ow + px) * 3);  // < 3 * 32766^2 < 2^32
-    const uint32_t pix_step = (uint32_t)G.rstep * (uint32_t)P.ow * 3u;
+    const uint32_t pix_step = (uint32_t)TILE_ROWSTEP * (uint32_t)P.ow * 3u;
     // dword lane4 of the 12 bytes P0 P1 P2 P3: bytes of the own pixel (0-2) and of the next lane's (4-6)
     const uint32_t store_sel = lane4 == 0 ? 0x04020100u : (lane4 == 1 ? 0x05040201u : 0x06050402u);
 
@@ -598,7 +820,7 @@ __device__ __forceinline__ void draw_rest(
         }
     };
 
-    // ---- direct path: the quantised coordinates come from the plan's coordinate dump ----
+    // ---- table path: the quantised coordinates come from the plan's coordinate dump ----
     struct DirectPx {
         int ix[PXT], iy[PXT];
         uint32_t fx[PXT], fy[PXT];
@@ -609,7 +831,7 @@ __device__ __forceinline__ void draw_rest(
         for (int j = 0; j < PXT; ++j) {
             int2 c = make_int2(INT32_MIN, INT32_MIN);
             if (inside[j])
-                c = P.coords[((size_t)G.pitch_i * P.oh + (py0 + j * G.rstep)) * P.ow + px];
+                c = P.coords[((size_t)G.pitch_i * P.oh + (py0 + j * TILE_ROWSTEP)) * P.ow + px];
             d.ix[j] = sat_short(c.x >> 5);
             d.iy[j] = sat_short(c.y >> 5);
             d.fx[j] = (uint32_t)c.x & 31u;
@@ -621,63 +843,61 @@ __device__ __forceinline__ void draw_rest(
             d.live[j] = P.border == 0 ? inrange : inside[j];
         }
     };
-    auto direct_pixels = [&](const DirectPx& d, const uint8_t* __restrict__ S, int yi, uint32_t (&pix)[PXT]) {
-        // same arithmetic, taps gathered from global memory through the packed yaw table
+    auto direct_pixels = [&](const DirectPx& d, __amdgpu_buffer_rsrc_t S, int yi, uint32_t (&pix)[PXT]) {
+        // same arithmetic, taps gathered from global memory through the packed yaw table; the table's entries address
+        // the panorama through its descriptor
         const uint32_t* __restrict__ T = ytab + (size_t)yi * P.pw;
+        const uint32_t pitch = (uint32_t)P.src_pitch;
 #pragma unroll
         for (int j = 0; j < PXT; ++j) {
             pix[j] = 0;
             if (d.live[j] && P.border != 0) {
                 const int xa = border_interpolate(d.ix[j], P.pw, P.border), xb = border_interpolate(d.ix[j] + 1, P.pw, P.border);
                 const int ya = border_interpolate(d.iy[j], P.ph, P.border), yb = border_interpolate(d.iy[j] + 1, P.ph, P.border);
-                const uint8_t* row0p = S + (size_t)ya * P.src_pitch;
-                const uint8_t* row1p = S + (size_t)yb * P.src_pitch;
+                const uint32_t row0 = (uint32_t)ya * pitch, row1 = (uint32_t)yb * pitch;
                 const uint32_t t0 = T[xa], t1 = T[xb];
-                pix[j] = blend4(rot_pixel(row0p, t0), rot_pixel(row0p, t1), rot_pixel(row1p, t0), rot_pixel(row1p, t1),
+                pix[j] = blend4(rot_pixel_buf(P, S, row0, t0, AUD_TABLE_SRC), rot_pixel_buf(P, S, row0, t1, AUD_TABLE_SRC),
+                                rot_pixel_buf(P, S, row1, t0, AUD_TABLE_SRC), rot_pixel_buf(P, S, row1, t1, AUD_TABLE_SRC),
                                 d.fx[j], d.fy[j]);
             } else if (d.live[j]) {
                 const bool c0in = d.ix[j] >= 0, c1in = d.ix[j] + 1 < P.pw, r0in = d.iy[j] >= 0, r1in = d.iy[j] + 1 < P.ph;
-                const uint8_t* row0p = S + (ptrdiff_t)d.iy[j] * P.src_pitch;
-                const uint8_t* row1p = row0p + P.src_pitch;
+                const uint32_t row0 = (uint32_t)(r0in ? d.iy[j] : 0) * pitch, row1 = (uint32_t)(r1in ? d.iy[j] + 1 : 0) * pitch;
                 const uint32_t t0 = c0in ? T[d.ix[j]] : 0u, t1 = c1in ? T[d.ix[j] + 1] : 0u;
-                uint32_t a = (c0in && r0in) ? rot_pixel(row0p, t0) : 0u;
-                uint32_t b = (c1in && r0in) ? rot_pixel(row0p, t1) : 0u;
-                uint32_t c = (c0in && r1in) ? rot_pixel(row1p, t0) : 0u;
-                uint32_t dd = (c1in && r1in) ? rot_pixel(row1p, t1) : 0u;
+                uint32_t a = (c0in && r0in) ? rot_pixel_buf(P, S, row0, t0, AUD_TABLE_SRC) : 0u;
+                uint32_t b = (c1in && r0in) ? rot_pixel_buf(P, S, row0, t1, AUD_TABLE_SRC) : 0u;
+                uint32_t c = (c0in && r1in) ? rot_pixel_buf(P, S, row1, t0, AUD_TABLE_SRC) : 0u;
+                uint32_t dd = (c1in && r1in) ? rot_pixel_buf(P, S, row1, t1, AUD_TABLE_SRC) : 0u;
                 pix[j] = blend4(a, b, c, dd, d.fx[j], d.fy[j]);
             }
         }
     };
 
-    if constexpr (DIRECT) {
+    if constexpr (TABLE) {
         if (G.mode == 1)
             return;
         DirectPx d;
         load_direct(d);
-        const int pair0 = blockIdx.z * P.direct_ppb;
-        int pair1 = pair0 + P.direct_ppb;
-        if (pair1 > P.n_panos * P.n_yaw)
-            pair1 = P.n_panos * P.n_yaw;
-        int pano_i = pano_of_pair(P, pair0);
-        int yaw_i = pair0 - pano_i * P.n_yaw;
-        for (int pair = pair0; pair < pair1; ++pair) {
+        const bool list = P.use_pair_list != 0;
+        int first, count;
+        pair_chunk(P, list, P.gather_ppb, first, count);
+        for (int k = 0; k < count; ++k) {
+            const int pair = pair_of_lane(P, list, first, k, AUD_TABLE_PAIR);
+            const int pano_i = pano_of_pair(P, pair);
+            const int yaw_i = pair - pano_i * P.n_yaw;
             uint32_t pix[PXT];
-            direct_pixels(d, src + (size_t)pano_i * P.pano_stride, yaw_i, pix);
+            direct_pixels(d, make_buf(src + (size_t)pano_i * P.pano_stride, (uint32_t)P.pano_stride), yaw_i, pix);
             store_pixels(pair, pix);
-            if (++yaw_i == P.n_yaw) {
-                yaw_i = 0;
-                ++pano_i;
-            }
         }
         return;
     }
     if (G.mode != 1)
-        return;  // remap_views_direct_kernel's
+        return;  // the gather / table kernels'
+    P2P_AUD_LT(P.audit, AUD_REST_HDR, G.n_items, LDS_ITEMS_CAP + 1);
 
     // ---- LDS scheme, general loop ----
-    const bool listed = P.n_rest_pairs > 0;
-    const PairCtxs X = listed ? pair_contexts<true>(P, ydesc, h.c0, h.c1, t) : pair_contexts<false>(P, ydesc, h.c0, h.c1, t);
-    const int kfirst = main_draws_plain ? X.n3 : 0;  // the main kernel has classes 0..3 of its pieces
+    const bool listed = P.use_pair_list != 0;
+    const PairCtxs X = listed ? pair_contexts<true>(P, ydesc, G.c0, G.c1, t) : pair_contexts<false>(P, ydesc, G.c0, G.c1, t);
+    const int kfirst = main_draws_plain ? X.n3 : 0;  // the main kernel has classes 0..3 of its tiles
     if (kfirst >= X.npairs)
         return;
     uint32_t tap_up[PXT], tap_lo[PXT];
@@ -686,7 +906,7 @@ __device__ __forceinline__ void draw_rest(
     uint32_t slot_off[VIEWS_SLOTS], slot_g[VIEWS_SLOTS];
     decode_items(itw, t, G.n_items, P.src_pitch, slot_off, slot_g);
     const int wave_base = __builtin_amdgcn_readfirstlane(t & ~63);
-    const int n_items = G.n_items;
+    const int n_items = G.n_items < LDS_ITEMS_CAP ? G.n_items : LDS_ITEMS_CAP;
     const uint32_t row_bytes = 3u * (uint32_t)P.pw;
 
     auto pair_ctx = [&](int k) {
@@ -706,7 +926,7 @@ __device__ __forceinline__ void draw_rest(
         c.korig = (int)((uint32_t)w3 >> 26);
         return c;
     };
-    auto issue_loads = [&](const PairCtx& pc, const uint8_t* __restrict__ S, Q16 (&q)[VIEWS_SLOTS],
+    auto issue_loads = [&](const PairCtx& pc, __amdgpu_buffer_rsrc_t S, Q16 (&q)[VIEWS_SLOTS],
                            uint32_t (&fw)[VIEWS_SLOTS]) {
 #pragma unroll
         for (int k = 0; k < VIEWS_SLOTS; ++k) {
@@ -714,7 +934,9 @@ __device__ __forceinline__ void draw_rest(
                 uint32_t off = slot_off[k] + pc.goff;
                 if (slot_g[k] >= pc.wrap_g)
                     off -= row_bytes;
-                q[k] = *reinterpret_cast<const Q16*>(S + off);
+                P2P_AUD_RANGE(P.audit, AUD_REST_SRC, off, 16u, P.pano_stride);
+                const bu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(S, (int)off, 0, 0);
+                q[k].d[0] = v.x; q[k].d[1] = v.y; q[k].d[2] = v.z; q[k].d[3] = v.w;
                 if (pc.per_column) {
                     // rot column of the item's first pixel: its source column - s (mod pw)
                     int cf = 4 * (int)slot_g[k] + pc.cf0;
@@ -722,6 +944,8 @@ __device__ __forceinline__ void draw_rest(
                         cf -= P.pw;
                     if (cf < 0)
                         cf += P.pw;
+                    P2P_AUD_LT(P.audit, AUD_REST_F4, cf, P.pw);
+                    cf = (unsigned)cf < (unsigned)P.pw ? cf : 0;
                     fw[k] = f4tab[(size_t)pc.yaw_i * P.pw + cf];
                 }
             }
@@ -732,10 +956,10 @@ __device__ __forceinline__ void draw_rest(
     Q16 q[VIEWS_SLOTS];
     uint32_t fw[VIEWS_SLOTS];
     if (pc.fast)
-        issue_loads(pc, src + (size_t)pc.pano * P.pano_stride, q, fw);
+        issue_loads(pc, make_buf(src + (size_t)pc.pano * P.pano_stride, (uint32_t)P.pano_stride), q, fw);
     int buf = 0;
     for (int ki = kfirst; ki < X.npairs; ++ki) {
-        const uint8_t* __restrict__ S = src + (size_t)pc.pano * P.pano_stride;
+        const auto S = make_buf(src + (size_t)pc.pano * P.pano_stride, (uint32_t)P.pano_stride);
         const int cur_yaw = pc.yaw_i;
         const int pair = listed ? pc.pano * P.n_yaw + pc.yaw_i : X.pair0 + pc.korig;
         const bool has_next = ki + 1 < X.npairs;
@@ -799,7 +1023,7 @@ __device__ __forceinline__ void draw_rest(
             if (has_next) {
                 pc = pair_ctx(ki + 1);
                 if (pc.fast)
-                    issue_loads(pc, src + (size_t)pc.pano * P.pano_stride, q, fw);
+                    issue_loads(pc, make_buf(src + (size_t)pc.pano * P.pano_stride, (uint32_t)P.pano_stride), q, fw);
             }
 #pragma unroll
             for (int j = 0; j < PXT; ++j)
@@ -812,7 +1036,7 @@ __device__ __forceinline__ void draw_rest(
             if (has_next) {
                 pc = pair_ctx(ki + 1);
                 if (pc.fast)
-                    issue_loads(pc, src + (size_t)pc.pano * P.pano_stride, q, fw);
+                    issue_loads(pc, make_buf(src + (size_t)pc.pano * P.pano_stride, (uint32_t)P.pano_stride), q, fw);
             }
         }
         store_pixels(pair, pix);
@@ -820,109 +1044,121 @@ __device__ __forceinline__ void draw_rest(
 }
 
 // ---------------------------------------------------------------------------------------------
-// kernels: the pieces of split tiles sit in front of the tile workgroups (blockIdx.x < P.plan_gx), so that
-// the few long-running ones overlap with the bulk instead of trailing it
+// kernels
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views_kernel(
     ViewsParams P, const uint8_t* __restrict__ src, const YawDesc* __restrict__ ydesc, uint8_t* __restrict__ out,
-    const PieceHdr* __restrict__ hdr_main, const uint32_t* __restrict__ px_main, const uint32_t* __restrict__ items_main,
-    const PieceHdr* __restrict__ hdr_x, const uint32_t* __restrict__ px_x, const uint32_t* __restrict__ items_x)
+    const PieceHdr* __restrict__ hdr, const uint32_t* __restrict__ px, const uint32_t* __restrict__ items)
 {
     __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
     __shared__ __attribute__((aligned(16))) uint32_t stage[(VIEWS_BLOCK / 64) * VIEWS_PXT * 64];  // a dword per pixel
-    if ((int)blockIdx.x < P.plan_gx) {
-        const int ei = (int)blockIdx.y * P.plan_gx + (int)blockIdx.x;
-        if (ei >= P.x_n)
-            return;
-        const PieceHdr h = hdr_x[ei];
-        draw_tight<XTRA_PXT>(P, src, ydesc, out, h, px_x + (size_t)h.px_block * (VIEWS_BLOCK * XTRA_PXT),
-                             items_x + (size_t)h.item_block * LDS_ITEMS_CAP, tile4, stage);
-        return;
-    }
-    const int bx = (int)blockIdx.x - P.plan_gx, gx = (int)gridDim.x - P.plan_gx;
-    const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
-    const int chunk = gx >> 3;  // gx == 8 * ceil(tiles / 8)
-    const int tile_id = (bx & 7) * chunk + (bx >> 3);
-    if (tile_id >= tiles)
+    const int tile_id = tile_of_block(P, (int)blockIdx.x, (int)gridDim.x);
+    if (tile_id < 0)
         return;
     // heaviest views first (the host orders pitch_order by |pitch - 90| descending): a smoother tail
-    const int pitch_i = P.pitch_order[blockIdx.y];
-    const PieceHdr h = hdr_main[(size_t)pitch_i * tiles + tile_id];
-    draw_tight<VIEWS_PXT>(P, src, ydesc, out, h, px_main + (size_t)h.px_block * (VIEWS_BLOCK * VIEWS_PXT),
-                          items_main + (size_t)h.item_block * LDS_ITEMS_CAP, tile4, stage);
+    const int pitch_i = pitch_of_block(P, (int)blockIdx.y);
+    const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
+    const PieceHdr h = hdr[(size_t)pitch_i * tiles + tile_id];
+    const TileGeo G = tile_geo(P, h, pitch_i, tile_id, (int)threadIdx.x);
+    draw_tight(P, src, ydesc, out, G, px + (size_t)G.slot * (VIEWS_BLOCK * VIEWS_PXT), items + (size_t)G.slot * LDS_ITEMS_CAP,
+               tile4, stage);
 }
 
 __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_rest_kernel(
     ViewsParams P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab,
     const YawDesc* __restrict__ ydesc, const uint32_t* __restrict__ f4tab, uint8_t* __restrict__ out,
-    const PieceHdr* __restrict__ hdr_main, const uint32_t* __restrict__ px_main, const uint32_t* __restrict__ items_main,
-    const PieceHdr* __restrict__ hdr_x, const uint32_t* __restrict__ px_x, const uint32_t* __restrict__ items_x)
+    const PieceHdr* __restrict__ hdr, const uint32_t* __restrict__ px, const uint32_t* __restrict__ items)
 {
     __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
-    if ((int)blockIdx.x < P.plan_gx) {
-        const int ei = (int)blockIdx.y * P.plan_gx + (int)blockIdx.x;
-        if (ei >= P.x_n)
-            return;
-        const PieceHdr h = hdr_x[ei];
-        draw_rest<XTRA_PXT, false>(P, src, ytab, ydesc, f4tab, out, h, px_x + (size_t)h.px_block * (VIEWS_BLOCK * XTRA_PXT),
-                            items_x + (size_t)h.item_block * LDS_ITEMS_CAP, tile4);
+    const int tile_id = tile_of_block(P, (int)blockIdx.x, (int)gridDim.x);
+    if (tile_id < 0)
         return;
-    }
-    const int bx = (int)blockIdx.x - P.plan_gx, gx = (int)gridDim.x - P.plan_gx;
+    const int pitch_i = pitch_of_block(P, (int)blockIdx.y);
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
-    const int chunk = gx >> 3;
-    const int tile_id = (bx & 7) * chunk + (bx >> 3);
-    if (tile_id >= tiles)
-        return;
-    const int pitch_i = P.pitch_order[blockIdx.y];
-    const PieceHdr h = hdr_main[(size_t)pitch_i * tiles + tile_id];
-    if ((h.mode_items & 3u) == 0u)
-        return;  // a split tile: drawn by its pieces
-    draw_rest<VIEWS_PXT, false>(P, src, ytab, ydesc, f4tab, out, h, px_main + (size_t)h.px_block * (VIEWS_BLOCK * VIEWS_PXT),
-                         items_main + (size_t)h.item_block * LDS_ITEMS_CAP, tile4);
+    const PieceHdr h = hdr[(size_t)pitch_i * tiles + tile_id];
+    const TileGeo G = tile_geo(P, h, pitch_i, tile_id, (int)threadIdx.x);
+    draw_rest<false>(P, src, ytab, ydesc, f4tab, out, G, px + (size_t)G.slot * (VIEWS_BLOCK * VIEWS_PXT),
+                     items + (size_t)G.slot * LDS_ITEMS_CAP, tile4);
 }
 
-// One workgroup per (direct-gather piece of the plan's list, chunk of pairs): the few pieces with a pole or the
-// panorama's border inside.  Launched over the whole grid (as part of the rest kernel, round 2's first version)
-// the thousands of workgroups with nothing to do cost more than the gathers.
-#ifndef P2P_DIRECT_WAVES
-#define P2P_DIRECT_WAVES 6  // measured 2 / 4 / 5 / 6 / 8 on the reference CLI's default view set: 108 / 104 / 102 / 101 / 110 us
-#endif
-__global__ __launch_bounds__(VIEWS_BLOCK, P2P_DIRECT_WAVES) void remap_views_direct_kernel(
-    ViewsParams P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab, uint8_t* __restrict__ out,
-    const PieceHdr* __restrict__ hdr_main, const PieceHdr* __restrict__ hdr_x, const uint32_t* __restrict__ direct_list)
+// the plan's list of mode 2 tiles -> (pitch, tile); an entry beyond the plan's slots (never written by the plan
+// pass) is clamped
+__device__ __forceinline__ void tile_of_list(const ViewsParams& P, const uint32_t* __restrict__ list, uint32_t site, int& pitch_i, int& tile_id)
 {
-    const uint32_t id = direct_list[blockIdx.x];
-    if (id & 0x80000000u)
-        draw_rest<XTRA_PXT, true>(P, src, ytab, nullptr, nullptr, out, hdr_x[id & 0x7FFFFFFFu], nullptr, nullptr, nullptr);
-    else
-        draw_rest<VIEWS_PXT, true>(P, src, ytab, nullptr, nullptr, out, hdr_main[id], nullptr, nullptr, nullptr);
+    const uint32_t tiles = (uint32_t)(((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H));
+    uint32_t slot = list[blockIdx.x];
+    P2P_AUD_LT(P.audit, site, slot, tiles * (uint32_t)P.n_pitch);
+    if (slot >= tiles * (uint32_t)P.n_pitch)
+        slot = 0u;
+    pitch_i = (int)(slot / tiles);
+    tile_id = (int)(slot - (uint32_t)pitch_i * tiles);
 }
 
-// which = 0: the main kernel, 1: the rest, 2: the direct-gather pieces (the three write disjoint pixels; the host
-// launches the last two only when the plan or the yaw tables have something for them)
+// One workgroup per (mode 2 tile of the plan's list, chunk of pairs).
+#ifndef P2P_GATHER_WAVES
+#define P2P_GATHER_WAVES 4  // two sets of tap registers: 4 waves per SIMD, 16 x 6 KB of loads in flight per CU
+#endif
+__global__ __launch_bounds__(VIEWS_BLOCK, P2P_GATHER_WAVES) void remap_views_gather_kernel(
+    ViewsParams P, const uint8_t* __restrict__ src, const YawDesc* __restrict__ ydesc, uint8_t* __restrict__ out,
+    const PieceHdr* __restrict__ hdr, const uint32_t* __restrict__ gather_list)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t stage[(VIEWS_BLOCK / 64) * VIEWS_PXT * 64];
+    const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
+    int pitch_i, tile_id;
+    if (P.gather_all) {  // grid.x == tiles * n_pitch
+        pitch_i = (int)blockIdx.x / tiles;
+        tile_id = (int)blockIdx.x - pitch_i * tiles;
+    } else {
+        tile_of_list(P, gather_list, AUD_GATHER_LIST, pitch_i, tile_id);
+    }
+    const PieceHdr h = hdr[(size_t)pitch_i * tiles + tile_id];
+    const TileGeo G = tile_geo(P, h, pitch_i, tile_id, (int)threadIdx.x);
+    if (G.mode != 2 && !P.gather_all)
+        return;
+    draw_gather(P, src, ydesc, out, G, stage);
+}
+
+#ifndef P2P_DIRECT_WAVES
+#define P2P_DIRECT_WAVES 4
+#endif
+__global__ __launch_bounds__(VIEWS_BLOCK, P2P_DIRECT_WAVES) void remap_views_table_kernel(
+    ViewsParams P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab, uint8_t* __restrict__ out,
+    const PieceHdr* __restrict__ hdr, const uint32_t* __restrict__ gather_list)
+{
+    int pitch_i, tile_id;
+    tile_of_list(P, gather_list, AUD_TABLE_LIST, pitch_i, tile_id);
+    const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
+    const PieceHdr h = hdr[(size_t)pitch_i * tiles + tile_id];
+    const TileGeo G = tile_geo(P, h, pitch_i, tile_id, (int)threadIdx.x);
+    draw_rest<true>(P, src, ytab, nullptr, nullptr, out, G, nullptr, nullptr, nullptr);
+}
+
+// which = 0: the main kernel, 1: the rest, 2: the table kernel, 3: the gather kernel (they write disjoint pixels; the
+// host launches all but the first only when the plan or the yaw tables have something for them)
 hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
 {
-    if (which == 2) {
-        const int np = P.n_panos * P.n_yaw;
-        const dim3 grid(P.n_direct, 1, (np + P.direct_ppb - 1) / P.direct_ppb);
-        hipLaunchKernelGGL(remap_views_direct_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.out, P.hdr_main,
-                           P.hdr_x, P.direct_list);
+    const int n_pairs = P.n_panos * P.n_yaw;
+    if (which == 2 || which == 3) {
+        const int np = (which == 2 && P.use_pair_list) ? P.n_odd_pairs : n_pairs;
+        const int all = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H) * P.n_pitch;
+        const dim3 grid((which == 3 && P.gather_all) ? all : P.n_gather, 1, (np + P.gather_ppb - 1) / P.gather_ppb);
+        if (which == 2)
+            hipLaunchKernelGGL(remap_views_table_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.out, P.hdr, P.gather_list);
+        else
+            hipLaunchKernelGGL(remap_views_gather_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.hdr, P.gather_list);
         return hipGetLastError();
     }
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
-    const int n_pairs = P.n_panos * P.n_yaw;
     int zblocks = (n_pairs + P.pairs_per_block - 1) / P.pairs_per_block;
-    if (which == 1 && P.n_rest_pairs > 0)
-        zblocks = (P.n_rest_pairs + P.rest_ppb - 1) / P.rest_ppb;
-    // 8 XCDs, each a contiguous run of tiles; P.plan_gx is a multiple of 8 too
-    const dim3 grid(P.plan_gx + 8 * ((tiles + 7) / 8), P.n_pitch, zblocks);
+    if (which == 1 && P.use_pair_list)
+        zblocks = (P.n_odd_pairs + P.rest_ppb - 1) / P.rest_ppb;
+    // 8 XCDs, each a contiguous run of tiles
+    const dim3 grid(8 * ((tiles + 7) / 8), P.n_pitch, zblocks);
     if (which == 0)
-        hipLaunchKernelGGL(remap_views_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.hdr_main,
-                           P.px_main, P.items_main, P.hdr_x, P.px_x, P.items_x);
+        hipLaunchKernelGGL(remap_views_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.hdr, P.px, P.items);
     else
         hipLaunchKernelGGL(remap_views_rest_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc, P.f4tab,
-                           P.out, P.hdr_main, P.px_main, P.items_main, P.hdr_x, P.px_x, P.items_x);
+                           P.out, P.hdr, P.px, P.items);
     return hipGetLastError();
 }
 

@@ -9,7 +9,6 @@
 #include <vector>
 
 extern "C" int p2p_stub_device_count;
-extern "C" int p2p_stub_extras_wanted;
 
 #define CHECK(cond) do { if (!(cond)) { fprintf(stderr, "CHECK failed line %d: %s (%s)\n", __LINE__, #cond, p2p_last_error()); exit(1); } } while (0)
 
@@ -69,9 +68,7 @@ int main()
     CHECK(p2p_job_run(job) == P2P_ERR_STATE);                        // panorama 1 still missing
     CHECK(p2p_job_get_views(job, 0, views.data()) == P2P_ERR_STATE);
     CHECK(p2p_job_set_pano_async(job, 1, pano.data(), 192) == P2P_OK);
-    p2p_stub_extras_wanted = 100000;                                 // more pieces than the first pools: grow and re-plan
     CHECK(p2p_job_run(job) == P2P_OK);
-    p2p_stub_extras_wanted = 0;
     for (int i = 0; i < 300; ++i)                                    // past the ring of 256 event pairs
         CHECK(p2p_job_run(job) == P2P_OK);
     float ms[300];

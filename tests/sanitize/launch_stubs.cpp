@@ -4,7 +4,6 @@
 #include "p2p_device.h"
 #include <string.h>
 extern "C" int p2p_stub_device_count = 1;
-extern "C" int p2p_stub_extras_wanted = 0;  // what the "plan pass" reports: exercises the grow-and-replan path
 
 namespace p2p {
 hipError_t launch_yaw_tables(uint32_t* packed, float* rows, int pw, int n_yaw, const double* yaw_rad, hipStream_t)
@@ -43,26 +42,22 @@ hipError_t launch_plan(const PlanParams& P, hipStream_t)
 {
     const size_t tiles = (size_t)((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
     for (size_t s = 0; s < tiles * P.n_pitch; ++s) {
-        P.hdr_main[s] = PieceHdr{0u, (uint32_t)TILE_W | 16u << 8, 2u, 0, 0, (uint32_t)s, (uint32_t)s, 0u};
-        P.px_main[s * 256 * VIEWS_PXT + 256 * VIEWS_PXT - 1] = 0u;
-        P.items_main[s * LDS_ITEMS_CAP + LDS_ITEMS_CAP - 1] = 0u;
+        P.hdr[s] = PieceHdr{2u, 0, -1, 0u};
+        P.px[s * 256 * VIEWS_PXT + 256 * VIEWS_PXT - 1] = 0u;
+        P.items[s * LDS_ITEMS_CAP + LDS_ITEMS_CAP - 1] = 0u;
+        P.gather_list[s] = (uint32_t)s;
     }
     memset(P.coords, 0, (size_t)P.n_pitch * P.oh * P.ow * sizeof(int2));
-    const uint32_t want = (uint32_t)p2p_stub_extras_wanted;
-    for (uint32_t e = 0; e < want && e < P.x_cap; ++e) {
-        P.hdr_x[e] = PieceHdr{0u, 16u | 8u << 8, 2u, 0, 0, e, e, 0u};
-        P.px_x[(size_t)e * 256 * XTRA_PXT + 256 * XTRA_PXT - 1] = 0u;
-        P.items_x[(size_t)e * LDS_ITEMS_CAP + LDS_ITEMS_CAP - 1] = 0u;
-    }
-    P.x_count[0] = want;
-    P.x_count[1] = (uint32_t)(tiles * P.n_pitch);
+    P.n_gather[0] = (uint32_t)(tiles * P.n_pitch);
     return hipSuccess;
 }
 hipError_t launch_remap_views(const ViewsParams& P, int, hipStream_t)
 {
     const size_t n = (size_t)P.n_panos * P.n_yaw * P.n_pitch * P.oh * P.ow * 3;
     P.out[0] = P.src[0];
-    P.out[n - 1] = P.src[(size_t)(P.n_panos - 1) * P.pano_stride + (size_t)(P.ph - 1) * P.src_pitch + 3 * P.pw - 1];
+    // the last byte of the last row's wrap pad: the upload's second 2-D copy must have filled it
+    P.out[n - 1] = P.src[(size_t)(P.n_panos - 1) * P.pano_stride + (size_t)(P.ph - 1) * P.src_pitch +
+                         3 * (P.pw + (P.pw < PANO_PAD ? P.pw : PANO_PAD)) - 1];
     return hipSuccess;
 }
 hipError_t launch_remap_maps(const RemapParams& P, int cn, int, hipStream_t)
