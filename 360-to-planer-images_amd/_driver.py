@@ -94,10 +94,12 @@ class DevicePipeline:
 
 _ctx_lock = threading.Lock()
 _ctxs = {}
+_groups = {}  # device slot -> (geometry key, [(job, pitch index, yaw indices)]): the slot's resident jobs
 
 
 def _shared_ctx(slot):
-    """One context per (device slot) for the sharded path, kept for the life of the process."""
+    """One context per (device slot) for the sharded path, kept for the life of the process -- and with it the
+    plans and yaw tables of every geometry it has seen (the context's table caches)."""
     with _ctx_lock:
         c = _ctxs.get(slot)
         if c is None:
@@ -105,31 +107,61 @@ def _shared_ctx(slot):
         return c
 
 
+def release_sharded():
+    """Free the jobs and contexts process_views_sharded keeps between images."""
+    with _ctx_lock:
+        for _, jobs in _groups.values():
+            for job, _, _ in reversed(jobs):
+                job.close()
+        _groups.clear()
+        for c in _ctxs.values():
+            c.close()
+        _ctxs.clear()
+
+
 def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0):
     """Every (yaw, pitch) view of ONE panorama drawn by several GPUs: views dealt round-robin, pitch-major
     (shard_views); each device uploads the panorama once, draws its (pitch, yaw subset) groups and downloads them;
-    the host stitches [n_yaw][n_pitch][oh][ow][3].  `devices` may name a device twice (two contexts on one GPU)."""
+    the host stitches [n_yaw][n_pitch][oh][ow][3].  `devices` may name a device twice (two contexts on one GPU).
+    A device slot keeps its jobs (device buffers, plan, yaw tables) for the next image of the same geometry, as the
+    reference keeps its maps from image to image (P:17-18): a second image pays uploads, view kernels and downloads."""
     pano = _native.as_image(pano, "pano_image")
     ph, pw = pano.shape[:2]
     yaws, pitches = [float(y) for y in yaws], [float(p) for p in pitches]
     out = np.empty((len(yaws), len(pitches), int(oh), int(ow), 3), dtype=np.uint8)
     world = len(devices)
+    geo = (pw, ph, tuple(yaws), tuple(pitches), float(fov), int(ow), int(oh), int(flags), world)
 
     def one_device(rank):
         groups = shard_views(len(yaws), len(pitches), world, rank)
         if not groups:
             return
-        ctx = _shared_ctx((rank, int(devices[rank])))
-        jobs, owner = [], None
+        slot = (rank, int(devices[rank]))
+        ctx = _shared_ctx(slot)
+        kept = _groups.get(slot)
+        if kept is not None and kept[0] != geo:
+            for job, _, _ in reversed(kept[1]):  # borrowers before the owner
+                job.close()
+            kept = None
+            _groups.pop(slot, None)
+        if kept is None:
+            jobs, owner = [], None
+            try:
+                for pi, yis in sorted(groups.items()):
+                    job = _native.Job(ctx, pw, ph, 1, [yaws[y] for y in yis], [pitches[pi]], fov, ow, oh, flags=flags)
+                    jobs.append((job, pi, yis))
+                    if owner is None:
+                        owner = job
+                    else:
+                        job.share_panos(owner)
+            except Exception:
+                for job, _, _ in reversed(jobs):
+                    job.close()
+                raise
+            _groups[slot] = (geo, jobs)
+        jobs = _groups[slot][1]
         try:
-            for pi, yis in sorted(groups.items()):
-                job = _native.Job(ctx, pw, ph, 1, [yaws[y] for y in yis], [pitches[pi]], fov, ow, oh, flags=flags)
-                jobs.append((job, pi, yis))
-                if owner is None:
-                    owner = job
-                    owner.set_pano(0, pano, wait=False)  # once per device
-                else:
-                    job.share_panos(owner)
+            jobs[0][0].set_pano(0, pano, wait=False)  # once per device
             pending = []
             for job, pi, yis in jobs:
                 job.run()
@@ -139,9 +171,11 @@ def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0):
             for views, pi, yis in pending:
                 for k, y in enumerate(yis):
                     out[y, pi] = views[k, 0]
-        finally:
-            for job, _, _ in reversed(jobs):  # borrowers before the owner
+        except Exception:
+            for job, _, _ in reversed(jobs):
                 job.close()
+            _groups.pop(slot, None)
+            raise
 
     with ThreadPoolExecutor(max_workers=world) as ex:
         for f in [ex.submit(one_device, r) for r in range(world)]:

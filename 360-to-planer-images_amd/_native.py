@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     "p2p_remap_maps_batch_u8",
     "p2p_build_pitch_map", "p2p_build_yaw_row", "p2p_build_rot_map",
     "p2p_ctx_create", "p2p_ctx_destroy", "p2p_ctx_synchronize", "p2p_ctx_mark", "p2p_ctx_marked_ms",
-    "p2p_job_time_launches",
+    "p2p_job_time_launches", "p2p_job_plan_ms",
     "p2p_job_create", "p2p_job_create_f64", "p2p_job_set_yaws_f64", "p2p_job_destroy", "p2p_job_set_pano",
     "p2p_job_set_pano_async", "p2p_job_share_panos", "p2p_job_get_views_async", "p2p_job_wait", "p2p_job_set_maps", "p2p_job_run",
     "p2p_job_get_views", "p2p_job_kernel_ms", "p2p_job_kernel_ms_last", "p2p_job_device_out", "p2p_job_get_coords",
@@ -133,6 +133,8 @@ def lib():
     L.p2p_job_run.argtypes = [c_vp]
     L.p2p_job_get_views.restype = c_int
     L.p2p_job_get_views.argtypes = [c_vp, c_int, c_vp]
+    L.p2p_job_plan_ms.restype = c_int
+    L.p2p_job_plan_ms.argtypes = [c_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.p2p_job_kernel_ms.restype = c_int
     L.p2p_job_kernel_ms.argtypes = [c_vp, ctypes.POINTER(ctypes.c_float)]
     L.p2p_job_kernel_ms_last.restype = c_int
@@ -534,6 +536,12 @@ class Job:
 
     def time_launches(self, on):
         check(lib().p2p_job_time_launches(self._h, int(bool(on))))
+
+    def plan_ms(self):
+        """(plan pass, yaw tables) build times in ms of the tables this job uses (built once per geometry and context)."""
+        a, b = ctypes.c_float(), ctypes.c_float()
+        check(lib().p2p_job_plan_ms(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     def kernel_ms(self):
         ms = ctypes.c_float()

@@ -90,7 +90,10 @@ struct ViewsParams {
     const PitchConst* pitch; // [n_pitch]
     MapGeom geom;
     int ow, oh;
-    uint8_t* out;            // [n_panos][n_yaw][n_pitch][oh][ow][3]
+    uint8_t* out;            // [n_panos][n_yaw][n_pitch][oh] rows of out_row bytes ([ow][3] pixels, then padding)
+    int out_row;             // bytes per view row on the device: 3 * ow rounded up to whole dwords x 3 (a multiple of 12),
+                             // so that every row starts dword-aligned whatever the width; the host copies rows out
+    size_t view_bytes;       // oh * out_row
     int border;              // stage-2 border mode (0 = BORDER_CONSTANT 0, the reference's current tool)
     const uint16_t* pitch_order;  // [n_pitch] blockIdx.y -> pitch index, heaviest view first
     const int2* coords;      // [n_pitch][oh][ow] quantised pitch-stage coordinates (sx, sy), written by the plan pass
@@ -149,6 +152,8 @@ hipError_t launch_rot_map(float* U, float* V, int ow, int oh, const MapGeom& g, 
 hipError_t launch_pitch_map(float* U, float* V, int ow, int oh, const MapGeom& g, float c, float s,
                             hipStream_t st);
 hipError_t launch_plan(const PlanParams& P, hipStream_t st);
+// padded device view rows (src_row bytes apart, row_bytes used) -> contiguous bytes, dst sized to whole dwords
+hipError_t launch_compact_rows(void* dst, const uint8_t* src, size_t n_bytes, int row_bytes, int src_row, hipStream_t st);
 hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st);
 hipError_t launch_remap_maps(const RemapParams& P, int cn, int interpolation, hipStream_t st);
 hipError_t launch_cubic_tab(short* tab, hipStream_t st);

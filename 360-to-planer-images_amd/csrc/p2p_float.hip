@@ -116,7 +116,7 @@ __device__ __forceinline__ void draw_float(
     uint32_t slot_off[VIEWS_SLOTS], slot_g[VIEWS_SLOTS];
     decode_items(itw, t, G.n_items, P.src_pitch, slot_off, slot_g);
     const uint32_t row_bytes = 3u * (uint32_t)P.pw;
-    const size_t view_bytes = (size_t)P.oh * P.ow * 3;
+    const size_t view_bytes = P.view_bytes;
     const int ngroups = P.pw >> 2;
 
     // ---- per-pair contexts in lane k: the yaw's integer column shift places the source pieces, its fraction is
@@ -149,7 +149,7 @@ __device__ __forceinline__ void draw_float(
     const int x4 = 4 * (ln & 15), sj = ln >> 4;
     const int srow = ((wv * 64 + x4) >> TILE_LW) + sj * TILE_ROWSTEP, scol = x4 & (TILE_W - 1);
     const bool s_ok = sj < PXT && srow < TILE_H && G.y0 + srow < P.oh && G.x0 + scol < P.ow;
-    const uint32_t out_off12 = s_ok ? (uint32_t)(((size_t)(G.y0 + srow) * P.ow + G.x0 + scol) * 3) : 0xFFFFFFFFu;
+    const uint32_t out_off12 = s_ok ? (uint32_t)(G.y0 + srow) * (uint32_t)P.out_row + 3u * (uint32_t)(G.x0 + scol) : 0xFFFFFFFFu;
     const uint32_t stg_rd = (uint32_t)(sj * 64 + x4);
 
     const int wave_base = __builtin_amdgcn_readfirstlane(t & ~63);
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void float_views_rest_kernel(
     int pair1 = pair0 + P.gather_ppb;
     if (pair1 > P.n_panos * P.n_yaw)
         pair1 = P.n_panos * P.n_yaw;
-    const size_t view_bytes = (size_t)P.oh * P.ow * 3;
+    const size_t view_bytes = P.view_bytes;
     const int px = G.x0 + G.col;
     for (int j = 0; j < VIEWS_PXT; ++j) {
         const int row = G.row0 + j * TILE_ROWSTEP, py = G.y0 + row;
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void float_views_rest_kernel(
         y0 = y0 < 0 ? 0 : (y0 > P.ph - 1 ? P.ph - 1 : y0);
         const float wy = dead ? 0.0f : V - (float)y0;
         const int y1 = y0 + 1 < P.ph ? y0 + 1 : y0;
-        const size_t px_off = ((size_t)py * P.ow + px) * 3;
+        const size_t px_off = (size_t)py * P.out_row + 3 * (size_t)px;
         for (int pair = pair0; pair < pair1; ++pair) {
             const int pano = pano_of_pair(P, pair), yi = pair - pano * P.n_yaw;
             uint8_t* O = out + ((size_t)pair * P.n_pitch + G.pitch_i) * view_bytes + px_off;

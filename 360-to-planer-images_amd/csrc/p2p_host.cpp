@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -53,6 +54,213 @@ int env_int(const char* name, int dflt)
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------
+// Device memory pool.  Every device buffer of the library comes from here and goes back here: nothing returns to
+// the driver in steady state.  Not (only) a speed matter: on the round-3 GPU pool, device memory that has JUST been
+// allocated loses what a kernel or a host copy wrote into it -- page-sized runs read back as zeros or as other
+// data -- about once in 6 000 allocate-write-check-free rounds when several processes allocate and free on one GPU
+// at the same time (tools/platform/alloc_churn.hip reproduces it with no code of this library: 345 bad rounds in
+// 2.1 M; a buffer allocated once and reused: 0 in 0.9 M beside the same neighbours).  That is what round 2's
+// "wrong output, then a memory fault" was: a plan table with garbage in it.  The kernels now clamp or range-check
+// every table-derived offset (p2p_audit.h), and with the pool a fresh allocation happens only while the pool warms up.
+// Blocks are kept in size classes (<= 12.5 % rounding), P2P_POOL_MB (default 32768) bounds the idle bytes per
+// device (the largest idle blocks go back to the driver first), p2p_release_cache empties it.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct DevPool {
+    std::mutex mu;
+    struct PerDev {
+        std::multimap<size_t, void*> idle;        // class size -> block
+        std::map<void*, size_t> live;             // block -> class size
+        size_t idle_bytes = 0;
+    };
+    std::map<int, PerDev> dev;
+};
+
+DevPool& dev_pool()
+{
+    static DevPool* p = new DevPool();  // never destroyed: no HIP call after the runtime's own shutdown
+    return *p;
+}
+
+size_t pool_class(size_t bytes)
+{
+    if (bytes < 256)
+        return 256;
+    int lg = 63 - __builtin_clzll((unsigned long long)bytes);
+    if ((size_t)1 << lg == bytes)
+        return bytes;
+    const size_t step = lg >= 20 ? (size_t)1 << (lg - 3) : (size_t)1 << lg;  // eighths of a power of two from 1 MB up
+    return (bytes + step - 1) / step * step;
+}
+
+hipError_t dev_alloc(void** out, size_t bytes)
+{
+    *out = nullptr;
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess)
+        return e;
+    const size_t cls = pool_class(bytes);
+    DevPool& P = dev_pool();
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        DevPool::PerDev& D = P.dev[device];
+        auto it = D.idle.find(cls);
+        if (it != D.idle.end()) {
+            *out = it->second;
+            D.idle.erase(it);
+            D.idle_bytes -= cls;
+            D.live[*out] = cls;
+            return hipSuccess;
+        }
+    }
+    e = hipMalloc(out, cls);
+    if (e != hipSuccess) {
+        // out of device memory: give the idle blocks back and try once more
+        std::vector<void*> drop;
+        {
+            std::lock_guard<std::mutex> lk(P.mu);
+            DevPool::PerDev& D = P.dev[device];
+            for (auto& kv : D.idle) drop.push_back(kv.second);
+            D.idle.clear();
+            D.idle_bytes = 0;
+        }
+        for (void* q : drop) (void)hipFree(q);
+        (void)hipGetLastError();
+        e = hipMalloc(out, cls);
+        if (e != hipSuccess) {
+            *out = nullptr;
+            return e;
+        }
+    }
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.dev[device].live[*out] = cls;
+    return hipSuccess;
+}
+template <class T>
+hipError_t dev_alloc(T** out, size_t bytes) { return dev_alloc((void**)out, bytes); }
+
+hipError_t dev_free(void* ptr)
+{
+    if (!ptr)
+        return hipSuccess;
+    DevPool& P = dev_pool();
+    std::vector<void*> drop;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        for (auto& dv : P.dev) {
+            auto it = dv.second.live.find(ptr);
+            if (it == dv.second.live.end())
+                continue;
+            const size_t cls = it->second;
+            dv.second.live.erase(it);
+            dv.second.idle.emplace(cls, ptr);
+            dv.second.idle_bytes += cls;
+            const size_t budget = (size_t)std::max(0, env_int("P2P_POOL_MB", 32768)) << 20;
+            while (dv.second.idle_bytes > budget && !dv.second.idle.empty()) {  // largest idle blocks first
+                auto big = std::prev(dv.second.idle.end());
+                dv.second.idle_bytes -= big->first;
+                drop.push_back(big->second);
+                dv.second.idle.erase(big);
+            }
+            ptr = nullptr;
+            break;
+        }
+    }
+    for (void* q : drop) (void)hipFree(q);
+    if (ptr)
+        return hipFree(ptr);  // not ours (cannot happen through this file)
+    return hipSuccess;
+}
+
+void dev_pool_trim()
+{
+    DevPool& P = dev_pool();
+    std::vector<std::pair<int, void*>> drop;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        for (auto& dv : P.dev) {
+            for (auto& kv : dv.second.idle) drop.emplace_back(dv.first, kv.second);
+            dv.second.idle.clear();
+            dv.second.idle_bytes = 0;
+        }
+    }
+    for (auto& d : drop) {
+        (void)hipSetDevice(d.first);
+        (void)hipFree(d.second);
+    }
+}
+
+}  // namespace
+
+// What the reference keeps for the life of the process in pitch_mapping_cache / yaw_mapping_cache (P:17-18, P:42-73):
+// here the device tables built from a job geometry, kept by the CONTEXT and shared by every job on it that has
+// the same key -- a second image of one geometry, on any path (one-shot, two-slot pipeline, view-sharded driver),
+// launches nothing but the view kernels.
+struct PlanKey {  // the reference's key (ow, oh, pitch, pw, ph, fov), for the whole pitch list, plus what shapes the tables
+    int pw, ph, ow, oh, flags, border;
+    double fov;
+    std::vector<double> pitch;
+    bool operator<(const PlanKey& o) const
+    {
+        if (pw != o.pw) return pw < o.pw;
+        if (ph != o.ph) return ph < o.ph;
+        if (ow != o.ow) return ow < o.ow;
+        if (oh != o.oh) return oh < o.oh;
+        if (flags != o.flags) return flags < o.flags;
+        if (border != o.border) return border < o.border;
+        if (fov != o.fov) return fov < o.fov;
+        return pitch < o.pitch;
+    }
+};
+
+struct Plan {  // the plan pass's tables (p2p_plan.hip)
+    int device = 0;
+    int2* d_coords = nullptr;            // [n_pitch][oh][ow] quantised coordinates
+    p2p::PieceHdr* d_hdr = nullptr;      // [n_pitch][tiles]
+    uint32_t* d_px = nullptr;            // [n_pitch][tiles][256 * VIEWS_PXT]
+    uint32_t* d_items = nullptr;         // [n_pitch][tiles][LDS_ITEMS_CAP]
+    uint32_t* d_px2 = nullptr;           // float pixel path only: 16-bit coordinate fractions
+    uint32_t* d_n_gather = nullptr;
+    uint32_t* d_gather_list = nullptr;   // [n_pitch * tiles] tiles the plan marks for gathers
+    int n_gather = 0;
+    bool built = false;
+    float plan_ms = 0.0f;                // device time of the plan pass
+    size_t bytes = 0;
+    unsigned long long stamp = 0;        // last use (eviction order)
+    ~Plan()
+    {
+        (void)hipSetDevice(device);
+        (void)dev_free(d_coords); (void)dev_free(d_hdr); (void)dev_free(d_px); (void)dev_free(d_items);
+        (void)dev_free(d_px2); (void)dev_free(d_n_gather); (void)dev_free(d_gather_list);
+    }
+};
+
+struct YawKey {  // the reference's key (pano_width, pano_height, yaw_angle), for the whole yaw list (rows do not depend on ph)
+    int pw;
+    std::vector<double> yaw;
+    bool operator<(const YawKey& o) const { return pw != o.pw ? pw < o.pw : yaw < o.yaw; }
+};
+
+struct YawTabs {  // yaw_table_kernel / yaw_desc_kernel outputs
+    int device = 0;
+    uint32_t* d_ytab = nullptr;
+    uint32_t* d_f4tab = nullptr;
+    p2p::YawDesc* d_ydesc = nullptr;
+    double* d_yaw_rad = nullptr;
+    std::vector<p2p::YawDesc> desc;      // host copy (which yaws are odd)
+    float tables_ms = 0.0f;
+    size_t bytes = 0;
+    unsigned long long stamp = 0;
+    ~YawTabs()
+    {
+        (void)hipSetDevice(device);
+        (void)dev_free(d_ytab); (void)dev_free(d_f4tab); (void)dev_free(d_ydesc); (void)dev_free(d_yaw_rad);
+    }
+};
+
 struct p2p_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // kernels
@@ -61,10 +269,17 @@ struct p2p_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     short* d_ctab = nullptr;  // INTER_CUBIC weight table, built on first use
     // grow-only scratch of the generic remap entry point (source image, output, two maps): kept with the context
-    // instead of four hipMalloc / hipFree per call
+    // instead of four allocations per call
     void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[4] = {0, 0, 0, 0};
     uint32_t* d_audit = nullptr;  // -DP2P_AUDIT builds: the kernels' violation record (p2p_audit.h)
+    // geometry-keyed table caches (see PlanKey / YawKey); entries no job refers to go first when the byte budget
+    // (P2P_PLAN_CACHE_MB, default 4096) is exceeded
+    std::mutex cache_mu;
+    std::map<PlanKey, std::shared_ptr<Plan>> plans;
+    std::map<YawKey, std::shared_ptr<YawTabs>> yaw_tabs;
+    unsigned long long cache_clock = 0;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // timing of the plan pass / the table kernels
 };
 
 struct p2p_job {
@@ -85,7 +300,11 @@ struct p2p_job {
     size_t pano_stride = 0;
     int src_pitch = 0;
     uint8_t* d_out = nullptr;
-    size_t out_bytes = 0;
+    size_t out_bytes = 0;            // device bytes of all views: n_views * oh * out_row
+    uint8_t* d_pack = nullptr;       // odd view widths only: one panorama's views without the row padding, for the download            // device bytes of all views: n_views * oh * out_row
+    int out_row = 0;                 // bytes per view row on the device (12-byte groups: ViewsParams::out_row)
+    std::shared_ptr<Plan> plan_ref;      // owns the plan tables below (shared through the context's cache, or private)
+    std::shared_ptr<YawTabs> yaw_ref;    // owns the yaw tables below
     uint32_t* d_ytab = nullptr;
     uint32_t* d_f4tab = nullptr;
     p2p::YawDesc* d_ydesc = nullptr;
@@ -101,11 +320,9 @@ struct p2p_job {
     uint32_t* d_px = nullptr;            // [n_pitch][tiles][256 * VIEWS_PXT]
     uint32_t* d_items = nullptr;         // [n_pitch][tiles][LDS_ITEMS_CAP]
     uint32_t* d_px2 = nullptr;           // float pixel path only: 16-bit coordinate fractions
-    uint32_t* d_n_gather = nullptr;
     uint32_t* d_gather_list = nullptr;   // [n_pitch * tiles] tiles the plan marks for gathers
     uint32_t* d_odd_pairs = nullptr;     // (panorama, yaw) pairs whose yaw is not a plain shift with one weight
     int n_odd_pairs = 0;
-    bool planned = false;                // the plan has been built for the current maps
     int n_gather = 0;                    // tiles the plan marks for gathers
     int n_odd_yaws = 0;                  // yaws that are not a plain shift with one weight (YawDesc.mode != 0)
     uint16_t* d_pitch_order = nullptr;   // [n_pitch] heaviest view first
@@ -297,8 +514,10 @@ int p2p_ctx_create(int device, p2p_ctx** out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_down, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_t0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_t1);
 #ifdef P2P_AUDIT
-    if (e == hipSuccess) e = hipMalloc((void**)&c->d_audit, p2p::AUDIT_WORDS * sizeof(uint32_t));
+    if (e == hipSuccess) e = dev_alloc((void**)&c->d_audit, p2p::AUDIT_WORDS * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(c->d_audit, 0, p2p::AUDIT_WORDS * sizeof(uint32_t));
 #endif
     if (e != hipSuccess) {
@@ -319,12 +538,14 @@ void p2p_ctx_destroy(p2p_ctx* c)
             (void)hipStreamSynchronize(*st);
             (void)hipStreamDestroy(*st);
         }
-    (void)hipFree(c->d_ctab);
-    (void)hipFree(c->d_audit);
+    c->plans.clear();     // (jobs still alive keep their tables through their own references)
+    c->yaw_tabs.clear();
+    (void)dev_free(c->d_ctab);
+    (void)dev_free(c->d_audit);
     for (void* p : c->scratch)
-        (void)hipFree(p);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+        (void)dev_free(p);
+    for (hipEvent_t e : {c->ev0, c->ev1, c->ev_t0, c->ev_t1})
+        if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -352,54 +573,126 @@ void p2p_job_destroy(p2p_job* j)
     for (hipEvent_t e : {j->ev_up, j->ev_run, j->ev_down})
         if (e) (void)hipEventDestroy(e);
     if (j->owns_src)
-        (void)hipFree(j->d_src);
-    (void)hipFree(j->d_out);
-    (void)hipFree(j->d_ytab);
-    (void)hipFree(j->d_f4tab);
-    (void)hipFree(j->d_ydesc);
-    (void)hipFree(j->d_yaw_rad);
-    (void)hipFree(j->d_pitch);
-    (void)hipFree(j->d_mapU);
-    (void)hipFree(j->d_mapV);
-    (void)hipFree(j->d_rows);
-    (void)hipFree(j->d_coords);
-    (void)hipFree(j->d_hdr);
-    (void)hipFree(j->d_px);
-    (void)hipFree(j->d_items);
-    (void)hipFree(j->d_px2);
-    (void)hipFree(j->d_n_gather);
-    (void)hipFree(j->d_gather_list);
-    (void)hipFree(j->d_odd_pairs);
-    (void)hipFree(j->d_pitch_order);
+        (void)dev_free(j->d_src);
+    (void)dev_free(j->d_out);
+    (void)dev_free(j->d_pack);
+    j->plan_ref.reset();  // the tables themselves go when the last job and the context's cache let go of them
+    j->yaw_ref.reset();
+    (void)dev_free(j->d_pitch);
+    (void)dev_free(j->d_mapU);
+    (void)dev_free(j->d_mapV);
+    (void)dev_free(j->d_rows);
+    (void)dev_free(j->d_odd_pairs);
+    (void)dev_free(j->d_pitch_order);
     for (hipEvent_t e : j->ev_ring)
         (void)hipEventDestroy(e);
     delete j;
 }
 
-// how many of the job's yaws need the rest kernel (per-column weights, or a caller row that is not a shift)
-static int count_odd_yaws(p2p_job* j)
+// ---- the context's table caches ------------------------------------------------------------------------------
+static size_t cache_budget() { return (size_t)std::max(0, env_int("P2P_PLAN_CACHE_MB", 4096)) << 20; }
+
+// drop cached tables nobody uses, least recently used first, until the budget holds (mutex held by the caller)
+static void cache_trim(p2p_ctx* c)
 {
-    std::vector<p2p::YawDesc> yd(j->d.n_yaw);
-    HIP_TRY(hipMemcpyAsync(yd.data(), j->d_ydesc, yd.size() * sizeof(p2p::YawDesc), hipMemcpyDeviceToHost, j->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+    size_t total = 0;
+    for (auto& kv : c->plans) total += kv.second->bytes;
+    for (auto& kv : c->yaw_tabs) total += kv.second->bytes;
+    const size_t budget = cache_budget();
+    while (total > budget) {
+        unsigned long long best = ~0ull;
+        int which = 0;
+        std::map<PlanKey, std::shared_ptr<Plan>>::iterator bp;
+        std::map<YawKey, std::shared_ptr<YawTabs>>::iterator by;
+        for (auto it = c->plans.begin(); it != c->plans.end(); ++it)
+            if (it->second.use_count() == 1 && it->second->stamp < best) { best = it->second->stamp; bp = it; which = 1; }
+        for (auto it = c->yaw_tabs.begin(); it != c->yaw_tabs.end(); ++it)
+            if (it->second.use_count() == 1 && it->second->stamp < best) { best = it->second->stamp; by = it; which = 2; }
+        if (!which)
+            break;  // everything left is in use
+        if (which == 1) { total -= bp->second->bytes; c->plans.erase(bp); }
+        else { total -= by->second->bytes; c->yaw_tabs.erase(by); }
+    }
+}
+
+// point the job's table pointers at its (shared or private) YawTabs and list its odd pairs: every panorama x the
+// yaws with per-column weights or rows that are not a shift
+static int job_adopt_yaw_tabs(p2p_job* j, std::shared_ptr<YawTabs> yt)
+{
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream));  // nothing in flight reads the old tables or the old list
+    j->yaw_ref = std::move(yt);
+    const YawTabs& T = *j->yaw_ref;
+    j->d_ytab = T.d_ytab; j->d_f4tab = T.d_f4tab; j->d_ydesc = T.d_ydesc; j->d_yaw_rad = T.d_yaw_rad;
     j->n_odd_yaws = 0;
-    for (const auto& d : yd)
+    for (const auto& d : T.desc)
         j->n_odd_yaws += d.mode != 0;
-    // the odd-pair list: every panorama x the yaws with per-column weights or rows that are not a shift
-    HIP_TRY(hipStreamSynchronize(j->ctx->stream));  // nothing in flight reads the old list
-    (void)hipFree(j->d_odd_pairs);
+    (void)dev_free(j->d_odd_pairs);
     j->d_odd_pairs = nullptr;
     j->n_odd_pairs = 0;
     if (j->n_odd_yaws > 0) {
         std::vector<uint32_t> pairs;
         for (int p = 0; p < j->d.n_panos; ++p)
             for (int y = 0; y < j->d.n_yaw; ++y)
-                if (yd[y].mode != 0)
+                if (T.desc[y].mode != 0)
                     pairs.push_back((uint32_t)p * (uint32_t)j->d.n_yaw + (uint32_t)y);
-        HIP_TRY(hipMalloc((void**)&j->d_odd_pairs, pairs.size() * sizeof(uint32_t)));
+        HIP_TRY(dev_alloc((void**)&j->d_odd_pairs, pairs.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(j->d_odd_pairs, pairs.data(), pairs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         j->n_odd_pairs = (int)pairs.size();
     }
+    return P2P_OK;
+}
+
+// Yaw tables for a list of yaw angles (degrees) or for caller float rows: built by yaw_table_kernel /
+// yaw_pack_kernel + yaw_desc_kernel on the context's stream.  rows == nullptr: looked up in / entered into the
+// context's cache (the reference's yaw_mapping_cache, P:17, P:42-52); caller rows make private tables.
+static int yaw_tabs_get(p2p_ctx* ctx, int pw, const std::vector<double>& yaw_deg, const float* rows, float* d_rows,
+                        std::shared_ptr<YawTabs>* out)
+{
+    const int n_yaw = (int)yaw_deg.size();
+    YawKey key{pw, yaw_deg};
+    const bool cached = rows == nullptr && env_int("P2P_PLAN_CACHE", 1) != 0;
+    if (cached) {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        auto it = ctx->yaw_tabs.find(key);
+        if (it != ctx->yaw_tabs.end()) {
+            it->second->stamp = ++ctx->cache_clock;
+            *out = it->second;
+            return P2P_OK;
+        }
+    }
+    auto T = std::make_shared<YawTabs>();
+    T->device = ctx->device;
+    const size_t n = (size_t)n_yaw * pw;
+    HIP_TRY(dev_alloc((void**)&T->d_ytab, n * sizeof(uint32_t)));
+    HIP_TRY(dev_alloc((void**)&T->d_f4tab, n * sizeof(uint32_t)));
+    HIP_TRY(dev_alloc((void**)&T->d_ydesc, (size_t)n_yaw * sizeof(p2p::YawDesc)));
+    HIP_TRY(dev_alloc((void**)&T->d_yaw_rad, (size_t)n_yaw * sizeof(double)));
+    T->bytes = 2 * n * sizeof(uint32_t) + (size_t)n_yaw * (sizeof(p2p::YawDesc) + sizeof(double));
+    std::vector<double> yr(n_yaw);
+    for (int i = 0; i < n_yaw; ++i)
+        yr[i] = deg2rad(yaw_deg[i]);  // P:85
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(T->d_yaw_rad, yr.data(), yr.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(ctx->ev_t0, st));
+    if (rows) {
+        HIP_TRY(hipMemcpyAsync(d_rows, rows, n * sizeof(float), hipMemcpyHostToDevice, st));
+        HIP_TRY(p2p::launch_yaw_pack(T->d_ytab, d_rows, n, st));
+    } else {
+        HIP_TRY(p2p::launch_yaw_tables(T->d_ytab, nullptr, pw, n_yaw, T->d_yaw_rad, st));
+    }
+    HIP_TRY(p2p::launch_yaw_desc(T->d_ydesc, T->d_f4tab, T->d_ytab, pw, n_yaw, st));
+    HIP_TRY(hipEventRecord(ctx->ev_t1, st));
+    T->desc.resize(n_yaw);
+    HIP_TRY(hipMemcpyAsync(T->desc.data(), T->d_ydesc, T->desc.size() * sizeof(p2p::YawDesc), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));  // yr (and the caller's rows) are stack-lifetime host buffers
+    (void)hipEventElapsedTime(&T->tables_ms, ctx->ev_t0, ctx->ev_t1);
+    if (cached) {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        T->stamp = ++ctx->cache_clock;
+        ctx->yaw_tabs[key] = T;
+        cache_trim(ctx);
+    }
+    *out = T;
     return P2P_OK;
 }
 
@@ -445,7 +738,8 @@ static int job_create_core(p2p_ctx* ctx, const p2p_job_desc& d, const double* ya
 
     j->src_pitch = (3 * (d.pw + p2p::PANO_PAD) + 15) & ~15;  // every row is followed by a copy of its first pixels
     j->pano_stride = (((size_t)j->src_pitch * d.ph + kSlack) + 255) & ~(size_t)255;
-    j->out_bytes = (size_t)d.n_panos * d.n_yaw * d.n_pitch * d.oh * d.ow * 3;
+    j->out_row = 12 * ((d.ow + 3) / 4);  // whole 4-pixel groups: every row starts dword-aligned, whatever the width
+    j->out_bytes = (size_t)d.n_panos * d.n_yaw * d.n_pitch * d.oh * j->out_row;
 
     // scalars NumPy evaluates in float64 once per map (P:64-68, P:119, P:129-131, P:142-149)
     const double fov_rad = deg2rad(fov_deg);
@@ -460,21 +754,13 @@ static int job_create_core(p2p_ctx* ctx, const p2p_job_desc& d, const double* ya
         pc[i].c = (float)std::cos(pr);
         pc[i].s = (float)std::sin(pr);
     }
-    std::vector<double> yr(d.n_yaw);
-    for (int i = 0; i < d.n_yaw; ++i)
-        yr[i] = deg2rad(j->yaw[i]);  // P:85
 
-    hipError_t e = hipMalloc((void**)&j->d_src, j->pano_stride * d.n_panos);
+    hipError_t e = dev_alloc((void**)&j->d_src, j->pano_stride * d.n_panos);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&j->ev_up, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&j->ev_run, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&j->ev_down, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void**)&j->d_out, j->out_bytes + 16);
-    if (e == hipSuccess) e = hipMalloc((void**)&j->d_ytab, (size_t)d.n_yaw * d.pw * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&j->d_f4tab, (size_t)d.n_yaw * d.pw * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&j->d_ydesc, (size_t)d.n_yaw * sizeof(p2p::YawDesc));
-    if (e == hipSuccess) e = hipMalloc((void**)&j->d_yaw_rad, (size_t)d.n_yaw * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&j->d_pitch, (size_t)d.n_pitch * sizeof(p2p::PitchConst));
-    const bool float_path = (d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)) != 0;
+    if (e == hipSuccess) e = dev_alloc((void**)&j->d_out, j->out_bytes + 16);
+    if (e == hipSuccess) e = dev_alloc((void**)&j->d_pitch, (size_t)d.n_pitch * sizeof(p2p::PitchConst));
     j->n_tiles = (size_t)((d.ow + p2p::TILE_W - 1) / p2p::TILE_W) * ((d.oh + p2p::TILE_H - 1) / p2p::TILE_H);
     {
         const size_t slots = j->n_tiles * d.n_pitch;
@@ -482,15 +768,7 @@ static int job_create_core(p2p_ctx* ctx, const p2p_job_desc& d, const double* ya
             p2p_job_destroy(j);
             return fail(P2P_ERR_INVALID, "too many tiles (%zu): fewer pitch angles or smaller views per job", slots);
         }
-        if (float_path && e == hipSuccess)
-            e = hipMalloc((void**)&j->d_px2, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&j->d_coords, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2));
-        if (e == hipSuccess) e = hipMalloc((void**)&j->d_hdr, slots * sizeof(p2p::PieceHdr));
-        if (e == hipSuccess) e = hipMalloc((void**)&j->d_px, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&j->d_items, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&j->d_n_gather, sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&j->d_gather_list, slots * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&j->d_pitch_order, (size_t)d.n_pitch * sizeof(uint16_t));
+        if (e == hipSuccess) e = dev_alloc((void**)&j->d_pitch_order, (size_t)d.n_pitch * sizeof(uint16_t));
         // views looking further from the horizon have larger source footprints: launch them first
         std::vector<uint16_t> ord(d.n_pitch);
         for (int i = 0; i < d.n_pitch; ++i)
@@ -502,20 +780,19 @@ static int job_create_core(p2p_ctx* ctx, const p2p_job_desc& d, const double* ya
             e = hipMemcpy(j->d_pitch_order, ord.data(), ord.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess)
-        e = hipMemcpyAsync(j->d_yaw_rad, yr.data(), yr.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess)
         e = hipMemcpyAsync(j->d_pitch, pc.data(), pc.size() * sizeof(p2p::PitchConst), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
-        e = p2p::launch_yaw_tables(j->d_ytab, nullptr, d.pw, d.n_yaw, j->d_yaw_rad, ctx->stream);
-    if (e == hipSuccess)
-        e = p2p::launch_yaw_desc(j->d_ydesc, j->d_f4tab, j->d_ytab, d.pw, d.n_yaw, ctx->stream);
-    if (e == hipSuccess)
-        e = hipStreamSynchronize(ctx->stream);  // yr / pc are stack-lifetime host buffers
+        e = hipStreamSynchronize(ctx->stream);  // pc is a stack-lifetime host buffer
     if (e != hipSuccess) {
         p2p_job_destroy(j);
         return fail(e == hipErrorOutOfMemory ? P2P_ERR_OOM : P2P_ERR_HIP, "p2p_job_create: %s", hipGetErrorString(e));
     }
-    if (int rc = count_odd_yaws(j)) {
+    // the yaw tables: the context's, if it has built them for these angles before (P:42-52)
+    std::shared_ptr<YawTabs> yt;
+    int rc = yaw_tabs_get(ctx, d.pw, j->yaw, nullptr, nullptr, &yt);
+    if (rc == P2P_OK)
+        rc = job_adopt_yaw_tabs(j, yt);
+    if (rc != P2P_OK) {
         p2p_job_destroy(j);
         return rc;
     }
@@ -614,7 +891,7 @@ int p2p_job_share_panos(p2p_job* j, p2p_job* owner)
     HIP_TRY(hipSetDevice(j->ctx->device));
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));
     if (j->owns_src)
-        (void)hipFree(j->d_src);
+        (void)dev_free(j->d_src);
     j->d_src = owner->d_src;
     j->owns_src = false;
     j->src_owner = owner;
@@ -631,15 +908,11 @@ int p2p_job_set_yaws_f64(p2p_job* j, const double* yaw_deg)
             return fail(P2P_ERR_INVALID, "yaw angle %d is not finite", i);
     HIP_TRY(hipSetDevice(j->ctx->device));
     j->yaw.assign(yaw_deg, yaw_deg + d.n_yaw);
-    std::vector<double> yr(d.n_yaw);
-    for (int i = 0; i < d.n_yaw; ++i)
-        yr[i] = deg2rad(j->yaw[i]);  // P:85
-    HIP_TRY(hipMemcpyAsync(j->d_yaw_rad, yr.data(), yr.size() * sizeof(double), hipMemcpyHostToDevice, j->ctx->stream));
-    HIP_TRY(p2p::launch_yaw_tables(j->d_ytab, nullptr, d.pw, d.n_yaw, j->d_yaw_rad, j->ctx->stream));
-    HIP_TRY(p2p::launch_yaw_desc(j->d_ydesc, j->d_f4tab, j->d_ytab, d.pw, d.n_yaw, j->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(j->ctx->stream));  // yr is a stack-lifetime host buffer
+    std::shared_ptr<YawTabs> yt;
+    if (int rc = yaw_tabs_get(j->ctx, d.pw, j->yaw, nullptr, nullptr, &yt))
+        return rc;
     j->rows_from_host = false;
-    return count_odd_yaws(j);
+    return job_adopt_yaw_tabs(j, yt);
 }
 
 int p2p_job_set_yaws(p2p_job* j, const int32_t* yaw_deg)
@@ -665,22 +938,24 @@ int p2p_job_set_maps(p2p_job* j, const float* yaw_rows, const float* U, const fl
             if (!(yaw_rows[k] >= 0.0f && yaw_rows[k] <= (float)(d.pw - 1)))
                 return fail(P2P_ERR_INVALID, "yaw_rows[%zu] = %g outside [0, pw-1] (P:105 clips it)", k, (double)yaw_rows[k]);
     }
-    if (!j->d_mapU) HIP_TRY(hipMalloc((void**)&j->d_mapU, n_map * sizeof(float)));
-    if (!j->d_mapV) HIP_TRY(hipMalloc((void**)&j->d_mapV, n_map * sizeof(float)));
-    j->planned = false;  // the plan follows the maps (also when a later step of this call fails)
+    if (!j->d_mapU) HIP_TRY(dev_alloc((void**)&j->d_mapU, n_map * sizeof(float)));
+    if (!j->d_mapV) HIP_TRY(dev_alloc((void**)&j->d_mapV, n_map * sizeof(float)));
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream));  // no launch in flight reads the plan that is about to go
+    j->plan_ref.reset();  // the plan follows the maps (also when a later step of this call fails): a private one is built
     HIP_TRY(hipMemcpyAsync(j->d_mapU, U, n_map * sizeof(float), hipMemcpyHostToDevice, j->ctx->stream));
     HIP_TRY(hipMemcpyAsync(j->d_mapV, V, n_map * sizeof(float), hipMemcpyHostToDevice, j->ctx->stream));
-    if (yaw_rows) {
-        const size_t n = (size_t)d.n_yaw * d.pw;
-        if (!j->d_rows) HIP_TRY(hipMalloc((void**)&j->d_rows, n * sizeof(float)));
-        HIP_TRY(hipMemcpyAsync(j->d_rows, yaw_rows, n * sizeof(float), hipMemcpyHostToDevice, j->ctx->stream));
-        HIP_TRY(p2p::launch_yaw_pack(j->d_ytab, j->d_rows, n, j->ctx->stream));
-        j->rows_from_host = true;
-        HIP_TRY(p2p::launch_yaw_desc(j->d_ydesc, j->d_f4tab, j->d_ytab, d.pw, d.n_yaw, j->ctx->stream));
-    }
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));
     j->host_maps = true;
-    return yaw_rows ? count_odd_yaws(j) : P2P_OK;
+    if (yaw_rows) {
+        const size_t n = (size_t)d.n_yaw * d.pw;
+        if (!j->d_rows) HIP_TRY(dev_alloc((void**)&j->d_rows, n * sizeof(float)));
+        std::shared_ptr<YawTabs> yt;  // private tables: caller rows have no key
+        if (int rc = yaw_tabs_get(j->ctx, d.pw, j->yaw, yaw_rows, j->d_rows, &yt))
+            return rc;
+        j->rows_from_host = true;
+        return job_adopt_yaw_tabs(j, yt);
+    }
+    return P2P_OK;
 }
 
 // Build the job's plan (p2p_plan.hip) for its current maps: once per job geometry, like the yaw tables.  It
@@ -689,47 +964,85 @@ int p2p_job_set_maps(p2p_job* j, const float* yaw_rows, const float* U, const fl
 static int job_build_plan(p2p_job* j)
 {
     const p2p_job_desc& d = j->d;
-    hipStream_t st = j->ctx->stream;
+    p2p_ctx* ctx = j->ctx;
+    hipStream_t st = ctx->stream;
+    const bool float_path = (d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)) != 0;
+    const size_t slots = j->n_tiles * d.n_pitch;
+    // device maps: the plan is a function of the key alone -- the context may have it already
+    PlanKey key{d.pw, d.ph, d.ow, d.oh, d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16 | P2P_FLAG_PIXEL_CENTRES), j->border,
+                j->fov, j->pitch};
+    const bool cached = !j->host_maps && env_int("P2P_PLAN_CACHE", 1) != 0;
+    if (cached) {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        auto it = ctx->plans.find(key);
+        if (it != ctx->plans.end() && it->second->built) {
+            it->second->stamp = ++ctx->cache_clock;
+            j->plan_ref = it->second;
+            return P2P_OK;
+        }
+    }
+    auto Pl = std::make_shared<Plan>();
+    Pl->device = ctx->device;
+    if (float_path)
+        HIP_TRY(dev_alloc((void**)&Pl->d_px2, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t)));
+    HIP_TRY(dev_alloc((void**)&Pl->d_coords, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2)));
+    HIP_TRY(dev_alloc((void**)&Pl->d_hdr, slots * sizeof(p2p::PieceHdr)));
+    HIP_TRY(dev_alloc((void**)&Pl->d_px, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t)));
+    HIP_TRY(dev_alloc((void**)&Pl->d_items, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t)));
+    HIP_TRY(dev_alloc((void**)&Pl->d_n_gather, sizeof(uint32_t)));
+    HIP_TRY(dev_alloc((void**)&Pl->d_gather_list, slots * sizeof(uint32_t)));
+    Pl->bytes = (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2) +
+                slots * (sizeof(p2p::PieceHdr) + (256 * p2p::VIEWS_PXT * (float_path ? 2 : 1) + p2p::LDS_ITEMS_CAP + 1) * sizeof(uint32_t));
     p2p::PlanParams Q{};
     Q.pw = d.pw; Q.ph = d.ph; Q.ow = d.ow; Q.oh = d.oh; Q.n_pitch = d.n_pitch; Q.border = j->border;
     Q.geom = j->geom;
     Q.pitch = j->d_pitch;
     Q.mapU = j->host_maps ? j->d_mapU : nullptr;
     Q.mapV = j->host_maps ? j->d_mapV : nullptr;
-    Q.coords = j->d_coords;
-    Q.hdr = j->d_hdr;
-    Q.px = j->d_px;
-    Q.items = j->d_items;
-    Q.n_gather = j->d_n_gather;
-    Q.gather_list = j->d_gather_list;
-    Q.float_path = (d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)) != 0;
+    Q.coords = Pl->d_coords;
+    Q.hdr = Pl->d_hdr;
+    Q.px = Pl->d_px;
+    Q.items = Pl->d_items;
+    Q.n_gather = Pl->d_n_gather;
+    Q.gather_list = Pl->d_gather_list;
+    Q.float_path = float_path;
     Q.centre = (d.flags & P2P_FLAG_PIXEL_CENTRES) ? 0.5f : 0.0f;
-    Q.px2 = j->d_px2;
+    Q.px2 = Pl->d_px2;
 #ifdef P2P_AUDIT
     {
         // every pool poisoned: a kernel that reads a slot the plan pass did not write gets 0xFF.. and the audit sees it
-        const size_t slots = j->n_tiles * d.n_pitch;
-        HIP_TRY(hipMemsetAsync(j->d_hdr, 0xFF, slots * sizeof(p2p::PieceHdr), st));
-        HIP_TRY(hipMemsetAsync(j->d_px, 0xFF, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(j->d_items, 0xFF, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(j->d_gather_list, 0xFF, slots * sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(j->d_coords, 0xFF, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2), st));
-        if (j->d_px2)
-            HIP_TRY(hipMemsetAsync(j->d_px2, 0xFF, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(Pl->d_hdr, 0xFF, slots * sizeof(p2p::PieceHdr), st));
+        HIP_TRY(hipMemsetAsync(Pl->d_px, 0xFF, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(Pl->d_items, 0xFF, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(Pl->d_gather_list, 0xFF, slots * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(Pl->d_coords, 0xFF, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2), st));
+        if (Pl->d_px2)
+            HIP_TRY(hipMemsetAsync(Pl->d_px2, 0xFF, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t), st));
     }
 #endif
     // (the plan pass writes every header, every per-pixel word and every item slot of every tile: nothing to clear)
-    HIP_TRY(hipMemsetAsync(j->d_n_gather, 0, sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(Pl->d_n_gather, 0, sizeof(uint32_t), st));
+    HIP_TRY(hipEventRecord(ctx->ev_t0, st));
     HIP_TRY(p2p::launch_plan(Q, st));
+    HIP_TRY(hipEventRecord(ctx->ev_t1, st));
     uint32_t cnt = 0;
-    HIP_TRY(hipMemcpyAsync(&cnt, j->d_n_gather, sizeof(cnt), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&cnt, Pl->d_n_gather, sizeof(cnt), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if ((size_t)cnt > j->n_tiles * d.n_pitch)
-        return fail(P2P_ERR_HIP, "the plan pass listed %u gather tiles of %zu", cnt, j->n_tiles * d.n_pitch);
-    j->n_gather = (int)cnt;
-    j->planned = true;
+    (void)hipEventElapsedTime(&Pl->plan_ms, ctx->ev_t0, ctx->ev_t1);
+    if ((size_t)cnt > slots)
+        return fail(P2P_ERR_HIP, "the plan pass listed %u gather tiles of %zu", cnt, slots);
+    Pl->n_gather = (int)cnt;
+    Pl->built = true;
     if (env_int("P2P_VERBOSE", 0))
-        fprintf(stderr, "p2p plan: %u of %zu tiles gather (%dx%d views, %d pitches)\n", cnt, j->n_tiles * d.n_pitch, d.ow, d.oh, d.n_pitch);
+        fprintf(stderr, "p2p plan: %u of %zu tiles gather (%dx%d views, %d pitches), %.1f us\n", cnt, slots, d.ow, d.oh, d.n_pitch,
+                Pl->plan_ms * 1e3);
+    if (cached) {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        Pl->stamp = ++ctx->cache_clock;
+        ctx->plans[key] = Pl;
+        cache_trim(ctx);
+    }
+    j->plan_ref = Pl;
     return P2P_OK;
 }
 
@@ -788,6 +1101,8 @@ int p2p_job_run(p2p_job* j)
     P.geom = j->geom;
     P.audit = j->ctx->d_audit;
     P.ow = j->d.ow;
+    P.out_row = j->out_row;
+    P.view_bytes = (size_t)j->d.oh * j->out_row;
     P.oh = j->d.oh;
     P.out = j->d_out;
     P.border = j->border;
@@ -801,10 +1116,15 @@ int p2p_job_run(p2p_job* j)
     const bool float_path = (j->d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)) != 0;
     if (float_path && j->host_maps)
         return fail(P2P_ERR_STATE, "the float pixel path evaluates its own maps; caller maps are not supported");
-    if (!j->planned) {
+    if (!j->plan_ref) {
         int rc = job_build_plan(j);
         if (rc != P2P_OK)
             return rc;
+    }
+    {   // the job's view of its plan
+        const Plan& Pl = *j->plan_ref;
+        j->d_coords = Pl.d_coords; j->d_hdr = Pl.d_hdr; j->d_px = Pl.d_px; j->d_items = Pl.d_items; j->d_px2 = Pl.d_px2;
+        j->d_gather_list = Pl.d_gather_list; j->n_gather = Pl.n_gather;
     }
     P.pairs_per_block = choose_pairs_per_block(j->d);
     P.pitch_order = j->d_pitch_order;
@@ -816,8 +1136,8 @@ int p2p_job_run(p2p_job* j)
     P.n_gather = j->n_gather;
     // With view rows of whole dwords the main and the gather kernel draw every plain-shift yaw, and the rest / table
     // kernels only the listed odd pairs (up to 16 per workgroup: one set-up for all of them); otherwise those two draw all
-    const bool fast_width = (j->d.ow & 3) == 0 && env_int("P2P_FORCE_REST", 0) == 0;
-    const bool gather_ok = fast_width && j->border == 0;  // the gather kernel: BORDER_CONSTANT 0, 12-byte stores
+    const bool fast_width = env_int("P2P_FORCE_REST", 0) == 0;  // (diagnosis: 1 = everything through the general loops)
+    const bool gather_ok = fast_width && j->border == 0;  // the gather kernel: BORDER_CONSTANT 0
     P.odd_pairs = j->d_odd_pairs;
     P.n_odd_pairs = j->n_odd_pairs;
     P.rest_ppb = std::min(16, std::max(1, j->n_odd_pairs));
@@ -905,6 +1225,17 @@ int p2p_job_run(p2p_job* j)
     return P2P_OK;
 }
 
+int p2p_job_plan_ms(p2p_job* j, float* plan_ms, float* tables_ms)
+{
+    if (!j || !plan_ms || !tables_ms)
+        return fail(P2P_ERR_INVALID, "NULL argument");
+    if (!j->plan_ref || !j->yaw_ref)
+        return fail(P2P_ERR_STATE, "p2p_job_run has not been called");
+    *plan_ms = j->plan_ref->plan_ms;
+    *tables_ms = j->yaw_ref->tables_ms;
+    return P2P_OK;
+}
+
 int p2p_job_time_launches(p2p_job* j, int on)
 {
     if (!j)
@@ -975,7 +1306,18 @@ int p2p_job_get_views_async(p2p_job* j, int index, uint8_t* out)
     if (int rc = mark_run(j))
         return rc;
     HIP_TRY(hipStreamWaitEvent(j->ctx->stream_down, j->ev_run, 0));
-    HIP_TRY(hipMemcpyAsync(out, j->d_out + per * index, per, hipMemcpyDeviceToHost, j->ctx->stream_down));
+    const size_t row = (size_t)3 * j->d.ow;
+    if ((size_t)j->out_row == row) {
+        HIP_TRY(hipMemcpyAsync(out, j->d_out + per * index, per, hipMemcpyDeviceToHost, j->ctx->stream_down));
+    } else {
+        // device rows are padded to whole 4-pixel groups, the caller's array is not: packed on the device (a row-wise
+        // DMA copy costs microseconds per row), then one copy
+        const size_t rows = (size_t)j->d.n_yaw * j->d.n_pitch * j->d.oh, packed = rows * row;
+        if (!j->d_pack)
+            HIP_TRY(dev_alloc((void**)&j->d_pack, (packed + 3) & ~(size_t)3));
+        HIP_TRY(p2p::launch_compact_rows(j->d_pack, j->d_out + per * index, packed, (int)row, j->out_row, j->ctx->stream_down));
+        HIP_TRY(hipMemcpyAsync(out, j->d_pack, packed, hipMemcpyDeviceToHost, j->ctx->stream_down));
+    }
     HIP_TRY(hipEventRecord(j->ev_down, j->ctx->stream_down));
     j->down_pending = true;
     return P2P_OK;
@@ -1084,7 +1426,7 @@ int p2p_release_cache(void)
                 if (s->ctx) {
                     (void)hipSetDevice(s->device);
                     for (int i = 0; i < 4; ++i) {
-                        (void)hipFree(s->ctx->scratch[i]);
+                        (void)dev_free(s->ctx->scratch[i]);
                         s->ctx->scratch[i] = nullptr;
                         s->ctx->scratch_bytes[i] = 0;
                     }
@@ -1093,6 +1435,7 @@ int p2p_release_cache(void)
     }
     for (p2p_job* j : victims)
         p2p_job_destroy(j);
+    dev_pool_trim();
     return P2P_OK;
 }
 
@@ -1274,17 +1617,18 @@ int p2p_remap_maps_interp_u8(const uint8_t* src, int sw, int sh, int64_t row_str
     hipError_t e = hipSuccess;
     auto scratch = [&](int i, size_t bytes) -> void* {
         if (e == hipSuccess && ctx->scratch_bytes[i] < bytes) {
-            (void)hipFree(ctx->scratch[i]);
+            (void)hipStreamSynchronize(ctx->stream);  // an earlier call that failed half-way may have left work in flight
+            (void)dev_free(ctx->scratch[i]);
             ctx->scratch[i] = nullptr;
             ctx->scratch_bytes[i] = 0;
-            e = hipMalloc(&ctx->scratch[i], bytes);
+            e = dev_alloc(&ctx->scratch[i], bytes);
             if (e == hipSuccess)
                 ctx->scratch_bytes[i] = bytes;
         }
         return ctx->scratch[i];
     };
     if (interpolation == P2P_INTER_CUBIC && !ctx->d_ctab) {
-        e = hipMalloc((void**)&ctx->d_ctab, 1024 * 16 * sizeof(short));
+        e = dev_alloc((void**)&ctx->d_ctab, 1024 * 16 * sizeof(short));
         if (e == hipSuccess) e = p2p::launch_cubic_tab(ctx->d_ctab, ctx->stream);
     }
     uint8_t* d_src = (uint8_t*)scratch(0, (size_t)pitch * sh + kSlack);
@@ -1332,14 +1676,14 @@ int p2p_build_pitch_map(int ow, int oh, double fov_rad, double pitch_rad, int pw
     const double pr = pitch_rad;
     const size_t n = (size_t)ow * oh;
     float *dU = nullptr, *dV = nullptr;
-    hipError_t e = hipMalloc((void**)&dU, n * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&dV, n * sizeof(float));
+    hipError_t e = dev_alloc((void**)&dU, n * sizeof(float));
+    if (e == hipSuccess) e = dev_alloc((void**)&dV, n * sizeof(float));
     if (e == hipSuccess) e = p2p::launch_pitch_map(dU, dV, ow, oh, g, (float)std::cos(pr), (float)std::sin(pr), ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(U, dU, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(V, dV, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(dU);
-    (void)hipFree(dV);
+    (void)dev_free(dU);
+    (void)dev_free(dV);
     if (e != hipSuccess)
         return fail(e == hipErrorOutOfMemory ? P2P_ERR_OOM : P2P_ERR_HIP, "p2p_build_pitch_map: %s", hipGetErrorString(e));
     return P2P_OK;
@@ -1365,14 +1709,14 @@ int p2p_build_rot_map(int ow, int oh, double fov_rad, const float* R9, int pw, i
     g.ph_f = (float)ph;
     const size_t n = (size_t)ow * oh;
     float *dU = nullptr, *dV = nullptr;
-    hipError_t e = hipMalloc((void**)&dU, n * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&dV, n * sizeof(float));
+    hipError_t e = dev_alloc((void**)&dU, n * sizeof(float));
+    if (e == hipSuccess) e = dev_alloc((void**)&dV, n * sizeof(float));
     if (e == hipSuccess) e = p2p::launch_rot_map(dU, dV, ow, oh, g, R9, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(U, dU, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(V, dV, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(dU);
-    (void)hipFree(dV);
+    (void)dev_free(dU);
+    (void)dev_free(dV);
     if (e != hipSuccess)
         return fail(e == hipErrorOutOfMemory ? P2P_ERR_OOM : P2P_ERR_HIP, "p2p_build_rot_map: %s", hipGetErrorString(e));
     return P2P_OK;
@@ -1392,14 +1736,14 @@ int p2p_build_yaw_row(int pw, double yaw_rad, float* U_row, int device)
     const double yr = yaw_rad;  // np.radians(yaw_angle), P:85
     double* d_yr = nullptr;
     float* d_row = nullptr;
-    hipError_t e = hipMalloc((void**)&d_yr, sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_row, (size_t)pw * sizeof(float));
+    hipError_t e = dev_alloc((void**)&d_yr, sizeof(double));
+    if (e == hipSuccess) e = dev_alloc((void**)&d_row, (size_t)pw * sizeof(float));
     if (e == hipSuccess) e = hipMemcpyAsync(d_yr, &yr, sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = p2p::launch_yaw_tables(nullptr, d_row, pw, 1, d_yr, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(U_row, d_row, (size_t)pw * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_yr);
-    (void)hipFree(d_row);
+    (void)dev_free(d_yr);
+    (void)dev_free(d_row);
     if (e != hipSuccess)
         return fail(e == hipErrorOutOfMemory ? P2P_ERR_OOM : P2P_ERR_HIP, "p2p_build_yaw_row: %s", hipGetErrorString(e));
     return P2P_OK;

@@ -217,8 +217,43 @@ __global__ void rot_map_kernel(float* __restrict__ U, float* __restrict__ V, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// Views whose width is not divisible by 4 have device rows padded to whole 4-pixel groups (ViewsParams::out_row);
+// the caller's array is contiguous.  One dword of the contiguous image per thread, its four bytes fetched from
+// the padded rows (a row-wise DMA copy instead costs microseconds per row).
+// ---------------------------------------------------------------------------------------------
+__global__ void compact_rows_kernel(uint32_t* __restrict__ dst, const uint8_t* __restrict__ src, size_t n_bytes,
+                                    uint32_t row_bytes, uint32_t src_row)
+{
+    const size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t b0 = 4 * d;
+    if (b0 >= n_bytes)
+        return;
+    size_t r = b0 / row_bytes;
+    uint32_t c = (uint32_t)(b0 - r * row_bytes);
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (b0 + k < n_bytes)
+            w |= (uint32_t)src[r * src_row + c] << (8 * k);
+        if (++c == row_bytes) {
+            c = 0;
+            ++r;
+        }
+    }
+    dst[d] = w;  // (the staging buffer holds whole dwords)
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers (called from p2p_host.cpp through p2p_device.h)
 // ---------------------------------------------------------------------------------------------
+hipError_t launch_compact_rows(void* dst, const uint8_t* src, size_t n_bytes, int row_bytes, int src_row, hipStream_t st)
+{
+    const size_t n = (n_bytes + 3) / 4;
+    hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (uint32_t*)dst, src, n_bytes,
+                       (uint32_t)row_bytes, (uint32_t)src_row);
+    return hipGetLastError();
+}
+
 hipError_t launch_yaw_tables(uint32_t* packed, float* rows, int pw, int n_yaw, const double* yaw_rad,
                              hipStream_t st)
 {

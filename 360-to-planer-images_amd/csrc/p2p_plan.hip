@@ -159,9 +159,9 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
     const int nrow = any_live ? r1 - r0 + 2 : 0;
     // The LDS scheme needs the whole footprint strictly inside the panorama (no tap is a border tap) and a
     // panorama width divisible by 4 (12-byte items never straddle a row end).
-    // (float path: taps reach one column further, and its stores need view rows of whole dwords)
+    // (float path: taps reach one column further)
     bool ok = any_live && !stray && (P.pw & 3) == 0 && c0 >= 0 && r0 >= 0 && c1 + 1 + P.float_path < P.pw &&
-              r1 + 1 < P.ph && nrow <= PLAN_MAX_ROWS && !(P.float_path && (P.ow & 3) != 0);
+              r1 + 1 < P.ph && nrow <= PLAN_MAX_ROWS;
     uint32_t n_items = 0;
     if (ok) {
         // ---- per rot row: the span of columns the taps read ----

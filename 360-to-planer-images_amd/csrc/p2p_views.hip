@@ -158,13 +158,14 @@ __device__ __forceinline__ uint32_t blend4_packed(uint32_t a, uint32_t b, uint32
 // Four kernels share this arithmetic:
 //   remap_views_kernel         mode 1 tiles x yaws that are plain shifts -- nothing but three branch-free loops
 //                              (copy / blend / blend with the clipped column patched), no spills;
-//   remap_views_gather_kernel  mode 2 tiles x yaws that are plain shifts, BORDER_CONSTANT, view rows of whole dwords
+//   remap_views_gather_kernel  mode 2 tiles x yaws that are plain shifts, BORDER_CONSTANT
 //                              -- three branch-free loops again (copy / blend / seam inside the tile);
-//   remap_views_rest_kernel    mode 1 tiles, the general LDS loop with its case distinctions: yaws with per-column
-//                              weights, yaw rows that are not a shift (gathered per pixel), byte stores for view
-//                              widths not divisible by 4.  With view rows of whole dwords only the job's odd pairs;
+//   remap_views_rest_kernel    mode 1 tiles x the job's odd pairs, the general LDS loop with its case distinctions:
+//                              yaws with per-column weights, yaw rows that are not a shift (gathered per pixel);
 //   remap_views_table_kernel   mode 2 tiles through the packed yaw table and cv::borderInterpolate: every pair when
-//                              the gather kernel does not apply (other border modes, odd widths), else the odd pairs.
+//                              the gather kernel does not apply (the legacy tool's border modes), else the odd pairs.
+// Device view rows are padded to whole 4-pixel groups (ViewsParams::out_row), so every lane's 12 bytes are
+// dword-aligned for any view width; the host copies rows out.
 // The kernels write disjoint pixels; all but the first are launched (same stream, before it) only when the plan or
 // the yaw tables have something for them.
 //
@@ -174,10 +175,10 @@ __device__ __forceinline__ uint32_t blend4_packed(uint32_t a, uint32_t b, uint32
 // a store outside its buffer (p2p_audit.h; the -DP2P_AUDIT build records every such event).
 // ---------------------------------------------------------------------------------------------
 
-// the tiles the main kernel draws: LDS scheme, view rows of whole dwords (its stores are 12 bytes = 4 pixels)
+// the tiles the main kernel draws: LDS scheme (device view rows are whole 12-byte groups for every width: ViewsParams::out_row)
 __device__ __forceinline__ bool tight_tile(const TileGeo& g, const ViewsParams& P)
 {
-    return g.mode == 1 && (P.ow & 3) == 0;
+    return g.mode == 1;
 }
 
 // ---- per-pair contexts: lane k of every wave works out pair pair0 + k once; the loops read them back with
@@ -306,7 +307,7 @@ __device__ __forceinline__ StoreCtx store_ctx(const ViewsParams& P, const TileGe
     const int x4 = 4 * (s.ln & 15), sj = s.ln >> 4;  // the group's first pixel as a lane of this wave; which of the thread's pixels
     const int srow = ((wv * 64 + x4) >> TILE_LW) + sj * TILE_ROWSTEP, scol = x4 & (TILE_W - 1);
     const bool s_ok = sj < VIEWS_PXT && srow < TILE_H && G.y0 + srow < P.oh && G.x0 + scol < P.ow;
-    s.out_off12 = s_ok ? (uint32_t)(((size_t)(G.y0 + srow) * P.ow + G.x0 + scol) * 3) : 0xFFFFFFFFu;
+    s.out_off12 = s_ok ? (uint32_t)(G.y0 + srow) * (uint32_t)P.out_row + 3u * (uint32_t)(G.x0 + scol) : 0xFFFFFFFFu;
     s.stg_rd = (uint32_t)(sj * 64 + x4);
     return s;
 }
@@ -368,7 +369,7 @@ __device__ __forceinline__ void draw_tight(
     uint32_t slot_off[VIEWS_SLOTS], slot_g[VIEWS_SLOTS];
     decode_items(itw, t, G.n_items, P.src_pitch, slot_off, slot_g);
     const uint32_t row_bytes = 3u * (uint32_t)P.pw;
-    const size_t view_bytes = (size_t)P.oh * P.ow * 3;
+    const size_t view_bytes = P.view_bytes;
     const StoreCtx SC = store_ctx(P, G, stage, t);
 
     const int wave_base = __builtin_amdgcn_readfirstlane(t & ~63);
@@ -382,18 +383,30 @@ __device__ __forceinline__ void draw_tight(
 
     uint32_t buf_bytes = 0u;
     Q16 qc[VIEWS_SLOTS], qn[VIEWS_SLOTS];
-    auto load_pieces = [&](auto ns_c, int k, Q16 (&qq)[VIEWS_SLOTS]) {
+    // the context words of the pair being drawn, as scalars: read from their lane once, when the pair's pieces are
+    // requested (one pair ahead), and handed on -- three v_readlane_b32 per pair instead of six
+    struct PairWords { uint32_t w0, w1; int w3; };
+    auto pair_words = [&](int k) {
+        PairWords w;
+        w.w0 = (uint32_t)__builtin_amdgcn_readlane((int)X.cw0, k);
+        w.w1 = (uint32_t)__builtin_amdgcn_readlane((int)X.cw1, k);
+        w.w3 = __builtin_amdgcn_readlane(X.cw3, k);
+        return w;
+    };
+    PairWords pwc = pair_words(0);
+    auto load_pieces = [&](auto ns_c, const PairWords& W, Q16 (&qq)[VIEWS_SLOTS]) {
         constexpr int NS = decltype(ns_c)::value;
-        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)X.cw0, k);
-        const uint32_t wrap_g = (uint32_t)__builtin_amdgcn_readlane((int)X.cw1, k) & 0xFFFFu;
+        const uint32_t w0 = W.w0;
+        const uint32_t wrap_g = W.w1 & 0xFFFFu;
         // one descriptor per panorama: an item word that points outside it loads zeros instead of faulting
-        const auto S = make_buf(src + (size_t)(__builtin_amdgcn_readlane(X.cw3, k) & 0x3FFFFFF) * P.pano_stride,
-                                (uint32_t)P.pano_stride);
+        const auto S = make_buf(src + (size_t)(W.w3 & 0x3FFFFFF) * P.pano_stride, (uint32_t)P.pano_stride);
         const uint32_t goff = w0 & 0xFFFFFu;
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
             uint32_t off = slot_off[sl] + goff;
+#ifndef P2P_ABLATE_WRAP  // (timing experiment: what rows padded with a copy of their first columns would save)
             off = slot_g[sl] >= wrap_g ? off - row_bytes : off;  // items past the end of the row continue at its start
+#endif
 #ifdef P2P_ABLATE_LOADS2
             off &= 0x3FFFu;  // timing experiment (wrong pixels): every load issued, all of them hits in 16 KB
 #endif
@@ -403,11 +416,11 @@ __device__ __forceinline__ void draw_tight(
         }
     };
     // MODE 0: copy, 1: blend, 2: blend, and the rot pixel whose source column is pw - 1 (P:105's clip) is a copy
-    auto stage1 = [&](auto ns_c, auto mode_c, int k, const Q16 (&qq)[VIEWS_SLOTS], uint4* tl4) {
+    auto stage1 = [&](auto ns_c, auto mode_c, const PairWords& W, const Q16 (&qq)[VIEWS_SLOTS], uint4* tl4) {
         constexpr int NS = decltype(ns_c)::value;
         constexpr int MODE = decltype(mode_c)::value;
-        const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)X.cw0, k) >> 24;
-        const uint32_t last_g = ((uint32_t)__builtin_amdgcn_readlane((int)X.cw1, k) & 0xFFFFu) - 1u;
+        const uint32_t f = W.w0 >> 24;
+        const uint32_t last_g = (W.w1 & 0xFFFFu) - 1u;
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
             // the piece holds source pixels 0..4 at byte offsets 0, 3, 6, 9, 12; one v_perm_b32
@@ -459,9 +472,9 @@ __device__ __forceinline__ void draw_tight(
     auto one_pair = [&](auto ns_c, auto mode_c, int k, const Q16 (&cur)[VIEWS_SLOTS], Q16 (&nxt)[VIEWS_SLOTS]) {
         {
             uint4* tl4 = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(&tile4[0][0]) + buf_bytes);
-            stage1(ns_c, mode_c, k, cur, tl4);
+            stage1(ns_c, mode_c, pwc, cur, tl4);
             // LDS position of rot column c0 within its row's first item: 0..3, from the yaw's shift
-            uint32_t soff = buf_bytes + 4u * (((uint32_t)__builtin_amdgcn_readlane((int)X.cw0, k) >> 20) & 3u);
+            uint32_t soff = buf_bytes + 4u * ((pwc.w0 >> 20) & 3u);
             asm volatile("" : "+s"(soff));  // one scalar: keeps the buffer base out of separate vector adds
 #ifndef P2P_ABLATE_BARRIER
             __syncthreads();
@@ -479,11 +492,10 @@ __device__ __forceinline__ void draw_tight(
             }
             // the next pair's pieces (the last pair asks for its own again: no branch on the memory path); asking
             // for them a whole pair earlier, before stage 1, changes nothing (92.9 vs 93.0 us): not latency-bound
-            const int kn = k + 1 < nplain ? k + 1 : k;
+            const PairWords pwn = pair_words(k + 1 < nplain ? k + 1 : k);
 #ifndef P2P_ABLATE_LOADS
-            load_pieces(ns_c, kn, nxt);
+            load_pieces(ns_c, pwn, nxt);
 #else
-            (void)kn;
 #pragma unroll
             for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
                 nxt[sl] = cur[sl];
@@ -492,12 +504,13 @@ __device__ __forceinline__ void draw_tight(
 #pragma unroll
             for (int j = 0; j < PXT; ++j)
                 pix[j] = blend4_packed(ta[j][0], ta[j][1], ta[j][2], ta[j][3], tw[j]);
-            const int pair = X.pair0 + (int)((uint32_t)__builtin_amdgcn_readlane(X.cw3, k) >> 26);
+            const int pair = X.pair0 + (int)((uint32_t)pwc.w3 >> 26);
 #ifdef P2P_ABLATE_STORES
             if (pix[0] == 0x12345678u && pix[PXT - 1] == 0x9ABCDEF0u)
 #endif
             store_wave_pixels(SC, pix, out + ((size_t)pair * P.n_pitch + G.pitch_i) * view_bytes, view_bytes);  // [pano][yaw][pitch][oh][ow][3]
             buf_bytes ^= (uint32_t)sizeof(tile4[0]);
+            pwc = pwn;
         }
     };
     // the pieces ping-pong between two register sets (pairs two at a time), so nothing is copied per pair
@@ -515,7 +528,7 @@ __device__ __forceinline__ void draw_tight(
         }
     };
     auto run_ns = [&](auto ns_c) {
-        load_pieces(ns_c, 0, qc);
+        load_pieces(ns_c, pwc, qc);
         // Inside the loops the pieces of pair k + 1 are followed by the store of pair k, so "pieces landed" is
         // vmcnt(1).  Entering the first loop straight after the first loads the compiler would have to assume
         // vmcnt(0) for both paths.  One store that writes nothing (a buffer store through a descriptor of zero
@@ -572,8 +585,9 @@ __device__ __forceinline__ void draw_gather(
     // the rot columns this tile taps, as the plan's header has them -- validated: everything below stays inside a
     // panorama for any header
     const int last_col = P.pw - 1;
-    P2P_AUD_LT(P.audit, AUD_GATHER_BOX, G.c1 < G.c0 ? 0 : G.c0, P.pw);
-    P2P_AUD_LT(P.audit, AUD_GATHER_BOX, G.c1 < G.c0 ? 0 : G.c1, P.pw);
+    // (a live pixel's left tap may sit one column outside: -1 is a legal c0)
+    P2P_AUD_LT(P.audit, AUD_GATHER_BOX, G.c1 < G.c0 ? 0 : G.c0 + 1, P.pw + 1);
+    P2P_AUD_LT(P.audit, AUD_GATHER_BOX, G.c1 < G.c0 ? 0 : G.c1 + 1, P.pw + 1);
     const int c0v = G.c0 < 0 ? 0 : (G.c0 > last_col ? last_col : G.c0);
     const int c1v = G.c1 < c0v ? c0v : (G.c1 > last_col ? last_col : G.c1);
 
@@ -646,7 +660,7 @@ __device__ __forceinline__ void draw_gather(
         off_up[j] = (uint32_t)yu * (uint32_t)P.src_pitch + 3u * (uint32_t)x;
         d_lo[j] = (uint32_t)(yl - yu) * (uint32_t)P.src_pitch;
     }
-    const size_t view_bytes = (size_t)P.oh * P.ow * 3;
+    const size_t view_bytes = P.view_bytes;
     const StoreCtx SC = store_ctx(P, G, stage, t);
     const uint32_t row_bytes = 3u * (uint32_t)P.pw;
     uint32_t bias_br = 0x00800080u;
@@ -783,17 +797,19 @@ __device__ __forceinline__ void draw_rest(
     const int t = threadIdx.x;
     const bool main_draws_plain = tight_tile(G, P);
     const int px = G.x0 + G.col, py0 = G.y0 + G.row0;
-    bool inside[PXT];
+    bool inside[PXT], inside4[PXT];  // the pixel is in the view; its 4-pixel group starts in the view
 #pragma unroll
-    for (int j = 0; j < PXT; ++j)
-        inside[j] = G.row0 + j * TILE_ROWSTEP < TILE_H && px < P.ow && py0 + j * TILE_ROWSTEP < P.oh;
+    for (int j = 0; j < PXT; ++j) {
+        const bool row_ok = G.row0 + j * TILE_ROWSTEP < TILE_H && py0 + j * TILE_ROWSTEP < P.oh;
+        inside[j] = row_ok && px < P.ow;
+        inside4[j] = row_ok && (px & ~3) < P.ow;
+    }
 
     // output addressing: 4 horizontally adjacent pixels = 12 bytes = 3 aligned dwords
     const int lane4 = t & 3;
-    const bool fast_store = (P.ow & 3) == 0;
-    const size_t view_bytes = (size_t)P.oh * P.ow * 3;
-    const uint32_t pix_off = (uint32_t)(((size_t)py0 * P.ow + px) * 3);  // < 3 * 32766^2 < 2^32
-    const uint32_t pix_step = (uint32_t)TILE_ROWSTEP * (uint32_t)P.ow * 3u;
+    const size_t view_bytes = P.view_bytes;
+    const uint32_t pix_off = (uint32_t)py0 * (uint32_t)P.out_row + 3u * (uint32_t)px;  // < 3 * 32768^2 < 2^32
+    const uint32_t pix_step = (uint32_t)TILE_ROWSTEP * (uint32_t)P.out_row;
     // dword lane4 of the 12 bytes P0 P1 P2 P3: bytes of the own pixel (0-2) and of the next lane's (4-6)
     const uint32_t store_sel = lane4 == 0 ? 0x04020100u : (lane4 == 1 ? 0x05040201u : 0x06050402u);
 
@@ -802,21 +818,15 @@ __device__ __forceinline__ void draw_rest(
 #pragma unroll
         for (int j = 0; j < PXT; ++j) {
             const uint32_t off = pix_off + (uint32_t)j * pix_step;
-            if (fast_store) {
-                // lanes 4k..4k+3 hold pixels P0..P3; lanes with lane4 < 3 emit dword lane4 of the 12 bytes
-                // neighbour lane's pixel: row_shl:1 DPP (lane4 groups never straddle a 16-lane row)
-                uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pix[j], 0x101, 0xF, 0xF, true);
-                uint32_t dw = __builtin_amdgcn_perm(nxt, pix[j], store_sel);
-                uint32_t voff = off + (uint32_t)lane4;
-                asm volatile("" : "+v"(voff));
-                if (inside[j] && lane4 < 3)
-                    __builtin_nontemporal_store(dw, reinterpret_cast<uint32_t*>(O + voff));
-            } else if (inside[j]) {
-                uint8_t* o = O + off;
-                o[0] = (uint8_t)pix[j];
-                o[1] = (uint8_t)(pix[j] >> 8);
-                o[2] = (uint8_t)(pix[j] >> 16);
-            }
+            // lanes 4k..4k+3 hold pixels P0..P3; lanes with lane4 < 3 emit dword lane4 of the 12 bytes
+            // neighbour lane's pixel: row_shl:1 DPP (lane4 groups never straddle a 16-lane row)
+            uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pix[j], 0x101, 0xF, 0xF, true);
+            uint32_t dw = __builtin_amdgcn_perm(nxt, pix[j], store_sel);
+            uint32_t voff = off + (uint32_t)lane4;
+            asm volatile("" : "+v"(voff));
+            // (a group that starts inside the view may end in the row's padding: the device row holds whole groups)
+            if (inside4[j] && lane4 < 3)
+                __builtin_nontemporal_store(dw, reinterpret_cast<uint32_t*>(O + voff));
         }
     };
 

@@ -127,12 +127,21 @@ _PIXEL_PATHS = {"u8": 0, "f32": _native.FLAG_PIXELS_F32, "f16": _native.FLAG_PIX
 
 
 def process_views(pano_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg=90, device=None,
-                  pixel_path="u8"):
+                  pixel_path="u8", maps=None):
     """All yaws x pitches of one panorama in one kernel launch.
     Returns uint8 [n_yaw][n_pitch][output_height][output_width][3]; the array lives in page-locked host
     memory (pooled; P2P_PINNED=0 for ordinary memory) so that the copy back from the GPU is one DMA.
     pixel_path: "u8" = the reference's arithmetic (two fixed-point cv2.remap stages, the default and the only
-    parity mode); "f32" / "f16" = the opt-in single float resample with wrap-around (not in the reference)."""
+    parity mode); "f32" / "f16" = the opt-in single float resample with wrap-around (not in the reference).
+    maps: None = the coordinate maps are evaluated on the device (the reference's within +-1 on band-limited
+    panoramas); (yaw_rows, U, V) = the exact route of INTEGRATION.md "Option C": yaw_rows [n_yaw][pano_width] =
+    row 0 of every get_yaw_mapping()[0] (P:42-52), U / V [n_pitch][H][W] = get_pitch_mapping() outputs (P:55-73) --
+    given the reference's own maps the views are the reference's bytes."""
+    if maps is not None:
+        if pixel_path != "u8":
+            raise ValueError("caller maps go through the fixed-point path only")
+        yaw_rows, U, V = maps
+        return _native.remap_views_maps(pano_image, yaw_rows, U, V, _DEVICE if device is None else device)
     yaws = [_angle(y, "yaw angle") for y in yaw_angles]
     pitches = [_angle(p, "pitch angle") for p in pitch_angles]
     return _native.remap_views_f64(pano_image, yaws, pitches, _angle(fov_deg, "FOV"),

@@ -51,6 +51,9 @@ WORKLOADS = {
                  name="16384x8192 pano -> 4096x4096, FOV 60, 72 yaw x 5 pitch = 360 views"),
     "cfg5": dict(pw=8192, ph=4096, ow=1920, oh=1080, fov=90, yaws=list(range(360)), pitches=[90],
                  name="8192x4096 pano -> 1920x1080, FOV 90, 360 yaw x 1 pitch = 360 views"),
+    # the reference CLI's own defaults (P:412-437) on an 8K panorama: strongly minifying, two pole views
+    "cli": dict(pw=8192, ph=4096, ow=800, oh=800, fov=90, yaws=[0, 90, 180, 270], pitches=[30, 60, 90, 120, 150],
+                name="8192x4096 pano -> 800x800, FOV 90, yaw 0/90/180/270 x pitch 30/60/90/120/150 (the reference CLI's defaults)"),
 }
 
 
@@ -178,6 +181,76 @@ def cpu_baseline(w, budget_s=12.0):
     }
 
 
+def secondary_lines(nat, ctx, pano8k, device):
+    """The other BASELINE configs and the reference CLI's default view set, each timed over a few back-to-back
+    launches (HIP events on the job's stream around the region, inputs and outputs resident) after the headline
+    region: {name: {workload, ms_per_launch, launches, Gpix_s, frac_of_hbm_peak, algorithmic_bytes, kernels}}.
+    Panorama content does not enter the timing: config 3's share re-uses one 8K panorama for its 8 resident ones and
+    config 4's 16K panorama is the 8K one tiled 2 x 2."""
+    import numpy as np
+
+    out = {}
+    plans = [
+        ("cfg3_share_8_panos", "cfg3", 8, 0, 60, "one GPU's share of config 3 at 8 GPUs: 8 panoramas resident, 288 views per launch"),
+        ("cfg4", "cfg4", 1, 0, 5, None),
+        ("cfg5_u8", "cfg5", 1, 0, 60, None),
+        ("cfg5_f16_quality_mode", "cfg5", 1, nat.FLAG_PIXELS_F16, 60,
+         "opt-in float pixel path (one float resample, not the reference's arithmetic): a quality mode, no throughput claim"),
+        ("cli_default_view_set", "cli", 1, 0, 200, None),
+    ]
+    for name, wl, n_panos, flags, launches, note in plans:
+        w = WORKLOADS[wl]
+        try:
+            pano = pano8k if w["pw"] == 8192 else np.ascontiguousarray(np.tile(pano8k, (w["ph"] // 4096, w["pw"] // 8192, 1)))
+            job = nat.Job(ctx, w["pw"], w["ph"], n_panos, w["yaws"], w["pitches"], w["fov"], w["ow"], w["oh"], flags=flags)
+            for i in range(n_panos):
+                job.set_pano(i, pano)
+            job.time_launches(False)
+            for _ in range(max(2, launches // 4)):
+                job.run()
+            ctx.mark(0)
+            for _ in range(launches):
+                job.run()
+            ctx.mark(1)
+            ms = ctx.marked_ms() / launches
+            plan_ms, tables_ms = job.plan_ms()
+            views = n_panos * len(w["yaws"]) * len(w["pitches"])
+            b_alg = algorithmic_bytes(w, n_panos)
+            out[name] = {"workload": note or w["name"], "ms_per_launch": ms, "launches": launches,
+                         "Gpix_s": views * w["ow"] * w["oh"] / ms / 1e6, "algorithmic_bytes": b_alg,
+                         "frac_of_hbm_peak": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "plan_ms": plan_ms, "yaw_tables_ms": tables_ms,
+                         "kernels": "float_views_kernel" if flags else "remap_views_kernel + remap_views_gather_kernel (tiles that do not fit the LDS scheme)"}
+            job.close()
+            del pano
+        except Exception as e:  # a secondary line never takes the headline down
+            out[name] = {"error": repr(e)}
+    return out
+
+
+def cold_first_image(nat, w, pano, device):
+    """What ONE image through a context that has not seen its geometry pays on the device, next to the steady state
+    the headline quotes: yaw tables + plan pass + view kernel (the reference's first image pays its map builders,
+    P:79-175, the same way).  A fresh context, so that nothing comes from the table caches."""
+    ctx = nat.Context(device)
+    try:
+        job = nat.Job(ctx, w["pw"], w["ph"], 1, w["yaws"], w["pitches"], w["fov"], w["ow"], w["oh"])
+        job.set_pano(0, pano)
+        ctx.mark(0)
+        job.run()   # plan pass (device), its gather-tile count read back (host), the view kernel
+        ctx.mark(1)
+        first = ctx.marked_ms()
+        plan_ms, tables_ms = job.plan_ms()
+        k = job.kernel_ms()
+        job.close()
+        return {"plan_ms": plan_ms, "yaw_tables_ms": tables_ms, "first_run_ms": first, "view_kernel_ms_in_first_run": k,
+                "cold_one_image_ms": tables_ms + first,
+                "how": "fresh context and job; first_run_ms = HIP events around the first p2p_job_run (plan pass, host "
+                       "read-back of its counter, view kernel); yaw tables are built at job creation"}
+    finally:
+        ctx.close()
+
+
 def read_sclk_mhz():
     """Current shader clock of each GPU from sysfs (pp_dpm_sclk marks the active level with '*'), or None."""
     out = []
@@ -227,7 +300,7 @@ def measure_counters(args):
     if under_profiler():
         return None
     kernel = "remap_views_kernel" if args.pixel_path == "u8" else "float_views_kernel"
-    base = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2", "--no-preroll", "--no-cpu-baseline",
+    base = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2", "--no-preroll", "--no-cpu-baseline", "--no-secondary",
             "--counters", "none", "--workload", args.workload, "--panos-per-gpu", str(args.panos_per_gpu),
             "--scaling", args.scaling,
             "--maps", args.maps, "--kind", args.kind, "--pixel-path", args.pixel_path]
@@ -306,6 +379,9 @@ def main():
                     help="u8: the reference's two fixed-point remap stages (default; the parity path). "
                          "f32 / f16: the opt-in single float resample, which the reference does not have")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary lines (configs 3-share / 4 / 5, the reference CLI's default view set) and the "
+                         "cold-image figures the default cfg2 run at --gpus 1 appends")
     ap.add_argument("--preroll-s", type=float, default=0.5,
                     help="seconds of untimed launches BEFORE the --warmup steps, whatever --steps / --warmup are: an idle "
                          "MI355X sits at a low shader clock and needs a few hundred ms of load to reach its working "
@@ -518,6 +594,12 @@ def main():
         "preroll_s": preroll_s, "preroll_launches": preroll_launches,
         "sclk_mhz": {"before_preroll": sclk_before, "after_timed_region": sclk_after},
     }
+    if dist.rank == 0 and dist.world == 1 and args.workload == "cfg2" and args.scaling == "weak" and npg == 1 and \
+            args.pixel_path == "u8" and args.maps == "fused" and not args.no_secondary:
+        pano8k = synth.synth_pano(8192, 4096, 1000, args.kind)
+        out["cold"] = cold_first_image(nat, w, pano8k, dist.local_rank)
+        out["secondary"] = secondary_lines(nat, ctx, pano8k, dist.local_rank)
+        del pano8k
     if dist.rank == 0 and dist.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w)
     elif dist.rank == 0:

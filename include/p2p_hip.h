@@ -237,12 +237,19 @@ int p2p_job_wait(p2p_job* job);
 /* By default every p2p_job_run brackets its kernel with its own HIP event pair (p2p_job_kernel_ms*); on = 0
    turns that off (two event records less per launch), on = 1 back on.  Either call restarts the history. */
 int p2p_job_time_launches(p2p_job* job, int on);
+/* Device time it took to build the job's plan (the pitch maps' tables, once per geometry: the reference's
+   pitch_mapping_cache, P:17-18, P:55-73) and its yaw tables (yaw_mapping_cache, P:42-52), in ms.  The context keeps
+   both by geometry, so these are the times of whichever job built them first.  After the first p2p_job_run. */
+int p2p_job_plan_ms(p2p_job* job, float* plan_ms, float* tables_ms);
 /* Device time of the last p2p_job_run's view kernel(s), from HIP events on the job's stream. */
 int p2p_job_kernel_ms(p2p_job* job, float* ms);
 /* Device times of the last n p2p_job_run launches (n <= 256), oldest first; synchronises once.
    Each launch is bracketed by its own HIP event pair on the job's stream. */
 int p2p_job_kernel_ms_last(p2p_job* job, float* ms, int n);
-/* Device address / byte size of the output block [n_panos][n_yaw][n_pitch][oh][ow][3]. */
+/* Device address / byte size of the output block [n_panos][n_yaw][n_pitch][oh] rows.  A device row holds the view
+   row's ow pixels (3 bytes each) padded to whole 4-pixel groups: 12 * ceil(ow / 4) bytes, = 3 * ow when ow is
+   divisible by 4 -- every row then starts dword-aligned and the kernels write 12 bytes per lane for any width;
+   p2p_job_get_views copies rows out into the caller's contiguous [..][oh][ow][3] array. */
 void* p2p_job_device_out(p2p_job* job, int64_t* bytes);
 /* The pitch-stage coordinates in 1/32 px the job's plan holds (after the first p2p_job_run),
    int32 [n_pitch][oh][ow][2] = (sx, sy); INT32_MIN marks a NaN coordinate (black pixel).  Jobs of the float

@@ -33,6 +33,7 @@ static inline const char* hipGetErrorString(hipError_t e) { return e == hipSucce
 static inline hipError_t hipGetLastError(void) { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = p2p_stub_device_count; return hipSuccess; }
 static inline hipError_t hipSetDevice(int d) { return d >= 0 && d < p2p_stub_device_count ? hipSuccess : hipErrorInvalidValue; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }

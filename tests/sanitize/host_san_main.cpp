@@ -95,7 +95,21 @@ int main()
     CHECK(p2p_job_run(job2) == P2P_OK);
     std::vector<uint8_t> v2((size_t)16 * 16 * 3);
     CHECK(p2p_job_get_views(job2, 1, v2.data()) == P2P_OK);
+    // the context's table caches: a third job of job2's geometry shares its plan and yaw tables (the build times
+    // reported are those of the first build), outlives it, and survives a budget of zero
+    p2p_job* job3 = nullptr;
+    CHECK(p2p_job_create_f64(ctx, &d2, &job3) == P2P_OK && p2p_job_share_panos(job3, job) == P2P_OK);
+    float pm = -1.0f, tm = -1.0f;
+    CHECK(p2p_job_plan_ms(job3, &pm, &tm) == P2P_ERR_STATE);          // not run yet
+    CHECK(p2p_job_run(job3) == P2P_OK && p2p_job_plan_ms(job3, &pm, &tm) == P2P_OK && pm >= 0.0f && tm >= 0.0f);
     p2p_job_destroy(job2);
+    setenv("P2P_PLAN_CACHE_MB", "0", 1);                             // every unused entry goes at the next insertion
+    const double y3[1] = {13.5};
+    CHECK(p2p_job_set_yaws_f64(job3, y3) == P2P_OK && p2p_job_run(job3) == P2P_OK);
+    std::vector<float> U3((size_t)16 * 16, 2.0f);
+    CHECK(p2p_job_set_maps(job3, nullptr, U3.data(), U3.data()) == P2P_OK && p2p_job_run(job3) == P2P_OK);  // private plan
+    unsetenv("P2P_PLAN_CACHE_MB");
+    p2p_job_destroy(job3);
     p2p_job_destroy(job);
     p2p_job_destroy(nullptr);
     void* host = nullptr;

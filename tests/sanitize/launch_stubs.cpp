@@ -51,6 +51,12 @@ hipError_t launch_plan(const PlanParams& P, hipStream_t)
     P.n_gather[0] = (uint32_t)(tiles * P.n_pitch);
     return hipSuccess;
 }
+hipError_t launch_compact_rows(void* dst, const uint8_t* src, size_t n_bytes, int row_bytes, int src_row, hipStream_t)
+{
+    for (size_t b = 0; b < n_bytes; ++b)
+        ((uint8_t*)dst)[b] = src[(b / row_bytes) * src_row + b % row_bytes];
+    return hipSuccess;
+}
 hipError_t launch_remap_views(const ViewsParams& P, int, hipStream_t)
 {
     const size_t n = (size_t)P.n_panos * P.n_yaw * P.n_pitch * P.oh * P.ow * 3;

@@ -235,3 +235,19 @@ def test_view_sharding_pitch_major_round_robin(pkg):
         assert max(sizes) - min(sizes) <= 1
     # config 2 on 8 GPUs: 36 views -> 4 or 5 per device; the 7.2x cap of SURVEY 8(e)
     assert sorted(sum(len(v) for v in d.shard_views(12, 3, 8, r).values()) for r in range(8)) == [4] * 4 + [5] * 4
+
+
+def test_integration_stubs_compile_and_bind_exported_entry_points(nat):
+    """Every Python block of INTEGRATION.md (the stubs a reference maintainer pastes into P) is valid Python and
+    binds only symbols the library exports, with as many argtypes as the header's prototype has parameters."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    header = open(os.path.join(ROOT, "include", "p2p_hip.h")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, re.S)
+    assert len(blocks) >= 3
+    for b in blocks:
+        compile(b, "INTEGRATION.md", "exec")
+        for sym in set(re.findall(r"_p2p\.(p2p_[a-z0-9_]+)", b)):
+            assert sym in nat.ABI_SYMBOLS, sym
+        for sym, args in re.findall(r"_p2p\.(p2p_[a-z0-9_]+)\.argtypes = \[(.*?)\n(?=_p2p\.|def |\Z)", b, re.S):
+            proto = re.search(r"\bint %s\s*\(([^;]*?)\);" % sym, header, re.S).group(1)
+            assert len(re.findall(r"ctypes\.c_\w+", args)) == proto.count(",") + 1, sym

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/bench_$TAG
 mkdir -p $OUT
 cd $ROOT
-B="python3 bench.py --no-cpu-baseline --counters none"
+B="python3 bench.py --no-cpu-baseline --no-secondary --counters none"
 $B --workload cfg1                                   > $OUT/cfg1_bench.json 2> $OUT/cfg1.err
 python3 bench.py                                     > $OUT/cfg2_bench.json 2> $OUT/cfg2.err
 python3 bench.py --steps 20 --warmup 5               > $OUT/cfg2_bench_driver_cmdline.json 2> $OUT/cfg2d.err

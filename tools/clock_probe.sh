@@ -3,7 +3,7 @@
 # Usage on the GPU box: bash tools/clock_probe.sh [bench args...]
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
-python3 bench.py --no-cpu-baseline --steps 40000 --warmup 50 "$@" > gpurun_out/clock_bench.json 2> gpurun_out/clock_bench.err &
+python3 bench.py --no-cpu-baseline --no-secondary --steps 40000 --warmup 50 "$@" > gpurun_out/clock_bench.json 2> gpurun_out/clock_bench.err &
 BP=$!
 sleep 5
 for i in $(seq 1 16); do

@@ -5,15 +5,15 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline --counters none > $OUT/bench_under_trace.json 2> $OUT/trace.log
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline --no-secondary --counters none > $OUT/bench_under_trace.json 2> $OUT/trace.log
 # the driver's own command line, under the trace too (20 timed launches after the disclosed pre-roll)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_driver -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --counters none > $OUT/bench_driver_under_trace.json 2> $OUT/trace_driver.log
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_driver -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --counters none > $OUT/bench_driver_under_trace.json 2> $OUT/trace_driver.log
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 120 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-preroll --counters none > /dev/null 2> $OUT/pmc_$c.log
+  timeout 120 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-preroll --counters none > /dev/null 2> $OUT/pmc_$c.log
   timeout 120 rocprofv3 --pmc $c --output-format csv -d $OUT/calib_$c -- $ROOT/tools/ubench/fetch_calib > /dev/null 2> $OUT/calib_$c.log
 done
-timeout 120 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $OUT/pmc_ea -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-preroll --counters none > /dev/null 2> $OUT/pmc_ea.log
-timeout 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum --output-format csv -d $OUT/pmc_tcc -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-preroll --counters none > /dev/null 2> $OUT/pmc_tcc.log
+timeout 120 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $OUT/pmc_ea -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-preroll --counters none > /dev/null 2> $OUT/pmc_ea.log
+timeout 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum --output-format csv -d $OUT/pmc_tcc -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-preroll --counters none > /dev/null 2> $OUT/pmc_tcc.log
 cd $ROOT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err
