@@ -86,6 +86,7 @@ struct ViewsParams {
     const uint32_t* f4tab;   // [n_yaw][pw] weights of columns c..c+3 (mod pw), one byte each
     int n_yaw, n_pitch, n_panos;
     int pairs_per_block;     // (panorama, yaw) pairs looped over by one workgroup
+    int chunk_outer;         // tile grids: 0 = (tile, chunk, pitch view), 1 = (tile, pitch view, chunk) -- see pair_chunk
     uint32_t n_yaw_magic;    // ceil(2^32 / n_yaw): pair / n_yaw == umulhi(pair, magic) while pair * n_yaw < 2^32
     const PitchConst* pitch; // [n_pitch]
     MapGeom geom;

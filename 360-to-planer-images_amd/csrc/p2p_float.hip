@@ -86,7 +86,7 @@ __device__ __forceinline__ void draw_float(
     if (G.mode != 1)
         return;  // the rest kernel's
     P2P_AUD_LT(P.audit, AUD_FLOAT_HDR, G.n_items, LDS_ITEMS_CAP + 1);
-    const int pair0 = blockIdx.z * P.pairs_per_block;
+    const int pair0 = (P.chunk_outer ? blockIdx.z : blockIdx.y) * P.pairs_per_block;  // grid order as the exact kernel's
     int pair1 = pair0 + P.pairs_per_block;
     if (pair1 > P.n_panos * P.n_yaw)
         pair1 = P.n_panos * P.n_yaw;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void float_views
     const int tile_id = tile_of_block(P, (int)blockIdx.x, (int)gridDim.x);
     if (tile_id < 0)
         return;
-    const int pitch_i = pitch_of_block(P, (int)blockIdx.y);
+    const int pitch_i = pitch_of_block(P, (int)(P.chunk_outer ? blockIdx.y : blockIdx.z));
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
     const PieceHdr h = hdr[(size_t)pitch_i * tiles + tile_id];
     const TileGeo G = tile_geo(P, h, pitch_i, tile_id, (int)threadIdx.x);
@@ -356,7 +356,7 @@ hipError_t launch_float_views(const ViewsParams& P, bool half, int which, hipStr
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
     const int n_pairs = P.n_panos * P.n_yaw;
     const int zblocks = (n_pairs + P.pairs_per_block - 1) / P.pairs_per_block;
-    const dim3 grid(8 * ((tiles + 7) / 8), P.n_pitch, zblocks);
+    const dim3 grid(8 * ((tiles + 7) / 8), P.chunk_outer ? P.n_pitch : zblocks, P.chunk_outer ? zblocks : P.n_pitch);
     if (which == 0) {
         if (half)
             hipLaunchKernelGGL(float_views_kernel<true>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.out, P.hdr, P.px, P.px2, P.items);

@@ -1127,6 +1127,7 @@ int p2p_job_run(p2p_job* j)
         j->d_gather_list = Pl.d_gather_list; j->n_gather = Pl.n_gather;
     }
     P.pairs_per_block = choose_pairs_per_block(j->d);
+    P.chunk_outer = env_int("P2P_CHUNK_OUTER", j->d.n_panos > 1 ? 1 : 0);
     P.pitch_order = j->d_pitch_order;
     P.coords = j->d_coords;
     P.hdr = j->d_hdr;

@@ -55,7 +55,7 @@ __device__ __forceinline__ int pano_of_pair(const ViewsParams& P, int pair)
     return P.n_yaw == 1 ? pair : (int)__umulhi((uint32_t)pair, P.n_yaw_magic);
 }
 
-// blockIdx.y -> pitch view, heaviest first; the table is the host's, its values are clamped all the same
+// pitch block of the grid -> pitch view, heaviest first; the table is the host's, its values are clamped all the same
 __device__ __forceinline__ int pitch_of_block(const ViewsParams& P, int by)
 {
     int p = P.pitch_order[by];

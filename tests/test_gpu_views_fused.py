@@ -66,9 +66,11 @@ def test_noise_mismatch_fraction_is_small(gpu, pkg, synth):
     want = oracle_views(pano, yaws, pitches, 480, 270, 90)
     mx, frac_gt1, frac_any = diff_stats(got, want)
     print("noise: max |diff| %d, >1: %.4g, any: %.4g" % (mx, frac_gt1, frac_any))
-    # each flipped 1/32-px coordinate moves a noise pixel by up to ~8 levels; flips must stay rare
+    # each flipped 1/32-px coordinate moves a noise pixel by a few levels; flips must stay rare.  Measured
+    # (tests/fuzz/parity_report.py): max 6 - 8 levels; off by more than 1: 0.022 % of the bytes here
+    # (0.008 % at config 1's size, 0.081 % at config 2's); the bounds are about twice what this case measures
     assert mx <= 16
-    assert frac_gt1 < 0.02
+    assert frac_gt1 < 0.0005
 
 
 def _directions(U, V, pw, ph):
@@ -109,7 +111,10 @@ def test_pitch_map_matches_reference_1e5(gpu, pkg, args):
     rx, ry, _, _ = cpu_ref.quantise_maps(Ur, Vr)
     flips = float(((sx != rx) | (sy != ry))[ok].mean())
     print("quantised coordinate flips: %.4g" % flips)
-    assert flips < 0.05
+    # measured 0 - 0.017 % on the BASELINE configurations, 0.033 % on the 64 x 48 map one degree
+    # from the pole: the bound is three times the worst of them (the reference side of the comparison is NumPy's
+    # arccos / arctan2, which vary with the host's build)
+    assert flips < 0.001
 
 
 @pytest.mark.parametrize("pw", [256, 2048, 8192, 16384, 1000, 4095])

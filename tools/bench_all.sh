@@ -19,6 +19,7 @@ $B --workload cfg5 --steps 200 --warmup 40           > $OUT/cfg5_bench.json 2> $
 $B --workload cfg5 --pixel-path f16 --steps 200 --warmup 40 > $OUT/cfg5_f16_bench.json 2> $OUT/cfg5h.err
 $B --workload cfg5 --pixel-path f32 --steps 200 --warmup 40 > $OUT/cfg5_f32_bench.json 2> $OUT/cfg5f.err
 $B --scaling strong --workload cfg2                  > $OUT/cfg2_views_sharded_1rank_bench.json 2> $OUT/cfg2s.err
+$B --workload cli --steps 1000 --warmup 200          > $OUT/cli_default_bench.json 2> $OUT/cli.err
 python3 - <<PY
 import glob, json, os
 for f in sorted(glob.glob("$OUT/*_bench*.json")):

@@ -8,6 +8,11 @@ cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline --no-secondary --counters none > $OUT/bench_under_trace.json 2> $OUT/trace.log
 # the driver's own command line, under the trace too (20 timed launches after the disclosed pre-roll)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_driver -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --counters none > $OUT/bench_driver_under_trace.json 2> $OUT/trace_driver.log
+# the other BASELINE configs and the reference CLI's default view set: per-kernel split (main / gather / plan)
+for wl in cfg4 cfg5 cli; do
+  case $wl in cfg4) st="--steps 8 --warmup 3";; cfg5) st="--steps 100 --warmup 20";; *) st="--steps 1000 --warmup 200";; esac
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -- python3 $ROOT/bench.py --workload $wl $st --no-cpu-baseline --no-secondary --counters none > $OUT/bench_${wl}_under_trace.json 2> $OUT/trace_$wl.log
+done
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 120 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-preroll --counters none > /dev/null 2> $OUT/pmc_$c.log
   timeout 120 rocprofv3 --pmc $c --output-format csv -d $OUT/calib_$c -- $ROOT/tools/ubench/fetch_calib > /dev/null 2> $OUT/calib_$c.log
@@ -41,4 +46,5 @@ print(json.dumps(res, indent=1))
 PY
 cat $(find $OUT/trace -name "*kernel_stats.csv" | head -1) | cut -c1-160
 cat $(find $OUT/trace_driver -name "*kernel_stats.csv" | head -1) | cut -c1-160
+for wl in cfg4 cfg5 cli; do cat $(find $OUT/trace_$wl -name "*kernel_stats.csv" | head -1) | cut -c1-160; done
 cat $OUT/bench.json

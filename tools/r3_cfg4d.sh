@@ -1,0 +1,7 @@
+#!/bin/bash
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $ROOT
+echo "pitch 90, 360 yaws (18 GB of views, one pitch)"; python3 tools/probe_job.py 16384 8192 4096 4096 60 0:360:1 90 6 2>&1 | grep -E "us per"
+echo "five pitches, 14 yaws (3.5 GB of views)"; python3 tools/probe_job.py 16384 8192 4096 4096 60 0:350:25 30,60,90,120,150 10 2>&1 | grep -E "us per"
+echo "five times pitch 90, 14 yaws"; python3 tools/probe_job.py 16384 8192 4096 4096 60 0:350:25 90,90,90,90,90 10 2>&1 | grep -E "us per"
+echo "pitch 90, 72 yaws, chunks of 24"; P2P_MAX_PAIRS_PER_BLOCK=24 python3 tools/probe_job.py 16384 8192 4096 4096 60 0:360:5 90 20 2>&1 | grep -E "us per"
