@@ -117,6 +117,32 @@ def test_cfg4_noise_panorama_pole_and_horizon_vs_oracle(gpu, synth):
         assert bad.size == 0, (pitch, len(bad), bad[:4].tolist())
 
 
+def test_cfg4_five_pitch_job_sampled_views_vs_oracle(gpu, synth):
+    """Config 4 as ONE job with all five pitch views (the shape that behaves differently: five plans resident, pole tiles
+    of pitch 30 / 150 drawn by the gather kernel beside the LDS-scheme tiles, chunks of pairs per pitch view): a handful
+    of (yaw, pitch) views of the job, byte for byte against the oracle on a noise panorama.  10 yaws keep the job's
+    5 GB of views and the CPU oracle's time in bounds; the 72-yaw job itself runs in bench.py."""
+    pw, ph, ow, oh, fov = 16384, 8192, 4096, 4096, 60
+    pano = synth.synth_pano(pw, ph, 1004, "N")
+    yaws, pitches = list(range(0, 360, 36)), [30, 60, 90, 120, 150]
+    rows, U, V = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
+    ctx = gpu.Context(0)
+    job = gpu.Job(ctx, pw, ph, 1, yaws, pitches, fov, ow, oh)
+    job.set_pano(0, pano)
+    job.set_maps(rows, U, V)
+    job.run()
+    got = job.get_views(0)
+    job.close()
+    ctx.close()
+    yi = 3  # yaw 108: a fractional shift on 16384 columns
+    want = oracle_views_threaded(pano, [yaws[yi]], pitches, ow, oh, fov)
+    for pi, pitch in enumerate(pitches):
+        bad = np.argwhere(got[yi, pi] != want[0, pi])
+        assert bad.size == 0, (pitch, len(bad), bad[:4].tolist())
+    # and a whole-column shift of the same job (stage 1 is a copy: the other loop of the kernels) on the horizon view
+    assert np.array_equal(got[0, 2], oracle_views_threaded(pano, [0], [90], ow, oh, fov)[0, 0])
+
+
 def test_cfg5_yaw_sweep_at_8k(gpu, pkg, pano8k):
     c = CFG2
     pitches = [90]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # counters of the main view kernel on config 4's geometry: one pitch vs five in one job
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r3_cfg4_pmc
+OUT=$ROOT/gpurun_out/cfg4_pmc
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name pitches counters...
