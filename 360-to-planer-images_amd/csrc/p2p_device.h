@@ -153,6 +153,7 @@ hipError_t launch_rot_map(float* U, float* V, int ow, int oh, const MapGeom& g, 
 hipError_t launch_pitch_map(float* U, float* V, int ow, int oh, const MapGeom& g, float c, float s,
                             hipStream_t st);
 hipError_t launch_plan(const PlanParams& P, hipStream_t st);
+hipError_t launch_scramble(void* p, size_t bytes, uint32_t seed, hipStream_t st);  // robustness self-test only
 // padded device view rows (src_row bytes apart, row_bytes used) -> contiguous bytes, dst sized to whole dwords
 hipError_t launch_compact_rows(void* dst, const uint8_t* src, size_t n_bytes, int row_bytes, int src_row, hipStream_t st);
 hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st);

@@ -1033,6 +1033,31 @@ static int job_build_plan(p2p_job* j)
         return fail(P2P_ERR_HIP, "the plan pass listed %u gather tiles of %zu", cnt, slots);
     Pl->n_gather = (int)cnt;
     Pl->built = true;
+    if (const int seed = env_int("P2P_SCRAMBLE_PLAN", 0)) {
+        // Robustness self-test (tests/fuzz/scramble_tables.py), never set in normal use: every table of the plan -- and
+        // with bit 30 of the value the job's yaw tables too -- overwritten with pseudo-random words AFTER the plan pass.
+        // The view kernels must then draw garbage and nothing worse: every table-derived offset is clamped or goes
+        // through an exact-extent buffer descriptor (csrc/p2p_audit.h).  Such a plan is never entered in the cache.
+        const uint32_t sd = (uint32_t)seed;
+        HIP_TRY(p2p::launch_scramble(Pl->d_hdr, slots * sizeof(p2p::PieceHdr), sd + 1, st));
+        HIP_TRY(p2p::launch_scramble(Pl->d_px, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t), sd + 2, st));
+        HIP_TRY(p2p::launch_scramble(Pl->d_items, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t), sd + 3, st));
+        HIP_TRY(p2p::launch_scramble(Pl->d_gather_list, slots * sizeof(uint32_t), sd + 4, st));
+        HIP_TRY(p2p::launch_scramble(Pl->d_coords, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2), sd + 5, st));
+        if (Pl->d_px2)
+            HIP_TRY(p2p::launch_scramble(Pl->d_px2, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t), sd + 6, st));
+        if ((seed & (1 << 30)) && j->yaw_ref && j->yaw_ref.use_count() == 1) {  // private (uncached) yaw tables only
+            const size_t n = (size_t)d.n_yaw * d.pw * sizeof(uint32_t);
+            HIP_TRY(p2p::launch_scramble(j->d_ytab, n, sd + 7, st));
+            HIP_TRY(p2p::launch_scramble(j->d_f4tab, n, sd + 8, st));
+            HIP_TRY(p2p::launch_scramble(j->d_ydesc, (size_t)d.n_yaw * sizeof(p2p::YawDesc), sd + 9, st));
+        }
+        if (seed & (1 << 29))
+            Pl->n_gather = (int)slots;  // every list entry is launched: the scrambled ones too
+        HIP_TRY(hipStreamSynchronize(st));
+        j->plan_ref = Pl;
+        return P2P_OK;
+    }
     if (env_int("P2P_VERBOSE", 0))
         fprintf(stderr, "p2p plan: %u of %zu tiles gather (%dx%d views, %d pitches), %.1f us\n", cnt, slots, d.ow, d.oh, d.n_pitch,
                 Pl->plan_ms * 1e3);

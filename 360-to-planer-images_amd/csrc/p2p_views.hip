@@ -257,7 +257,7 @@ __device__ __forceinline__ PairCtxs pair_contexts(const ViewsParams& P, const Ya
         const bool per_column = yd.mode == 1 || clamp_in;
         cw0 = 12u * (uint32_t)g0 | (uint32_t)(i_first & 3) << 20 | (uint32_t)(yd.mode != 2) << 22 |
               (uint32_t)per_column << 23 | (uint32_t)yd.f << 24;
-        cw1 = (uint32_t)(ngroups - g0) | (uint32_t)yi << 16;
+        cw1 = ((uint32_t)(ngroups - g0) & 0xFFFFu) | (uint32_t)yi << 16;  // (masked: a garbage descriptor must not reach the yaw field)
         cw2 = 4 * g0 - yd.s;
         cw3 |= k << 26;  // n_panos < 2^26 (host check): the chunk-local pair index rides along
         // items reach group ((c1 + 1 - c0) + 3) >> 2 past the first; beyond the row's last group they wrap
@@ -940,6 +940,8 @@ __device__ __forceinline__ void draw_rest(
         c.f = w0 >> 24;
         c.wrap_g = w1 & 0xFFFFu;
         c.yaw_i = (int)(w1 >> 16);
+        P2P_AUD_LT(P.audit, AUD_REST_PAIR, c.yaw_i, P.n_yaw);
+        c.yaw_i = c.yaw_i < P.n_yaw ? c.yaw_i : P.n_yaw - 1;  // it indexes the yaw tables and the output views
         c.cf0 = __builtin_amdgcn_readlane(X.cw2, k);
         const int w3 = __builtin_amdgcn_readlane(X.cw3, k);
         c.pano = w3 & 0x3FFFFFF;

@@ -51,6 +51,7 @@ hipError_t launch_plan(const PlanParams& P, hipStream_t)
     P.n_gather[0] = (uint32_t)(tiles * P.n_pitch);
     return hipSuccess;
 }
+hipError_t launch_scramble(void*, size_t, uint32_t, hipStream_t) { return hipSuccess; }
 hipError_t launch_compact_rows(void* dst, const uint8_t* src, size_t n_bytes, int row_bytes, int src_row, hipStream_t)
 {
     for (size_t b = 0; b < n_bytes; ++b)
