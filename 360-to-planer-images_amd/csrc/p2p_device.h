@@ -49,7 +49,8 @@ struct PieceHdr {
     uint32_t mode_items;  // mode (1: LDS scheme, 2: gathers) | n_items << 8
     int32_t c0, c1;       // rot columns the taps of the tile's live pixels read: c0 .. c1 + 1 (c1 < c0: no live pixel).
                           // mode 1: LDS position 0 of every row is a column congruent to c0 mod 4
-    uint32_t pad;
+    uint32_t rows;        // (first rot row of the upper taps + 1) | (last + 1) << 16; 0: no live pixel.  Read by the host only
+                          // (the order of the gather lists), never by a kernel
 };
 static_assert(sizeof(PieceHdr) == 16, "PieceHdr is read as one s_load_dwordx4");
 // per-pixel word: tap_up (dwords into an LDS buffer, PXW_UP_BITS) | (tap_lo - tap_up) << 12 (PXW_DL_BITS, 0 = the
@@ -86,6 +87,8 @@ struct ViewsParams {
     const uint32_t* f4tab;   // [n_yaw][pw] weights of columns c..c+3 (mod pw), one byte each
     int n_yaw, n_pitch, n_panos;
     int pairs_per_block;     // (panorama, yaw) pairs looped over by one workgroup
+    int pf_lead;             // main kernel: > 0 = every (PF_GROUP + 1)-th workgroup of an XCD's run draws nothing and touches the plan
+                             // tables of the PF_GROUP tiles that start pf_lead groups later (p2p_tile.h: main_block_role)
     int chunk_outer;         // tile grids: 0 = (tile, chunk, pitch view), 1 = (tile, pitch view, chunk) -- see pair_chunk
     uint32_t n_yaw_magic;    // ceil(2^32 / n_yaw): pair / n_yaw == umulhi(pair, magic) while pair * n_yaw < 2^32
     const PitchConst* pitch; // [n_pitch]
@@ -110,6 +113,7 @@ struct ViewsParams {
     const uint32_t* gather_list;  // the plan's mode-2 tiles (pitch * tiles + tile), in no particular order, and how many
     int n_gather;
     int gather_ppb;          // (panorama, yaw) pairs per workgroup of the gather / table kernels
+    int n_list;              // gather kernel: gather_list is [8][n_list], one work list per XCD, ~0 = no tile (p2p_host.cpp: xcd_lists)
     int gather_all;          // 1: the gather kernel draws EVERY tile (few of the job's tiles fit the LDS scheme: one launch less)
     float centre;            // float pixel path only: 0 = the reference's sampling convention, 0.5 = pixel centres
     uint32_t* audit;         // -DP2P_AUDIT builds: the context's violation record (see p2p_audit.h); else nullptr

@@ -224,7 +224,10 @@ struct Plan {  // the plan pass's tables (p2p_plan.hip)
     uint32_t* d_items = nullptr;         // [n_pitch][tiles][LDS_ITEMS_CAP]
     uint32_t* d_px2 = nullptr;           // float pixel path only: 16-bit coordinate fractions
     uint32_t* d_n_gather = nullptr;
-    uint32_t* d_gather_list = nullptr;   // [n_pitch * tiles] tiles the plan marks for gathers
+    uint32_t* d_gather_list = nullptr;   // [n_pitch * tiles] tiles the plan marks for gathers (in the order the plan pass met them)
+    uint32_t* d_xcd_list = nullptr;      // [8][xcd_stride] the same tiles dealt to the XCDs by source position (xcd_lists), ~0: none
+    uint32_t* d_xcd_all = nullptr;       // [8][xcd_all_stride] every tile, likewise (only when most tiles gather: ViewsParams::gather_all)
+    int xcd_stride = 0, xcd_all_stride = 0;
     int n_gather = 0;
     bool built = false;
     float plan_ms = 0.0f;                // device time of the plan pass
@@ -234,9 +237,93 @@ struct Plan {  // the plan pass's tables (p2p_plan.hip)
     {
         (void)hipSetDevice(device);
         (void)dev_free(d_coords); (void)dev_free(d_hdr); (void)dev_free(d_px); (void)dev_free(d_items);
-        (void)dev_free(d_px2); (void)dev_free(d_n_gather); (void)dev_free(d_gather_list);
+        (void)dev_free(d_px2); (void)dev_free(d_n_gather); (void)dev_free(d_gather_list); (void)dev_free(d_xcd_list); (void)dev_free(d_xcd_all);
     }
 };
+
+// Z-order of the centre of a tile's footprint in the SOURCE panorama, in cells of 64 columns x 32 rows (xcd_lists).
+uint64_t source_order_key(const p2p::PieceHdr& h)
+{
+    if (h.c1 < h.c0 || h.rows == 0u)
+        return ~0ull;  // no live pixel: reads nothing
+    const uint32_t cx = (uint32_t)std::max(0, (h.c0 + h.c1) / 2) >> 6;
+    const uint32_t cy = (((h.rows & 0xFFFFu) + (h.rows >> 16)) / 2u) >> 5;
+    uint64_t key = 0;
+    for (int b = 0; b < 16; ++b)
+        key |= (uint64_t)((cx >> b) & 1u) << (2 * b) | (uint64_t)((cy >> b) & 1u) << (2 * b + 1);
+    return key;
+}
+
+// The gather kernel's tiles, dealt to the 8 XCDs (workgroup b runs on XCD b & 7 and takes entry b >> 3 of that XCD's
+// list).  Views of different pitch read overlapping parts of the panorama -- the reference CLI's defaults draw five
+// pitch views per yaw, each covering a quarter of it -- and every XCD has its own L2: a source line that tiles on
+// several XCDs want crosses the fabric several times (446 MB per launch of the CLI's default set, for a 100 MB
+// panorama).  So the tiles are grouped by the BLOCK of the source their footprint is centred in (Z-order cells,
+// 512 x 256 pixels, smaller when that gives fewer than 64 groups), whole groups go to one XCD -- the tiles that share
+// lines run at the same time on the same L2 -- and the groups are dealt heaviest first to the XCD with the least work
+// so far (tiles whose footprint spans most of a row, next to a pole, count double).  CLI default set at 8K: 307 MB,
+// 85 -> 73 us; blocks of 128 x 64 ... 256 x 128 pixels 79 / 75 us, 1024 x 512 83 us; one contiguous run of the order
+// per XCD 104 us (the XCDs with the polar tiles are busy long after the others).
+// by_source false: the tiles in list order, dealt round-robin (what the kernel's grid did before).
+std::vector<uint32_t> xcd_lists(const std::vector<uint32_t>& tiles, const std::vector<p2p::PieceHdr>& hh, int pw, bool by_source,
+                                int* stride)
+{
+    std::vector<std::vector<uint32_t>> per(8);
+    if (!by_source) {
+        for (size_t i = 0; i < tiles.size(); ++i)
+            per[i & 7].push_back(tiles[i]);
+    } else {
+        std::vector<std::pair<uint64_t, uint32_t>> order;
+        order.reserve(tiles.size());
+        for (uint32_t s : tiles)
+            order.emplace_back(source_order_key(hh[s]), s);
+        std::sort(order.begin(), order.end());
+        int g = std::min(8, std::max(0, env_int("P2P_GATHER_GROUP", 3)));  // 2^g x 2^g cells: 512 x 256 source pixels
+        const size_t min_groups = 64;
+        for (; g > 0; --g) {
+            size_t groups = 0;
+            for (size_t i = 0; i < order.size(); ++i)
+                groups += i == 0 || (order[i].first >> (2 * g)) != (order[i - 1].first >> (2 * g));
+            if (groups >= min_groups)
+                break;
+        }
+        struct Group { size_t first, last; uint64_t key; long cost; };
+        std::vector<Group> groups;
+        for (size_t i = 0; i < order.size(); ++i) {
+            const uint64_t k = order[i].first >> (2 * g);
+            if (groups.empty() || k != groups.back().key)
+                groups.push_back(Group{i, i, k, 0});
+            groups.back().last = i + 1;
+            const p2p::PieceHdr& h = hh[order[i].second];
+            groups.back().cost += 1 + (h.c1 - h.c0 > pw / 2);
+        }
+        std::vector<size_t> by_cost(groups.size());
+        for (size_t i = 0; i < by_cost.size(); ++i)
+            by_cost[i] = i;
+        std::stable_sort(by_cost.begin(), by_cost.end(), [&](size_t a, size_t b) { return groups[a].cost > groups[b].cost; });
+        long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        std::vector<std::vector<size_t>> mine(8);
+        for (size_t gi : by_cost) {
+            const int x = (int)(std::min_element(load, load + 8) - load);
+            load[x] += groups[gi].cost;
+            mine[x].push_back(gi);
+        }
+        for (int x = 0; x < 8; ++x) {
+            std::sort(mine[x].begin(), mine[x].end());  // an XCD walks its groups in source order
+            for (size_t gi : mine[x])
+                for (size_t i = groups[gi].first; i < groups[gi].last; ++i)
+                    per[x].push_back(order[i].second);
+        }
+    }
+    size_t longest = 1;
+    for (const auto& v : per)
+        longest = std::max(longest, v.size());
+    std::vector<uint32_t> table(8 * longest, ~0u);
+    for (int x = 0; x < 8; ++x)
+        std::copy(per[x].begin(), per[x].end(), table.begin() + x * longest);
+    *stride = (int)longest;
+    return table;
+}
 
 struct YawKey {  // the reference's key (pano_width, pano_height, yaw_angle), for the whole yaw list (rows do not depend on ph)
     int pw;
@@ -321,6 +408,8 @@ struct p2p_job {
     uint32_t* d_items = nullptr;         // [n_pitch][tiles][LDS_ITEMS_CAP]
     uint32_t* d_px2 = nullptr;           // float pixel path only: 16-bit coordinate fractions
     uint32_t* d_gather_list = nullptr;   // [n_pitch * tiles] tiles the plan marks for gathers
+    uint32_t* d_xcd_list = nullptr, *d_xcd_all = nullptr;  // the gather kernel's per-XCD work lists (see Plan)
+    int xcd_stride = 0, xcd_all_stride = 0;
     uint32_t* d_odd_pairs = nullptr;     // (panorama, yaw) pairs whose yaw is not a plain shift with one weight
     int n_odd_pairs = 0;
     int n_gather = 0;                    // tiles the plan marks for gathers
@@ -1033,6 +1122,34 @@ static int job_build_plan(p2p_job* j)
         return fail(P2P_ERR_HIP, "the plan pass listed %u gather tiles of %zu", cnt, slots);
     Pl->n_gather = (int)cnt;
     Pl->built = true;
+    if (cnt > 0) {
+        // the gather kernel's work lists, one per XCD (once per geometry): xcd_lists
+        std::vector<p2p::PieceHdr> hh(slots);
+        HIP_TRY(hipMemcpyAsync(hh.data(), Pl->d_hdr, slots * sizeof(p2p::PieceHdr), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const bool by_source = env_int("P2P_GATHER_ORDER", 1) != 0;
+        std::vector<uint32_t> marked, all;
+        for (size_t s = 0; s < slots; ++s)
+            if ((hh[s].mode_items & 3u) == 2u)
+                marked.push_back((uint32_t)s);
+        if (marked.size() != (size_t)cnt)
+            return fail(P2P_ERR_HIP, "the plan's headers mark %zu gather tiles, its counter %u", marked.size(), cnt);
+        const std::vector<uint32_t> tg = xcd_lists(marked, hh, d.pw, by_source, &Pl->xcd_stride);
+        HIP_TRY(dev_alloc((void**)&Pl->d_xcd_list, tg.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(Pl->d_xcd_list, tg.data(), tg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        Pl->bytes += tg.size() * sizeof(uint32_t);
+        std::vector<uint32_t> ta;
+        if ((slots - (size_t)cnt) * 4 <= slots) {  // the gather kernel may draw every tile (p2p_job_run: gather_all)
+            all.resize(slots);
+            for (size_t s = 0; s < slots; ++s)
+                all[s] = (uint32_t)s;
+            ta = xcd_lists(all, hh, d.pw, by_source, &Pl->xcd_all_stride);
+            HIP_TRY(dev_alloc((void**)&Pl->d_xcd_all, ta.size() * sizeof(uint32_t)));
+            HIP_TRY(hipMemcpyAsync(Pl->d_xcd_all, ta.data(), ta.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            Pl->bytes += ta.size() * sizeof(uint32_t);
+        }
+        HIP_TRY(hipStreamSynchronize(st));  // the vectors go out of scope
+    }
     if (const int seed = env_int("P2P_SCRAMBLE_PLAN", 0)) {
         // Robustness self-test (tests/fuzz/scramble_tables.py), never set in normal use: every table of the plan -- and
         // with bit 30 of the value the job's yaw tables too -- overwritten with pseudo-random words AFTER the plan pass.
@@ -1043,6 +1160,8 @@ static int job_build_plan(p2p_job* j)
         HIP_TRY(p2p::launch_scramble(Pl->d_px, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t), sd + 2, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_items, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t), sd + 3, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_gather_list, slots * sizeof(uint32_t), sd + 4, st));
+        HIP_TRY(p2p::launch_scramble(Pl->d_xcd_list, Pl->d_xcd_list ? 8 * (size_t)Pl->xcd_stride * sizeof(uint32_t) : 0, sd + 10, st));
+        HIP_TRY(p2p::launch_scramble(Pl->d_xcd_all, Pl->d_xcd_all ? 8 * (size_t)Pl->xcd_all_stride * sizeof(uint32_t) : 0, sd + 11, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_coords, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2), sd + 5, st));
         if (Pl->d_px2)
             HIP_TRY(p2p::launch_scramble(Pl->d_px2, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t), sd + 6, st));
@@ -1149,10 +1268,17 @@ int p2p_job_run(p2p_job* j)
     {   // the job's view of its plan
         const Plan& Pl = *j->plan_ref;
         j->d_coords = Pl.d_coords; j->d_hdr = Pl.d_hdr; j->d_px = Pl.d_px; j->d_items = Pl.d_items; j->d_px2 = Pl.d_px2;
-        j->d_gather_list = Pl.d_gather_list; j->n_gather = Pl.n_gather;
+        j->d_gather_list = Pl.d_gather_list; j->d_xcd_list = Pl.d_xcd_list; j->d_xcd_all = Pl.d_xcd_all;
+        j->xcd_stride = Pl.xcd_stride; j->xcd_all_stride = Pl.xcd_all_stride; j->n_gather = Pl.n_gather;
     }
     P.pairs_per_block = choose_pairs_per_block(j->d);
     P.chunk_outer = env_int("P2P_CHUNK_OUTER", j->d.n_panos > 1 ? 1 : 0);
+    // table-prefetch workgroups (p2p_tile.h: main_block_role) when one launch's plan tables cannot stay in the Infinity
+    // Cache next to the panorama (config 4: 565 MB): 2 groups = 64 tiles of lead per XCD
+    {
+        const size_t table_bytes = j->n_tiles * (size_t)j->d.n_pitch * (256 * p2p::VIEWS_PXT + p2p::LDS_ITEMS_CAP) * sizeof(uint32_t);
+        P.pf_lead = std::max(0, env_int("P2P_PREFETCH_LEAD", table_bytes > ((size_t)128 << 20) ? 2 : 0));
+    }
     P.pitch_order = j->d_pitch_order;
     P.coords = j->d_coords;
     P.hdr = j->d_hdr;
@@ -1209,7 +1335,7 @@ int p2p_job_run(p2p_job* j)
     // Few tiles left for the LDS scheme (the edge tiles of a strongly minifying view set): the gather kernel, which
     // needs nothing but the coordinates, draws those too, and the main kernel's launch (6 us for a handful of
     // tiles) is saved.  The odd pairs of those tiles stay the rest kernel's.
-    P.gather_all = (gather_ok && j->n_gather > 0 && (slots - (size_t)j->n_gather) * 4 <= slots &&
+    P.gather_all = (gather_ok && j->n_gather > 0 && j->d_xcd_all && (slots - (size_t)j->n_gather) * 4 <= slots &&
                     env_int("P2P_GATHER_ALL", 1) != 0) ? 1 : 0;
     // (the gather kernel of a big job on a side stream, forked and joined by events, so that its cache waits overlap
     // the main kernel's arithmetic: config 4's pitch 30 1647 vs 1621 us, all five pitches 8021 vs 7988 -- the two
@@ -1220,9 +1346,13 @@ int p2p_job_run(p2p_job* j)
             if (P.gather_all) {
                 const long long np = (long long)j->d.n_panos * j->d.n_yaw;
                 const long long ppb = (np * (long long)slots + 2047) / 2048;
-                P.gather_ppb = (int)std::min<long long>(std::max<long long>(ppb, 1), std::min<long long>(np, 16));
+                P.gather_ppb = (int)std::min<long long>(std::max<long long>(ppb, 1), std::min<long long>(np, std::min(16, std::max(1, env_int("P2P_GATHER_PPB", 16)))));
             }
-            HIP_TRY(p2p::launch_remap_views(P, 3, j->ctx->stream));
+            P.gather_list = P.gather_all ? j->d_xcd_all : j->d_xcd_list;
+            P.n_list = P.gather_all ? j->xcd_all_stride : j->xcd_stride;
+            if (P.gather_list && P.n_list > 0)
+                HIP_TRY(p2p::launch_remap_views(P, 3, j->ctx->stream));
+            P.gather_list = j->d_gather_list;
         }
         // the table kernel: every pair where the gather kernel does not apply, else the odd pairs
         P.use_pair_list = gather_ok ? 1 : 0;

@@ -40,13 +40,34 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* s_scan
     return base;
 }
 
+// min / max over the 64 lanes of a wave, in every lane: a Hillis-Steele scan inside each row of 16 lanes (DPP
+// row_shr), the rows' totals passed on by row_bcast, the wave's total read from lane 63.  Lanes that a step gives
+// no source keep their value.
+template <bool MAX>
+__device__ __forceinline__ int wave_reduce(int v)
+{
+#define P2P_DPP_STEP(ctrl, row_mask)                                                  \
+    {                                                                                 \
+        const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, row_mask, 0xf, false);  \
+        v = MAX ? max(v, o) : min(v, o);                                              \
+    }
+    P2P_DPP_STEP(0x111, 0xf)  // row_shr:1
+    P2P_DPP_STEP(0x112, 0xf)  // row_shr:2
+    P2P_DPP_STEP(0x114, 0xf)  // row_shr:4
+    P2P_DPP_STEP(0x118, 0xf)  // row_shr:8
+    P2P_DPP_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1 and 3
+    P2P_DPP_STEP(0x143, 0xc)  // row_bcast:31 -> rows 2 and 3
+#undef P2P_DPP_STEP
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 }  // namespace
 
 template <bool CALLER_MAPS>
 __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
 {
-    __shared__ int s_box[4];    // min ix, max ix, min iy, max iy of the tile's live pixels
-    __shared__ int s_flags[2];  // any live pixel, any pixel outside the panorama under a non-constant border
+    __shared__ int4 s_wbox[VIEWS_BLOCK / 64];   // per wave: min ix, max ix, min iy, max iy of its live pixels
+    __shared__ int s_wflags[VIEWS_BLOCK / 64];  // per wave: bit 0 any live pixel, bit 1 any pixel outside the panorama under a non-constant border
     __shared__ int s_rmin[PLAN_MAX_ROWS], s_rmax[PLAN_MAX_ROWS];
     __shared__ uint32_t s_rbase[PLAN_MAX_ROWS + 1];
     __shared__ uint32_t s_scan[4];
@@ -61,10 +82,6 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
     const int tx = t % TILE_W, ty0 = t / TILE_W;
     const int px = x0 + tx;
     const uint32_t slot = (uint32_t)(pitch_i * tiles_x * tiles_y + tile_id);
-    if (t == 0) {
-        s_box[0] = INT32_MAX; s_box[1] = INT32_MIN; s_box[2] = INT32_MAX; s_box[3] = INT32_MIN;
-        s_flags[0] = 0; s_flags[1] = 0;
-    }
 
     // ---- the pitch-stage coordinate of every pixel of the tile, quantised as cv::remap does ----
     int ix[PXT], iy[PXT];
@@ -141,21 +158,37 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
         inrange[j] = inside[j] && ix[j] >= -1 && iy[j] >= -1 && ix[j] < P.pw && iy[j] < P.ph;
     }
 
-    // ---- bounding box of the live pixels' coordinates ----
-    __syncthreads();
+    // ---- bounding box of the live pixels' coordinates: per thread, per wave (DPP), then over the waves' four entries.
+    // (An atomicMin on ONE LDS word per pixel is turned into a scalar loop over the wave's lanes by the compiler:
+    // sixteen of them were a thousand v_readlane per wave, two thirds of this kernel's instructions.)
+    int bx0 = INT32_MAX, bx1 = INT32_MIN, by0 = INT32_MAX, by1 = INT32_MIN;
+    bool live = false, strayp = false;
 #pragma unroll
     for (int j = 0; j < PXT; ++j) {
         if (inrange[j]) {
-            atomicMin(&s_box[0], ix[j]); atomicMax(&s_box[1], ix[j]);
-            atomicMin(&s_box[2], iy[j]); atomicMax(&s_box[3], iy[j]);
-            s_flags[0] = 1;
+            bx0 = min(bx0, ix[j]); bx1 = max(bx1, ix[j]);
+            by0 = min(by0, iy[j]); by1 = max(by1, iy[j]);
+            live = true;
         } else if (inside[j] && P.border != 0) {
-            s_flags[1] = 1;  // reads reflected / wrapped / replicated pixels: cv::borderInterpolate, table path
+            strayp = true;  // reads reflected / wrapped / replicated pixels: cv::borderInterpolate, table path
         }
     }
+    bx0 = wave_reduce<false>(bx0); bx1 = wave_reduce<true>(bx1);
+    by0 = wave_reduce<false>(by0); by1 = wave_reduce<true>(by1);
+    const bool wlive = __ballot(live) != 0ull, wstray = __ballot(strayp) != 0ull;
+    if ((t & 63) == 0) {
+        s_wbox[t >> 6] = make_int4(bx0, bx1, by0, by1);
+        s_wflags[t >> 6] = (int)wlive | (int)wstray << 1;
+    }
     __syncthreads();
-    const int c0 = s_box[0], c1 = s_box[1], r0 = s_box[2], r1 = s_box[3];
-    const bool any_live = s_flags[0] != 0, stray = s_flags[1] != 0;
+    int c0 = INT32_MAX, c1 = INT32_MIN, r0 = INT32_MAX, r1 = INT32_MIN, fl = 0;
+#pragma unroll
+    for (int w = 0; w < VIEWS_BLOCK / 64; ++w) {
+        const int4 b = s_wbox[w];
+        c0 = min(c0, b.x); c1 = max(c1, b.y); r0 = min(r0, b.z); r1 = max(r1, b.w);
+        fl |= s_wflags[w];
+    }
+    const bool any_live = (fl & 1) != 0, stray = (fl & 2) != 0;
     const int nrow = any_live ? r1 - r0 + 2 : 0;
     // The LDS scheme needs the whole footprint strictly inside the panorama (no tap is a border tap) and a
     // panorama width divisible by 4 (12-byte items never straddle a row end).
@@ -164,7 +197,8 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
               r1 + 1 < P.ph && nrow <= PLAN_MAX_ROWS;
     uint32_t n_items = 0;
     if (ok) {
-        // ---- per rot row: the span of columns the taps read ----
+        // ---- per rot row: the span of columns the taps read.  A pixel's taps sit in rows iy and iy + 1: two atomics
+        // per pixel on its own row, then the rows' threads join row r with row r - 1 ----
         if (t < nrow) {
             s_rmin[t] = INT32_MAX;
             s_rmax[t] = -1;
@@ -174,10 +208,24 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
         for (int j = 0; j < PXT; ++j)
             if (inrange[j]) {
                 const int r = iy[j] - r0;
-                atomicMin(&s_rmin[r], ix[j]);     atomicMax(&s_rmax[r], ix[j] + 1 + P.float_path);
-                atomicMin(&s_rmin[r + 1], ix[j]); atomicMax(&s_rmax[r + 1], ix[j] + 1 + P.float_path);
+                atomicMin(&s_rmin[r], ix[j]);
+                atomicMax(&s_rmax[r], ix[j] + 1 + P.float_path);
             }
         __syncthreads();
+        int jmin = INT32_MAX, jmax = -1;
+        if (t < nrow) {
+            jmin = s_rmin[t];
+            jmax = s_rmax[t];
+            if (t > 0) {
+                jmin = min(jmin, s_rmin[t - 1]);
+                jmax = max(jmax, s_rmax[t - 1]);
+            }
+        }
+        __syncthreads();
+        if (t < nrow) {
+            s_rmin[t] = jmin;
+            s_rmax[t] = jmax;
+        }
         // a row's LDS span starts at a column congruent to c0 mod 4 (so that one per-yaw alignment serves
         // every row) and leaves room for the yaw's alignment 0..3 within the first item
         int o = 0;
@@ -241,7 +289,8 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
         h.mode_items = ok ? (1u | n_items << 8) : 2u;
         h.c0 = any_live ? c0 : 0;
         h.c1 = any_live ? c1 : -1;
-        h.pad = 0u;
+        // rot rows of the live pixels' upper taps, + 1 (16 bits each): the host orders the gather list by source position
+        h.rows = any_live ? ((uint32_t)(r0 + 1) & 0xFFFFu) | (uint32_t)(r1 + 1) << 16 : 0u;
         P.hdr[slot] = h;
     }
 }

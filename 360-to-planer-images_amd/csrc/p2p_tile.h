@@ -73,6 +73,51 @@ __device__ __forceinline__ int tile_of_block(const ViewsParams& P, int bx, int g
     return tile_id < tiles ? tile_id : -1;
 }
 
+// The main kernel's grid with table prefetch.  A workgroup starts with a chain of dependent loads (header -> per-pixel
+// words, items, yaw descriptors -> first source pieces); when the plan tables of a job exceed the Infinity Cache
+// (config 4: 113 MB per pitch view) their first touch in a launch comes from HBM, behind the launch's own write stream,
+// and the workgroup -- four waves, 26 KB of LDS -- sits idle for tens of microseconds.  Loads complete in issue order
+// per wave, so a drawing wave cannot fetch ahead for others without waiting for that fetch itself.  Hence: in every
+// XCD's run of the tile raster, one workgroup in PF_GROUP + 1 draws nothing; it touches the tables of the PF_GROUP
+// tiles that the same XCD starts pf_lead groups later (workgroups are dispatched to an XCD in index order), so those
+// find them in L2.  gridDim.x == 8 * groups * (PF_GROUP + 1), groups = ceil(ceil(tiles / 8) / PF_GROUP).
+constexpr int PF_GROUP = 32;
+constexpr int PF_PX_LINES = VIEWS_BLOCK * VIEWS_PXT * 4 / 128;  // 128-byte lines of a tile's per-pixel words
+constexpr int PF_ITEM_LINES = 12;                               // ... of its item list that are touched (384 items)
+struct BlockRole {
+    int tile_id;             // >= 0: draw this tile
+    int pf_first, pf_count;  // pf_count > 0: touch the tables of tiles pf_first .. pf_first + pf_count - 1
+};
+
+__device__ __forceinline__ BlockRole main_block_role(const ViewsParams& P, int bx)
+{
+    const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
+    const int per_xcd = (tiles + 7) >> 3;
+    const int xcd = bx & 7, q = bx >> 3;
+    BlockRole r;
+    r.tile_id = -1;
+    r.pf_first = r.pf_count = 0;
+    int idx = q;
+    if (P.pf_lead > 0) {
+        const int g = q / (PF_GROUP + 1), s = q - g * (PF_GROUP + 1);
+        idx = g * PF_GROUP + s - 1;
+        if (s == 0) {
+            const int first = (g + P.pf_lead) * PF_GROUP;
+            int count = per_xcd - first;
+            count = count < PF_GROUP ? count : PF_GROUP;
+            if (xcd * per_xcd + first + count > tiles)
+                count = tiles - (xcd * per_xcd + first);
+            r.pf_first = xcd * per_xcd + first;
+            r.pf_count = count > 0 ? count : 0;
+            return r;
+        }
+    }
+    const int tile_id = xcd * per_xcd + idx;
+    if (idx < per_xcd && tile_id < tiles)
+        r.tile_id = tile_id;
+    return r;
+}
+
 __device__ __forceinline__ void decode_items(const uint32_t* __restrict__ itw, int t, int n_items, int src_pitch,
                                              uint32_t (&slot_off)[VIEWS_SLOTS], uint32_t (&slot_g)[VIEWS_SLOTS])
 {

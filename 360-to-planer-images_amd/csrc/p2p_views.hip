@@ -1074,14 +1074,42 @@ __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views
 {
     __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
     __shared__ __attribute__((aligned(16))) uint32_t stage[(VIEWS_BLOCK / 64) * VIEWS_PXT * 64];  // a dword per pixel
-    const int tile_id = tile_of_block(P, (int)blockIdx.x, (int)gridDim.x);
-    if (tile_id < 0)
-        return;
+    const BlockRole role = main_block_role(P, (int)blockIdx.x);
     // heaviest views first (the host orders pitch_order by |pitch - 90| descending): a smoother tail
     const int pitch_i = pitch_of_block(P, tile_grid_pitch_block(P));
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
+    if (role.pf_count > 0) {
+        // one dword of every 128-byte line of the tiles' tables; the values are not used (addresses follow from the
+        // block index: inside the tables by construction)
+        constexpr int LINES = PF_PX_LINES + PF_ITEM_LINES;
+        uint32_t acc = 0u;
+        const size_t slot0 = (size_t)pitch_i * tiles + role.pf_first;
+        for (int i = (int)threadIdx.x; i < role.pf_count * LINES; i += VIEWS_BLOCK) {
+            const int tj = i / LINES, l = i - tj * LINES;
+            const uint32_t* a = l < PF_PX_LINES ? px + (slot0 + tj) * (VIEWS_BLOCK * VIEWS_PXT) + l * 32
+                                                : items + (slot0 + tj) * LDS_ITEMS_CAP + (l - PF_PX_LINES) * 32;
+            acc |= *a;
+        }
+        if ((int)threadIdx.x < role.pf_count)
+            acc |= hdr[slot0 + threadIdx.x].mode_items;
+        asm volatile("" ::"v"(acc));
+        return;
+    }
+    const int tile_id = role.tile_id;
+    if (tile_id < 0)
+        return;
+#ifdef P2P_ABLATE_ONE_TABLE  // timing experiment (right pixels only when all pitch views are the same): every pitch view reads the first one's plan tables
+    const PieceHdr h = hdr[tile_id];
+    TileGeo G = tile_geo(P, h, pitch_i, tile_id, (int)threadIdx.x);
+    G.slot = (uint32_t)tile_id;
+#elif defined(P2P_ABLATE_TABLE_WINDOW)  // timing experiment (wrong pixels): all plan-table reads inside a window of 64 tiles -- what tables of no size would give
+    const PieceHdr h = hdr[(size_t)pitch_i * tiles + tile_id];
+    TileGeo G = tile_geo(P, h, pitch_i, tile_id, (int)threadIdx.x);
+    G.slot = (uint32_t)(tile_id & 63);
+#else
     const PieceHdr h = hdr[(size_t)pitch_i * tiles + tile_id];
     const TileGeo G = tile_geo(P, h, pitch_i, tile_id, (int)threadIdx.x);
+#endif
     draw_tight(P, src, ydesc, out, G, px + (size_t)G.slot * (VIEWS_BLOCK * VIEWS_PXT), items + (size_t)G.slot * LDS_ITEMS_CAP,
                tile4, stage);
 }
@@ -1105,15 +1133,25 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_rest_kernel(
 
 // the plan's list of mode 2 tiles -> (pitch, tile); an entry beyond the plan's slots (never written by the plan
 // pass) is clamped
-__device__ __forceinline__ void tile_of_list(const ViewsParams& P, const uint32_t* __restrict__ list, uint32_t site, int& pitch_i, int& tile_id)
+// XCD_LISTS (the gather kernel): the list is [8][P.n_list], one work list per XCD, grouped by the tiles' position in
+// the SOURCE so that tiles of different pitch views that read the same part of the panorama meet in one L2
+// (p2p_host.cpp: xcd_lists); gridDim.x == 8 * n_list, ~0 = no tile (returns false).
+template <bool XCD_LISTS>
+__device__ __forceinline__ bool tile_of_list(const ViewsParams& P, const uint32_t* __restrict__ list, uint32_t site, int& pitch_i, int& tile_id)
 {
     const uint32_t tiles = (uint32_t)(((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H));
-    uint32_t slot = list[blockIdx.x];
+    uint32_t idx = blockIdx.x;
+    if (XCD_LISTS)
+        idx = (blockIdx.x & 7u) * (uint32_t)P.n_list + (blockIdx.x >> 3);
+    uint32_t slot = list[idx];
+    if (XCD_LISTS && slot == ~0u)
+        return false;
     P2P_AUD_LT(P.audit, site, slot, tiles * (uint32_t)P.n_pitch);
     if (slot >= tiles * (uint32_t)P.n_pitch)
         slot = 0u;
     pitch_i = (int)(slot / tiles);
     tile_id = (int)(slot - (uint32_t)pitch_i * tiles);
+    return true;
 }
 
 // One workgroup per (mode 2 tile of the plan's list, chunk of pairs).
@@ -1127,12 +1165,8 @@ __global__ __launch_bounds__(VIEWS_BLOCK, P2P_GATHER_WAVES) void remap_views_gat
     __shared__ __attribute__((aligned(16))) uint32_t stage[(VIEWS_BLOCK / 64) * VIEWS_PXT * 64];
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
     int pitch_i, tile_id;
-    if (P.gather_all) {  // grid.x == tiles * n_pitch
-        pitch_i = (int)blockIdx.x / tiles;
-        tile_id = (int)blockIdx.x - pitch_i * tiles;
-    } else {
-        tile_of_list(P, gather_list, AUD_GATHER_LIST, pitch_i, tile_id);
-    }
+    if (!tile_of_list<true>(P, gather_list, AUD_GATHER_LIST, pitch_i, tile_id))  // (gather_all: the list of ALL tiles)
+        return;
     const PieceHdr h = hdr[(size_t)pitch_i * tiles + tile_id];
     const TileGeo G = tile_geo(P, h, pitch_i, tile_id, (int)threadIdx.x);
     if (G.mode != 2 && !P.gather_all)
@@ -1148,7 +1182,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, P2P_DIRECT_WAVES) void remap_views_tab
     const PieceHdr* __restrict__ hdr, const uint32_t* __restrict__ gather_list)
 {
     int pitch_i, tile_id;
-    tile_of_list(P, gather_list, AUD_TABLE_LIST, pitch_i, tile_id);
+    tile_of_list<false>(P, gather_list, AUD_TABLE_LIST, pitch_i, tile_id);
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
     const PieceHdr h = hdr[(size_t)pitch_i * tiles + tile_id];
     const TileGeo G = tile_geo(P, h, pitch_i, tile_id, (int)threadIdx.x);
@@ -1162,8 +1196,7 @@ hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
     const int n_pairs = P.n_panos * P.n_yaw;
     if (which == 2 || which == 3) {
         const int np = (which == 2 && P.use_pair_list) ? P.n_odd_pairs : n_pairs;
-        const int all = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H) * P.n_pitch;
-        const dim3 grid((which == 3 && P.gather_all) ? all : P.n_gather, 1, (np + P.gather_ppb - 1) / P.gather_ppb);
+        const dim3 grid(which == 3 ? 8 * P.n_list : P.n_gather, 1, (np + P.gather_ppb - 1) / P.gather_ppb);
         if (which == 2)
             hipLaunchKernelGGL(remap_views_table_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.out, P.hdr, P.gather_list);
         else
@@ -1175,7 +1208,9 @@ hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
     if (which == 1 && P.use_pair_list)
         zblocks = (P.n_odd_pairs + P.rest_ppb - 1) / P.rest_ppb;
     // 8 XCDs, each a contiguous run of tiles; (tile, chunk, pitch view): see pair_chunk
-    const dim3 grid(8 * ((tiles + 7) / 8), P.chunk_outer ? P.n_pitch : zblocks, P.chunk_outer ? zblocks : P.n_pitch);
+    dim3 grid(8 * ((tiles + 7) / 8), P.chunk_outer ? P.n_pitch : zblocks, P.chunk_outer ? zblocks : P.n_pitch);
+    if (which == 0 && P.pf_lead > 0)  // one table-prefetch workgroup in PF_GROUP + 1 (p2p_tile.h: main_block_role)
+        grid.x = 8 * (((tiles + 7) / 8 + PF_GROUP - 1) / PF_GROUP) * (PF_GROUP + 1);
     if (which == 0)
         hipLaunchKernelGGL(remap_views_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.hdr, P.px, P.items);
     else
