@@ -227,7 +227,8 @@ struct Plan {  // the plan pass's tables (p2p_plan.hip)
     uint32_t* d_gather_list = nullptr;   // [n_pitch * tiles] tiles the plan marks for gathers (in the order the plan pass met them)
     uint32_t* d_xcd_list = nullptr;      // [8][xcd_stride] the same tiles dealt to the XCDs by source position (xcd_lists), ~0: none
     uint32_t* d_xcd_all = nullptr;       // [8][xcd_all_stride] every tile, likewise (only when most tiles gather: ViewsParams::gather_all)
-    int xcd_stride = 0, xcd_all_stride = 0;
+    uint32_t* d_main_list = nullptr;     // [8][main_stride] the LDS-scheme tiles, dealt to the XCDs in source order (xcd_main_lists)
+    int xcd_stride = 0, xcd_all_stride = 0, main_stride = 0;
     int n_gather = 0;
     bool built = false;
     float plan_ms = 0.0f;                // device time of the plan pass
@@ -237,7 +238,7 @@ struct Plan {  // the plan pass's tables (p2p_plan.hip)
     {
         (void)hipSetDevice(device);
         (void)dev_free(d_coords); (void)dev_free(d_hdr); (void)dev_free(d_px); (void)dev_free(d_items);
-        (void)dev_free(d_px2); (void)dev_free(d_n_gather); (void)dev_free(d_gather_list); (void)dev_free(d_xcd_list); (void)dev_free(d_xcd_all);
+        (void)dev_free(d_px2); (void)dev_free(d_n_gather); (void)dev_free(d_gather_list); (void)dev_free(d_xcd_list); (void)dev_free(d_xcd_all); (void)dev_free(d_main_list);
     }
 };
 
@@ -252,6 +253,50 @@ uint64_t source_order_key(const p2p::PieceHdr& h)
     for (int b = 0; b < 16; ++b)
         key |= (uint64_t)((cx >> b) & 1u) << (2 * b) | (uint64_t)((cy >> b) & 1u) << (2 * b + 1);
     return key;
+}
+
+// The main kernel's tiles (mode 1), dealt to the 8 XCDs (workgroup b runs on XCD b & 7).  In the grid's own order --
+// the tile raster of one pitch view after the other -- every view reads its band of the panorama through the XCDs' L2s
+// by itself, and neighbouring pitch views overlap by half (config 2: 60 / 90 / 120 degrees, 59 degrees high each):
+// 244 MB of reads per launch for a 100 MB panorama and 35 MB of tables.  Here the tiles of ALL pitch views are ordered
+// by the band of 64 source rows their footprint is centred in, then by view and raster position, and every XCD takes
+// a contiguous part of that order: the tiles of two views that read the same rows follow each other on one XCD and
+// find them in its L2 (117 MB; config 2 -2 ... -3.5 %, config 4 -4.5 %).  Used for jobs with ONE resident panorama:
+// with several, streamed from HBM, the grid's own order is faster.
+std::vector<uint32_t> xcd_main_lists(const std::vector<p2p::PieceHdr>& hh, size_t tiles, int* stride)
+{
+    std::vector<std::pair<uint64_t, uint32_t>> order;
+    for (size_t s = 0; s < hh.size(); ++s) {
+        const p2p::PieceHdr& h = hh[s];
+        if ((h.mode_items & 3u) != 1u)
+            continue;
+        const uint64_t cy = ((h.rows & 0xFFFFu) + (h.rows >> 16)) / 2u;
+        order.emplace_back((cy >> 6) << 40 | (uint64_t)(s / tiles) << 24 | (uint64_t)(s % tiles), (uint32_t)s);
+    }
+    std::sort(order.begin(), order.end());
+    // equal WORK per XCD, not equal counts: a tile costs about 600 + its footprint's items (stage 2 and the way out,
+    // plus stage 1 per item), and the footprints grow towards the poles -- with equal counts the two XCDs that hold the
+    // polar bands finish last (config 3's share: 7.6 ms against 6.5 in grid order)
+    const size_t n = order.size();
+    std::vector<uint64_t> upto(n + 1, 0);
+    for (size_t i = 0; i < n; ++i)
+        upto[i + 1] = upto[i] + 600u + (hh[order[i].second].mode_items >> 8);
+    size_t first[9];
+    first[0] = 0;
+    for (int x = 1; x < 8; ++x)
+        first[x] = (size_t)(std::lower_bound(upto.begin(), upto.end(), upto[n] * (uint64_t)x / 8u) - upto.begin());
+    first[8] = n;
+    size_t per = 1;
+    for (int x = 0; x < 8; ++x) {
+        first[x + 1] = std::max(first[x + 1], first[x]);
+        per = std::max(per, first[x + 1] - first[x]);
+    }
+    std::vector<uint32_t> table(8 * per, ~0u);
+    for (int x = 0; x < 8; ++x)
+        for (size_t i = first[x]; i < first[x + 1]; ++i)
+            table[x * per + (i - first[x])] = order[i].second;
+    *stride = (int)per;
+    return table;
 }
 
 // The gather kernel's tiles, dealt to the 8 XCDs (workgroup b runs on XCD b & 7 and takes entry b >> 3 of that XCD's
@@ -410,6 +455,8 @@ struct p2p_job {
     uint32_t* d_gather_list = nullptr;   // [n_pitch * tiles] tiles the plan marks for gathers
     uint32_t* d_xcd_list = nullptr, *d_xcd_all = nullptr;  // the gather kernel's per-XCD work lists (see Plan)
     int xcd_stride = 0, xcd_all_stride = 0;
+    uint32_t* d_main_list = nullptr;     // the main kernel's per-XCD work lists (see Plan)
+    int main_stride = 0;
     uint32_t* d_odd_pairs = nullptr;     // (panorama, yaw) pairs whose yaw is not a plain shift with one weight
     int n_odd_pairs = 0;
     int n_gather = 0;                    // tiles the plan marks for gathers
@@ -1122,11 +1169,22 @@ static int job_build_plan(p2p_job* j)
         return fail(P2P_ERR_HIP, "the plan pass listed %u gather tiles of %zu", cnt, slots);
     Pl->n_gather = (int)cnt;
     Pl->built = true;
-    if (cnt > 0) {
-        // the gather kernel's work lists, one per XCD (once per geometry): xcd_lists
-        std::vector<p2p::PieceHdr> hh(slots);
+    const bool main_order = env_int("P2P_MAIN_ORDER", 1) != 0 && (size_t)cnt < slots;
+    std::vector<p2p::PieceHdr> hh;
+    if (cnt > 0 || main_order) {  // the work lists are made from the plan's headers, once per geometry
+        hh.resize(slots);
         HIP_TRY(hipMemcpyAsync(hh.data(), Pl->d_hdr, slots * sizeof(p2p::PieceHdr), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (main_order) {
+        const std::vector<uint32_t> tm = xcd_main_lists(hh, j->n_tiles, &Pl->main_stride);
+        HIP_TRY(dev_alloc((void**)&Pl->d_main_list, tm.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(Pl->d_main_list, tm.data(), tm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        Pl->bytes += tm.size() * sizeof(uint32_t);
+    }
+    if (cnt > 0) {
+        // the gather kernel's work lists, one per XCD: xcd_lists
         const bool by_source = env_int("P2P_GATHER_ORDER", 1) != 0;
         std::vector<uint32_t> marked, all;
         for (size_t s = 0; s < slots; ++s)
@@ -1161,6 +1219,7 @@ static int job_build_plan(p2p_job* j)
         HIP_TRY(p2p::launch_scramble(Pl->d_items, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t), sd + 3, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_gather_list, slots * sizeof(uint32_t), sd + 4, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_xcd_list, Pl->d_xcd_list ? 8 * (size_t)Pl->xcd_stride * sizeof(uint32_t) : 0, sd + 10, st));
+        HIP_TRY(p2p::launch_scramble(Pl->d_main_list, Pl->d_main_list ? 8 * (size_t)Pl->main_stride * sizeof(uint32_t) : 0, sd + 12, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_xcd_all, Pl->d_xcd_all ? 8 * (size_t)Pl->xcd_all_stride * sizeof(uint32_t) : 0, sd + 11, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_coords, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2), sd + 5, st));
         if (Pl->d_px2)
@@ -1270,9 +1329,18 @@ int p2p_job_run(p2p_job* j)
         j->d_coords = Pl.d_coords; j->d_hdr = Pl.d_hdr; j->d_px = Pl.d_px; j->d_items = Pl.d_items; j->d_px2 = Pl.d_px2;
         j->d_gather_list = Pl.d_gather_list; j->d_xcd_list = Pl.d_xcd_list; j->d_xcd_all = Pl.d_xcd_all;
         j->xcd_stride = Pl.xcd_stride; j->xcd_all_stride = Pl.xcd_all_stride; j->n_gather = Pl.n_gather;
+        j->d_main_list = Pl.d_main_list; j->main_stride = Pl.main_stride;
     }
     P.pairs_per_block = choose_pairs_per_block(j->d);
     P.chunk_outer = env_int("P2P_CHUNK_OUTER", j->d.n_panos > 1 ? 1 : 0);
+    // the main kernel's grid: list order (source bands, all pitch views together) unless the plan has no list
+    P.main_list = (j->d.n_panos == 1 || env_int("P2P_MAIN_ORDER", 1) == 2) ? j->d_main_list : nullptr;
+    P.main_stride = j->main_stride;
+    P.main_chunks = (j->d.n_panos * j->d.n_yaw + P.pairs_per_block - 1) / P.pairs_per_block;
+    // entries drawn for one chunk of pairs before the next chunk: with ONE panorama a short run (the entries' plan tables
+    // and source rows are still in L2 for the next chunk), with several all of them (a chunk's panoramas serve every
+    // tile before the next ones are touched: see pair_chunk)
+    P.main_group = P.chunk_outer ? std::max(1, j->main_stride) : std::max(1, std::min(j->main_stride, env_int("P2P_MAIN_GROUP", 192)));
     // table-prefetch workgroups (p2p_tile.h: main_block_role) when one launch's plan tables cannot stay in the Infinity
     // Cache next to the panorama (config 4: 565 MB): 2 groups = 64 tiles of lead per XCD
     {

@@ -235,10 +235,10 @@ __device__ __forceinline__ int pair_of_lane(const ViewsParams& P, bool list, int
 // LIST: the chunk's pairs come from P.odd_pairs (the rest kernel drawing only the yaws left to it) instead of being
 // the contiguous run chunk * pairs_per_block ...
 template <bool LIST = false>
-__device__ __forceinline__ PairCtxs pair_contexts(const ViewsParams& P, const YawDesc* __restrict__ ydesc, int c0, int c1, int t)
+__device__ __forceinline__ PairCtxs pair_contexts(const ViewsParams& P, const YawDesc* __restrict__ ydesc, int c0, int c1, int t, int chunk)
 {
     PairCtxs X;
-    pair_chunk(P, LIST, LIST ? P.rest_ppb : P.pairs_per_block, tile_grid_chunk(P), X.pair0, X.npairs);
+    pair_chunk(P, LIST, LIST ? P.rest_ppb : P.pairs_per_block, chunk, X.pair0, X.npairs);
     const int ngroups = P.pw >> 2;
     uint32_t cw0 = 0, cw1 = 0;
     int cw2 = 0, cw3 = 0, cls = 4;
@@ -349,14 +349,14 @@ __device__ __forceinline__ void store_wave_pixels(const StoreCtx& s, const uint3
 __device__ __forceinline__ void draw_tight(
     const ViewsParams& P, const uint8_t* __restrict__ src, const YawDesc* __restrict__ ydesc,
     uint8_t* __restrict__ out, const TileGeo& G, const uint32_t* __restrict__ pxw, const uint32_t* __restrict__ itw,
-    uint4 (*tile4)[LDS_ITEMS_CAP], uint32_t* stage)
+    uint4 (*tile4)[LDS_ITEMS_CAP], uint32_t* stage, int chunk)
 {
     constexpr int PXT = VIEWS_PXT;
     const int t = threadIdx.x;
     if (!tight_tile(G, P))
         return;  // the other kernels'
     P2P_AUD_LT(P.audit, AUD_MAIN_HDR, G.n_items, LDS_ITEMS_CAP + 1);
-    const PairCtxs X = pair_contexts(P, ydesc, G.c0, G.c1, t);
+    const PairCtxs X = pair_contexts(P, ydesc, G.c0, G.c1, t, chunk);
     const int nplain = X.n3;
     if (nplain == 0)
         return;
@@ -916,7 +916,8 @@ __device__ __forceinline__ void draw_rest(
 
     // ---- LDS scheme, general loop ----
     const bool listed = P.use_pair_list != 0;
-    const PairCtxs X = listed ? pair_contexts<true>(P, ydesc, G.c0, G.c1, t) : pair_contexts<false>(P, ydesc, G.c0, G.c1, t);
+    const PairCtxs X = listed ? pair_contexts<true>(P, ydesc, G.c0, G.c1, t, tile_grid_chunk(P))
+                              : pair_contexts<false>(P, ydesc, G.c0, G.c1, t, tile_grid_chunk(P));
     const int kfirst = main_draws_plain ? X.n3 : 0;  // the main kernel has classes 0..3 of its tiles
     if (kfirst >= X.npairs)
         return;
@@ -1074,30 +1075,75 @@ __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views
 {
     __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
     __shared__ __attribute__((aligned(16))) uint32_t stage[(VIEWS_BLOCK / 64) * VIEWS_PXT * 64];  // a dword per pixel
-    const BlockRole role = main_block_role(P, (int)blockIdx.x);
-    // heaviest views first (the host orders pitch_order by |pitch - 90| descending): a smoother tail
-    const int pitch_i = pitch_of_block(P, tile_grid_pitch_block(P));
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
-    if (role.pf_count > 0) {
-        // one dword of every 128-byte line of the tiles' tables; the values are not used (addresses follow from the
-        // block index: inside the tables by construction)
-        constexpr int LINES = PF_PX_LINES + PF_ITEM_LINES;
-        uint32_t acc = 0u;
-        const size_t slot0 = (size_t)pitch_i * tiles + role.pf_first;
-        for (int i = (int)threadIdx.x; i < role.pf_count * LINES; i += VIEWS_BLOCK) {
-            const int tj = i / LINES, l = i - tj * LINES;
-            const uint32_t* a = l < PF_PX_LINES ? px + (slot0 + tj) * (VIEWS_BLOCK * VIEWS_PXT) + l * 32
-                                                : items + (slot0 + tj) * LDS_ITEMS_CAP + (l - PF_PX_LINES) * 32;
-            acc |= *a;
+    int tile_id, pitch_i, chunk;
+    if (P.main_list) {
+        // List order (p2p_host.cpp: xcd_main_lists): workgroup b runs on XCD b & 7 and is that XCD's q-th, q = b >> 3.
+        // The XCD draws main_group entries of its list for one chunk of pairs, the same entries for the next chunk
+        // (their plan tables and source rows are still in its L2), and so on, then the next main_group entries.
+        // With pf_lead > 0 (plan tables beyond the Infinity Cache: config 4) one more workgroup per block, dispatched
+        // ahead of the block's last chunk, draws nothing and touches the plan tables of the NEXT block's entries.
+        const uint32_t q = blockIdx.x >> 3, group = (uint32_t)P.main_group, chunks = (uint32_t)P.main_chunks;
+        const uint32_t pf = P.pf_lead > 0 ? 1u : 0u, pf_pos = group * (chunks - 1u);
+        const uint32_t per_block = group * chunks + pf;
+        const uint32_t blk = q / per_block;
+        uint32_t r = q - blk * per_block;
+        if (pf && r == pf_pos) {
+            constexpr uint32_t LINES = PF_PX_LINES + PF_ITEM_LINES;
+            const uint32_t* mine = P.main_list + (blockIdx.x & 7u) * (uint32_t)P.main_stride;
+            uint32_t acc = 0u;
+            for (uint32_t i = threadIdx.x; i < group * LINES; i += VIEWS_BLOCK) {
+                const uint32_t tj = i / LINES, l = i - tj * LINES, e = (blk + 1u) * group + tj;
+                const uint32_t slot = e < (uint32_t)P.main_stride ? mine[e] : ~0u;
+                if (slot < (uint32_t)(tiles * P.n_pitch)) {
+                    const uint32_t* a = l < PF_PX_LINES ? px + (size_t)slot * (VIEWS_BLOCK * VIEWS_PXT) + l * 32
+                                                        : items + (size_t)slot * LDS_ITEMS_CAP + (l - PF_PX_LINES) * 32;
+                    acc |= *a;
+                    if (l == 0)
+                        acc |= hdr[slot].mode_items;
+                }
+            }
+            asm volatile("" ::"v"(acc));
+            return;
         }
-        if ((int)threadIdx.x < role.pf_count)
-            acc |= hdr[slot0 + threadIdx.x].mode_items;
-        asm volatile("" ::"v"(acc));
-        return;
+        r -= (pf && r > pf_pos) ? 1u : 0u;
+        chunk = (int)(r / group);
+        const uint32_t e = blk * group + (r - (uint32_t)chunk * group);
+        if (e >= (uint32_t)P.main_stride)
+            return;
+        uint32_t slot = P.main_list[(blockIdx.x & 7u) * (uint32_t)P.main_stride + e];
+        if (slot == ~0u)
+            return;
+        P2P_AUD_LT(P.audit, AUD_MAIN_PITCH, slot, (uint32_t)(tiles * P.n_pitch));
+        slot = slot < (uint32_t)(tiles * P.n_pitch) ? slot : 0u;  // (a garbage list draws a valid tile)
+        pitch_i = (int)(slot / (uint32_t)tiles);
+        tile_id = (int)(slot - (uint32_t)pitch_i * (uint32_t)tiles);
+    } else {
+        const BlockRole role = main_block_role(P, (int)blockIdx.x);
+        // heaviest views first (the host orders pitch_order by |pitch - 90| descending): a smoother tail
+        pitch_i = pitch_of_block(P, tile_grid_pitch_block(P));
+        chunk = tile_grid_chunk(P);
+        if (role.pf_count > 0) {
+            // one dword of every 128-byte line of the tiles' tables; the values are not used (addresses follow from the
+            // block index: inside the tables by construction)
+            constexpr int LINES = PF_PX_LINES + PF_ITEM_LINES;
+            uint32_t acc = 0u;
+            const size_t slot0 = (size_t)pitch_i * tiles + role.pf_first;
+            for (int i = (int)threadIdx.x; i < role.pf_count * LINES; i += VIEWS_BLOCK) {
+                const int tj = i / LINES, l = i - tj * LINES;
+                const uint32_t* a = l < PF_PX_LINES ? px + (slot0 + tj) * (VIEWS_BLOCK * VIEWS_PXT) + l * 32
+                                                    : items + (slot0 + tj) * LDS_ITEMS_CAP + (l - PF_PX_LINES) * 32;
+                acc |= *a;
+            }
+            if ((int)threadIdx.x < role.pf_count)
+                acc |= hdr[slot0 + threadIdx.x].mode_items;
+            asm volatile("" ::"v"(acc));
+            return;
+        }
+        tile_id = role.tile_id;
+        if (tile_id < 0)
+            return;
     }
-    const int tile_id = role.tile_id;
-    if (tile_id < 0)
-        return;
 #ifdef P2P_ABLATE_ONE_TABLE  // timing experiment (right pixels only when all pitch views are the same): every pitch view reads the first one's plan tables
     const PieceHdr h = hdr[tile_id];
     TileGeo G = tile_geo(P, h, pitch_i, tile_id, (int)threadIdx.x);
@@ -1111,7 +1157,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views
     const TileGeo G = tile_geo(P, h, pitch_i, tile_id, (int)threadIdx.x);
 #endif
     draw_tight(P, src, ydesc, out, G, px + (size_t)G.slot * (VIEWS_BLOCK * VIEWS_PXT), items + (size_t)G.slot * LDS_ITEMS_CAP,
-               tile4, stage);
+               tile4, stage, chunk);
 }
 
 __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_rest_kernel(
@@ -1209,7 +1255,9 @@ hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
         zblocks = (P.n_odd_pairs + P.rest_ppb - 1) / P.rest_ppb;
     // 8 XCDs, each a contiguous run of tiles; (tile, chunk, pitch view): see pair_chunk
     dim3 grid(8 * ((tiles + 7) / 8), P.chunk_outer ? P.n_pitch : zblocks, P.chunk_outer ? zblocks : P.n_pitch);
-    if (which == 0 && P.pf_lead > 0)  // one table-prefetch workgroup in PF_GROUP + 1 (p2p_tile.h: main_block_role)
+    if (which == 0 && P.main_list)  // list order: (blocks of main_group entries) x chunks, per XCD
+        grid = dim3(8 * ((P.main_stride + P.main_group - 1) / P.main_group) * (P.main_group * P.main_chunks + (P.pf_lead > 0 ? 1 : 0)), 1, 1);
+    else if (which == 0 && P.pf_lead > 0)  // one table-prefetch workgroup in PF_GROUP + 1 (p2p_tile.h: main_block_role)
         grid.x = 8 * (((tiles + 7) / 8 + PF_GROUP - 1) / PF_GROUP) * (PF_GROUP + 1);
     if (which == 0)
         hipLaunchKernelGGL(remap_views_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.hdr, P.px, P.items);
