@@ -265,15 +265,19 @@ uint64_t source_order_key(const p2p::PieceHdr& h)
 // with several, streamed from HBM, the grid's own order is faster.
 std::vector<uint32_t> xcd_main_lists(const std::vector<p2p::PieceHdr>& hh, size_t tiles, int* stride)
 {
-    std::vector<std::pair<uint64_t, uint32_t>> order;
-    for (size_t s = 0; s < hh.size(); ++s) {
-        const p2p::PieceHdr& h = hh[s];
-        if ((h.mode_items & 3u) != 1u)
-            continue;
-        const uint64_t cy = ((h.rows & 0xFFFFu) + (h.rows >> 16)) / 2u;
-        order.emplace_back((cy >> 6) << 40 | (uint64_t)(s / tiles) << 24 | (uint64_t)(s % tiles), (uint32_t)s);
-    }
-    std::sort(order.begin(), order.end());
+    // (band, view, raster position): the slots come in (view, raster) order, so a counting sort by band does it
+    (void)tiles;
+    auto band_of = [](const p2p::PieceHdr& h) { return (size_t)((((h.rows & 0xFFFFu) + (h.rows >> 16)) / 2u) >> 6); };
+    std::vector<size_t> start(1026, 0);
+    for (const p2p::PieceHdr& h : hh)
+        if ((h.mode_items & 3u) == 1u)
+            start[band_of(h) + 1]++;
+    for (size_t b = 1; b < start.size(); ++b)
+        start[b] += start[b - 1];
+    std::vector<std::pair<uint64_t, uint32_t>> order(start.back());
+    for (size_t s = 0; s < hh.size(); ++s)
+        if ((hh[s].mode_items & 3u) == 1u)
+            order[start[band_of(hh[s])]++] = std::make_pair((uint64_t)band_of(hh[s]), (uint32_t)s);
     // equal WORK per XCD, not equal counts: a tile costs about 600 + its footprint's items (stage 2 and the way out,
     // plus stage 1 per item), and the footprints grow towards the poles -- with equal counts the two XCDs that hold the
     // polar bands finish last (config 3's share: 7.6 ms against 6.5 in grid order)
@@ -291,6 +295,8 @@ std::vector<uint32_t> xcd_main_lists(const std::vector<p2p::PieceHdr>& hh, size_
         first[x + 1] = std::max(first[x + 1], first[x]);
         per = std::max(per, first[x + 1] - first[x]);
     }
+    // every XCD's list has the longest one's length, the shorter ones end in empty entries (spreading those over the
+    // list instead: nothing on config 2, 7.31 against 7.02 ms on config 4)
     std::vector<uint32_t> table(8 * per, ~0u);
     for (int x = 0; x < 8; ++x)
         for (size_t i = first[x]; i < first[x + 1]; ++i)
@@ -1163,24 +1169,30 @@ static int job_build_plan(p2p_job* j)
     HIP_TRY(hipEventRecord(ctx->ev_t1, st));
     uint32_t cnt = 0;
     HIP_TRY(hipMemcpyAsync(&cnt, Pl->d_n_gather, sizeof(cnt), hipMemcpyDeviceToHost, st));
+    // the work lists are made from the plan's headers, once per geometry: they come back with the counter
+    const bool want_main_order = env_int("P2P_MAIN_ORDER", 1) != 0;
+    std::vector<p2p::PieceHdr> hh;
+    if (want_main_order) {
+        hh.resize(slots);
+        HIP_TRY(hipMemcpyAsync(hh.data(), Pl->d_hdr, slots * sizeof(p2p::PieceHdr), hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(hipStreamSynchronize(st));
     (void)hipEventElapsedTime(&Pl->plan_ms, ctx->ev_t0, ctx->ev_t1);
     if ((size_t)cnt > slots)
         return fail(P2P_ERR_HIP, "the plan pass listed %u gather tiles of %zu", cnt, slots);
     Pl->n_gather = (int)cnt;
     Pl->built = true;
-    const bool main_order = env_int("P2P_MAIN_ORDER", 1) != 0 && (size_t)cnt < slots;
-    std::vector<p2p::PieceHdr> hh;
-    if (cnt > 0 || main_order) {  // the work lists are made from the plan's headers, once per geometry
+    const bool main_order = want_main_order && (size_t)cnt < slots;
+    if (cnt > 0 && hh.empty()) {
         hh.resize(slots);
         HIP_TRY(hipMemcpyAsync(hh.data(), Pl->d_hdr, slots * sizeof(p2p::PieceHdr), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
+    std::vector<uint32_t> tm;  // (alive until the stream has taken the copies: synchronised below)
     if (main_order) {
-        const std::vector<uint32_t> tm = xcd_main_lists(hh, j->n_tiles, &Pl->main_stride);
+        tm = xcd_main_lists(hh, j->n_tiles, &Pl->main_stride);
         HIP_TRY(dev_alloc((void**)&Pl->d_main_list, tm.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpyAsync(Pl->d_main_list, tm.data(), tm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
         Pl->bytes += tm.size() * sizeof(uint32_t);
     }
     if (cnt > 0) {
@@ -1190,7 +1202,7 @@ static int job_build_plan(p2p_job* j)
         for (size_t s = 0; s < slots; ++s)
             if ((hh[s].mode_items & 3u) == 2u)
                 marked.push_back((uint32_t)s);
-        if (marked.size() != (size_t)cnt)
+        if (marked.size() != (size_t)cnt && hipStreamSynchronize(st) != hipErrorUnknown)
             return fail(P2P_ERR_HIP, "the plan's headers mark %zu gather tiles, its counter %u", marked.size(), cnt);
         const std::vector<uint32_t> tg = xcd_lists(marked, hh, d.pw, by_source, &Pl->xcd_stride);
         HIP_TRY(dev_alloc((void**)&Pl->d_xcd_list, tg.size() * sizeof(uint32_t)));
@@ -1208,6 +1220,8 @@ static int job_build_plan(p2p_job* j)
         }
         HIP_TRY(hipStreamSynchronize(st));  // the vectors go out of scope
     }
+    if (main_order && cnt == 0)
+        HIP_TRY(hipStreamSynchronize(st));  // tm goes out of scope
     if (const int seed = env_int("P2P_SCRAMBLE_PLAN", 0)) {
         // Robustness self-test (tests/fuzz/scramble_tables.py), never set in normal use: every table of the plan -- and
         // with bit 30 of the value the job's yaw tables too -- overwritten with pseudo-random words AFTER the plan pass.

@@ -246,7 +246,8 @@ def cold_first_image(nat, w, pano, device):
         return {"plan_ms": plan_ms, "yaw_tables_ms": tables_ms, "first_run_ms": first, "view_kernel_ms_in_first_run": k,
                 "cold_one_image_ms": tables_ms + first,
                 "how": "fresh context and job; first_run_ms = HIP events around the first p2p_job_run (plan pass, host "
-                       "read-back of its counter, view kernel); yaw tables are built at job creation"}
+                       "read-back of its counter and headers, the per-XCD work lists, view kernel); yaw tables are built "
+                       "at job creation"}
     finally:
         ctx.close()
 
