@@ -1202,8 +1202,10 @@ static int job_build_plan(p2p_job* j)
         for (size_t s = 0; s < slots; ++s)
             if ((hh[s].mode_items & 3u) == 2u)
                 marked.push_back((uint32_t)s);
-        if (marked.size() != (size_t)cnt && hipStreamSynchronize(st) != hipErrorUnknown)
+        if (marked.size() != (size_t)cnt) {
+            (void)hipStreamSynchronize(st);  // the list copy still reads `tm`
             return fail(P2P_ERR_HIP, "the plan's headers mark %zu gather tiles, its counter %u", marked.size(), cnt);
+        }
         const std::vector<uint32_t> tg = xcd_lists(marked, hh, d.pw, by_source, &Pl->xcd_stride);
         HIP_TRY(dev_alloc((void**)&Pl->d_xcd_list, tg.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpyAsync(Pl->d_xcd_list, tg.data(), tg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
