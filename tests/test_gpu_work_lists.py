@@ -1,0 +1,65 @@
+"""GPU parity of the work lists (csrc/p2p_host.cpp: xcd_main_lists, xcd_lists): which XCD draws which tile, and when,
+must not change a byte.  Every combination of main-kernel order (grid / list / list for several panoramas), turn length
+per chunk of pairs, table-prefetch workgroups and gather-tile order is checked against the CPU restatement of the
+reference's two cv2.remap stages (P:181-221) on a job that has LDS-scheme tiles, gather tiles (a pole in view),
+several chunks of pairs and a flickering yaw."""
+import itertools
+
+import numpy as np
+import pytest
+
+from _util import oracle_maps, oracle_views
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(gpu, panos, yaws, pitches, ow, oh, fov, maps):
+    ph, pw = panos[0].shape[:2]
+    ctx = gpu.Context(0)
+    try:
+        job = gpu.Job(ctx, pw, ph, len(panos), yaws, pitches, fov, ow, oh)
+        if maps is not None:
+            job.set_maps(*maps)
+        for i, p in enumerate(panos):
+            job.set_pano(i, p)
+        job.run()
+        out = [job.get_views(i) for i in range(len(panos))]
+        job.close()
+        return out
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("n_panos", [1, 2])
+def test_every_work_list_order_draws_the_oracles_bytes(gpu, synth, monkeypatch, n_panos):
+    pw, ph, ow, oh, fov = 2048, 1024, 333, 210, 90
+    yaws = [0, 14.0625, 33, 90, 123.4, 180, 200, 270, 301, 359]   # whole-column, fractional and (14.0625 on 2048: none) plain ones
+    pitches = [8, 60, 90, 150]                                    # pitch 8: a pole in view -> gather tiles
+    panos = [synth.synth_pano(pw, ph, 4200 + i, "N") for i in range(n_panos)]
+    maps = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
+    want = [oracle_views(p, yaws, pitches, ow, oh, fov) for p in panos]
+    monkeypatch.setenv("P2P_PLAN_CACHE", "0")
+    monkeypatch.setenv("P2P_PAIRS_PER_BLOCK", "3")   # several chunks of pairs per tile
+    combos = list(itertools.product(("0", "1", "2"), ("1", "5", "192"), ("0", "1"), ("0", "1")))
+    for main_order, group, prefetch, gather_order in combos:
+        monkeypatch.setenv("P2P_MAIN_ORDER", main_order)
+        monkeypatch.setenv("P2P_MAIN_GROUP", group)
+        monkeypatch.setenv("P2P_PREFETCH_LEAD", prefetch)
+        monkeypatch.setenv("P2P_GATHER_ORDER", gather_order)
+        got = _run(gpu, panos, yaws, pitches, ow, oh, fov, maps)
+        for i in range(n_panos):
+            bad = np.argwhere(got[i] != want[i])
+            assert bad.size == 0, (main_order, group, prefetch, gather_order, i, len(bad), bad[:3])
+
+
+def test_device_maps_job_is_the_same_in_list_and_grid_order(gpu, synth, monkeypatch):
+    # the default path (maps evaluated on the device): list order and grid order must agree byte for byte
+    pw, ph, ow, oh, fov = 4096, 2048, 640, 360, 90
+    yaws, pitches = list(range(0, 360, 20)), [45, 90, 135]
+    pano = synth.synth_pano(pw, ph, 4300, "N")
+    monkeypatch.setenv("P2P_PLAN_CACHE", "0")
+    outs = []
+    for main_order in ("0", "1"):
+        monkeypatch.setenv("P2P_MAIN_ORDER", main_order)
+        outs.append(_run(gpu, [pano], yaws, pitches, ow, oh, fov, None)[0])
+    assert np.array_equal(outs[0], outs[1])
