@@ -44,7 +44,8 @@ constexpr int AUDIT_WORDS = 8;  // the audit build's violation record: hit, site
 // items (per-row spans) and, per pixel, the LDS offsets of its taps and its two 5-bit weights.  mode 2 (gathers): a
 // footprint that does not fit the LDS buffers (strong minification, a pole inside the tile) or touches the
 // panorama's border; the gather kernel draws it from the plan's quantised coordinates.  16 bytes, read with one
-// scalar load; the tile's position and its pitch view come from the workgroup's index, never from memory.
+// scalar load; the tile's position and its pitch view come from its slot number (the workgroup's index, or a work-list
+// entry clamped to the plan's slots), never from the tables.
 struct PieceHdr {
     uint32_t mode_items;  // mode (1: LDS scheme, 2: gathers) | n_items << 8
     int32_t c0, c1;       // rot columns the taps of the tile's live pixels read: c0 .. c1 + 1 (c1 < c0: no live pixel).

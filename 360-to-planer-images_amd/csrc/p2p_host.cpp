@@ -314,7 +314,8 @@ std::vector<uint32_t> xcd_main_lists(const std::vector<p2p::PieceHdr>& hh, size_
 // lines run at the same time on the same L2 -- and the groups are dealt heaviest first to the XCD with the least work
 // so far (tiles whose footprint spans most of a row, next to a pole, count double).  CLI default set at 8K: 307 MB,
 // 85 -> 73 us; blocks of 128 x 64 ... 256 x 128 pixels 79 / 75 us, 1024 x 512 83 us; one contiguous run of the order
-// per XCD 104 us (the XCDs with the polar tiles are busy long after the others).
+// per XCD 104 us, contiguous source bands of equal cost per XCD (what serves the main kernel) 97-100 us: the polar
+// tiles' cost is not a number the host can guess, and the XCDs that hold them are busy long after the others.
 // by_source false: the tiles in list order, dealt round-robin (what the kernel's grid did before).
 std::vector<uint32_t> xcd_lists(const std::vector<uint32_t>& tiles, const std::vector<p2p::PieceHdr>& hh, int pw, bool by_source,
                                 int* stride)

@@ -21,7 +21,8 @@ constexpr int TILE_LW = TILE_W == 64 ? 6 : (TILE_W == 32 ? 5 : 4);
 static_assert((1 << TILE_LW) == TILE_W, "TILE_W must be 16, 32 or 64");
 constexpr int TILE_ROWSTEP = VIEWS_BLOCK / TILE_W;  // rows between a thread's pixels
 
-// A tile's place in its view follows from the workgroup's index alone (never from memory); the plan's header adds
+// A tile's place in its view follows from its slot number alone (the workgroup's index, or a clamped work-list entry:
+// never from the plan's tables); the plan's header adds
 // how it is drawn (mode), the size of its footprint and its rot columns.
 struct TileGeo {
     int x0, y0, pitch_i, mode, n_items;

@@ -169,7 +169,8 @@ __device__ __forceinline__ uint32_t blend4_packed(uint32_t a, uint32_t b, uint32
 // The kernels write disjoint pixels; all but the first are launched (same stream, before it) only when the plan or
 // the yaw tables have something for them.
 //
-// Addressing: a tile's position, its pitch view and its table slots follow from the workgroup index.  Every offset
+// Addressing: a tile's position, its pitch view and its table slots follow from its slot number (the workgroup index,
+// or a work-list entry clamped to the plan's slots).  Every offset
 // that comes out of a table (source offsets from items, coordinates and yaw tables; pair lists; tile lists) is either
 // clamped or goes through a buffer descriptor with the exact extent, so no content of the tables can take a load or
 // a store outside its buffer (p2p_audit.h; the -DP2P_AUDIT build records every such event).
