@@ -17,7 +17,10 @@ namespace p2p {
 #endif
 constexpr int TILE_W = P2P_TILE_W;  // output tile of one workgroup
 constexpr int TILE_H = 16;
-constexpr int VIEWS_BLOCK = 256;
+#ifndef P2P_BLOCK
+#define P2P_BLOCK 256
+#endif
+constexpr int VIEWS_BLOCK = P2P_BLOCK;  // threads of a tile's workgroup
 constexpr int VIEWS_PXT = TILE_W * TILE_H / VIEWS_BLOCK;  // output pixels per thread (rows ROWSTEP apart)
 #ifndef P2P_SLOTS
 #define P2P_SLOTS 3
@@ -28,8 +31,8 @@ constexpr int VIEWS_PXT = TILE_W * TILE_H / VIEWS_BLOCK;  // output pixels per t
 constexpr int VIEWS_SLOTS = P2P_SLOTS;  // 16-byte footprint items one thread produces per (panorama, yaw) pair, at most
 constexpr int LDS_ITEMS_CAP = P2P_CAP;  // items (4 rot pixels each) per LDS buffer
 static_assert(LDS_ITEMS_CAP <= VIEWS_SLOTS * VIEWS_BLOCK && LDS_ITEMS_CAP > (VIEWS_SLOTS - 1) * VIEWS_BLOCK, "slots vs cap");
-constexpr int PXW_UP_BITS = 12;     // per-pixel word: bits of the upper tap's LDS offset (dwords; 4 * LDS_ITEMS_CAP <= 4096)
-constexpr int PXW_DL_BITS = 10;     //                 bits of (lower tap - upper tap)
+constexpr int PXW_UP_BITS = 4 * LDS_ITEMS_CAP <= 4096 ? 12 : 13;  // per-pixel word: bits of the upper tap's LDS offset (dwords)
+constexpr int PXW_DL_BITS = 22 - PXW_UP_BITS;                     //                 bits of (lower tap - upper tap)
 static_assert(4 * LDS_ITEMS_CAP <= (1 << PXW_UP_BITS), "tap offsets must fit the per-pixel word");
 constexpr int VIEWS_WAVES_PER_SIMD = P2P_WAVES;  // __launch_bounds__ of the main view kernel: 80 VGPRs, and 6 x 26.5 KB of LDS
 constexpr int PLAN_MAX_ROWS = 256;  // rot rows a tile's footprint may span (one plan thread per row)

@@ -147,7 +147,7 @@ __device__ __forceinline__ void draw_float(
     const int wv = t >> 6, ln = t & 63;
     uint32_t* const stg = stage + wv * (PXT * 64);
     const int x4 = 4 * (ln & 15), sj = ln >> 4;
-    const int srow = ((wv * 64 + x4) >> TILE_LW) + sj * TILE_ROWSTEP, scol = x4 & (TILE_W - 1);
+    const int srow = ((wv * 64 + x4) >> TILE_LW) + sj * TILE_ROWSTEP, scol = (wv * 64 + x4) & (TILE_W - 1);
     const bool s_ok = sj < PXT && srow < TILE_H && G.y0 + srow < P.oh && G.x0 + scol < P.ow;
     const uint32_t out_off12 = s_ok ? (uint32_t)(G.y0 + srow) * (uint32_t)P.out_row + 3u * (uint32_t)(G.x0 + scol) : 0xFFFFFFFFu;
     const uint32_t stg_rd = (uint32_t)(sj * 64 + x4);

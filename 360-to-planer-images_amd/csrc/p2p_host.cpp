@@ -1127,15 +1127,15 @@ static int job_build_plan(p2p_job* j)
     auto Pl = std::make_shared<Plan>();
     Pl->device = ctx->device;
     if (float_path)
-        HIP_TRY(dev_alloc((void**)&Pl->d_px2, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t)));
+        HIP_TRY(dev_alloc((void**)&Pl->d_px2, slots * p2p::VIEWS_BLOCK * p2p::VIEWS_PXT * sizeof(uint32_t)));
     HIP_TRY(dev_alloc((void**)&Pl->d_coords, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2)));
     HIP_TRY(dev_alloc((void**)&Pl->d_hdr, slots * sizeof(p2p::PieceHdr)));
-    HIP_TRY(dev_alloc((void**)&Pl->d_px, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t)));
+    HIP_TRY(dev_alloc((void**)&Pl->d_px, slots * p2p::VIEWS_BLOCK * p2p::VIEWS_PXT * sizeof(uint32_t)));
     HIP_TRY(dev_alloc((void**)&Pl->d_items, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t)));
     HIP_TRY(dev_alloc((void**)&Pl->d_n_gather, sizeof(uint32_t)));
     HIP_TRY(dev_alloc((void**)&Pl->d_gather_list, slots * sizeof(uint32_t)));
     Pl->bytes = (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2) +
-                slots * (sizeof(p2p::PieceHdr) + (256 * p2p::VIEWS_PXT * (float_path ? 2 : 1) + p2p::LDS_ITEMS_CAP + 1) * sizeof(uint32_t));
+                slots * (sizeof(p2p::PieceHdr) + (p2p::VIEWS_BLOCK * p2p::VIEWS_PXT * (float_path ? 2 : 1) + p2p::LDS_ITEMS_CAP + 1) * sizeof(uint32_t));
     p2p::PlanParams Q{};
     Q.pw = d.pw; Q.ph = d.ph; Q.ow = d.ow; Q.oh = d.oh; Q.n_pitch = d.n_pitch; Q.border = j->border;
     Q.geom = j->geom;
@@ -1155,12 +1155,12 @@ static int job_build_plan(p2p_job* j)
     {
         // every pool poisoned: a kernel that reads a slot the plan pass did not write gets 0xFF.. and the audit sees it
         HIP_TRY(hipMemsetAsync(Pl->d_hdr, 0xFF, slots * sizeof(p2p::PieceHdr), st));
-        HIP_TRY(hipMemsetAsync(Pl->d_px, 0xFF, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(Pl->d_px, 0xFF, slots * p2p::VIEWS_BLOCK * p2p::VIEWS_PXT * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(Pl->d_items, 0xFF, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(Pl->d_gather_list, 0xFF, slots * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(Pl->d_coords, 0xFF, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2), st));
         if (Pl->d_px2)
-            HIP_TRY(hipMemsetAsync(Pl->d_px2, 0xFF, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t), st));
+            HIP_TRY(hipMemsetAsync(Pl->d_px2, 0xFF, slots * p2p::VIEWS_BLOCK * p2p::VIEWS_PXT * sizeof(uint32_t), st));
     }
 #endif
     // (the plan pass writes every header, every per-pixel word and every item slot of every tile: nothing to clear)
@@ -1232,7 +1232,7 @@ static int job_build_plan(p2p_job* j)
         // through an exact-extent buffer descriptor (csrc/p2p_audit.h).  Such a plan is never entered in the cache.
         const uint32_t sd = (uint32_t)seed;
         HIP_TRY(p2p::launch_scramble(Pl->d_hdr, slots * sizeof(p2p::PieceHdr), sd + 1, st));
-        HIP_TRY(p2p::launch_scramble(Pl->d_px, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t), sd + 2, st));
+        HIP_TRY(p2p::launch_scramble(Pl->d_px, slots * p2p::VIEWS_BLOCK * p2p::VIEWS_PXT * sizeof(uint32_t), sd + 2, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_items, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t), sd + 3, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_gather_list, slots * sizeof(uint32_t), sd + 4, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_xcd_list, Pl->d_xcd_list ? 8 * (size_t)Pl->xcd_stride * sizeof(uint32_t) : 0, sd + 10, st));
@@ -1240,7 +1240,7 @@ static int job_build_plan(p2p_job* j)
         HIP_TRY(p2p::launch_scramble(Pl->d_xcd_all, Pl->d_xcd_all ? 8 * (size_t)Pl->xcd_all_stride * sizeof(uint32_t) : 0, sd + 11, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_coords, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2), sd + 5, st));
         if (Pl->d_px2)
-            HIP_TRY(p2p::launch_scramble(Pl->d_px2, slots * 256 * p2p::VIEWS_PXT * sizeof(uint32_t), sd + 6, st));
+            HIP_TRY(p2p::launch_scramble(Pl->d_px2, slots * p2p::VIEWS_BLOCK * p2p::VIEWS_PXT * sizeof(uint32_t), sd + 6, st));
         if ((seed & (1 << 30)) && j->yaw_ref && j->yaw_ref.use_count() == 1) {  // private (uncached) yaw tables only
             const size_t n = (size_t)d.n_yaw * d.pw * sizeof(uint32_t);
             HIP_TRY(p2p::launch_scramble(j->d_ytab, n, sd + 7, st));
@@ -1361,7 +1361,7 @@ int p2p_job_run(p2p_job* j)
     // table-prefetch workgroups (p2p_tile.h: main_block_role) when one launch's plan tables cannot stay in the Infinity
     // Cache next to the panorama (config 4: 565 MB): 2 groups = 64 tiles of lead per XCD
     {
-        const size_t table_bytes = j->n_tiles * (size_t)j->d.n_pitch * (256 * p2p::VIEWS_PXT + p2p::LDS_ITEMS_CAP) * sizeof(uint32_t);
+        const size_t table_bytes = j->n_tiles * (size_t)j->d.n_pitch * (p2p::VIEWS_BLOCK * p2p::VIEWS_PXT + p2p::LDS_ITEMS_CAP) * sizeof(uint32_t);
         P.pf_lead = std::max(0, env_int("P2P_PREFETCH_LEAD", table_bytes > ((size_t)128 << 20) ? 2 : 0));
     }
     P.pitch_order = j->d_pitch_order;

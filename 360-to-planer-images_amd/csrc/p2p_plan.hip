@@ -19,7 +19,7 @@ namespace p2p {
 
 namespace {
 
-// block-wide exclusive scan of one value per thread (256 threads); returns the exclusive prefix, total in *total
+// block-wide exclusive scan of one value per thread; returns the exclusive prefix, total in *total
 __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* s_scan, uint32_t* total)
 {
     const int t = threadIdx.x;
@@ -33,10 +33,13 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* s_scan
     if ((t & 63) == 63)
         s_scan[t >> 6] = incl;
     __syncthreads();
-    uint32_t base = incl - v;
-    for (int w = 0; w < (t >> 6); ++w)
-        base += s_scan[w];
-    *total = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+    uint32_t base = incl - v, all = 0u;
+#pragma unroll
+    for (int w = 0; w < VIEWS_BLOCK / 64; ++w) {
+        base += w < (t >> 6) ? s_scan[w] : 0u;
+        all += s_scan[w];
+    }
+    *total = all;
     return base;
 }
 
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
     __shared__ int s_wflags[VIEWS_BLOCK / 64];  // per wave: bit 0 any live pixel, bit 1 any pixel outside the panorama under a non-constant border
     __shared__ int s_rmin[PLAN_MAX_ROWS], s_rmax[PLAN_MAX_ROWS];
     __shared__ uint32_t s_rbase[PLAN_MAX_ROWS + 1];
-    __shared__ uint32_t s_scan[4];
+    __shared__ uint32_t s_scan[VIEWS_BLOCK / 64];
 
     constexpr int PXT = VIEWS_PXT;
     constexpr int ROWSTEP = VIEWS_BLOCK / TILE_W;

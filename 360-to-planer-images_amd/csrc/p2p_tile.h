@@ -17,8 +17,8 @@ __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cas
 #define P2P_STORE_AUX 2  // cache policy of the view stores: 2 = nt
 #endif
 
-constexpr int TILE_LW = TILE_W == 64 ? 6 : (TILE_W == 32 ? 5 : 4);
-static_assert((1 << TILE_LW) == TILE_W, "TILE_W must be 16, 32 or 64");
+constexpr int TILE_LW = TILE_W == 128 ? 7 : (TILE_W == 64 ? 6 : (TILE_W == 32 ? 5 : 4));
+static_assert((1 << TILE_LW) == TILE_W, "TILE_W must be 16, 32, 64 or 128");
 constexpr int TILE_ROWSTEP = VIEWS_BLOCK / TILE_W;  // rows between a thread's pixels
 
 // A tile's place in its view follows from its slot number alone (the workgroup's index, or a clamped work-list entry:

@@ -316,7 +316,7 @@ __device__ __forceinline__ StoreCtx store_ctx(const ViewsParams& P, const TileGe
     s.ln = t & 63;
     s.stg = stage + wv * (VIEWS_PXT * 64);
     const int x4 = 4 * (s.ln & 15), sj = s.ln >> 4;  // the group's first pixel as a lane of this wave; which of the thread's pixels
-    const int srow = ((wv * 64 + x4) >> TILE_LW) + sj * TILE_ROWSTEP, scol = x4 & (TILE_W - 1);
+    const int srow = ((wv * 64 + x4) >> TILE_LW) + sj * TILE_ROWSTEP, scol = (wv * 64 + x4) & (TILE_W - 1);
     const bool s_ok = sj < VIEWS_PXT && srow < TILE_H && G.y0 + srow < P.oh && G.x0 + scol < P.ow;
     s.out_off12 = s_ok ? (uint32_t)(G.y0 + srow) * (uint32_t)P.out_row + 3u * (uint32_t)(G.x0 + scol) : 0xFFFFFFFFu;
     s.stg_rd = (uint32_t)(sj * 64 + x4);
