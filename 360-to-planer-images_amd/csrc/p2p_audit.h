@@ -18,6 +18,7 @@
 #include "p2p_device.h"
 
 namespace p2p {
+namespace P2P_SHAPE_NS {
 
 // sites (kernel << 8 | what)
 enum AuditSite : uint32_t {
@@ -70,5 +71,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_buf(const void* base, uin
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
+}  // namespace P2P_SHAPE_NS
 }  // namespace p2p
 #endif  // P2P_AUDIT_H

@@ -9,32 +9,7 @@
 
 namespace p2p {
 
-#ifndef P2P_TILE_W
-#define P2P_TILE_W 64
-#endif
-#ifndef P2P_WAVES
-#define P2P_WAVES 6
-#endif
-constexpr int TILE_W = P2P_TILE_W;  // output tile of one workgroup
-constexpr int TILE_H = 16;
-#ifndef P2P_BLOCK
-#define P2P_BLOCK 256
-#endif
-constexpr int VIEWS_BLOCK = P2P_BLOCK;  // threads of a tile's workgroup
-constexpr int VIEWS_PXT = TILE_W * TILE_H / VIEWS_BLOCK;  // output pixels per thread (rows ROWSTEP apart)
-#ifndef P2P_SLOTS
-#define P2P_SLOTS 3
-#endif
-#ifndef P2P_CAP
-#define P2P_CAP 704  // 6 workgroups (waves per SIMD) fit the 160 KB of LDS; the largest tile footprint of config 2 is 678
-#endif
-constexpr int VIEWS_SLOTS = P2P_SLOTS;  // 16-byte footprint items one thread produces per (panorama, yaw) pair, at most
-constexpr int LDS_ITEMS_CAP = P2P_CAP;  // items (4 rot pixels each) per LDS buffer
-static_assert(LDS_ITEMS_CAP <= VIEWS_SLOTS * VIEWS_BLOCK && LDS_ITEMS_CAP > (VIEWS_SLOTS - 1) * VIEWS_BLOCK, "slots vs cap");
-constexpr int PXW_UP_BITS = 4 * LDS_ITEMS_CAP <= 4096 ? 12 : 13;  // per-pixel word: bits of the upper tap's LDS offset (dwords)
-constexpr int PXW_DL_BITS = 22 - PXW_UP_BITS;                     //                 bits of (lower tap - upper tap)
-static_assert(4 * LDS_ITEMS_CAP <= (1 << PXW_UP_BITS), "tap offsets must fit the per-pixel word");
-constexpr int VIEWS_WAVES_PER_SIMD = P2P_WAVES;  // __launch_bounds__ of the main view kernel: 80 VGPRs, and 6 x 26.5 KB of LDS
+constexpr int TILE_H = 16;          // rows of an output tile (both tile shapes)
 constexpr int PLAN_MAX_ROWS = 256;  // rot rows a tile's footprint may span (one plan thread per row)
 // Every device panorama row is followed by a copy of the row's first PANO_PAD pixels: the source pixels of two
 // neighbouring rot columns are then three contiguous pixels also where the yaw shift runs across the row's end
@@ -163,14 +138,72 @@ hipError_t launch_yaw_desc(YawDesc* desc, uint32_t* f4tab, const uint32_t* packe
 hipError_t launch_rot_map(float* U, float* V, int ow, int oh, const MapGeom& g, const float* R9, hipStream_t st);
 hipError_t launch_pitch_map(float* U, float* V, int ow, int oh, const MapGeom& g, float c, float s,
                             hipStream_t st);
-hipError_t launch_plan(const PlanParams& P, hipStream_t st);
 hipError_t launch_scramble(void* p, size_t bytes, uint32_t seed, hipStream_t st);  // robustness self-test only
 // padded device view rows (src_row bytes apart, row_bytes used) -> contiguous bytes, dst sized to whole dwords
 hipError_t launch_compact_rows(void* dst, const uint8_t* src, size_t n_bytes, int row_bytes, int src_row, hipStream_t st);
-hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st);
 hipError_t launch_remap_maps(const RemapParams& P, int cn, int interpolation, hipStream_t st);
 hipError_t launch_cubic_tab(short* tab, hipStream_t st);
+
+// ---- tile shapes.  The plan pass and the view kernels (p2p_plan / p2p_views / p2p_float .hip) are compiled once per
+// tile shape, each in its own namespace:
+//   w64   64 x 16 output pixels per workgroup of 256 threads, LDS buffers of 704 items (six workgroups per CU): the
+//         shape of jobs whose views mostly stay in the Infinity Cache (config 2: 85 us against 95);
+//   w128  128 x 16 pixels per workgroup of 512 threads, 1408 items: a wave's store covers whole 128-byte lines (2 rows x
+//         384 bytes instead of 4 x 192), which is what counts when tens of gigabytes of views stream to HBM
+//         (config 4: 6.5 ms against 7.2; config 2 loses 12 %, the CLI's default set 25 %).
+// The host picks a shape per job (p2p_host.cpp: choose_shape) and calls through ShapeOps.
+struct TileShape {
+    int tile_w, tile_h, block, pxt, cap;  // TILE_W, TILE_H, VIEWS_BLOCK, VIEWS_PXT, LDS_ITEMS_CAP of the shape
+};
+struct ShapeOps {
+    TileShape shape;
+    hipError_t (*plan)(const PlanParams& P, hipStream_t st);
+    hipError_t (*views)(const ViewsParams& P, int which, hipStream_t st);
+    hipError_t (*float_views)(const ViewsParams& P, bool half, int which, hipStream_t st);
+};
+const ShapeOps& shape_ops_w64();
+const ShapeOps& shape_ops_w128();
+
+#ifndef P2P_HOST  // device translation units: the constants of THEIR shape
+#ifndef P2P_SHAPE_NS
+#define P2P_SHAPE_NS w64
+#endif
+namespace P2P_SHAPE_NS {
+#ifndef P2P_TILE_W
+#define P2P_TILE_W 64
+#endif
+#ifndef P2P_WAVES
+#define P2P_WAVES 6
+#endif
+constexpr int TILE_W = P2P_TILE_W;  // output tile of one workgroup
+#ifndef P2P_BLOCK
+#define P2P_BLOCK 256
+#endif
+constexpr int VIEWS_BLOCK = P2P_BLOCK;  // threads of a tile's workgroup
+constexpr int VIEWS_PXT = TILE_W * TILE_H / VIEWS_BLOCK;  // output pixels per thread (rows ROWSTEP apart)
+#ifndef P2P_SLOTS
+#define P2P_SLOTS 3
+#endif
+#ifndef P2P_CAP
+#define P2P_CAP 704  // 6 workgroups (waves per SIMD) fit the 160 KB of LDS; the largest tile footprint of config 2 is 678
+#endif
+constexpr int VIEWS_SLOTS = P2P_SLOTS;  // 16-byte footprint items one thread produces per (panorama, yaw) pair, at most
+constexpr int LDS_ITEMS_CAP = P2P_CAP;  // items (4 rot pixels each) per LDS buffer
+static_assert(LDS_ITEMS_CAP <= VIEWS_SLOTS * VIEWS_BLOCK && LDS_ITEMS_CAP > (VIEWS_SLOTS - 1) * VIEWS_BLOCK, "slots vs cap");
+constexpr int PXW_UP_BITS = 4 * LDS_ITEMS_CAP <= 4096 ? 12 : 13;  // per-pixel word: bits of the upper tap's LDS offset (dwords)
+constexpr int PXW_DL_BITS = 22 - PXW_UP_BITS;                     //                 bits of (lower tap - upper tap)
+static_assert(4 * LDS_ITEMS_CAP <= (1 << PXW_UP_BITS), "tap offsets must fit the per-pixel word");
+constexpr int VIEWS_WAVES_PER_SIMD = P2P_WAVES;  // __launch_bounds__ of the main view kernel: 80 VGPRs, and 6 x 26.5 KB of LDS
+hipError_t launch_plan(const PlanParams& P, hipStream_t st);
+hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st);
 hipError_t launch_float_views(const ViewsParams& P, bool half, int which, hipStream_t st);
+}  // namespace P2P_SHAPE_NS
+using namespace P2P_SHAPE_NS;
+#define P2P_SHAPE_OPS_NAME2(ns) shape_ops_##ns
+#define P2P_SHAPE_OPS_NAME1(ns) P2P_SHAPE_OPS_NAME2(ns)
+#define P2P_SHAPE_OPS_NAME P2P_SHAPE_OPS_NAME1(P2P_SHAPE_NS)
+#endif
 
 }  // namespace p2p
+
 #endif

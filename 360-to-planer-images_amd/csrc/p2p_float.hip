@@ -23,6 +23,7 @@
 #include "p2p_tile.h"
 
 namespace p2p {
+namespace P2P_SHAPE_NS {
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
@@ -372,4 +373,5 @@ hipError_t launch_float_views(const ViewsParams& P, bool half, int which, hipStr
     return hipGetLastError();
 }
 
+}  // namespace P2P_SHAPE_NS
 }  // namespace p2p

@@ -3,6 +3,7 @@
 // the CPU here; the only host maths is the handful of float64 scalars NumPy also evaluates once
 // per call (np.radians, focal length, cos/sin of the pitch: P:64-68, P:85, P:119, P:142-149).
 #include "../../include/p2p_hip.h"
+#define P2P_HOST 1  // no tile-shape constants here: every shape through p2p::ShapeOps
 #include "p2p_device.h"
 
 #include <hip/hip_runtime.h>
@@ -203,8 +204,10 @@ struct PlanKey {  // the reference's key (ow, oh, pitch, pw, ph, fov), for the w
     int pw, ph, ow, oh, flags, border;
     double fov;
     std::vector<double> pitch;
+    int shape;  // tile shape of the tables (0: 64 x 16, 1: 128 x 16)
     bool operator<(const PlanKey& o) const
     {
+        if (shape != o.shape) return shape < o.shape;
         if (pw != o.pw) return pw < o.pw;
         if (ph != o.ph) return ph < o.ph;
         if (ow != o.ow) return ow < o.ow;
@@ -470,6 +473,7 @@ struct p2p_job {
     int n_odd_yaws = 0;                  // yaws that are not a plain shift with one weight (YawDesc.mode != 0)
     uint16_t* d_pitch_order = nullptr;   // [n_pitch] heaviest view first
     size_t n_tiles = 0;
+    int shape = 0;                       // tile shape of the job's plan and kernels (choose_shape)
     p2p::MapGeom geom{};
     bool host_maps = false;
     bool rows_from_host = false;  // yaw tables were packed from caller float rows, not built from yaw_deg
@@ -596,9 +600,25 @@ struct SlotGuard {  // gives the slot back on every return path
     ~SlotGuard() { if (s) slot_release(s); }
 };
 
-int choose_pairs_per_block(const p2p_job_desc& d)
+const p2p::ShapeOps& shape_ops(int shape) { return shape ? p2p::shape_ops_w128() : p2p::shape_ops_w64(); }
+
+// Tile shape of a job (p2p_device.h: tile shapes): 128-wide tiles when the launch's views go well beyond the Infinity
+// Cache and stream to HBM -- whole 128-byte lines per wave store -- (config 4: 18 GB, 6.5 ms against 7.2; config 3 on
+// one GPU: 14 GB, 6.1 against 6.4), 64-wide tiles otherwise (config 2: 85 us against 95; config 5's 2.2 GB: 750
+// against 768; the CLI's default set 73 against 93).
+int choose_shape(const p2p_job_desc& d)
 {
-    const int tiles = ((d.ow + p2p::TILE_W - 1) / p2p::TILE_W) * ((d.oh + p2p::TILE_H - 1) / p2p::TILE_H);
+    const int forced = env_int("P2P_TILE_SHAPE", 0);
+    if (forced == 64 || forced == 128)
+        return forced == 128;
+    const size_t out_row = 12 * (((size_t)d.ow + 3) / 4);
+    const size_t bytes = (size_t)d.n_panos * d.n_yaw * d.n_pitch * d.oh * out_row;
+    return bytes >= ((size_t)4 << 30) && d.ow >= 256;
+}
+
+int choose_pairs_per_block(const p2p_job_desc& d, const p2p::TileShape& S)
+{
+    const int tiles = ((d.ow + S.tile_w - 1) / S.tile_w) * ((d.oh + S.tile_h - 1) / S.tile_h);
     const long long base = (long long)tiles * d.n_pitch;  // workgroups per pair chunk
     const int n_pairs = d.n_panos * d.n_yaw;
     int forced = env_int("P2P_PAIRS_PER_BLOCK", 0);
@@ -904,7 +924,11 @@ static int job_create_core(p2p_ctx* ctx, const p2p_job_desc& d, const double* ya
     if (e == hipSuccess) e = hipEventCreateWithFlags(&j->ev_down, hipEventDisableTiming);
     if (e == hipSuccess) e = dev_alloc((void**)&j->d_out, j->out_bytes + 16);
     if (e == hipSuccess) e = dev_alloc((void**)&j->d_pitch, (size_t)d.n_pitch * sizeof(p2p::PitchConst));
-    j->n_tiles = (size_t)((d.ow + p2p::TILE_W - 1) / p2p::TILE_W) * ((d.oh + p2p::TILE_H - 1) / p2p::TILE_H);
+    j->shape = choose_shape(d);
+    {
+        const p2p::TileShape& S = shape_ops(j->shape).shape;
+        j->n_tiles = (size_t)((d.ow + S.tile_w - 1) / S.tile_w) * ((d.oh + S.tile_h - 1) / S.tile_h);
+    }
     {
         const size_t slots = j->n_tiles * d.n_pitch;
         if (slots >= 0x7FFFFFFFull) {
@@ -1113,7 +1137,8 @@ static int job_build_plan(p2p_job* j)
     const size_t slots = j->n_tiles * d.n_pitch;
     // device maps: the plan is a function of the key alone -- the context may have it already
     PlanKey key{d.pw, d.ph, d.ow, d.oh, d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16 | P2P_FLAG_PIXEL_CENTRES), j->border,
-                j->fov, j->pitch};
+                j->fov, j->pitch, j->shape};
+    const p2p::TileShape& S = shape_ops(j->shape).shape;
     const bool cached = !j->host_maps && env_int("P2P_PLAN_CACHE", 1) != 0;
     if (cached) {
         std::lock_guard<std::mutex> lk(ctx->cache_mu);
@@ -1127,15 +1152,15 @@ static int job_build_plan(p2p_job* j)
     auto Pl = std::make_shared<Plan>();
     Pl->device = ctx->device;
     if (float_path)
-        HIP_TRY(dev_alloc((void**)&Pl->d_px2, slots * p2p::VIEWS_BLOCK * p2p::VIEWS_PXT * sizeof(uint32_t)));
+        HIP_TRY(dev_alloc((void**)&Pl->d_px2, slots * S.block * S.pxt * sizeof(uint32_t)));
     HIP_TRY(dev_alloc((void**)&Pl->d_coords, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2)));
     HIP_TRY(dev_alloc((void**)&Pl->d_hdr, slots * sizeof(p2p::PieceHdr)));
-    HIP_TRY(dev_alloc((void**)&Pl->d_px, slots * p2p::VIEWS_BLOCK * p2p::VIEWS_PXT * sizeof(uint32_t)));
-    HIP_TRY(dev_alloc((void**)&Pl->d_items, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t)));
+    HIP_TRY(dev_alloc((void**)&Pl->d_px, slots * S.block * S.pxt * sizeof(uint32_t)));
+    HIP_TRY(dev_alloc((void**)&Pl->d_items, slots * S.cap * sizeof(uint32_t)));
     HIP_TRY(dev_alloc((void**)&Pl->d_n_gather, sizeof(uint32_t)));
     HIP_TRY(dev_alloc((void**)&Pl->d_gather_list, slots * sizeof(uint32_t)));
     Pl->bytes = (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2) +
-                slots * (sizeof(p2p::PieceHdr) + (p2p::VIEWS_BLOCK * p2p::VIEWS_PXT * (float_path ? 2 : 1) + p2p::LDS_ITEMS_CAP + 1) * sizeof(uint32_t));
+                slots * (sizeof(p2p::PieceHdr) + (S.block * S.pxt * (float_path ? 2 : 1) + S.cap + 1) * sizeof(uint32_t));
     p2p::PlanParams Q{};
     Q.pw = d.pw; Q.ph = d.ph; Q.ow = d.ow; Q.oh = d.oh; Q.n_pitch = d.n_pitch; Q.border = j->border;
     Q.geom = j->geom;
@@ -1155,18 +1180,18 @@ static int job_build_plan(p2p_job* j)
     {
         // every pool poisoned: a kernel that reads a slot the plan pass did not write gets 0xFF.. and the audit sees it
         HIP_TRY(hipMemsetAsync(Pl->d_hdr, 0xFF, slots * sizeof(p2p::PieceHdr), st));
-        HIP_TRY(hipMemsetAsync(Pl->d_px, 0xFF, slots * p2p::VIEWS_BLOCK * p2p::VIEWS_PXT * sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(Pl->d_items, 0xFF, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(Pl->d_px, 0xFF, slots * S.block * S.pxt * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(Pl->d_items, 0xFF, slots * S.cap * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(Pl->d_gather_list, 0xFF, slots * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(Pl->d_coords, 0xFF, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2), st));
         if (Pl->d_px2)
-            HIP_TRY(hipMemsetAsync(Pl->d_px2, 0xFF, slots * p2p::VIEWS_BLOCK * p2p::VIEWS_PXT * sizeof(uint32_t), st));
+            HIP_TRY(hipMemsetAsync(Pl->d_px2, 0xFF, slots * S.block * S.pxt * sizeof(uint32_t), st));
     }
 #endif
     // (the plan pass writes every header, every per-pixel word and every item slot of every tile: nothing to clear)
     HIP_TRY(hipMemsetAsync(Pl->d_n_gather, 0, sizeof(uint32_t), st));
     HIP_TRY(hipEventRecord(ctx->ev_t0, st));
-    HIP_TRY(p2p::launch_plan(Q, st));
+    HIP_TRY(shape_ops(j->shape).plan(Q, st));
     HIP_TRY(hipEventRecord(ctx->ev_t1, st));
     uint32_t cnt = 0;
     HIP_TRY(hipMemcpyAsync(&cnt, Pl->d_n_gather, sizeof(cnt), hipMemcpyDeviceToHost, st));
@@ -1232,15 +1257,15 @@ static int job_build_plan(p2p_job* j)
         // through an exact-extent buffer descriptor (csrc/p2p_audit.h).  Such a plan is never entered in the cache.
         const uint32_t sd = (uint32_t)seed;
         HIP_TRY(p2p::launch_scramble(Pl->d_hdr, slots * sizeof(p2p::PieceHdr), sd + 1, st));
-        HIP_TRY(p2p::launch_scramble(Pl->d_px, slots * p2p::VIEWS_BLOCK * p2p::VIEWS_PXT * sizeof(uint32_t), sd + 2, st));
-        HIP_TRY(p2p::launch_scramble(Pl->d_items, slots * p2p::LDS_ITEMS_CAP * sizeof(uint32_t), sd + 3, st));
+        HIP_TRY(p2p::launch_scramble(Pl->d_px, slots * S.block * S.pxt * sizeof(uint32_t), sd + 2, st));
+        HIP_TRY(p2p::launch_scramble(Pl->d_items, slots * S.cap * sizeof(uint32_t), sd + 3, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_gather_list, slots * sizeof(uint32_t), sd + 4, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_xcd_list, Pl->d_xcd_list ? 8 * (size_t)Pl->xcd_stride * sizeof(uint32_t) : 0, sd + 10, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_main_list, Pl->d_main_list ? 8 * (size_t)Pl->main_stride * sizeof(uint32_t) : 0, sd + 12, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_xcd_all, Pl->d_xcd_all ? 8 * (size_t)Pl->xcd_all_stride * sizeof(uint32_t) : 0, sd + 11, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_coords, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2), sd + 5, st));
         if (Pl->d_px2)
-            HIP_TRY(p2p::launch_scramble(Pl->d_px2, slots * p2p::VIEWS_BLOCK * p2p::VIEWS_PXT * sizeof(uint32_t), sd + 6, st));
+            HIP_TRY(p2p::launch_scramble(Pl->d_px2, slots * S.block * S.pxt * sizeof(uint32_t), sd + 6, st));
         if ((seed & (1 << 30)) && j->yaw_ref && j->yaw_ref.use_count() == 1) {  // private (uncached) yaw tables only
             const size_t n = (size_t)d.n_yaw * d.pw * sizeof(uint32_t);
             HIP_TRY(p2p::launch_scramble(j->d_ytab, n, sd + 7, st));
@@ -1348,7 +1373,7 @@ int p2p_job_run(p2p_job* j)
         j->xcd_stride = Pl.xcd_stride; j->xcd_all_stride = Pl.xcd_all_stride; j->n_gather = Pl.n_gather;
         j->d_main_list = Pl.d_main_list; j->main_stride = Pl.main_stride;
     }
-    P.pairs_per_block = choose_pairs_per_block(j->d);
+    P.pairs_per_block = choose_pairs_per_block(j->d, shape_ops(j->shape).shape);
     P.chunk_outer = env_int("P2P_CHUNK_OUTER", j->d.n_panos > 1 ? 1 : 0);
     // the main kernel's grid: list order (source bands, all pitch views together) unless the plan has no list
     P.main_list = (j->d.n_panos == 1 || env_int("P2P_MAIN_ORDER", 1) == 2) ? j->d_main_list : nullptr;
@@ -1357,11 +1382,12 @@ int p2p_job_run(p2p_job* j)
     // entries drawn for one chunk of pairs before the next chunk: with ONE panorama a short run (the entries' plan tables
     // and source rows are still in L2 for the next chunk), with several all of them (a chunk's panoramas serve every
     // tile before the next ones are touched: see pair_chunk)
-    P.main_group = P.chunk_outer ? std::max(1, j->main_stride) : std::max(1, std::min(j->main_stride, env_int("P2P_MAIN_GROUP", 192)));
+    P.main_group = P.chunk_outer ? std::max(1, j->main_stride) : std::max(1, std::min(j->main_stride, env_int("P2P_MAIN_GROUP", j->shape ? 96 : 192)));  // the workgroups an XCD holds at a time
     // table-prefetch workgroups (p2p_tile.h: main_block_role) when one launch's plan tables cannot stay in the Infinity
     // Cache next to the panorama (config 4: 565 MB): 2 groups = 64 tiles of lead per XCD
     {
-        const size_t table_bytes = j->n_tiles * (size_t)j->d.n_pitch * (p2p::VIEWS_BLOCK * p2p::VIEWS_PXT + p2p::LDS_ITEMS_CAP) * sizeof(uint32_t);
+        const p2p::TileShape& S = shape_ops(j->shape).shape;
+        const size_t table_bytes = j->n_tiles * (size_t)j->d.n_pitch * (S.block * S.pxt + S.cap) * sizeof(uint32_t);
         P.pf_lead = std::max(0, env_int("P2P_PREFETCH_LEAD", table_bytes > ((size_t)128 << 20) ? 2 : 0));
     }
     P.pitch_order = j->d_pitch_order;
@@ -1394,8 +1420,8 @@ int p2p_job_run(p2p_job* j)
         if (timed)
             HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
         if (j->n_gather > 0)
-            HIP_TRY(p2p::launch_float_views(P, half, 1, j->ctx->stream));
-        HIP_TRY(p2p::launch_float_views(P, half, 0, j->ctx->stream));
+            HIP_TRY(shape_ops(j->shape).float_views(P, half, 1, j->ctx->stream));
+        HIP_TRY(shape_ops(j->shape).float_views(P, half, 0, j->ctx->stream));
         if (timed)
             HIP_TRY(hipEventRecord(j->ev_ring[2 * slot + 1], j->ctx->stream));
 #ifdef P2P_AUDIT
@@ -1436,21 +1462,21 @@ int p2p_job_run(p2p_job* j)
             P.gather_list = P.gather_all ? j->d_xcd_all : j->d_xcd_list;
             P.n_list = P.gather_all ? j->xcd_all_stride : j->xcd_stride;
             if (P.gather_list && P.n_list > 0)
-                HIP_TRY(p2p::launch_remap_views(P, 3, j->ctx->stream));
+                HIP_TRY(shape_ops(j->shape).views(P, 3, j->ctx->stream));
             P.gather_list = j->d_gather_list;
         }
         // the table kernel: every pair where the gather kernel does not apply, else the odd pairs
         P.use_pair_list = gather_ok ? 1 : 0;
         if (!gather_ok || j->n_odd_pairs > 0)
-            HIP_TRY(p2p::launch_remap_views(P, 2, j->ctx->stream));
+            HIP_TRY(shape_ops(j->shape).views(P, 2, j->ctx->stream));
     }
     if (need_rest) {
         P.use_pair_list = (fast_width && j->n_odd_pairs > 0) ? 1 : 0;
-        HIP_TRY(p2p::launch_remap_views(P, 1, j->ctx->stream));
+        HIP_TRY(shape_ops(j->shape).views(P, 1, j->ctx->stream));
     }
     P.use_pair_list = 0;
     if (fast_width && any_lds && !P.gather_all)
-        HIP_TRY(p2p::launch_remap_views(P, 0, j->ctx->stream));
+        HIP_TRY(shape_ops(j->shape).views(P, 0, j->ctx->stream));
     if (timed)
         HIP_TRY(hipEventRecord(j->ev_ring[2 * slot + 1], j->ctx->stream));
 #ifdef P2P_AUDIT

@@ -293,4 +293,24 @@ hipError_t launch_rot_map(float* U, float* V, int ow, int oh, const MapGeom& g, 
     return hipGetLastError();
 }
 
+// Robustness self-test (P2P_SCRAMBLE_PLAN, tests/fuzz/scramble_tables.py): overwrite a table with pseudo-random words.
+// The view kernels must draw garbage from garbage tables -- and nothing worse.
+__global__ void scramble_kernel(uint32_t* __restrict__ p, size_t n_words, uint32_t seed)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u ^ seed;
+        h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+        // a mix of wild values, small values and all-ones, so that every clamp sees both sides
+        p[i] = (h & 3u) == 0u ? 0xFFFFFFFFu : ((h & 3u) == 1u ? (h >> 20) : h);
+    }
+}
+
+hipError_t launch_scramble(void* p, size_t bytes, uint32_t seed, hipStream_t st)
+{
+    if (!p || bytes < 4)
+        return hipSuccess;
+    hipLaunchKernelGGL(scramble_kernel, dim3(1024), dim3(256), 0, st, (uint32_t*)p, bytes / 4, seed);
+    return hipGetLastError();
+}
+
 }  // namespace p2p

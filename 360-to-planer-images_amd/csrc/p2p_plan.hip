@@ -16,6 +16,7 @@
 #include "p2p_inline.h"
 
 namespace p2p {
+namespace P2P_SHAPE_NS {
 
 namespace {
 
@@ -298,26 +299,6 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
     }
 }
 
-// Robustness self-test (P2P_SCRAMBLE_PLAN, tests/fuzz/scramble_tables.py): overwrite a table with pseudo-random words.
-// The view kernels must draw garbage from garbage tables -- and nothing worse.
-__global__ void scramble_kernel(uint32_t* __restrict__ p, size_t n_words, uint32_t seed)
-{
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) {
-        uint32_t h = (uint32_t)i * 2654435761u ^ seed;
-        h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
-        // a mix of wild values, small values and all-ones, so that every clamp sees both sides
-        p[i] = (h & 3u) == 0u ? 0xFFFFFFFFu : ((h & 3u) == 1u ? (h >> 20) : h);
-    }
-}
-
-hipError_t launch_scramble(void* p, size_t bytes, uint32_t seed, hipStream_t st)
-{
-    if (!p || bytes < 4)
-        return hipSuccess;
-    hipLaunchKernelGGL(scramble_kernel, dim3(1024), dim3(256), 0, st, (uint32_t*)p, bytes / 4, seed);
-    return hipGetLastError();
-}
-
 hipError_t launch_plan(const PlanParams& P, hipStream_t st)
 {
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
@@ -326,6 +307,16 @@ hipError_t launch_plan(const PlanParams& P, hipStream_t st)
     else
         hipLaunchKernelGGL(plan_kernel<false>, dim3(tiles, P.n_pitch), dim3(VIEWS_BLOCK), 0, st, P);
     return hipGetLastError();
+}
+
+}  // namespace P2P_SHAPE_NS
+
+// what the host calls this shape through (p2p_device.h: tile shapes)
+const ShapeOps& P2P_SHAPE_OPS_NAME()
+{
+    static const ShapeOps ops = {{P2P_SHAPE_NS::TILE_W, TILE_H, P2P_SHAPE_NS::VIEWS_BLOCK, P2P_SHAPE_NS::VIEWS_PXT, P2P_SHAPE_NS::LDS_ITEMS_CAP},
+                                 &P2P_SHAPE_NS::launch_plan, &P2P_SHAPE_NS::launch_remap_views, &P2P_SHAPE_NS::launch_float_views};
+    return ops;
 }
 
 }  // namespace p2p

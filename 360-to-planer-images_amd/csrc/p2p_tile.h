@@ -7,6 +7,7 @@
 #include "p2p_audit.h"
 
 namespace p2p {
+namespace P2P_SHAPE_NS {
 
 struct __attribute__((aligned(4))) Q16 { uint32_t d[4]; };
 
@@ -149,5 +150,6 @@ __device__ __forceinline__ int sort_lanes_by_class(int k, bool valid, int cls, i
     return r;
 }
 
+}  // namespace P2P_SHAPE_NS
 }  // namespace p2p
 #endif  // P2P_TILE_H

@@ -12,6 +12,7 @@
 #include "p2p_tile.h"
 
 namespace p2p {
+namespace P2P_SHAPE_NS {
 
 // ---------------------------------------------------------------------------------------------
 // Stage 1, P:192-199: one pixel of the yaw-resampled panorama ("rot") from two horizontally
@@ -1268,4 +1269,5 @@ hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
     return hipGetLastError();
 }
 
+}  // namespace P2P_SHAPE_NS
 }  // namespace p2p

@@ -1,6 +1,7 @@
 // Stand-ins for the kernel launchers of p2p_device.h in the host-only sanitizer build (tests/test_sanitizers.py):
 // they touch the buffers the host code reads back afterwards (piece headers, counters, yaw descriptors) with the
 // sizes the real kernels use, so that ASan sees every host-side allocation being addressed, and do no pixel work.
+#define P2P_HOST 1
 #include "p2p_device.h"
 #include <string.h>
 extern "C" int p2p_stub_device_count = 1;
@@ -38,13 +39,16 @@ hipError_t launch_pitch_map(float* U, float* V, int ow, int oh, const MapGeom&, 
     memset(U, 0, (size_t)ow * oh * sizeof(float)); memset(V, 0, (size_t)ow * oh * sizeof(float));
     return hipSuccess;
 }
-hipError_t launch_plan(const PlanParams& P, hipStream_t)
+// the plan pass of one tile shape: every tile marked for gathers, the last word of every table touched
+template <int TILE_W, int BLOCK, int CAP>
+static hipError_t stub_plan(const PlanParams& P, hipStream_t)
 {
+    constexpr int PXT = TILE_W * TILE_H / BLOCK;
     const size_t tiles = (size_t)((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
     for (size_t s = 0; s < tiles * P.n_pitch; ++s) {
         P.hdr[s] = PieceHdr{2u, 0, -1, 0u};
-        P.px[s * 256 * VIEWS_PXT + 256 * VIEWS_PXT - 1] = 0u;
-        P.items[s * LDS_ITEMS_CAP + LDS_ITEMS_CAP - 1] = 0u;
+        P.px[s * BLOCK * PXT + BLOCK * PXT - 1] = 0u;
+        P.items[s * CAP + CAP - 1] = 0u;
         P.gather_list[s] = (uint32_t)s;
     }
     memset(P.coords, 0, (size_t)P.n_pitch * P.oh * P.ow * sizeof(int2));
@@ -58,7 +62,7 @@ hipError_t launch_compact_rows(void* dst, const uint8_t* src, size_t n_bytes, in
         ((uint8_t*)dst)[b] = src[(b / row_bytes) * src_row + b % row_bytes];
     return hipSuccess;
 }
-hipError_t launch_remap_views(const ViewsParams& P, int, hipStream_t)
+static hipError_t stub_views(const ViewsParams& P, int, hipStream_t)
 {
     const size_t n = (size_t)P.n_panos * P.n_yaw * P.n_pitch * P.oh * P.ow * 3;
     P.out[0] = P.src[0];
@@ -73,9 +77,19 @@ hipError_t launch_remap_maps(const RemapParams& P, int cn, int, hipStream_t)
     return hipSuccess;
 }
 hipError_t launch_cubic_tab(short* tab, hipStream_t) { memset(tab, 0, 1024 * 16 * sizeof(short)); return hipSuccess; }
-hipError_t launch_float_views(const ViewsParams& P, bool, int, hipStream_t)
+static hipError_t stub_float_views(const ViewsParams& P, bool, int, hipStream_t)
 {
     P.out[(size_t)P.n_panos * P.n_yaw * P.n_pitch * P.oh * P.ow * 3 - 1] = 0;
     return hipSuccess;
+}
+const ShapeOps& shape_ops_w64()
+{
+    static const ShapeOps ops = {{64, TILE_H, 256, 4, 704}, &stub_plan<64, 256, 704>, &stub_views, &stub_float_views};
+    return ops;
+}
+const ShapeOps& shape_ops_w128()
+{
+    static const ShapeOps ops = {{128, TILE_H, 512, 4, 1408}, &stub_plan<128, 512, 1408>, &stub_views, &stub_float_views};
+    return ops;
 }
 }  // namespace p2p

@@ -2,7 +2,7 @@
 must not change a byte.  Every combination of main-kernel order (grid / list / list for several panoramas), turn length
 per chunk of pairs, table-prefetch workgroups and gather-tile order is checked against the CPU restatement of the
 reference's two cv2.remap stages (P:181-221) on a job that has LDS-scheme tiles, gather tiles (a pole in view),
-several chunks of pairs and a flickering yaw."""
+several chunks of pairs and a flickering yaw -- in both tile shapes the library is built with."""
 import itertools
 
 import numpy as np
@@ -30,8 +30,9 @@ def _run(gpu, panos, yaws, pitches, ow, oh, fov, maps):
         ctx.close()
 
 
+@pytest.mark.parametrize("tile_shape", ["64", "128"])
 @pytest.mark.parametrize("n_panos", [1, 2])
-def test_every_work_list_order_draws_the_oracles_bytes(gpu, synth, monkeypatch, n_panos):
+def test_every_work_list_order_draws_the_oracles_bytes(gpu, synth, monkeypatch, n_panos, tile_shape):
     pw, ph, ow, oh, fov = 2048, 1024, 333, 210, 90
     yaws = [0, 14.0625, 33, 90, 123.4, 180, 200, 270, 301, 359]   # whole-column, fractional and (14.0625 on 2048: none) plain ones
     pitches = [8, 60, 90, 150]                                    # pitch 8: a pole in view -> gather tiles
@@ -39,6 +40,7 @@ def test_every_work_list_order_draws_the_oracles_bytes(gpu, synth, monkeypatch, 
     maps = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
     want = [oracle_views(p, yaws, pitches, ow, oh, fov) for p in panos]
     monkeypatch.setenv("P2P_PLAN_CACHE", "0")
+    monkeypatch.setenv("P2P_TILE_SHAPE", tile_shape)  # both tile shapes of the library (csrc/p2p_device.h)
     monkeypatch.setenv("P2P_PAIRS_PER_BLOCK", "3")   # several chunks of pairs per tile
     combos = list(itertools.product(("0", "1", "2"), ("1", "5", "192"), ("0", "1"), ("0", "1")))
     for main_order, group, prefetch, gather_order in combos:
@@ -49,17 +51,20 @@ def test_every_work_list_order_draws_the_oracles_bytes(gpu, synth, monkeypatch, 
         got = _run(gpu, panos, yaws, pitches, ow, oh, fov, maps)
         for i in range(n_panos):
             bad = np.argwhere(got[i] != want[i])
-            assert bad.size == 0, (main_order, group, prefetch, gather_order, i, len(bad), bad[:3])
+            assert bad.size == 0, (tile_shape, main_order, group, prefetch, gather_order, i, len(bad), bad[:3])
 
 
-def test_device_maps_job_is_the_same_in_list_and_grid_order(gpu, synth, monkeypatch):
-    # the default path (maps evaluated on the device): list order and grid order must agree byte for byte
+def test_device_maps_job_is_the_same_in_every_order_and_tile_shape(gpu, synth, monkeypatch):
+    # the default path (maps evaluated on the device): list order, grid order and both tile shapes agree byte for byte
     pw, ph, ow, oh, fov = 4096, 2048, 640, 360, 90
     yaws, pitches = list(range(0, 360, 20)), [45, 90, 135]
     pano = synth.synth_pano(pw, ph, 4300, "N")
     monkeypatch.setenv("P2P_PLAN_CACHE", "0")
     outs = []
-    for main_order in ("0", "1"):
-        monkeypatch.setenv("P2P_MAIN_ORDER", main_order)
-        outs.append(_run(gpu, [pano], yaws, pitches, ow, oh, fov, None)[0])
-    assert np.array_equal(outs[0], outs[1])
+    for tile_shape in ("64", "128"):
+        for main_order in ("0", "1"):
+            monkeypatch.setenv("P2P_TILE_SHAPE", tile_shape)
+            monkeypatch.setenv("P2P_MAIN_ORDER", main_order)
+            outs.append(_run(gpu, [pano], yaws, pitches, ow, oh, fov, None)[0])
+    for o in outs[1:]:
+        assert np.array_equal(outs[0], o)

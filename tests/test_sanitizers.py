@@ -16,8 +16,8 @@ FLAGS = ["-g", "-O1", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
 ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
 
 
-def _run(exe):
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=ENV)
+def _run(exe, **env):
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(ENV, **env))
     report = r.stdout[-2000:] + r.stderr[-6000:]
     assert r.returncode == 0 and "ERROR: AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr and \
         "LeakSanitizer" not in r.stderr, report
@@ -33,6 +33,9 @@ def test_host_shim_under_asan_ubsan(tmp_path):
         os.path.join(ROOT, "360-to-planer-images_amd", "csrc", "p2p_host.cpp"),
         os.path.join(SAN, "launch_stubs.cpp"), os.path.join(SAN, "host_san_main.cpp"), "-o", exe, "-lpthread"])
     assert "host sanitizer run OK" in _run(exe)
+    # once more with the other tile shape's table sizes (csrc/p2p_device.h: tile shapes; the job picks 128-wide tiles
+    # by itself only for launches of several GB)
+    assert "host sanitizer run OK" in _run(exe, P2P_TILE_SHAPE="128")
 
 
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
