@@ -29,4 +29,4 @@ def main(path, kernel):
         sal = sum(1 for i in ins if i.startswith("s_"))
         if n + sal > 4:
             print("%-50s valu %3d  cycles %4d  salu %3d  %s" % (name, n, c, sal, "LOOP" if "Loop" in name else ""))
-main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "_ZN3p2p18remap_views_kernelILi0ELi0E")
+main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "_ZN3p2p3w6418remap_views_kernelE")
