@@ -613,7 +613,10 @@ int choose_shape(const p2p_job_desc& d)
         return forced == 128;
     const size_t out_row = 12 * (((size_t)d.ow + 3) / 4);
     const size_t bytes = (size_t)d.n_panos * d.n_yaw * d.n_pitch * d.oh * out_row;
-    return bytes >= ((size_t)4 << 30) && d.ow >= 256;
+    // (several resident panoramas stream from HBM as well: 16 of config 2's, 3.6 GB of views, 1.59 against 1.64 ms; 8 of
+    // them, 1.8 GB, 0.785 against 0.80; ONE panorama and 2.2 GB, config 5, 768 against 750 us)
+    const size_t from = d.n_panos > 1 ? (size_t)3 << 29 : (size_t)4 << 30;
+    return bytes >= from && d.ow >= 256;
 }
 
 int choose_pairs_per_block(const p2p_job_desc& d, const p2p::TileShape& S)
