@@ -15,6 +15,9 @@ constexpr int PLAN_MAX_ROWS = 256;  // rot rows a tile's footprint may span (one
 // neighbouring rot columns are then three contiguous pixels also where the yaw shift runs across the row's end
 // (the gather kernel loads them with one 12-byte load).
 constexpr int PANO_PAD = 8;
+// gather kernel: a tile in which some output row of 64 pixels runs across this many source rows or more is drawn in
+// blocks of 16 x 4 pixels per wave instruction (see PieceHdr::mode_items)
+constexpr int GATHER_BLOCKY_FROM = 12;
 constexpr int AUDIT_WORDS = 8;  // the audit build's violation record: hit, site, block x, y, z, thread, value, limit (p2p_audit.h)
 
 // One tile of TILE_W x TILE_H output pixels of one pitch view, with everything that depends on the maps only worked
@@ -25,7 +28,8 @@ constexpr int AUDIT_WORDS = 8;  // the audit build's violation record: hit, site
 // scalar load; the tile's position and its pitch view come from its slot number (the workgroup's index, or a work-list
 // entry clamped to the plan's slots), never from the tables.
 struct PieceHdr {
-    uint32_t mode_items;  // mode (1: LDS scheme, 2: gathers) | n_items << 8
+    uint32_t mode_items;  // mode (1: LDS scheme, 2: gathers) | 4 if the gather kernel should draw 16 x 4 blocks (the rows of 64
+                          // output pixels run ACROSS the source rows: next to a pole, every lane of a row in another line) | n_items << 8
     int32_t c0, c1;       // rot columns the taps of the tile's live pixels read: c0 .. c1 + 1 (c1 < c0: no live pixel).
                           // mode 1: LDS position 0 of every row is a column congruent to c0 mod 4
     uint32_t rows;        // (first rot row of the upper taps + 1) | (last + 1) << 16; 0: no live pixel.  Read by the host only
@@ -114,6 +118,7 @@ struct PlanParams {
     int float_path;          // plan for the float pixel path: unclipped azimuth, 16-bit fractions in px2, spans one
     float centre;            // column wider (the yaw's fractional shift may carry); centre: 0 or 0.5 (pixel centres)
     uint32_t* px2;           // float path: [n_pitch][tiles][256 * VIEWS_PXT] frac(U) | frac(V) << 16, 1/65536 units
+    int blocky_from;         // a tile with an output row of 64 pixels across this many source rows is drawn in 16 x 4 blocks (GATHER_BLOCKY_FROM)
     uint32_t* n_gather;      // [0] tiles marked for gathers
     uint32_t* gather_list;   // [n_pitch * tiles] the tiles marked for gathers (pitch * tiles + tile), in no particular order
 };

@@ -1174,6 +1174,7 @@ static int job_build_plan(p2p_job* j)
     Q.hdr = Pl->d_hdr;
     Q.px = Pl->d_px;
     Q.items = Pl->d_items;
+    Q.blocky_from = std::max(0, env_int("P2P_GATHER_BLOCKY_FROM", p2p::GATHER_BLOCKY_FROM));
     Q.n_gather = Pl->d_n_gather;
     Q.gather_list = Pl->d_gather_list;
     Q.float_path = float_path;

@@ -177,12 +177,19 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
             strayp = true;  // reads reflected / wrapped / replicated pixels: cv::borderInterpolate, table path
         }
     }
+    // how many source rows one output row of 64 pixels runs across (the widest of the wave's rows)
+    int across = 0;
+#pragma unroll
+    for (int j = 0; j < PXT; ++j) {
+        const int lo = wave_reduce<false>(inrange[j] ? iy[j] : INT32_MAX), hi = wave_reduce<true>(inrange[j] ? iy[j] : INT32_MIN);
+        across = max(across, hi >= lo ? hi - lo : 0);
+    }
     bx0 = wave_reduce<false>(bx0); bx1 = wave_reduce<true>(bx1);
     by0 = wave_reduce<false>(by0); by1 = wave_reduce<true>(by1);
     const bool wlive = __ballot(live) != 0ull, wstray = __ballot(strayp) != 0ull;
     if ((t & 63) == 0) {
         s_wbox[t >> 6] = make_int4(bx0, bx1, by0, by1);
-        s_wflags[t >> 6] = (int)wlive | (int)wstray << 1;
+        s_wflags[t >> 6] = (int)wlive | (int)wstray << 1 | (across >= P.blocky_from ? 4 : 0);
     }
     __syncthreads();
     int c0 = INT32_MAX, c1 = INT32_MIN, r0 = INT32_MAX, r1 = INT32_MIN, fl = 0;
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
         if (!ok)  // tiles for the gather kernels, listed
             P.gather_list[atomicAdd(P.n_gather, 1u)] = slot;
         PieceHdr h;
-        h.mode_items = ok ? (1u | n_items << 8) : 2u;
+        h.mode_items = (ok ? (1u | n_items << 8) : 2u) | (uint32_t)(fl & 4);
         h.c0 = any_live ? c0 : 0;
         h.c1 = any_live ? c1 : -1;
         // rot rows of the live pixels' upper taps, + 1 (16 bits each): the host orders the gather list by source position

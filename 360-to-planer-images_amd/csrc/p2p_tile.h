@@ -27,6 +27,7 @@ constexpr int TILE_ROWSTEP = VIEWS_BLOCK / TILE_W;  // rows between a thread's p
 // how it is drawn (mode), the size of its footprint and its rot columns.
 struct TileGeo {
     int x0, y0, pitch_i, mode, n_items;
+    int blocky;  // gather kernel: its waves draw blocks of 16 x 4 pixels per instruction instead of rows of 64 (plan: see PieceHdr)
     int c0, c1;
     int col, row0;  // this thread's column and first row inside the tile
     uint32_t slot;  // pitch_i * tiles + tile: index of the tile's header, per-pixel words and item list
@@ -41,6 +42,7 @@ __device__ __forceinline__ TileGeo tile_geo(const ViewsParams& P, const PieceHdr
     g.y0 = (tile_id / tiles_x) * TILE_H;
     g.pitch_i = pitch_i;
     g.mode = (int)(h.mode_items & 3u);
+    g.blocky = (int)((h.mode_items >> 2) & 1u);
     g.n_items = (int)(h.mode_items >> 8);
     g.c0 = h.c0;
     g.c1 = h.c1;

@@ -585,14 +585,25 @@ __device__ __forceinline__ void draw_gather(
     const int t = threadIdx.x;
     // the pixels' quantised coordinates first: their address follows from the tile's position alone, the loads fly
     // while the header and the yaw descriptors arrive
-    const int px = G.x0 + G.col;
+    // Which pixels a wave instruction draws.  Rows: lane l draws column l of row j of the wave's four rows -- one or two
+    // cache lines per load where an output row runs along a source row.  Blocks (G.blocky, set by the plan where the
+    // output rows run ACROSS the source rows, next to a pole: 64 lanes, 64 lines, and the kernel waits for the L1's one
+    // line per cycle): lane l draws pixel (l & 15, l >> 4) of the j-th 16 x 4 block of the wave's 64 x 4 strip.
+    // Either way a lane's four stored pixels are four neighbours in one row (store_ctx).
+    constexpr int WPR = TILE_W / 64;  // waves side by side in a tile
+    const int wv = t >> 6, ln = t & 63;
+    int pxs[PXT], pys[PXT];
+#pragma unroll
+    for (int j = 0; j < PXT; ++j) {
+        pxs[j] = G.x0 + (G.blocky ? 64 * (wv % WPR) + 16 * j + (ln & 15) : G.col);
+        pys[j] = G.y0 + (G.blocky ? 4 * (wv / WPR) + (ln >> 4) : G.row0 + j * TILE_ROWSTEP);
+    }
     int2 cxy[PXT];
 #pragma unroll
     for (int j = 0; j < PXT; ++j) {
-        const int py = G.y0 + G.row0 + j * TILE_ROWSTEP;
         cxy[j] = make_int2(INT32_MIN, INT32_MIN);
-        if (px < P.ow && py < P.oh)
-            cxy[j] = P.coords[((size_t)G.pitch_i * P.oh + py) * P.ow + px];
+        if (pxs[j] < P.ow && pys[j] < P.oh)
+            cxy[j] = P.coords[((size_t)G.pitch_i * P.oh + pys[j]) * P.ow + pxs[j]];
     }
     // the rot columns this tile taps, as the plan's header has them -- validated: everything below stays inside a
     // panorama for any header
@@ -638,8 +649,7 @@ __device__ __forceinline__ void draw_gather(
     TapWeights tw[PXT];
 #pragma unroll
     for (int j = 0; j < PXT; ++j) {
-        const int py = G.y0 + G.row0 + j * TILE_ROWSTEP;
-        const bool inside = px < P.ow && py < P.oh;
+        const bool inside = pxs[j] < P.ow && pys[j] < P.oh;
         const int2 c = cxy[j];
         const int ix = sat_short(c.x >> 5), iy = sat_short(c.y >> 5);
         // cv::remap, BORDER_CONSTANT 0: a pixel whose 2x2 footprint misses the panorama is black, a tap outside it
@@ -673,7 +683,13 @@ __device__ __forceinline__ void draw_gather(
         d_lo[j] = (uint32_t)(yl - yu) * (uint32_t)P.src_pitch;
     }
     const size_t view_bytes = P.view_bytes;
-    const StoreCtx SC = store_ctx(P, G, stage, t);
+    StoreCtx SC = store_ctx(P, G, stage, t);
+    if (G.blocky) {  // lanes x4 .. x4 + 3 of instruction sj: columns 16 sj + (x4 & 15) ... of row x4 >> 4 of the strip
+        const int x4 = 4 * (ln & 15), sj = ln >> 4;
+        const int srow = 4 * (wv / WPR) + (x4 >> 4), scol = 64 * (wv % WPR) + 16 * sj + (x4 & 15);
+        const bool s_ok = srow < TILE_H && G.y0 + srow < P.oh && G.x0 + scol < P.ow;
+        SC.out_off12 = s_ok ? (uint32_t)(G.y0 + srow) * (uint32_t)P.out_row + 3u * (uint32_t)(G.x0 + scol) : 0xFFFFFFFFu;
+    }
     const uint32_t row_bytes = 3u * (uint32_t)P.pw;
     uint32_t bias_br = 0x00800080u;
     asm volatile("" : "+v"(bias_br));
