@@ -68,3 +68,24 @@ def test_device_maps_job_is_the_same_in_every_order_and_tile_shape(gpu, synth, m
             outs.append(_run(gpu, [pano], yaws, pitches, ow, oh, fov, None)[0])
     for o in outs[1:]:
         assert np.array_equal(outs[0], o)
+
+
+@pytest.mark.parametrize("blocky_from", ["0", "12", "1000000"])
+def test_gather_tiles_in_rows_and_in_blocks_draw_the_same_bytes(gpu, synth, monkeypatch, blocky_from):
+    # the gather kernel's lane layout (rows of 64 pixels / blocks of 16 x 4, csrc/p2p_views.hip: draw_gather) is chosen
+    # per tile by the plan; forcing every tile into blocks (0), none (a huge threshold) or the default must not change
+    # a byte: polar views (every tile gathers around the pole), a strongly minifying view set (every tile gathers),
+    # view sizes that are not multiples of the tile
+    monkeypatch.setenv("P2P_PLAN_CACHE", "0")
+    monkeypatch.setenv("P2P_GATHER_BLOCKY_FROM", blocky_from)
+    for (pw, ph, ow, oh, fov, yaws, pitches) in (
+            (2048, 1024, 301, 177, 90, [0, 33.3, 180, 270], [3, 90, 176]),
+            (4096, 2048, 203, 150, 110, [0, 90, 200], [30, 60, 150])):
+        pano = synth.synth_pano(pw, ph, 4400 + ow, "N")
+        maps = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
+        want = oracle_views(pano, yaws, pitches, ow, oh, fov)
+        for tile_shape in ("64", "128"):
+            monkeypatch.setenv("P2P_TILE_SHAPE", tile_shape)
+            got = _run(gpu, [pano], yaws, pitches, ow, oh, fov, maps)[0]
+            bad = np.argwhere(got != want)
+            assert bad.size == 0, (blocky_from, tile_shape, pw, ow, len(bad), bad[:3])
