@@ -616,7 +616,10 @@ int choose_shape(const p2p_job_desc& d)
     // (several resident panoramas stream from HBM as well: 16 of config 2's, 3.6 GB of views, 1.59 against 1.64 ms; 8 of
     // them, 1.8 GB, 0.785 against 0.80; ONE panorama and 2.2 GB, config 5, 768 against 750 us)
     const size_t from = d.n_panos > 1 ? (size_t)3 << 29 : (size_t)4 << 30;
-    return bytes >= from && d.ow >= 256;
+    // (a strongly minifying view set is drawn by the gather kernel, which gains nothing from wide tiles: 16K -> 2048^2
+    // at FOV 110, 4.5 GB, 5.28 ms with 64-wide tiles against 5.49)
+    const double src_px_per_out_px = (double)d.pw * d.fov_deg / (360.0 * d.ow);
+    return bytes >= from && d.ow >= 256 && src_px_per_out_px < 1.6;
 }
 
 int choose_pairs_per_block(const p2p_job_desc& d, const p2p::TileShape& S)
