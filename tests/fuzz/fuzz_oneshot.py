@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""One-off fuzz of the host-buffer (one-shot) entry points and their per-thread cache: random sequences of calls
+"""WARNING (round 3): both GPU boxes the round lost were running this script or fuzz_remap.py -- see README.md in this
+folder before running it on a shared pool.
+
+One-off fuzz of the host-buffer (one-shot) entry points and their per-thread cache: random sequences of calls
 over a few geometries (in-kernel maps / caller maps / float pixel paths / legacy remap, pinned or not, changing
 yaws and panoramas), from several threads at once; every result is compared with a fresh resident job."""
 import importlib, os, sys, threading, time
