@@ -4,6 +4,7 @@
 #define P2P_HOST 1
 #include "p2p_device.h"
 #include <string.h>
+#include <vector>
 extern "C" int p2p_stub_device_count = 1;
 
 namespace p2p {
@@ -45,14 +46,22 @@ static hipError_t stub_plan(const PlanParams& P, hipStream_t)
 {
     constexpr int PXT = TILE_W * TILE_H / BLOCK;
     const size_t tiles = (size_t)((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
+    // a mix of LDS-scheme and gather tiles with pseudo-random footprints (wild ones too: the host's work-list builders
+    // must cope with whatever the headers say), so that xcd_main_lists / xcd_lists run under the sanitizers
+    uint32_t n_gather = 0, h = 12345u + (uint32_t)(P.ow * 131 + P.oh);
     for (size_t s = 0; s < tiles * P.n_pitch; ++s) {
-        P.hdr[s] = PieceHdr{2u, 0, -1, 0u};
+        h = h * 1664525u + 1013904223u;
+        const bool gathers = (h >> 13) % 3u == 0u;
+        const int c0 = (int)((h >> 8) % 70000u) - 2000, c1 = c0 + (int)((h >> 3) % 40000u) - 10;
+        const uint32_t rows = (h % 5u == 0u) ? 0xFFFFFFFFu : ((h >> 4) & 0x0FFF0FFFu);
+        P.hdr[s] = PieceHdr{(gathers ? 2u : 1u) | ((h >> 20) & 4u) | (gathers ? 0u : ((h >> 7) % (uint32_t)(CAP + 1)) << 8), c0, c1, rows};
         P.px[s * BLOCK * PXT + BLOCK * PXT - 1] = 0u;
         P.items[s * CAP + CAP - 1] = 0u;
-        P.gather_list[s] = (uint32_t)s;
+        if (gathers)
+            P.gather_list[n_gather++] = (uint32_t)s;
     }
     memset(P.coords, 0, (size_t)P.n_pitch * P.oh * P.ow * sizeof(int2));
-    P.n_gather[0] = (uint32_t)(tiles * P.n_pitch);
+    P.n_gather[0] = n_gather;
     return hipSuccess;
 }
 hipError_t launch_scramble(void*, size_t, uint32_t, hipStream_t) { return hipSuccess; }
@@ -62,8 +71,36 @@ hipError_t launch_compact_rows(void* dst, const uint8_t* src, size_t n_bytes, in
         ((uint8_t*)dst)[b] = src[(b / row_bytes) * src_row + b % row_bytes];
     return hipSuccess;
 }
-static hipError_t stub_views(const ViewsParams& P, int, hipStream_t)
+// a work list [8][stride] must hold every slot the headers give the kernel, once, and nothing else
+static bool list_covers(const uint32_t* list, int stride, const PieceHdr* hdr, size_t slots, bool want_lds, bool want_gather)
 {
+    std::vector<int> seen(slots, 0);
+    for (size_t i = 0; i < (size_t)8 * stride; ++i) {
+        if (list[i] == ~0u)
+            continue;
+        if (list[i] >= slots || seen[list[i]]++)
+            return false;
+    }
+    for (size_t s = 0; s < slots; ++s) {
+        const uint32_t mode = hdr[s].mode_items & 3u;
+        if (seen[s] != ((mode == 1u && want_lds) || (mode == 2u && want_gather) ? 1 : 0))
+            return false;
+    }
+    return true;
+}
+template <int TILE_W>
+static hipError_t stub_views(const ViewsParams& P, int which, hipStream_t)
+{
+    const size_t slots = (size_t)((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H) * P.n_pitch;
+    if (which == 0 && P.main_list && (P.main_stride < 1 || P.main_group < 1 || P.main_chunks < 1 ||
+                                      !list_covers(P.main_list, P.main_stride, P.hdr, slots, true, false)))
+        return hipErrorInvalidValue;
+    if (which == 3 && (P.n_list < 1 || !list_covers(P.gather_list, P.n_list, P.hdr, slots, P.gather_all != 0, true)))
+        return hipErrorInvalidValue;
+    if ((which == 2 || which == 1) && P.n_gather > 0)
+        for (int i = 0; i < P.n_gather; ++i)
+            if (which == 2 && P.gather_list[i] >= slots)
+                return hipErrorInvalidValue;
     const size_t n = (size_t)P.n_panos * P.n_yaw * P.n_pitch * P.oh * P.ow * 3;
     P.out[0] = P.src[0];
     // the last byte of the last row's wrap pad: the upload's second 2-D copy must have filled it
@@ -84,12 +121,12 @@ static hipError_t stub_float_views(const ViewsParams& P, bool, int, hipStream_t)
 }
 const ShapeOps& shape_ops_w64()
 {
-    static const ShapeOps ops = {{64, TILE_H, 256, 4, 704}, &stub_plan<64, 256, 704>, &stub_views, &stub_float_views};
+    static const ShapeOps ops = {{64, TILE_H, 256, 4, 704}, &stub_plan<64, 256, 704>, &stub_views<64>, &stub_float_views};
     return ops;
 }
 const ShapeOps& shape_ops_w128()
 {
-    static const ShapeOps ops = {{128, TILE_H, 512, 4, 1408}, &stub_plan<128, 512, 1408>, &stub_views, &stub_float_views};
+    static const ShapeOps ops = {{128, TILE_H, 512, 4, 1408}, &stub_plan<128, 512, 1408>, &stub_views<128>, &stub_float_views};
     return ops;
 }
 }  // namespace p2p
