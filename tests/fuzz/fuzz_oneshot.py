@@ -1,8 +1,5 @@
 #!/usr/bin/env python3
-"""WARNING (round 3): both GPU boxes the round lost were running this script or fuzz_remap.py -- see README.md in this
-folder before running it on a shared pool.
-
-One-off fuzz of the host-buffer (one-shot) entry points and their per-thread cache: random sequences of calls
+"""One-off fuzz of the host-buffer (one-shot) entry points and their per-thread cache: random sequences of calls
 over a few geometries (in-kernel maps / caller maps / float pixel paths / legacy remap, pinned or not, changing
 yaws and panoramas), from several threads at once; every result is compared with a fresh resident job."""
 import importlib, os, sys, threading, time
@@ -12,8 +9,15 @@ sys.path.insert(0, ROOT)
 from oracle import maps
 pkg = importlib.import_module("360-to-planer-images_amd"); nat = pkg._native
 synth = importlib.import_module("360-to-planer-images_amd.synth")
+# Usage: python tests/fuzz/fuzz_oneshot.py [calls per thread] [threads, at most 32] [seed]
+# (the SECOND argument is the thread count, not a seed as in the other fuzzers: round 3 lost two GPU boxes to
+# "fuzz_oneshot.py 100000 8106" and "fuzz_oneshot.py 1000 9406" -- nine thousand threads, each creating contexts and
+# streams; hence the cap)
 n_calls = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 n_threads = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+if not 1 <= n_threads <= 32:
+    sys.exit("fuzz_oneshot: the second argument is the number of THREADS (1..32), got %d" % n_threads)
 GEOMS = [(512, 256, 96, 64, 90), (1024, 512, 200, 120, 90), (512, 256, 96, 64, 60), (2048, 1024, 320, 200, 100)]
 PANOS = {(pw, ph): [synth.synth_pano(pw, ph, 40 + i, "N") for i in range(3)] for pw, ph, *_ in GEOMS}
 errors = []
@@ -34,7 +38,7 @@ def truth(pano, yaws, pitches, fov, ow, oh, flags=0, maps_=None):
 
 
 def worker(tid):
-    rng = np.random.default_rng(1000 + tid)
+    rng = np.random.default_rng(seed0 + tid)
     for call in range(n_calls):
         pw, ph, ow, oh, fov = GEOMS[int(rng.integers(0, len(GEOMS)))]
         pano = PANOS[(pw, ph)][int(rng.integers(0, 3))]

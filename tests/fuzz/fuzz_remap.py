@@ -1,8 +1,5 @@
 #!/usr/bin/env python3
-"""WARNING (round 3): both GPU boxes the round lost were running this script or fuzz_oneshot.py -- see README.md in this
-folder before running it on a shared pool.
-
-One-off fuzz of p2p_remap_maps_interp_u8 (generic cv2.remap: three interpolations x five border modes x
+"""One-off fuzz of p2p_remap_maps_interp_u8 (generic cv2.remap: three interpolations x five border modes x
 1 / 3 / 4 channels, random sizes and maps incl. NaN / huge / out-of-range coordinates) and of the fused view path's
 self-consistency (in-kernel coordinates re-fed as caller maps reproduce the fused output).
 Usage: python tests/fuzz/fuzz_remap.py [n_cases] [seed]"""
