@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cmath>
 #include <cstdarg>
@@ -666,6 +667,12 @@ int p2p_device_count(void)
     return n < 0 ? 0 : n;
 }
 
+static std::atomic<int>& live_contexts()
+{
+    static std::atomic<int> n{0};
+    return n;
+}
+
 int p2p_ctx_create(int device, p2p_ctx** out)
 {
     if (!out)
@@ -674,9 +681,19 @@ int p2p_ctx_create(int device, p2p_ctx** out)
     int rc = use_device(device);
     if (rc != P2P_OK)
         return rc;
+    // A context owns three HIP streams (hardware queues) and a handful of events.  A process that creates them without
+    // bound takes the GPU down for everybody (round 3: a test script with nine thousand threads, a context each):
+    // beyond P2P_MAX_CONTEXTS (default 256) live contexts the call fails instead.
+    const int max_ctx = std::max(1, env_int("P2P_MAX_CONTEXTS", 256));
+    if (live_contexts().fetch_add(1) >= max_ctx) {
+        live_contexts().fetch_sub(1);
+        return fail(P2P_ERR_OOM, "p2p_ctx_create: %d contexts are alive in this process (P2P_MAX_CONTEXTS)", max_ctx);
+    }
     p2p_ctx* c = new (std::nothrow) p2p_ctx();
-    if (!c)
+    if (!c) {
+        live_contexts().fetch_sub(1);
         return fail(P2P_ERR_OOM, "host allocation failed");
+    }
     c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking);
@@ -701,6 +718,7 @@ void p2p_ctx_destroy(p2p_ctx* c)
 {
     if (!c)
         return;
+    live_contexts().fetch_sub(1);
     (void)hipSetDevice(c->device);
     for (hipStream_t* st : {&c->stream_up, &c->stream_down, &c->stream})
         if (*st) {

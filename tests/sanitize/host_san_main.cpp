@@ -54,6 +54,25 @@ int main()
     CHECK(p2p_remap_views_u8(px, 4, 4, 8, y0, 1, p_ok, 1, 90, 4, 4, px, 0, 0) == P2P_ERR_INVALID);  // row stride < 3 * pw
     p2p_ctx* ctx = nullptr;
     CHECK(p2p_ctx_create(0, nullptr) == P2P_ERR_INVALID && p2p_ctx_create(3, &ctx) == P2P_ERR_NO_DEVICE);
+    {   // the cap on live contexts (a process that creates them without bound takes the GPU down): P2P_MAX_CONTEXTS
+        setenv("P2P_MAX_CONTEXTS", "5", 1);
+        std::vector<p2p_ctx*> many;   // (the one-shot calls above may have left a slot's context alive: at most 5 fit, not exactly 5)
+        int refused = 0;
+        for (int i = 0; i < 8; ++i) {
+            p2p_ctx* c = nullptr;
+            const int rc = p2p_ctx_create(0, &c);
+            CHECK((rc == P2P_OK && c != nullptr && refused == 0) || (rc == P2P_ERR_OOM && c == nullptr));
+            if (c) many.push_back(c); else ++refused;
+        }
+        CHECK(refused >= 3 && !many.empty());
+        p2p_ctx_destroy(many.back());
+        many.pop_back();
+        p2p_ctx* again = nullptr;
+        CHECK(p2p_ctx_create(0, &again) == P2P_OK);   // a destroyed context makes room
+        many.push_back(again);
+        for (p2p_ctx* c : many) p2p_ctx_destroy(c);
+        unsetenv("P2P_MAX_CONTEXTS");
+    }
     CHECK(p2p_ctx_create(0, &ctx) == P2P_OK);
     p2p_job* job = nullptr;
     p2p_job_desc d = {64, 32, 2, 3, nullptr, 2, nullptr, 90, 70, 33, P2P_FLAG_DEFAULT};
