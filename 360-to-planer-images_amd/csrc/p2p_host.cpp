@@ -683,8 +683,8 @@ int p2p_ctx_create(int device, p2p_ctx** out)
         return rc;
     // A context owns three HIP streams (hardware queues) and a handful of events.  A process that creates them without
     // bound takes the GPU down for everybody (round 3: a test script with nine thousand threads, a context each):
-    // beyond P2P_MAX_CONTEXTS (default 1024) live contexts the call fails instead.
-    const int max_ctx = std::max(1, env_int("P2P_MAX_CONTEXTS", 1024));
+    // beyond P2P_MAX_CONTEXTS (default 64) live contexts the call fails instead.
+    const int max_ctx = std::max(1, env_int("P2P_MAX_CONTEXTS", 64));
     if (live_contexts().fetch_add(1) >= max_ctx) {
         live_contexts().fetch_sub(1);
         return fail(P2P_ERR_OOM, "p2p_ctx_create: %d contexts are alive in this process (P2P_MAX_CONTEXTS)", max_ctx);

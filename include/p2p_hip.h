@@ -192,7 +192,7 @@ typedef struct p2p_job_desc_f64 {
     int32_t flags;
 } p2p_job_desc_f64;
 
-/* A context owns three HIP streams and a few events.  At most P2P_MAX_CONTEXTS (environment, default 1024) contexts are
+/* A context owns three HIP streams and a few events.  At most P2P_MAX_CONTEXTS (environment, default 64) contexts are
    alive per process; beyond that p2p_ctx_create returns P2P_ERR_OOM. */
 int p2p_ctx_create(int device, p2p_ctx** out);
 void p2p_ctx_destroy(p2p_ctx* ctx);
