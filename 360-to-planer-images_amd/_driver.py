@@ -92,9 +92,28 @@ class DevicePipeline:
         self.ctx.close()
 
 
-_ctx_lock = threading.Lock()
+_ctx_lock = threading.Lock()  # guards the three dicts below
 _ctxs = {}
 _groups = {}  # device slot -> (geometry key, [(job, pitch index, yaw indices)]): the slot's resident jobs
+_slot_locks = {}  # device slot -> lock held for the whole of one image on that slot: two concurrent calls that name the
+                  # same (rank, device) take turns instead of interleaving set_pano / run / get_views on the same jobs
+
+
+def _slot_lock(slot):
+    with _ctx_lock:
+        lk = _slot_locks.get(slot)
+        if lk is None:
+            lk = _slot_locks[slot] = threading.Lock()
+        return lk
+
+
+def _close_group(slot):
+    """Close the jobs a slot keeps (borrowers before the owner).  The caller holds the slot's lock."""
+    with _ctx_lock:
+        kept = _groups.pop(slot, None)
+    if kept is not None:
+        for job, _, _ in reversed(kept[1]):
+            job.close()
 
 
 def _shared_ctx(slot):
@@ -110,13 +129,14 @@ def _shared_ctx(slot):
 def release_sharded():
     """Free the jobs and contexts process_views_sharded keeps between images."""
     with _ctx_lock:
-        for _, jobs in _groups.values():
-            for job, _, _ in reversed(jobs):
-                job.close()
-        _groups.clear()
-        for c in _ctxs.values():
-            c.close()
-        _ctxs.clear()
+        slots = list(_groups) + [s for s in _ctxs if s not in _groups]
+    for slot in slots:
+        with _slot_lock(slot):
+            _close_group(slot)
+            with _ctx_lock:
+                c = _ctxs.pop(slot, None)
+            if c is not None:
+                c.close()
 
 
 def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0):
@@ -132,18 +152,30 @@ def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0):
     world = len(devices)
     geo = (pw, ph, tuple(yaws), tuple(pitches), float(fov), int(ow), int(oh), int(flags), world)
 
+    # slots of earlier calls that this call does not use (other devices, a larger world): their jobs would hold
+    # panoramas and views until release_sharded()
+    mine = {(r, int(devices[r])) for r in range(world)}
+    with _ctx_lock:
+        stale = [s for s in _groups if s not in mine]
+    for slot in stale:
+        with _slot_lock(slot):
+            _close_group(slot)
+
     def one_device(rank):
+        slot = (rank, int(devices[rank]))
+        with _slot_lock(slot):
+            _one_device_locked(rank, slot)
+
+    def _one_device_locked(rank, slot):
         groups = shard_views(len(yaws), len(pitches), world, rank)
+        with _ctx_lock:
+            kept = _groups.get(slot)
+        if kept is not None and kept[0] != geo:
+            _close_group(slot)  # (also when this geometry leaves the rank with nothing to draw)
+            kept = None
         if not groups:
             return
-        slot = (rank, int(devices[rank]))
         ctx = _shared_ctx(slot)
-        kept = _groups.get(slot)
-        if kept is not None and kept[0] != geo:
-            for job, _, _ in reversed(kept[1]):  # borrowers before the owner
-                job.close()
-            kept = None
-            _groups.pop(slot, None)
         if kept is None:
             jobs, owner = [], None
             try:
@@ -158,8 +190,10 @@ def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0):
                 for job, _, _ in reversed(jobs):
                     job.close()
                 raise
-            _groups[slot] = (geo, jobs)
-        jobs = _groups[slot][1]
+            with _ctx_lock:
+                _groups[slot] = (geo, jobs)
+        with _ctx_lock:
+            jobs = _groups[slot][1]
         try:
             jobs[0][0].set_pano(0, pano, wait=False)  # once per device
             pending = []
@@ -172,9 +206,7 @@ def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0):
                 for k, y in enumerate(yis):
                     out[y, pi] = views[k, 0]
         except Exception:
-            for job, _, _ in reversed(jobs):
-                job.close()
-            _groups.pop(slot, None)
+            _close_group(slot)
             raise
 
     with ThreadPoolExecutor(max_workers=world) as ex:

@@ -34,6 +34,7 @@ ABI_SYMBOLS = (
     "p2p_job_set_pano_async", "p2p_job_share_panos", "p2p_job_get_views_async", "p2p_job_wait", "p2p_job_set_maps", "p2p_job_run",
     "p2p_job_get_views", "p2p_job_kernel_ms", "p2p_job_kernel_ms_last", "p2p_job_device_out", "p2p_job_get_coords",
     "p2p_job_get_yaw_tables", "p2p_job_set_yaws", "p2p_host_alloc", "p2p_host_free", "p2p_release_cache",
+    "p2p_reload_options", "p2p_job_get_info",
 )
 
 
@@ -41,6 +42,17 @@ class P2PError(RuntimeError):
     def __init__(self, code, message):
         super().__init__("libp2p_hip: %s (status %d)" % (message, code))
         self.code = code
+
+
+class JobInfo(ctypes.Structure):
+    """p2p_job_info (include/p2p_hip.h): how a job is drawn -- for tests and tools."""
+    _fields_ = [
+        ("tile_w", ctypes.c_int32), ("tile_h", ctypes.c_int32), ("pairs_per_block", ctypes.c_int32),
+        ("pair_chunks", ctypes.c_int32), ("list_order", ctypes.c_int32), ("main_group", ctypes.c_int32),
+        ("prefetch_lead", ctypes.c_int32), ("n_odd_yaws", ctypes.c_int32), ("n_tiles", ctypes.c_int64),
+        ("n_gather_tiles", ctypes.c_int64), ("timing_events", ctypes.c_int32), ("copy_streams", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 4),
+    ]
 
 
 class JobDesc(ctypes.Structure):
@@ -153,6 +165,10 @@ def lib():
     L.p2p_host_free.argtypes = [c_vp]
     L.p2p_release_cache.restype = c_int
     L.p2p_release_cache.argtypes = []
+    L.p2p_reload_options.restype = c_int
+    L.p2p_reload_options.argtypes = []
+    L.p2p_job_get_info.restype = c_int
+    L.p2p_job_get_info.argtypes = [c_vp, ctypes.POINTER(JobInfo)]
     _lib = L
     return L
 
@@ -164,6 +180,12 @@ def check(rc):
 
 def device_count():
     return lib().p2p_device_count()
+
+
+def reload_options():
+    """Re-read the P2P_* environment variables (the library reads them once per process and copies them into a job when
+    it is created).  Only while no other thread is inside the library: tests and tools that flip a knob between jobs."""
+    check(lib().p2p_reload_options())
 
 
 def version():
@@ -534,8 +556,15 @@ class Job:
     def run(self):
         check(lib().p2p_job_run(self._h))
 
-    def time_launches(self, on):
-        check(lib().p2p_job_time_launches(self._h, int(bool(on))))
+    def time_launches(self, n):
+        """Launch timing is off by default.  n launches to keep event pairs for (True = 256), 0 / False = off."""
+        check(lib().p2p_job_time_launches(self._h, 256 if n is True else int(n)))
+
+    def info(self):
+        """p2p_job_get_info as a dict: tile shape, pairs per workgroup, list order, gather tiles ..."""
+        i = JobInfo()
+        check(lib().p2p_job_get_info(self._h, ctypes.byref(i)))
+        return {k: getattr(i, k) for k, _ in JobInfo._fields_ if k != "reserved"}
 
     def plan_ms(self):
         """(plan pass, yaw tables) build times in ms of the tables this job uses (built once per geometry and context)."""

@@ -54,6 +54,98 @@ int env_int(const char* name, int dflt)
     return (v && *v) ? atoi(v) : dflt;
 }
 
+// Every P2P_* environment knob of the library.  The environment is read ONCE per process, at the first entry point
+// that needs a knob (and again only on p2p_reload_options(), which tests and tools call after changing a variable):
+// getenv is not safe beside a host's setenv, and a launch parameter belongs to the job it was resolved for.  A job
+// copies the per-job part at p2p_job_create; p2p_job_run, the memory pool and the kernels' dispatch read no
+// environment.  -1 = "not set: the library's own rule applies".
+struct Options {
+    // process-wide
+    long pool_mb = 8192;              // P2P_POOL_MB: idle bytes the device memory pool keeps per device
+    int max_contexts = 64;            // P2P_MAX_CONTEXTS
+    int oneshot_slots = 4;            // P2P_ONESHOT_SLOTS
+    int oneshot_cache = 1;            // P2P_ONESHOT_CACHE
+    long oneshot_cache_max_mb = 4096; // P2P_ONESHOT_CACHE_MAX_MB
+    long plan_cache_mb = 4096;        // P2P_PLAN_CACHE_MB (a context copies it at p2p_ctx_create)
+    // per job
+    int plan_cache = 1;               // P2P_PLAN_CACHE
+    int verbose = 0;                  // P2P_VERBOSE
+    int tile_shape = 0;               // P2P_TILE_SHAPE: 64 | 128 | 0 = choose_shape's rule
+    int pairs_per_block = 0;          // P2P_PAIRS_PER_BLOCK
+    int max_pairs_per_block = -1;     // P2P_MAX_PAIRS_PER_BLOCK
+    int chunk_outer = -1;             // P2P_CHUNK_OUTER
+    int main_order = -1;              // P2P_MAIN_ORDER: 0 grid order, 1 list order, 2 list order also with several panoramas; -1 = by job
+    int main_group = -1;              // P2P_MAIN_GROUP
+    int prefetch_lead = -1;           // P2P_PREFETCH_LEAD
+    int force_rest = 0;               // P2P_FORCE_REST
+    int gather_ppb = 16;              // P2P_GATHER_PPB
+    int gather_all = 1;               // P2P_GATHER_ALL
+    int gather_blocky_from = p2p::GATHER_BLOCKY_FROM;  // P2P_GATHER_BLOCKY_FROM
+    int gather_order = 1;             // P2P_GATHER_ORDER
+    int gather_group = 3;             // P2P_GATHER_GROUP
+    int scramble_plan = 0;            // P2P_SCRAMBLE_PLAN (robustness self-test only)
+};
+
+void pool_set_budget(size_t bytes);  // (the pool is defined below)
+std::mutex g_opt_mu;
+Options g_opt;
+bool g_opt_loaded = false;
+
+void options_load_locked()
+{
+    Options o;
+    o.pool_mb = std::max(0, env_int("P2P_POOL_MB", (int)o.pool_mb));
+    o.max_contexts = std::max(1, env_int("P2P_MAX_CONTEXTS", o.max_contexts));
+    o.oneshot_slots = std::max(1, env_int("P2P_ONESHOT_SLOTS", o.oneshot_slots));
+    o.oneshot_cache = env_int("P2P_ONESHOT_CACHE", o.oneshot_cache);
+    o.oneshot_cache_max_mb = std::max(0, env_int("P2P_ONESHOT_CACHE_MAX_MB", (int)o.oneshot_cache_max_mb));
+    o.plan_cache_mb = std::max(0, env_int("P2P_PLAN_CACHE_MB", (int)o.plan_cache_mb));
+    o.plan_cache = env_int("P2P_PLAN_CACHE", o.plan_cache);
+    o.verbose = env_int("P2P_VERBOSE", o.verbose);
+    o.tile_shape = env_int("P2P_TILE_SHAPE", o.tile_shape);
+    o.pairs_per_block = env_int("P2P_PAIRS_PER_BLOCK", o.pairs_per_block);
+    o.max_pairs_per_block = env_int("P2P_MAX_PAIRS_PER_BLOCK", o.max_pairs_per_block);
+    o.chunk_outer = env_int("P2P_CHUNK_OUTER", o.chunk_outer);
+    o.main_order = env_int("P2P_MAIN_ORDER", o.main_order);
+    o.main_group = env_int("P2P_MAIN_GROUP", o.main_group);
+    o.prefetch_lead = env_int("P2P_PREFETCH_LEAD", o.prefetch_lead);
+    o.force_rest = env_int("P2P_FORCE_REST", o.force_rest);
+    o.gather_ppb = env_int("P2P_GATHER_PPB", o.gather_ppb);
+    o.gather_all = env_int("P2P_GATHER_ALL", o.gather_all);
+    o.gather_blocky_from = std::max(0, env_int("P2P_GATHER_BLOCKY_FROM", o.gather_blocky_from));
+    o.gather_order = env_int("P2P_GATHER_ORDER", o.gather_order);
+    o.gather_group = std::min(8, std::max(0, env_int("P2P_GATHER_GROUP", o.gather_group)));
+    o.scramble_plan = env_int("P2P_SCRAMBLE_PLAN", o.scramble_plan);
+    g_opt = o;
+    g_opt_loaded = true;
+    pool_set_budget((size_t)o.pool_mb << 20);
+}
+
+Options options()  // a copy: callers keep what they resolved
+{
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    if (!g_opt_loaded)
+        options_load_locked();
+    return g_opt;
+}
+
+// the calling thread's current device, put back on scope exit: helpers that free another device's memory
+// (pool trim, table destructors, p2p_release_cache) must not leave the caller on that device
+struct DeviceRestore {
+    int dev = -1;
+    DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+
+// waits for a stream on every exit path that has not dismissed it: host vectors handed to hipMemcpyAsync and
+// device blocks about to go back to the pool must not be in use by queued work when an error return unwinds
+struct StreamSyncGuard {
+    hipStream_t st;
+    bool armed = true;
+    explicit StreamSyncGuard(hipStream_t s) : st(s) {}
+    ~StreamSyncGuard() { if (armed) (void)hipStreamSynchronize(st); }
+};
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -65,13 +157,18 @@ int env_int(const char* name, int dflt)
 // 2.1 M; a buffer allocated once and reused: 0 in 0.9 M beside the same neighbours).  That is what round 2's
 // "wrong output, then a memory fault" was: a plan table with garbage in it.  The kernels now clamp or range-check
 // every table-derived offset (p2p_audit.h), and with the pool a fresh allocation happens only while the pool warms up.
-// Blocks are kept in size classes (<= 12.5 % rounding), P2P_POOL_MB (default 32768) bounds the idle bytes per
-// device (the largest idle blocks go back to the driver first), p2p_release_cache empties it.
+// Blocks are kept in size classes (<= 12.5 % rounding), P2P_POOL_MB (default 8192) bounds the idle bytes per
+// device (the largest idle blocks go back to the driver first), p2p_release_cache empties it, and so does the
+// destruction of the process's last context.
+// A block goes back to the idle list only when nothing queued on the device can still touch it: every caller either
+// has synchronised the streams that used it (job / context destruction, table replacement) or frees behind a
+// StreamSyncGuard on its error paths.
 // ------------------------------------------------------------------------------------------
 namespace {
 
 struct DevPool {
     std::mutex mu;
+    std::atomic<size_t> budget{(size_t)8192 << 20};  // idle bytes kept per device (Options::pool_mb, set when the options load)
     struct PerDev {
         std::multimap<size_t, void*> idle;        // class size -> block
         std::map<void*, size_t> live;             // block -> class size
@@ -97,6 +194,8 @@ size_t pool_class(size_t bytes)
     return (bytes + step - 1) / step * step;
 }
 
+size_t caches_evict_all();  // (defined with the contexts' table caches)
+
 hipError_t dev_alloc(void** out, size_t bytes)
 {
     *out = nullptr;
@@ -120,7 +219,10 @@ hipError_t dev_alloc(void** out, size_t bytes)
     }
     e = hipMalloc(out, cls);
     if (e != hipSuccess) {
-        // out of device memory: give the idle blocks back and try once more
+        // out of device memory: the cached tables no job uses go to the pool, the pool's idle blocks go back to the
+        // driver, and the allocation is tried once more
+        (void)hipGetLastError();
+        (void)caches_evict_all();
         std::vector<void*> drop;
         {
             std::lock_guard<std::mutex> lk(P.mu);
@@ -160,7 +262,7 @@ hipError_t dev_free(void* ptr)
             dv.second.live.erase(it);
             dv.second.idle.emplace(cls, ptr);
             dv.second.idle_bytes += cls;
-            const size_t budget = (size_t)std::max(0, env_int("P2P_POOL_MB", 32768)) << 20;
+            const size_t budget = P.budget.load(std::memory_order_relaxed);
             while (dv.second.idle_bytes > budget && !dv.second.idle.empty()) {  // largest idle blocks first
                 auto big = std::prev(dv.second.idle.end());
                 dv.second.idle_bytes -= big->first;
@@ -177,6 +279,10 @@ hipError_t dev_free(void* ptr)
     return hipSuccess;
 }
 
+}  // namespace
+namespace { void pool_set_budget(size_t bytes) { dev_pool().budget.store(bytes, std::memory_order_relaxed); } }
+namespace {
+
 void dev_pool_trim()
 {
     DevPool& P = dev_pool();
@@ -189,6 +295,7 @@ void dev_pool_trim()
             dv.second.idle_bytes = 0;
         }
     }
+    DeviceRestore keep;
     for (auto& d : drop) {
         (void)hipSetDevice(d.first);
         (void)hipFree(d.second);
@@ -206,8 +313,13 @@ struct PlanKey {  // the reference's key (ow, oh, pitch, pw, ph, fov), for the w
     double fov;
     std::vector<double> pitch;
     int shape;  // tile shape of the tables (0: 64 x 16, 1: 128 x 16)
+    int knobs[4];  // the options that change the tables: gather_blocky_from (header bit), main_order (whether the main
+                   // list exists), gather_order / gather_group (the XCD lists) -- a plan built under one setting is
+                   // never served under another
     bool operator<(const PlanKey& o) const
     {
+        for (int i = 0; i < 4; ++i)
+            if (knobs[i] != o.knobs[i]) return knobs[i] < o.knobs[i];
         if (shape != o.shape) return shape < o.shape;
         if (pw != o.pw) return pw < o.pw;
         if (ph != o.ph) return ph < o.ph;
@@ -240,6 +352,7 @@ struct Plan {  // the plan pass's tables (p2p_plan.hip)
     unsigned long long stamp = 0;        // last use (eviction order)
     ~Plan()
     {
+        DeviceRestore keep;
         (void)hipSetDevice(device);
         (void)dev_free(d_coords); (void)dev_free(d_hdr); (void)dev_free(d_px); (void)dev_free(d_items);
         (void)dev_free(d_px2); (void)dev_free(d_n_gather); (void)dev_free(d_gather_list); (void)dev_free(d_xcd_list); (void)dev_free(d_xcd_all); (void)dev_free(d_main_list);
@@ -322,7 +435,7 @@ std::vector<uint32_t> xcd_main_lists(const std::vector<p2p::PieceHdr>& hh, size_
 // tiles' cost is not a number the host can guess, and the XCDs that hold them are busy long after the others.
 // by_source false: the tiles in list order, dealt round-robin (what the kernel's grid did before).
 std::vector<uint32_t> xcd_lists(const std::vector<uint32_t>& tiles, const std::vector<p2p::PieceHdr>& hh, int pw, bool by_source,
-                                int* stride)
+                                int group_log2, int* stride)
 {
     std::vector<std::vector<uint32_t>> per(8);
     if (!by_source) {
@@ -334,7 +447,7 @@ std::vector<uint32_t> xcd_lists(const std::vector<uint32_t>& tiles, const std::v
         for (uint32_t s : tiles)
             order.emplace_back(source_order_key(hh[s]), s);
         std::sort(order.begin(), order.end());
-        int g = std::min(8, std::max(0, env_int("P2P_GATHER_GROUP", 3)));  // 2^g x 2^g cells: 512 x 256 source pixels
+        int g = group_log2;  // 2^g x 2^g cells (3: 512 x 256 source pixels)
         const size_t min_groups = 64;
         for (; g > 0; --g) {
             size_t groups = 0;
@@ -399,6 +512,7 @@ struct YawTabs {  // yaw_table_kernel / yaw_desc_kernel outputs
     unsigned long long stamp = 0;
     ~YawTabs()
     {
+        DeviceRestore keep;
         (void)hipSetDevice(device);
         (void)dev_free(d_ytab); (void)dev_free(d_f4tab); (void)dev_free(d_ydesc); (void)dev_free(d_yaw_rad);
     }
@@ -406,10 +520,12 @@ struct YawTabs {  // yaw_table_kernel / yaw_desc_kernel outputs
 
 struct p2p_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;      // kernels
+    hipStream_t stream = nullptr;      // kernels, and the synchronous copies
+    // created on first use: a context that never copies asynchronously owns ONE hardware queue
     hipStream_t stream_up = nullptr;   // asynchronous panorama uploads (p2p_job_set_pano_async)
     hipStream_t stream_down = nullptr; // asynchronous view downloads (p2p_job_get_views_async)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::mutex stream_mu;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // p2p_ctx_mark
     short* d_ctab = nullptr;  // INTER_CUBIC weight table, built on first use
     // grow-only scratch of the generic remap entry point (source image, output, two maps): kept with the context
     // instead of four allocations per call
@@ -422,8 +538,45 @@ struct p2p_ctx {
     std::map<PlanKey, std::shared_ptr<Plan>> plans;
     std::map<YawKey, std::shared_ptr<YawTabs>> yaw_tabs;
     unsigned long long cache_clock = 0;
+    size_t cache_budget = (size_t)4096 << 20;     // P2P_PLAN_CACHE_MB as it stood when the context was created
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // timing of the plan pass / the table kernels
 };
+
+namespace {
+
+// every live context, so that p2p_release_cache and an out-of-memory retry can reach the table caches of contexts
+// the caller created itself (lock order: registry, then a context's cache_mu)
+struct CtxRegistry {
+    std::mutex mu;
+    std::vector<p2p_ctx*> all;
+};
+CtxRegistry& ctx_registry()
+{
+    static CtxRegistry* r = new CtxRegistry();
+    return *r;
+}
+
+// the context's copy streams, created when an asynchronous copy first asks for one
+hipError_t ctx_copy_stream(p2p_ctx* c, bool up, hipStream_t* out)
+{
+    std::lock_guard<std::mutex> lk(c->stream_mu);
+    hipStream_t& st = up ? c->stream_up : c->stream_down;
+    if (!st) {
+        hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            st = nullptr;
+            return e;
+        }
+    }
+    *out = st;
+    return hipSuccess;
+}
+
+// drop the cached tables of `c` that no job refers to (all of them, or until `budget` holds); returns bytes dropped.
+// The tables' device blocks go back to the pool: the caller trims the pool if the driver should have them.
+size_t cache_evict_unused(p2p_ctx* c, size_t budget);
+
+}  // namespace
 
 struct p2p_job {
     p2p_ctx* ctx = nullptr;
@@ -478,17 +631,20 @@ struct p2p_job {
     p2p::MapGeom geom{};
     bool host_maps = false;
     bool rows_from_host = false;  // yaw tables were packed from caller float rows, not built from yaw_deg
-    bool time_launches = true;  // bracket every launch with its own event pair (p2p_job_kernel_ms*)
+    bool time_launches = false; // bracket every launch with its own event pair (p2p_job_time_launches / p2p_job_kernel_ms*)
+    Options opt;                // the knobs as they stood at p2p_job_create (no environment is read after that)
     int border = 0;             // stage-2 border mode; non-zero only for the legacy single-remap entry point
     bool ran = false;
     std::vector<char> pano_set;
-    // ring of event pairs: one per p2p_job_run, so a caller can time K back-to-back launches
-    // without synchronising between them (bench.py's roofline figure)
-    std::vector<hipEvent_t> ev_ring;  // 2 * kEvRing events, created on first run
+    // ring of event pairs, one per p2p_job_run, so that a caller can time K back-to-back launches without
+    // synchronising between them (bench.py's roofline figure).  It exists only while p2p_job_time_launches(job, n)
+    // has asked for n pairs: a job that nobody times creates no timing event and records none.
+    std::vector<hipEvent_t> ev_ring;  // 2 * ring_pairs events
+    int ring_pairs = 0;
     long long runs = 0;
 };
 
-static constexpr int kEvRing = 256;
+static constexpr int kEvRingMax = 4096;
 
 namespace {
 
@@ -539,7 +695,7 @@ int slot_acquire(int device, F wants, OneShotSlot** out)
     int rc = use_device(device);
     if (rc != P2P_OK)
         return rc;
-    const int max_slots = std::max(1, env_int("P2P_ONESHOT_SLOTS", 4));
+    const int max_slots = options().oneshot_slots;
     OneShotPool& P = pool();
     std::unique_lock<std::mutex> lk(P.mu);
     for (;;) {
@@ -607,9 +763,9 @@ const p2p::ShapeOps& shape_ops(int shape) { return shape ? p2p::shape_ops_w128()
 // Cache and stream to HBM -- whole 128-byte lines per wave store -- (config 4: 18 GB, 6.5 ms against 7.2; config 3 on
 // one GPU: 14 GB, 6.1 against 6.4), 64-wide tiles otherwise (config 2: 85 us against 95; config 5's 2.2 GB: 750
 // against 768; the CLI's default set 73 against 93).
-int choose_shape(const p2p_job_desc& d)
+int choose_shape(const p2p_job_desc& d, const Options& opt)
 {
-    const int forced = env_int("P2P_TILE_SHAPE", 0);
+    const int forced = opt.tile_shape;
     if (forced == 64 || forced == 128)
         return forced == 128;
     const size_t out_row = 12 * (((size_t)d.ow + 3) / 4);
@@ -623,12 +779,12 @@ int choose_shape(const p2p_job_desc& d)
     return bytes >= from && d.ow >= 256 && src_px_per_out_px < 1.6;
 }
 
-int choose_pairs_per_block(const p2p_job_desc& d, const p2p::TileShape& S)
+int choose_pairs_per_block(const p2p_job_desc& d, const p2p::TileShape& S, const Options& opt)
 {
     const int tiles = ((d.ow + S.tile_w - 1) / S.tile_w) * ((d.oh + S.tile_h - 1) / S.tile_h);
     const long long base = (long long)tiles * d.n_pitch;  // workgroups per pair chunk
     const int n_pairs = d.n_panos * d.n_yaw;
-    int forced = env_int("P2P_PAIRS_PER_BLOCK", 0);
+    int forced = opt.pairs_per_block;
     if (forced > 64)
         forced = 64;  // the kernel keeps one pair context per lane of a wave
     if (forced > 0)
@@ -642,7 +798,7 @@ int choose_pairs_per_block(const p2p_job_desc& d, const p2p::TileShape& S)
     // measured on the plan-driven kernel (config 5, 360 yaws): 16 pairs per workgroup 0.885 ms, 30: 0.843, 45: 0.835,
     // 60: 0.832 -- the per-workgroup set-up is small now.  Chunks that run across several panoramas are another
     // matter (8 resident panoramas: 16 pairs 0.843 ms, 48 pairs 0.894): their sources compete for the caches
-    int cap = env_int("P2P_MAX_PAIRS_PER_BLOCK", d.n_panos > 1 ? 16 : 48);
+    int cap = opt.max_pairs_per_block >= 0 ? opt.max_pairs_per_block : (d.n_panos > 1 ? 16 : 48);
     if (cap > 64) cap = 64;
     if (cap < 1) cap = 1;
     if (ppb > cap) {
@@ -681,10 +837,13 @@ int p2p_ctx_create(int device, p2p_ctx** out)
     int rc = use_device(device);
     if (rc != P2P_OK)
         return rc;
-    // A context owns three HIP streams (hardware queues) and a handful of events.  A process that creates them without
-    // bound takes the GPU down for everybody (round 3: a test script with nine thousand threads, a context each):
-    // beyond P2P_MAX_CONTEXTS (default 64) live contexts the call fails instead.
-    const int max_ctx = std::max(1, env_int("P2P_MAX_CONTEXTS", 64));
+    // A context owns a HIP stream (a hardware queue; two more once it copies asynchronously) and four events.  A
+    // process that creates them without bound takes the GPU down for everybody (round 3: a test script with nine
+    // thousand threads, a context each): beyond P2P_MAX_CONTEXTS live contexts the call fails instead.  The default,
+    // 64, is what has run on this pool without incident (48 threads x 4 one-shot slots, 8 explicit contexts per test);
+    // nothing larger has been tried on a GPU, so nothing larger is the default.
+    const Options opt = options();
+    const int max_ctx = opt.max_contexts;
     if (live_contexts().fetch_add(1) >= max_ctx) {
         live_contexts().fetch_sub(1);
         return fail(P2P_ERR_OOM, "p2p_ctx_create: %d contexts are alive in this process (P2P_MAX_CONTEXTS)", max_ctx);
@@ -695,9 +854,8 @@ int p2p_ctx_create(int device, p2p_ctx** out)
         return fail(P2P_ERR_OOM, "host allocation failed");
     }
     c->device = device;
+    c->cache_budget = (size_t)opt.plan_cache_mb << 20;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_down, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_t0);
@@ -710,6 +868,11 @@ int p2p_ctx_create(int device, p2p_ctx** out)
         p2p_ctx_destroy(c);
         return fail(P2P_ERR_HIP, "stream/event creation: %s", hipGetErrorString(e));
     }
+    {
+        CtxRegistry& R = ctx_registry();
+        std::lock_guard<std::mutex> lk(R.mu);
+        R.all.push_back(c);
+    }
     *out = c;
     return P2P_OK;
 }
@@ -718,15 +881,24 @@ void p2p_ctx_destroy(p2p_ctx* c)
 {
     if (!c)
         return;
-    live_contexts().fetch_sub(1);
+    {
+        CtxRegistry& R = ctx_registry();
+        std::lock_guard<std::mutex> lk(R.mu);
+        R.all.erase(std::remove(R.all.begin(), R.all.end(), c), R.all.end());
+    }
+    const bool last = live_contexts().fetch_sub(1) == 1;
+    DeviceRestore keep;
     (void)hipSetDevice(c->device);
     for (hipStream_t* st : {&c->stream_up, &c->stream_down, &c->stream})
         if (*st) {
             (void)hipStreamSynchronize(*st);
             (void)hipStreamDestroy(*st);
         }
-    c->plans.clear();     // (jobs still alive keep their tables through their own references)
-    c->yaw_tabs.clear();
+    {
+        std::lock_guard<std::mutex> lk(c->cache_mu);
+        c->plans.clear();     // (jobs still alive keep their tables through their own references)
+        c->yaw_tabs.clear();
+    }
     (void)dev_free(c->d_ctab);
     (void)dev_free(c->d_audit);
     for (void* p : c->scratch)
@@ -734,6 +906,8 @@ void p2p_ctx_destroy(p2p_ctx* c)
     for (hipEvent_t e : {c->ev0, c->ev1, c->ev_t0, c->ev_t1})
         if (e) (void)hipEventDestroy(e);
     delete c;
+    if (last)
+        dev_pool_trim();  // the process's last context: the idle blocks go back to the driver (co-tenants, torch)
 }
 
 int p2p_ctx_synchronize(p2p_ctx* c)
@@ -741,9 +915,9 @@ int p2p_ctx_synchronize(p2p_ctx* c)
     if (!c)
         return fail(P2P_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream_up));
+    if (c->stream_up) HIP_TRY(hipStreamSynchronize(c->stream_up));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream_down));
+    if (c->stream_down) HIP_TRY(hipStreamSynchronize(c->stream_down));
     return P2P_OK;
 }
 
@@ -753,9 +927,8 @@ void p2p_job_destroy(p2p_job* j)
         return;
     if (j->ctx) {
         (void)hipSetDevice(j->ctx->device);
-        (void)hipStreamSynchronize(j->ctx->stream_up);
-        (void)hipStreamSynchronize(j->ctx->stream);
-        (void)hipStreamSynchronize(j->ctx->stream_down);
+        for (hipStream_t st : {j->ctx->stream_up, j->ctx->stream, j->ctx->stream_down})
+            if (st) (void)hipStreamSynchronize(st);  // nothing queued touches the blocks that go back to the pool below
     }
     for (hipEvent_t e : {j->ev_up, j->ev_run, j->ev_down})
         if (e) (void)hipEventDestroy(e);
@@ -777,15 +950,13 @@ void p2p_job_destroy(p2p_job* j)
 }
 
 // ---- the context's table caches ------------------------------------------------------------------------------
-static size_t cache_budget() { return (size_t)std::max(0, env_int("P2P_PLAN_CACHE_MB", 4096)) << 20; }
-
-// drop cached tables nobody uses, least recently used first, until the budget holds (mutex held by the caller)
-static void cache_trim(p2p_ctx* c)
+// drop cached tables nobody uses, least recently used first, until `budget` holds (mutex held by the caller);
+// returns the bytes dropped
+static size_t cache_trim_to(p2p_ctx* c, size_t budget)
 {
-    size_t total = 0;
+    size_t total = 0, dropped = 0;
     for (auto& kv : c->plans) total += kv.second->bytes;
     for (auto& kv : c->yaw_tabs) total += kv.second->bytes;
-    const size_t budget = cache_budget();
     while (total > budget) {
         unsigned long long best = ~0ull;
         int which = 0;
@@ -797,10 +968,37 @@ static void cache_trim(p2p_ctx* c)
             if (it->second.use_count() == 1 && it->second->stamp < best) { best = it->second->stamp; by = it; which = 2; }
         if (!which)
             break;  // everything left is in use
-        if (which == 1) { total -= bp->second->bytes; c->plans.erase(bp); }
-        else { total -= by->second->bytes; c->yaw_tabs.erase(by); }
+        if (which == 1) { total -= bp->second->bytes; dropped += bp->second->bytes; c->plans.erase(bp); }
+        else { total -= by->second->bytes; dropped += by->second->bytes; c->yaw_tabs.erase(by); }
     }
+    return dropped;
 }
+static void cache_trim(p2p_ctx* c) { (void)cache_trim_to(c, c->cache_budget); }
+
+extern "C++" {
+namespace {
+size_t cache_evict_unused(p2p_ctx* c, size_t budget)
+{
+    // an entry nobody uses was last touched by a job that has synchronised the context's streams since (job
+    // destruction, table replacement): nothing queued reads it
+    std::unique_lock<std::mutex> lk(c->cache_mu, std::try_to_lock);
+    if (!lk.owns_lock())
+        return 0;  // its owner is inserting right now: leave it
+    return cache_trim_to(c, budget);
+}
+
+// every live context's unused cached tables -> the pool (p2p_release_cache; dev_alloc's out-of-memory retry)
+size_t caches_evict_all()
+{
+    size_t dropped = 0;
+    CtxRegistry& R = ctx_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    for (p2p_ctx* c : R.all)
+        dropped += cache_evict_unused(c, 0);
+    return dropped;
+}
+}  // namespace
+}  // extern "C++"
 
 // point the job's table pointers at its (shared or private) YawTabs and list its odd pairs: every panorama x the
 // yaws with per-column weights or rows that are not a shift
@@ -833,11 +1031,11 @@ static int job_adopt_yaw_tabs(p2p_job* j, std::shared_ptr<YawTabs> yt)
 // yaw_pack_kernel + yaw_desc_kernel on the context's stream.  rows == nullptr: looked up in / entered into the
 // context's cache (the reference's yaw_mapping_cache, P:17, P:42-52); caller rows make private tables.
 static int yaw_tabs_get(p2p_ctx* ctx, int pw, const std::vector<double>& yaw_deg, const float* rows, float* d_rows,
-                        std::shared_ptr<YawTabs>* out)
+                        bool use_cache, std::shared_ptr<YawTabs>* out)
 {
     const int n_yaw = (int)yaw_deg.size();
     YawKey key{pw, yaw_deg};
-    const bool cached = rows == nullptr && env_int("P2P_PLAN_CACHE", 1) != 0;
+    const bool cached = rows == nullptr && use_cache;
     if (cached) {
         std::lock_guard<std::mutex> lk(ctx->cache_mu);
         auto it = ctx->yaw_tabs.find(key);
@@ -859,6 +1057,7 @@ static int yaw_tabs_get(p2p_ctx* ctx, int pw, const std::vector<double>& yaw_deg
     for (int i = 0; i < n_yaw; ++i)
         yr[i] = deg2rad(yaw_deg[i]);  // P:85
     hipStream_t st = ctx->stream;
+    StreamSyncGuard sync_on_exit(st);  // yr, the caller's rows and T's blocks outlive whatever an error return leaves queued
     HIP_TRY(hipMemcpyAsync(T->d_yaw_rad, yr.data(), yr.size() * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipEventRecord(ctx->ev_t0, st));
     if (rows) {
@@ -872,6 +1071,7 @@ static int yaw_tabs_get(p2p_ctx* ctx, int pw, const std::vector<double>& yaw_deg
     T->desc.resize(n_yaw);
     HIP_TRY(hipMemcpyAsync(T->desc.data(), T->d_ydesc, T->desc.size() * sizeof(p2p::YawDesc), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));  // yr (and the caller's rows) are stack-lifetime host buffers
+    sync_on_exit.armed = false;
     (void)hipEventElapsedTime(&T->tables_ms, ctx->ev_t0, ctx->ev_t1);
     if (cached) {
         std::lock_guard<std::mutex> lk(ctx->cache_mu);
@@ -915,6 +1115,7 @@ static int job_create_core(p2p_ctx* ctx, const p2p_job_desc& d, const double* ya
     if (!j)
         return fail(P2P_ERR_OOM, "host allocation failed");
     j->ctx = ctx;
+    j->opt = options();
     j->d = d;
     j->d.yaw_deg = nullptr;
     j->d.pitch_deg = nullptr;
@@ -948,7 +1149,7 @@ static int job_create_core(p2p_ctx* ctx, const p2p_job_desc& d, const double* ya
     if (e == hipSuccess) e = hipEventCreateWithFlags(&j->ev_down, hipEventDisableTiming);
     if (e == hipSuccess) e = dev_alloc((void**)&j->d_out, j->out_bytes + 16);
     if (e == hipSuccess) e = dev_alloc((void**)&j->d_pitch, (size_t)d.n_pitch * sizeof(p2p::PitchConst));
-    j->shape = choose_shape(d);
+    j->shape = choose_shape(d, j->opt);
     {
         const p2p::TileShape& S = shape_ops(j->shape).shape;
         j->n_tiles = (size_t)((d.ow + S.tile_w - 1) / S.tile_w) * ((d.oh + S.tile_h - 1) / S.tile_h);
@@ -980,7 +1181,7 @@ static int job_create_core(p2p_ctx* ctx, const p2p_job_desc& d, const double* ya
     }
     // the yaw tables: the context's, if it has built them for these angles before (P:42-52)
     std::shared_ptr<YawTabs> yt;
-    int rc = yaw_tabs_get(ctx, d.pw, j->yaw, nullptr, nullptr, &yt);
+    int rc = yaw_tabs_get(ctx, d.pw, j->yaw, nullptr, nullptr, j->opt.plan_cache != 0, &yt);
     if (rc == P2P_OK)
         rc = job_adopt_yaw_tabs(j, yt);
     if (rc != P2P_OK) {
@@ -1031,7 +1232,20 @@ static int mark_run(p2p_job* j)
     return P2P_OK;
 }
 
-int p2p_job_set_pano_async(p2p_job* j, int index, const uint8_t* pano, int64_t row_stride)
+// the two copies of one panorama upload: the rows, and behind every row a copy of its first pixels (PANO_PAD of them,
+// or the whole row if it is shorter) -- the gather kernel reads the pixels under a yaw shift that runs across the
+// row's end as one contiguous run
+static int enqueue_pano_copy(p2p_job* j, int index, const uint8_t* pano, int64_t row_stride, hipStream_t st)
+{
+    uint8_t* dst = j->d_src + (size_t)index * j->pano_stride;
+    HIP_TRY(hipMemcpy2DAsync(dst, (size_t)j->src_pitch, pano, (size_t)row_stride, (size_t)3 * j->d.pw, (size_t)j->d.ph,
+                             hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpy2DAsync(dst + (size_t)3 * j->d.pw, (size_t)j->src_pitch, pano, (size_t)row_stride,
+                             (size_t)3 * std::min(j->d.pw, p2p::PANO_PAD), (size_t)j->d.ph, hipMemcpyHostToDevice, st));
+    return P2P_OK;
+}
+
+static int set_pano_check(p2p_job* j, int index, const uint8_t* pano, int64_t row_stride)
 {
     if (!j || !pano)
         return fail(P2P_ERR_INVALID, "p2p_job_set_pano: NULL argument");
@@ -1041,33 +1255,44 @@ int p2p_job_set_pano_async(p2p_job* j, int index, const uint8_t* pano, int64_t r
         return fail(P2P_ERR_INVALID, "panorama index %d out of range", index);
     if (row_stride < (int64_t)3 * j->d.pw)
         return fail(P2P_ERR_INVALID, "row_stride %lld < 3*pw", (long long)row_stride);
+    return P2P_OK;
+}
+
+int p2p_job_set_pano_async(p2p_job* j, int index, const uint8_t* pano, int64_t row_stride)
+{
+    if (int rc = set_pano_check(j, index, pano, row_stride))
+        return rc;
     HIP_TRY(hipSetDevice(j->ctx->device));
+    hipStream_t up = nullptr;
+    HIP_TRY(ctx_copy_stream(j->ctx, true, &up));
     // on the upload stream, behind the last kernel that reads this job's panoramas: the copy overlaps whatever
     // other jobs of the context are running (the driver keeps two jobs per device and alternates)
     if (int rc = mark_run(j))
         return rc;
     if (j->ev_run_recorded)
-        HIP_TRY(hipStreamWaitEvent(j->ctx->stream_up, j->ev_run, 0));
-    uint8_t* dst = j->d_src + (size_t)index * j->pano_stride;
-    HIP_TRY(hipMemcpy2DAsync(dst, (size_t)j->src_pitch, pano, (size_t)row_stride, (size_t)3 * j->d.pw, (size_t)j->d.ph,
-                             hipMemcpyHostToDevice, j->ctx->stream_up));
-    // behind every row a copy of its first pixels (PANO_PAD of them, or the whole row if it is shorter): the
-    // gather kernel reads the pixels under a yaw shift that runs across the row's end as one contiguous run
-    HIP_TRY(hipMemcpy2DAsync(dst + (size_t)3 * j->d.pw, (size_t)j->src_pitch, pano, (size_t)row_stride,
-                             (size_t)3 * std::min(j->d.pw, p2p::PANO_PAD), (size_t)j->d.ph,
-                             hipMemcpyHostToDevice, j->ctx->stream_up));
-    HIP_TRY(hipEventRecord(j->ev_up, j->ctx->stream_up));
+        HIP_TRY(hipStreamWaitEvent(up, j->ev_run, 0));
+    if (int rc = enqueue_pano_copy(j, index, pano, row_stride, up))
+        return rc;
+    HIP_TRY(hipEventRecord(j->ev_up, up));
     j->up_pending = true;
     j->pano_set[index] = 1;
     return P2P_OK;
 }
 
+
 int p2p_job_set_pano(p2p_job* j, int index, const uint8_t* pano, int64_t row_stride)
 {
-    int rc = p2p_job_set_pano_async(j, index, pano, row_stride);
-    if (rc != P2P_OK)
+    if (int rc = set_pano_check(j, index, pano, row_stride))
         return rc;
-    HIP_TRY(hipStreamSynchronize(j->ctx->stream_up));  // the caller may release `pano` when we return
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    // in order on the kernel stream (behind every launch that reads the panoramas, ahead of the next one): no second
+    // hardware queue for callers that never overlap copies with kernels
+    StreamSyncGuard sync_on_exit(j->ctx->stream);  // the caller may release `pano` when we return, also on an error
+    if (int rc = enqueue_pano_copy(j, index, pano, row_stride, j->ctx->stream))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+    sync_on_exit.armed = false;
+    j->pano_set[index] = 1;
     return P2P_OK;
 }
 
@@ -1081,6 +1306,9 @@ int p2p_job_share_panos(p2p_job* j, p2p_job* owner)
         return fail(P2P_ERR_INVALID, "jobs that share panoramas need one context, one panorama size and one panorama count");
     HIP_TRY(hipSetDevice(j->ctx->device));
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+    if (j->ctx->stream_up)
+        HIP_TRY(hipStreamSynchronize(j->ctx->stream_up));  // an asynchronous upload into the block that goes back to the pool
+    j->up_pending = false;
     if (j->owns_src)
         (void)dev_free(j->d_src);
     j->d_src = owner->d_src;
@@ -1100,7 +1328,7 @@ int p2p_job_set_yaws_f64(p2p_job* j, const double* yaw_deg)
     HIP_TRY(hipSetDevice(j->ctx->device));
     j->yaw.assign(yaw_deg, yaw_deg + d.n_yaw);
     std::shared_ptr<YawTabs> yt;
-    if (int rc = yaw_tabs_get(j->ctx, d.pw, j->yaw, nullptr, nullptr, &yt))
+    if (int rc = yaw_tabs_get(j->ctx, d.pw, j->yaw, nullptr, nullptr, j->opt.plan_cache != 0, &yt))
         return rc;
     j->rows_from_host = false;
     return job_adopt_yaw_tabs(j, yt);
@@ -1133,20 +1361,35 @@ int p2p_job_set_maps(p2p_job* j, const float* yaw_rows, const float* U, const fl
     if (!j->d_mapV) HIP_TRY(dev_alloc((void**)&j->d_mapV, n_map * sizeof(float)));
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));  // no launch in flight reads the plan that is about to go
     j->plan_ref.reset();  // the plan follows the maps (also when a later step of this call fails): a private one is built
-    HIP_TRY(hipMemcpyAsync(j->d_mapU, U, n_map * sizeof(float), hipMemcpyHostToDevice, j->ctx->stream));
-    HIP_TRY(hipMemcpyAsync(j->d_mapV, V, n_map * sizeof(float), hipMemcpyHostToDevice, j->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+    {
+        StreamSyncGuard sync_on_exit(j->ctx->stream);  // U and V are the caller's: nothing may still read them after a return
+        HIP_TRY(hipMemcpyAsync(j->d_mapU, U, n_map * sizeof(float), hipMemcpyHostToDevice, j->ctx->stream));
+        HIP_TRY(hipMemcpyAsync(j->d_mapV, V, n_map * sizeof(float), hipMemcpyHostToDevice, j->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+        sync_on_exit.armed = false;
+    }
     j->host_maps = true;
     if (yaw_rows) {
         const size_t n = (size_t)d.n_yaw * d.pw;
         if (!j->d_rows) HIP_TRY(dev_alloc((void**)&j->d_rows, n * sizeof(float)));
         std::shared_ptr<YawTabs> yt;  // private tables: caller rows have no key
-        if (int rc = yaw_tabs_get(j->ctx, d.pw, j->yaw, yaw_rows, j->d_rows, &yt))
+        if (int rc = yaw_tabs_get(j->ctx, d.pw, j->yaw, yaw_rows, j->d_rows, false, &yt))
             return rc;
         j->rows_from_host = true;
         return job_adopt_yaw_tabs(j, yt);
     }
     return P2P_OK;
+}
+
+// List order for the main kernel (xcd_main_lists): 1 = jobs with ONE resident panorama, 2 = also with several, 0 = the
+// grid's own order.  By default: one panorama AND several pitch views -- the order exists to make views that read the
+// same source rows neighbours on an XCD; a single pitch view gains nothing from it and pays its index arithmetic
+// (config 5: 0.742 ms in list order against 0.713).
+static int job_main_order(const p2p_job* j)
+{
+    if (j->opt.main_order >= 0)
+        return j->opt.main_order;
+    return (j->d.n_panos == 1 && j->d.n_pitch > 1) ? 1 : 0;
 }
 
 // Build the job's plan (p2p_plan.hip) for its current maps: once per job geometry, like the yaw tables.  It
@@ -1160,10 +1403,12 @@ static int job_build_plan(p2p_job* j)
     const bool float_path = (d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)) != 0;
     const size_t slots = j->n_tiles * d.n_pitch;
     // device maps: the plan is a function of the key alone -- the context may have it already
+    const Options& opt = j->opt;
+    const int main_order = job_main_order(j);
     PlanKey key{d.pw, d.ph, d.ow, d.oh, d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16 | P2P_FLAG_PIXEL_CENTRES), j->border,
-                j->fov, j->pitch, j->shape};
+                j->fov, j->pitch, j->shape, {opt.gather_blocky_from, main_order != 0, opt.gather_order, opt.gather_group}};
     const p2p::TileShape& S = shape_ops(j->shape).shape;
-    const bool cached = !j->host_maps && env_int("P2P_PLAN_CACHE", 1) != 0;
+    const bool cached = !j->host_maps && opt.plan_cache != 0 && opt.scramble_plan == 0;
     if (cached) {
         std::lock_guard<std::mutex> lk(ctx->cache_mu);
         auto it = ctx->plans.find(key);
@@ -1175,6 +1420,9 @@ static int job_build_plan(p2p_job* j)
     }
     auto Pl = std::make_shared<Plan>();
     Pl->device = ctx->device;
+    // declared after Pl, so it runs first: on every error return the stream is drained before the host vectors below
+    // and the plan's blocks (back to the pool, where any thread may pick them up at once) go out of scope
+    StreamSyncGuard sync_on_exit(st);
     if (float_path)
         HIP_TRY(dev_alloc((void**)&Pl->d_px2, slots * S.block * S.pxt * sizeof(uint32_t)));
     HIP_TRY(dev_alloc((void**)&Pl->d_coords, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2)));
@@ -1195,7 +1443,7 @@ static int job_build_plan(p2p_job* j)
     Q.hdr = Pl->d_hdr;
     Q.px = Pl->d_px;
     Q.items = Pl->d_items;
-    Q.blocky_from = std::max(0, env_int("P2P_GATHER_BLOCKY_FROM", p2p::GATHER_BLOCKY_FROM));
+    Q.blocky_from = opt.gather_blocky_from;
     Q.n_gather = Pl->d_n_gather;
     Q.gather_list = Pl->d_gather_list;
     Q.float_path = float_path;
@@ -1221,7 +1469,7 @@ static int job_build_plan(p2p_job* j)
     uint32_t cnt = 0;
     HIP_TRY(hipMemcpyAsync(&cnt, Pl->d_n_gather, sizeof(cnt), hipMemcpyDeviceToHost, st));
     // the work lists are made from the plan's headers, once per geometry: they come back with the counter
-    const bool want_main_order = env_int("P2P_MAIN_ORDER", 1) != 0;
+    const bool want_main_order = main_order != 0;
     std::vector<p2p::PieceHdr> hh;
     if (want_main_order) {
         hh.resize(slots);
@@ -1233,14 +1481,14 @@ static int job_build_plan(p2p_job* j)
         return fail(P2P_ERR_HIP, "the plan pass listed %u gather tiles of %zu", cnt, slots);
     Pl->n_gather = (int)cnt;
     Pl->built = true;
-    const bool main_order = want_main_order && (size_t)cnt < slots;
+    const bool make_main_list = want_main_order && (size_t)cnt < slots;
     if (cnt > 0 && hh.empty()) {
         hh.resize(slots);
         HIP_TRY(hipMemcpyAsync(hh.data(), Pl->d_hdr, slots * sizeof(p2p::PieceHdr), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
     std::vector<uint32_t> tm;  // (alive until the stream has taken the copies: synchronised below)
-    if (main_order) {
+    if (make_main_list) {
         tm = xcd_main_lists(hh, j->n_tiles, &Pl->main_stride);
         HIP_TRY(dev_alloc((void**)&Pl->d_main_list, tm.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpyAsync(Pl->d_main_list, tm.data(), tm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
@@ -1248,16 +1496,15 @@ static int job_build_plan(p2p_job* j)
     }
     if (cnt > 0) {
         // the gather kernel's work lists, one per XCD: xcd_lists
-        const bool by_source = env_int("P2P_GATHER_ORDER", 1) != 0;
+        const bool by_source = opt.gather_order != 0;
         std::vector<uint32_t> marked, all;
         for (size_t s = 0; s < slots; ++s)
             if ((hh[s].mode_items & 3u) == 2u)
                 marked.push_back((uint32_t)s);
         if (marked.size() != (size_t)cnt) {
-            (void)hipStreamSynchronize(st);  // the list copy still reads `tm`
             return fail(P2P_ERR_HIP, "the plan's headers mark %zu gather tiles, its counter %u", marked.size(), cnt);
         }
-        const std::vector<uint32_t> tg = xcd_lists(marked, hh, d.pw, by_source, &Pl->xcd_stride);
+        const std::vector<uint32_t> tg = xcd_lists(marked, hh, d.pw, by_source, opt.gather_group, &Pl->xcd_stride);
         HIP_TRY(dev_alloc((void**)&Pl->d_xcd_list, tg.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpyAsync(Pl->d_xcd_list, tg.data(), tg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         Pl->bytes += tg.size() * sizeof(uint32_t);
@@ -1266,16 +1513,16 @@ static int job_build_plan(p2p_job* j)
             all.resize(slots);
             for (size_t s = 0; s < slots; ++s)
                 all[s] = (uint32_t)s;
-            ta = xcd_lists(all, hh, d.pw, by_source, &Pl->xcd_all_stride);
+            ta = xcd_lists(all, hh, d.pw, by_source, opt.gather_group, &Pl->xcd_all_stride);
             HIP_TRY(dev_alloc((void**)&Pl->d_xcd_all, ta.size() * sizeof(uint32_t)));
             HIP_TRY(hipMemcpyAsync(Pl->d_xcd_all, ta.data(), ta.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
             Pl->bytes += ta.size() * sizeof(uint32_t);
         }
         HIP_TRY(hipStreamSynchronize(st));  // the vectors go out of scope
     }
-    if (main_order && cnt == 0)
+    if (make_main_list && cnt == 0)
         HIP_TRY(hipStreamSynchronize(st));  // tm goes out of scope
-    if (const int seed = env_int("P2P_SCRAMBLE_PLAN", 0)) {
+    if (const int seed = opt.scramble_plan) {
         // Robustness self-test (tests/fuzz/scramble_tables.py), never set in normal use: every table of the plan -- and
         // with bit 30 of the value the job's yaw tables too -- overwritten with pseudo-random words AFTER the plan pass.
         // The view kernels must then draw garbage and nothing worse: every table-derived offset is clamped or goes
@@ -1300,10 +1547,12 @@ static int job_build_plan(p2p_job* j)
         if (seed & (1 << 29))
             Pl->n_gather = (int)slots;  // every list entry is launched: the scrambled ones too
         HIP_TRY(hipStreamSynchronize(st));
+        sync_on_exit.armed = false;
         j->plan_ref = Pl;
         return P2P_OK;
     }
-    if (env_int("P2P_VERBOSE", 0))
+    sync_on_exit.armed = false;  // every path above has synchronised the stream
+    if (opt.verbose)
         fprintf(stderr, "p2p plan: %u of %zu tiles gather (%dx%d views, %d pitches), %.1f us\n", cnt, slots, d.ow, d.oh, d.n_pitch,
                 Pl->plan_ms * 1e3);
     if (cached) {
@@ -1376,13 +1625,8 @@ int p2p_job_run(p2p_job* j)
     P.oh = j->d.oh;
     P.out = j->d_out;
     P.border = j->border;
-    if (j->ev_ring.empty()) {
-        j->ev_ring.resize(2 * kEvRing, nullptr);
-        for (auto& e : j->ev_ring)
-            HIP_TRY(hipEventCreate(&e));
-    }
-    const int slot = (int)(j->runs % kEvRing);
-    const bool timed = j->time_launches;
+    const bool timed = j->time_launches && j->ring_pairs > 0;
+    const int slot = timed ? (int)(j->runs % j->ring_pairs) : 0;
     const bool float_path = (j->d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)) != 0;
     if (float_path && j->host_maps)
         return fail(P2P_ERR_STATE, "the float pixel path evaluates its own maps; caller maps are not supported");
@@ -1398,22 +1642,24 @@ int p2p_job_run(p2p_job* j)
         j->xcd_stride = Pl.xcd_stride; j->xcd_all_stride = Pl.xcd_all_stride; j->n_gather = Pl.n_gather;
         j->d_main_list = Pl.d_main_list; j->main_stride = Pl.main_stride;
     }
-    P.pairs_per_block = choose_pairs_per_block(j->d, shape_ops(j->shape).shape);
-    P.chunk_outer = env_int("P2P_CHUNK_OUTER", j->d.n_panos > 1 ? 1 : 0);
+    const Options& opt = j->opt;
+    P.pairs_per_block = choose_pairs_per_block(j->d, shape_ops(j->shape).shape, opt);
+    P.chunk_outer = opt.chunk_outer >= 0 ? opt.chunk_outer : (j->d.n_panos > 1 ? 1 : 0);
     // the main kernel's grid: list order (source bands, all pitch views together) unless the plan has no list
-    P.main_list = (j->d.n_panos == 1 || env_int("P2P_MAIN_ORDER", 1) == 2) ? j->d_main_list : nullptr;
+    const int main_order = job_main_order(j);
+    P.main_list = (main_order == 2 || (main_order == 1 && j->d.n_panos == 1)) ? j->d_main_list : nullptr;
     P.main_stride = j->main_stride;
     P.main_chunks = (j->d.n_panos * j->d.n_yaw + P.pairs_per_block - 1) / P.pairs_per_block;
     // entries drawn for one chunk of pairs before the next chunk: with ONE panorama a short run (the entries' plan tables
     // and source rows are still in L2 for the next chunk), with several all of them (a chunk's panoramas serve every
     // tile before the next ones are touched: see pair_chunk)
-    P.main_group = P.chunk_outer ? std::max(1, j->main_stride) : std::max(1, std::min(j->main_stride, env_int("P2P_MAIN_GROUP", j->shape ? 96 : 192)));  // the workgroups an XCD holds at a time
+    P.main_group = P.chunk_outer ? std::max(1, j->main_stride) : std::max(1, std::min(j->main_stride, opt.main_group >= 0 ? opt.main_group : (j->shape ? 96 : 192)));  // the workgroups an XCD holds at a time
     // table-prefetch workgroups (p2p_tile.h: main_block_role) when one launch's plan tables cannot stay in the Infinity
     // Cache next to the panorama (config 4: 565 MB): 2 groups = 64 tiles of lead per XCD
     {
         const p2p::TileShape& S = shape_ops(j->shape).shape;
         const size_t table_bytes = j->n_tiles * (size_t)j->d.n_pitch * (S.block * S.pxt + S.cap) * sizeof(uint32_t);
-        P.pf_lead = std::max(0, env_int("P2P_PREFETCH_LEAD", table_bytes > ((size_t)128 << 20) ? 2 : 0));
+        P.pf_lead = opt.prefetch_lead >= 0 ? opt.prefetch_lead : (table_bytes > ((size_t)128 << 20) ? 2 : 0);
     }
     P.pitch_order = j->d_pitch_order;
     P.coords = j->d_coords;
@@ -1424,7 +1670,7 @@ int p2p_job_run(p2p_job* j)
     P.n_gather = j->n_gather;
     // With view rows of whole dwords the main and the gather kernel draw every plain-shift yaw, and the rest / table
     // kernels only the listed odd pairs (up to 16 per workgroup: one set-up for all of them); otherwise those two draw all
-    const bool fast_width = env_int("P2P_FORCE_REST", 0) == 0;  // (diagnosis: 1 = everything through the general loops)
+    const bool fast_width = opt.force_rest == 0;  // (diagnosis: 1 = everything through the general loops)
     const bool gather_ok = fast_width && j->border == 0;  // the gather kernel: BORDER_CONSTANT 0
     P.odd_pairs = j->d_odd_pairs;
     P.n_odd_pairs = j->n_odd_pairs;
@@ -1434,7 +1680,7 @@ int p2p_job_run(p2p_job* j)
         // (the tile's coordinates and weights are set up once per workgroup)
         const long long np = (long long)j->d.n_panos * j->d.n_yaw;
         long long ppb = (np * std::max(1, j->n_gather) + 2047) / 2048;
-        const long long cap = env_int("P2P_GATHER_PPB", 16);
+        const long long cap = opt.gather_ppb;
         P.gather_ppb = (int)std::min<long long>(std::max<long long>(ppb, 1), std::min<long long>(np, std::min<long long>(cap, 64)));
     }
     if (float_path) {
@@ -1472,7 +1718,7 @@ int p2p_job_run(p2p_job* j)
     // needs nothing but the coordinates, draws those too, and the main kernel's launch (6 us for a handful of
     // tiles) is saved.  The odd pairs of those tiles stay the rest kernel's.
     P.gather_all = (gather_ok && j->n_gather > 0 && j->d_xcd_all && (slots - (size_t)j->n_gather) * 4 <= slots &&
-                    env_int("P2P_GATHER_ALL", 1) != 0) ? 1 : 0;
+                    opt.gather_all != 0) ? 1 : 0;
     // (the gather kernel of a big job on a side stream, forked and joined by events, so that its cache waits overlap
     // the main kernel's arithmetic: config 4's pitch 30 1647 vs 1621 us, all five pitches 8021 vs 7988 -- the two
     // kernels do not interleave, not kept)
@@ -1482,7 +1728,7 @@ int p2p_job_run(p2p_job* j)
             if (P.gather_all) {
                 const long long np = (long long)j->d.n_panos * j->d.n_yaw;
                 const long long ppb = (np * (long long)slots + 2047) / 2048;
-                P.gather_ppb = (int)std::min<long long>(std::max<long long>(ppb, 1), std::min<long long>(np, std::min(16, std::max(1, env_int("P2P_GATHER_PPB", 16)))));
+                P.gather_ppb = (int)std::min<long long>(std::max<long long>(ppb, 1), std::min<long long>(np, std::min(16, std::max(1, opt.gather_ppb))));
             }
             P.gather_list = P.gather_all ? j->d_xcd_all : j->d_xcd_list;
             P.n_list = P.gather_all ? j->xcd_all_stride : j->xcd_stride;
@@ -1528,11 +1774,24 @@ int p2p_job_plan_ms(p2p_job* j, float* plan_ms, float* tables_ms)
     return P2P_OK;
 }
 
-int p2p_job_time_launches(p2p_job* j, int on)
+int p2p_job_time_launches(p2p_job* j, int n)
 {
     if (!j)
         return fail(P2P_ERR_INVALID, "job is NULL");
-    j->time_launches = on != 0;
+    if (n < 0 || n > kEvRingMax)
+        return fail(P2P_ERR_INVALID, "p2p_job_time_launches: n must be 0 (off) .. %d launches to keep", kEvRingMax);
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    if (n > j->ring_pairs) {  // the ring grows to what was asked for and is kept (two events per launch to keep)
+        HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+        j->ev_ring.reserve(2 * (size_t)n);
+        while ((int)j->ev_ring.size() < 2 * n) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreate(&e));
+            j->ev_ring.push_back(e);
+        }
+        j->ring_pairs = n;
+    }
+    j->time_launches = n != 0;
     j->runs = 0;  // the ring only describes launches made in the current mode
     return P2P_OK;
 }
@@ -1560,10 +1819,10 @@ int p2p_job_kernel_ms(p2p_job* j, float* ms)
 {
     if (!j || !ms)
         return fail(P2P_ERR_INVALID, "NULL argument");
-    if (!j->ran || !j->time_launches || j->runs < 1)
-        return fail(P2P_ERR_STATE, "no timed p2p_job_run has been made");
+    if (!j->ran || !j->time_launches || j->runs < 1 || j->ring_pairs < 1)
+        return fail(P2P_ERR_STATE, "no timed p2p_job_run has been made (p2p_job_time_launches(job, n) turns the timing on)");
     HIP_TRY(hipSetDevice(j->ctx->device));
-    const int slot = (int)((j->runs - 1) % kEvRing);
+    const int slot = (int)((j->runs - 1) % j->ring_pairs);
     HIP_TRY(hipEventSynchronize(j->ev_ring[2 * slot + 1]));
     HIP_TRY(hipEventElapsedTime(ms, j->ev_ring[2 * slot], j->ev_ring[2 * slot + 1]));
     return P2P_OK;
@@ -1573,18 +1832,37 @@ int p2p_job_kernel_ms_last(p2p_job* j, float* ms, int n)
 {
     if (!j || !ms || n < 1)
         return fail(P2P_ERR_INVALID, "bad argument");
-    if (!j->time_launches || j->runs < n || n > kEvRing)
-        return fail(P2P_ERR_STATE, "only %lld timed runs recorded (ring holds %d)", j->time_launches ? j->runs : 0LL, kEvRing);
+    if (!j->time_launches || j->runs < n || n > j->ring_pairs)
+        return fail(P2P_ERR_STATE, "only %lld timed runs recorded (the ring holds %d: p2p_job_time_launches)", j->time_launches ? j->runs : 0LL, j->ring_pairs);
     HIP_TRY(hipSetDevice(j->ctx->device));
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));
     for (int k = 0; k < n; ++k) {
-        const int slot = (int)((j->runs - n + k) % kEvRing);
+        const int slot = (int)((j->runs - n + k) % j->ring_pairs);
         HIP_TRY(hipEventElapsedTime(&ms[k], j->ev_ring[2 * slot], j->ev_ring[2 * slot + 1]));
     }
     return P2P_OK;
 }
 
-int p2p_job_get_views_async(p2p_job* j, int index, uint8_t* out)
+// the views of panorama `index` -> the caller's contiguous [n_yaw][n_pitch][oh][ow][3] array, on `st`
+static int enqueue_views_copy(p2p_job* j, int index, uint8_t* out, hipStream_t st)
+{
+    const size_t per = j->out_bytes / j->d.n_panos;
+    const size_t row = (size_t)3 * j->d.ow;
+    if ((size_t)j->out_row == row) {
+        HIP_TRY(hipMemcpyAsync(out, j->d_out + per * index, per, hipMemcpyDeviceToHost, st));
+    } else {
+        // device rows are padded to whole 4-pixel groups, the caller's array is not: packed on the device (a row-wise
+        // DMA copy costs microseconds per row), then one copy
+        const size_t rows = (size_t)j->d.n_yaw * j->d.n_pitch * j->d.oh, packed = rows * row;
+        if (!j->d_pack)
+            HIP_TRY(dev_alloc((void**)&j->d_pack, (packed + 3) & ~(size_t)3));
+        HIP_TRY(p2p::launch_compact_rows(j->d_pack, j->d_out + per * index, packed, (int)row, j->out_row, st));
+        HIP_TRY(hipMemcpyAsync(out, j->d_pack, packed, hipMemcpyDeviceToHost, st));
+    }
+    return P2P_OK;
+}
+
+static int get_views_check(p2p_job* j, int index, uint8_t* out)
 {
     if (!j || !out)
         return fail(P2P_ERR_INVALID, "NULL argument");
@@ -1592,25 +1870,23 @@ int p2p_job_get_views_async(p2p_job* j, int index, uint8_t* out)
         return fail(P2P_ERR_INVALID, "panorama index %d out of range", index);
     if (!j->ran)
         return fail(P2P_ERR_STATE, "p2p_job_run has not been called");
+    return P2P_OK;
+}
+
+int p2p_job_get_views_async(p2p_job* j, int index, uint8_t* out)
+{
+    if (int rc = get_views_check(j, index, out))
+        return rc;
     HIP_TRY(hipSetDevice(j->ctx->device));
-    const size_t per = j->out_bytes / j->d.n_panos;
+    hipStream_t down = nullptr;
+    HIP_TRY(ctx_copy_stream(j->ctx, false, &down));
     // on the download stream, behind the job's last run: the copy overlaps other jobs' kernels and uploads
     if (int rc = mark_run(j))
         return rc;
-    HIP_TRY(hipStreamWaitEvent(j->ctx->stream_down, j->ev_run, 0));
-    const size_t row = (size_t)3 * j->d.ow;
-    if ((size_t)j->out_row == row) {
-        HIP_TRY(hipMemcpyAsync(out, j->d_out + per * index, per, hipMemcpyDeviceToHost, j->ctx->stream_down));
-    } else {
-        // device rows are padded to whole 4-pixel groups, the caller's array is not: packed on the device (a row-wise
-        // DMA copy costs microseconds per row), then one copy
-        const size_t rows = (size_t)j->d.n_yaw * j->d.n_pitch * j->d.oh, packed = rows * row;
-        if (!j->d_pack)
-            HIP_TRY(dev_alloc((void**)&j->d_pack, (packed + 3) & ~(size_t)3));
-        HIP_TRY(p2p::launch_compact_rows(j->d_pack, j->d_out + per * index, packed, (int)row, j->out_row, j->ctx->stream_down));
-        HIP_TRY(hipMemcpyAsync(out, j->d_pack, packed, hipMemcpyDeviceToHost, j->ctx->stream_down));
-    }
-    HIP_TRY(hipEventRecord(j->ev_down, j->ctx->stream_down));
+    HIP_TRY(hipStreamWaitEvent(down, j->ev_run, 0));
+    if (int rc = enqueue_views_copy(j, index, out, down))
+        return rc;
+    HIP_TRY(hipEventRecord(j->ev_down, down));
     j->down_pending = true;
     return P2P_OK;
 }
@@ -1635,11 +1911,20 @@ int p2p_job_wait(p2p_job* j)
 
 int p2p_job_get_views(p2p_job* j, int index, uint8_t* out)
 {
-    int rc = p2p_job_get_views_async(j, index, out);
-    if (rc != P2P_OK)
+    if (int rc = get_views_check(j, index, out))
         return rc;
-    HIP_TRY(hipStreamSynchronize(j->ctx->stream_down));
-    j->down_pending = false;
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    // in order on the kernel stream, behind the job's last run (d_pack is shared with the asynchronous path: an
+    // asynchronous download still in flight is waited for first)
+    if (j->down_pending) {
+        HIP_TRY(hipEventSynchronize(j->ev_down));
+        j->down_pending = false;
+    }
+    StreamSyncGuard sync_on_exit(j->ctx->stream);  // `out` is the caller's
+    if (int rc = enqueue_views_copy(j, index, out, j->ctx->stream))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+    sync_on_exit.armed = false;
     return P2P_OK;
 }
 
@@ -1704,6 +1989,7 @@ int p2p_host_free(void* ptr)
 
 int p2p_release_cache(void)
 {
+    DeviceRestore keep;  // the calling thread stays on its device
     // every idle slot's cached job (busy ones belong to calls in flight on other threads)
     OneShotPool& P = pool();
     std::vector<p2p_job*> victims;
@@ -1717,6 +2003,7 @@ int p2p_release_cache(void)
                 }
                 if (s->ctx) {
                     (void)hipSetDevice(s->device);
+                    (void)hipStreamSynchronize(s->ctx->stream);
                     for (int i = 0; i < 4; ++i) {
                         (void)dev_free(s->ctx->scratch[i]);
                         s->ctx->scratch[i] = nullptr;
@@ -1727,7 +2014,42 @@ int p2p_release_cache(void)
     }
     for (p2p_job* j : victims)
         p2p_job_destroy(j);
+    // the tables and plans no job uses any more, of EVERY live context (the slots' and the caller's own), then the
+    // pool's idle blocks back to the driver
+    (void)caches_evict_all();
     dev_pool_trim();
+    return P2P_OK;
+}
+
+int p2p_reload_options(void)
+{
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    options_load_locked();
+    return P2P_OK;
+}
+
+int p2p_job_get_info(p2p_job* j, p2p_job_info* out)
+{
+    if (!j || !out)
+        return fail(P2P_ERR_INVALID, "NULL argument");
+    memset(out, 0, sizeof(*out));
+    const p2p::TileShape& S = shape_ops(j->shape).shape;
+    out->tile_w = S.tile_w;
+    out->tile_h = S.tile_h;
+    out->n_tiles = (int64_t)j->n_tiles * j->d.n_pitch;
+    out->pairs_per_block = choose_pairs_per_block(j->d, S, j->opt);
+    out->pair_chunks = (j->d.n_panos * j->d.n_yaw + out->pairs_per_block - 1) / out->pairs_per_block;
+    const int mo = job_main_order(j);
+    out->list_order = (mo == 2 || (mo == 1 && j->d.n_panos == 1)) ? 1 : 0;
+    out->main_group = j->opt.main_group >= 0 ? j->opt.main_group : (j->shape ? 96 : 192);
+    {
+        const size_t table_bytes = j->n_tiles * (size_t)j->d.n_pitch * (S.block * S.pxt + S.cap) * sizeof(uint32_t);
+        out->prefetch_lead = j->opt.prefetch_lead >= 0 ? j->opt.prefetch_lead : (table_bytes > ((size_t)128 << 20) ? 2 : 0);
+    }
+    out->n_gather_tiles = j->plan_ref ? (int64_t)j->plan_ref->n_gather : -1;
+    out->n_odd_yaws = j->n_odd_yaws;
+    out->timing_events = (int32_t)j->ev_ring.size();
+    out->copy_streams = (j->ctx->stream_up != nullptr) + (j->ctx->stream_down != nullptr);
     return P2P_OK;
 }
 
@@ -1759,9 +2081,17 @@ static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride
     d.fov_deg = fov_deg; d.ow = ow; d.oh = oh; d.flags = flags;
 
     // a slot of the one-shot pool, preferably one whose cached job has this call's geometry
+    const Options now = options();
+    auto same_options = [&](const Options& a) {
+        return a.plan_cache == now.plan_cache && a.tile_shape == now.tile_shape && a.pairs_per_block == now.pairs_per_block &&
+               a.max_pairs_per_block == now.max_pairs_per_block && a.chunk_outer == now.chunk_outer && a.main_order == now.main_order &&
+               a.main_group == now.main_group && a.prefetch_lead == now.prefetch_lead && a.force_rest == now.force_rest &&
+               a.gather_ppb == now.gather_ppb && a.gather_all == now.gather_all && a.gather_blocky_from == now.gather_blocky_from &&
+               a.gather_order == now.gather_order && a.gather_group == now.gather_group && a.scramble_plan == now.scramble_plan;
+    };
     auto same_geometry = [&](const p2p_job* c) {
         const p2p_job_desc& k = c->d;
-        return k.pw == pw && k.ph == ph && k.n_yaw == n_yaw && k.n_pitch == n_pitch && c->fov == fov_deg &&
+        return same_options(c->opt) && k.pw == pw && k.ph == ph && k.n_yaw == n_yaw && k.n_pitch == n_pitch && c->fov == fov_deg &&
                k.ow == ow && k.oh == oh && k.flags == flags && c->border == border && c->host_maps == (U != nullptr) &&
                std::equal(c->pitch.begin(), c->pitch.end(), pitch_deg);
     };
@@ -1801,8 +2131,7 @@ static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride
 
     const size_t held = j->pano_stride + j->out_bytes + (size_t)n_yaw * pw * 8 +
                         (size_t)n_pitch * ow * oh * (U ? 28 : 20);
-    const bool keep = rc == P2P_OK && env_int("P2P_ONESHOT_CACHE", 1) != 0 &&
-                      held <= (size_t)env_int("P2P_ONESHOT_CACHE_MAX_MB", 4096) * 1048576ull;
+    const bool keep = rc == P2P_OK && j->opt.oneshot_cache != 0 && held <= (size_t)j->opt.oneshot_cache_max_mb * 1048576ull;
     if (keep) {
         slot->cached = j;
     } else {
@@ -1942,8 +2271,10 @@ int p2p_remap_maps_interp_u8(const uint8_t* src, int sw, int sh, int64_t row_str
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_dst, n_map * cn, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess)
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(ctx->stream);  // the caller's buffers are its own again when this returns
         return fail(e == hipErrorOutOfMemory ? P2P_ERR_OOM : P2P_ERR_HIP, "p2p_remap_maps_u8: %s", hipGetErrorString(e));
+    }
     return P2P_OK;
 }
 
@@ -1974,6 +2305,7 @@ int p2p_build_pitch_map(int ow, int oh, double fov_rad, double pitch_rad, int pw
     if (e == hipSuccess) e = hipMemcpyAsync(U, dU, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(V, dV, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) (void)hipStreamSynchronize(ctx->stream);  // nothing queued may still touch the blocks freed below
     (void)dev_free(dU);
     (void)dev_free(dV);
     if (e != hipSuccess)
@@ -2007,6 +2339,7 @@ int p2p_build_rot_map(int ow, int oh, double fov_rad, const float* R9, int pw, i
     if (e == hipSuccess) e = hipMemcpyAsync(U, dU, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(V, dV, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) (void)hipStreamSynchronize(ctx->stream);  // nothing queued may still touch the blocks freed below
     (void)dev_free(dU);
     (void)dev_free(dV);
     if (e != hipSuccess)
@@ -2034,6 +2367,7 @@ int p2p_build_yaw_row(int pw, double yaw_rad, float* U_row, int device)
     if (e == hipSuccess) e = p2p::launch_yaw_tables(nullptr, d_row, pw, 1, d_yr, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(U_row, d_row, (size_t)pw * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) (void)hipStreamSynchronize(ctx->stream);  // nothing queued may still touch the blocks freed below
     (void)dev_free(d_yr);
     (void)dev_free(d_row);
     if (e != hipSuccess)

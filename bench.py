@@ -236,6 +236,7 @@ def cold_first_image(nat, w, pano, device):
     try:
         job = nat.Job(ctx, w["pw"], w["ph"], 1, w["yaws"], w["pitches"], w["fov"], w["ow"], w["oh"])
         job.set_pano(0, pano)
+        job.time_launches(1)
         ctx.mark(0)
         job.run()   # plan pass (device), its gather-tile count read back (host), the view kernel
         ctx.mark(1)

@@ -165,7 +165,7 @@ int p2p_build_yaw_row(int pw, double yaw_rad, float* U_row, int device);
  * Resident (device-buffer) API: the batch driver and bench.py keep panoramas and views in HBM
  * ---------------------------------------------------------------------------------------- */
 
-typedef struct p2p_ctx p2p_ctx;   /* one device + one HIP stream + events */
+typedef struct p2p_ctx p2p_ctx;   /* one device + one HIP stream (+ two copy streams once it copies asynchronously) + four events */
 typedef struct p2p_job p2p_job;   /* n_panos panoramas of one size x (yaw x pitch) view set */
 
 typedef struct p2p_job_desc {
@@ -192,8 +192,12 @@ typedef struct p2p_job_desc_f64 {
     int32_t flags;
 } p2p_job_desc_f64;
 
-/* A context owns three HIP streams and a few events.  At most P2P_MAX_CONTEXTS (environment, default 64) contexts are
-   alive per process; beyond that p2p_ctx_create returns P2P_ERR_OOM. */
+/* A context owns one HIP stream and four events; its two copy streams are created by the first
+   p2p_job_set_pano_async / p2p_job_get_views_async on it.  It also keeps, by the reference's cache keys, the device
+   tables of every geometry its jobs have used (yaw_mapping_cache / pitch_mapping_cache, P:17-18), up to
+   P2P_PLAN_CACHE_MB (default 4096; read when the context is created).  At most P2P_MAX_CONTEXTS (default 64: what
+   has been run on a GPU) contexts are alive per process; beyond that p2p_ctx_create returns P2P_ERR_OOM.
+   Destroying the process's last context returns the library's idle device memory to the driver. */
 int p2p_ctx_create(int device, p2p_ctx** out);
 void p2p_ctx_destroy(p2p_ctx* ctx);
 int p2p_ctx_synchronize(p2p_ctx* ctx);
@@ -205,8 +209,8 @@ int p2p_ctx_marked_ms(p2p_ctx* ctx, float* ms);
 int p2p_job_create(p2p_ctx* ctx, const p2p_job_desc* desc, p2p_job** out);
 int p2p_job_create_f64(p2p_ctx* ctx, const p2p_job_desc_f64* desc, p2p_job** out);
 void p2p_job_destroy(p2p_job* job);
-/* H2D copy of panorama `index` (uint8 [ph][pw][3]) on the job's stream; returns once the host buffer may
-   be reused or freed. */
+/* H2D copy of panorama `index` (uint8 [ph][pw][3]) on the context's kernel stream, in order with its launches;
+   returns once the host buffer may be reused or freed. */
 int p2p_job_set_pano(p2p_job* job, int index, const uint8_t* pano, int64_t row_stride);
 /* The same without waiting (cv2.imread of the NEXT image, P:244, overlaps the resampling of this one): the copy runs
    on the context's upload stream behind the job's last kernel; `pano` must stay valid and unchanged until
@@ -228,7 +232,8 @@ int p2p_job_set_yaws_f64(p2p_job* job, const double* yaw_deg);
 int p2p_job_set_maps(p2p_job* job, const float* yaw_rows, const float* U, const float* V);
 /* Enqueue the view-synthesis kernel for all panoramas x yaws x pitches (asynchronous). */
 int p2p_job_run(p2p_job* job);
-/* Wait, then copy all views of panorama `index` to host: uint8 [n_yaw][n_pitch][oh][ow][3]. */
+/* Copy all views of panorama `index` to host, uint8 [n_yaw][n_pitch][oh][ow][3], on the kernel stream behind the
+   job's last run; returns when `out` is complete. */
 int p2p_job_get_views(p2p_job* job, int index, uint8_t* out);
 /* The same without waiting (cv2.imwrite of image k, P:277, overlaps the resampling of image k+1): the copy runs on
    the context's download stream behind the job's last run; `out` is complete after p2p_job_wait /
@@ -236,17 +241,19 @@ int p2p_job_get_views(p2p_job* job, int index, uint8_t* out);
 int p2p_job_get_views_async(p2p_job* job, int index, uint8_t* out);
 /* Wait for everything the job has in flight: uploads, its last run, downloads. */
 int p2p_job_wait(p2p_job* job);
-/* By default every p2p_job_run brackets its kernel with its own HIP event pair (p2p_job_kernel_ms*); on = 0
-   turns that off (two event records less per launch), on = 1 back on.  Either call restarts the history. */
-int p2p_job_time_launches(p2p_job* job, int on);
+/* Launch timing, off by default (a job that nobody times creates no timing event and records none).  n >= 1: every
+   p2p_job_run from now on brackets its kernels with its own HIP event pair and the job keeps the pairs of the last n
+   launches (n <= 4096; 2 n events, created here) for p2p_job_kernel_ms / p2p_job_kernel_ms_last; n = 0: off again.
+   Either call restarts the history. */
+int p2p_job_time_launches(p2p_job* job, int n);
 /* Device time it took to build the job's plan (the pitch maps' tables, once per geometry: the reference's
    pitch_mapping_cache, P:17-18, P:55-73) and its yaw tables (yaw_mapping_cache, P:42-52), in ms.  The context keeps
    both by geometry, so these are the times of whichever job built them first.  After the first p2p_job_run. */
 int p2p_job_plan_ms(p2p_job* job, float* plan_ms, float* tables_ms);
 /* Device time of the last p2p_job_run's view kernel(s), from HIP events on the job's stream. */
 int p2p_job_kernel_ms(p2p_job* job, float* ms);
-/* Device times of the last n p2p_job_run launches (n <= 256), oldest first; synchronises once.
-   Each launch is bracketed by its own HIP event pair on the job's stream. */
+/* Device times of the last n p2p_job_run launches (n <= what p2p_job_time_launches asked for), oldest first;
+   synchronises once. */
 int p2p_job_kernel_ms_last(p2p_job* job, float* ms, int n);
 /* Device address / byte size of the output block [n_panos][n_yaw][n_pitch][oh] rows.  A device row holds the view
    row's ow pixels (3 bytes each) padded to whole 4-pixel groups: 12 * ceil(ow / 4) bytes, = 3 * ow when ow is
@@ -259,6 +266,23 @@ void* p2p_job_device_out(p2p_job* job, int64_t* bytes);
 int p2p_job_get_coords(p2p_job* job, int32_t* sxsy);
 /* The packed per-column yaw tables in use, uint32 [n_yaw][pw] = 3*ix | fx << 20. */
 int p2p_job_get_yaw_tables(p2p_job* job, uint32_t* packed);
+/* How the job is drawn: tile shape, pairs per workgroup, work-list order, what the plan found.  For tests and tools
+   ("the test names the shape it ran"); nothing here is needed to use the library. */
+typedef struct p2p_job_info {
+    int32_t tile_w, tile_h;        /* output tile of one workgroup: 64 x 16 or 128 x 16 */
+    int32_t pairs_per_block;       /* (panorama, yaw) pairs one workgroup loops over */
+    int32_t pair_chunks;           /* workgroups per tile = ceil(n_panos * n_yaw / pairs_per_block) */
+    int32_t list_order;            /* 1: the main kernel's tiles are drawn in source-band order from per-XCD lists */
+    int32_t main_group;            /* list entries an XCD draws for one chunk before it turns to the next chunk */
+    int32_t prefetch_lead;         /* > 0: table-prefetch workgroups, this many groups ahead */
+    int32_t n_odd_yaws;            /* yaws that are not a plain shift with one weight (rest / table kernels) */
+    int64_t n_tiles;               /* tiles of all pitch views */
+    int64_t n_gather_tiles;        /* of those, drawn by the gather kernel (-1 before the first p2p_job_run) */
+    int32_t timing_events;         /* HIP events of the launch-timing ring (0 unless p2p_job_time_launches asked) */
+    int32_t copy_streams;          /* copy streams the job's context has created so far (0..2) */
+    int32_t reserved[4];
+} p2p_job_info;
+int p2p_job_get_info(p2p_job* job, p2p_job_info* out);
 
 /* ------------------------------------------------------------------------------------------
  * Host memory and the one-shot cache
@@ -272,8 +296,18 @@ int p2p_job_get_yaw_tables(p2p_job* job, uint32_t* packed);
  * pitch list, FOV, output size) is handed that slot, re-uploads only the panorama and rebuilds the yaw tables if
  * the yaw values changed.  Callers beyond the pool size wait their turn.  P2P_ONESHOT_CACHE=0 turns the keeping
  * off; P2P_ONESHOT_CACHE_MAX_MB (default 4096) bounds what one slot keeps, so a device holds at most
- * slots x that.  p2p_release_cache frees what idle slots hold.  Nothing is torn down at process exit (no HIP
- * call after the runtime's own shutdown).
+ * slots x that.  Nothing is torn down at process exit (no HIP call after the runtime's own shutdown).
+ *
+ * Device memory: every buffer of the library comes from a per-device pool that keeps up to P2P_POOL_MB (default
+ * 8192) of idle blocks instead of returning them to the driver.  p2p_release_cache gives back what can be given
+ * back without disturbing work in flight: the cached jobs of idle one-shot slots, the cached tables and plans of
+ * EVERY live context that no job uses any more, and all idle blocks of the pool; the calling thread's current
+ * device is left as it was.  An allocation that fails for lack of device memory does the same once and retries.
+ *
+ * Environment: the P2P_* variables (INTEGRATION.md lists them) are read once per process, at the first call that
+ * needs one, and copied into a job when it is created -- no entry point reads the environment on a launch path.
+ * p2p_reload_options reads them again; call it only while no other thread is inside the library (tests and tools
+ * that flip a knob between two jobs do).
  *
  * p2p_host_alloc returns page-locked host memory: panoramas decoded into it and views copied back into it
  * move by DMA at PCIe rate instead of through the runtime's pageable staging.
@@ -282,6 +316,7 @@ int p2p_job_get_yaw_tables(p2p_job* job, uint32_t* packed);
 int p2p_host_alloc(size_t bytes, void** out);
 int p2p_host_free(void* ptr);
 int p2p_release_cache(void);
+int p2p_reload_options(void);
 
 #ifdef __cplusplus
 }

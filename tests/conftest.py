@@ -52,6 +52,19 @@ def gpu(nat):
     return nat
 
 
+@pytest.fixture
+def p2p_env(monkeypatch, nat):
+    """Set a P2P_* environment knob for this test.  The library reads its environment once per process and copies it
+    into a job at creation (include/p2p_hip.h: p2p_reload_options), so a changed variable is followed by a reload --
+    and by another one once the test's changes are undone."""
+    def set_(name, value):
+        monkeypatch.setenv(name, value)
+        nat.reload_options()
+    yield set_
+    monkeypatch.undo()
+    nat.reload_options()
+
+
 @pytest.fixture(scope="session")
 def synth():
     return importlib.import_module(PKG + ".synth")

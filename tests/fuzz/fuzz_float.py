@@ -11,8 +11,9 @@ from test_gpu_float_path import numpy_float_views
 pkg = importlib.import_module("360-to-planer-images_amd"); nat = pkg._native
 drv = importlib.import_module("360-to-planer-images_amd._driver")
 synth = importlib.import_module("360-to-planer-images_amd.synth")
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 77
+import _args  # named options with hard caps (tests/fuzz/_args.py)
+_a = _args.parser(__doc__, cases=100, seed=77).parse_args()
+n_cases, seed = _a.cases, _a.seed
 t0 = time.time(); bad = 0; worst16 = 0; worst32 = 0
 for case in range(int(os.environ.get("FUZZ_FIRST", "0")), n_cases):  # FUZZ_FIRST: resume a long run
     rng = np.random.default_rng(seed * 7919 + case)

@@ -9,8 +9,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from _util import oracle_views
 pkg = importlib.import_module("360-to-planer-images_amd"); nat = pkg._native
 synth = importlib.import_module("360-to-planer-images_amd.synth")
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+import _args  # named options with hard caps (tests/fuzz/_args.py)
+_a = _args.parser(__doc__, cases=100, seed=3).parse_args()
+n_cases, seed = _a.cases, _a.seed
 worst = 0; over = 0; t0 = time.time()
 for case in range(int(os.environ.get("FUZZ_FIRST", "0")), n_cases):  # FUZZ_FIRST: resume a long run
     rng = np.random.default_rng(seed * 100003 + case)

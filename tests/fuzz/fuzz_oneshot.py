@@ -9,32 +9,36 @@ sys.path.insert(0, ROOT)
 from oracle import maps
 pkg = importlib.import_module("360-to-planer-images_amd"); nat = pkg._native
 synth = importlib.import_module("360-to-planer-images_amd.synth")
-# Usage: python tests/fuzz/fuzz_oneshot.py [calls per thread] [threads, at most 32] [seed]
-# (the SECOND argument is the thread count, not a seed as in the other fuzzers: round 3 lost two GPU boxes to
-# "fuzz_oneshot.py 100000 8106" and "fuzz_oneshot.py 1000 9406" -- nine thousand threads, each creating contexts and
-# streams; hence the cap)
-n_calls = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-n_threads = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
-if not 1 <= n_threads <= 32:
-    sys.exit("fuzz_oneshot: the second argument is the number of THREADS (1..32), got %d" % n_threads)
+# Usage: python tests/fuzz/fuzz_oneshot.py --cases CALLS_PER_THREAD --threads N(<= 8) --seed S   (named options only:
+# round 3 lost two GPU boxes to "fuzz_oneshot.py 100000 8106" -- a seed in the thread-count position)
+import _args
+_a = _args.parser(__doc__, cases=200, seed=1000, threads=4).parse_args()
+n_calls, n_threads, seed0 = _a.cases, _a.threads, _a.seed
 GEOMS = [(512, 256, 96, 64, 90), (1024, 512, 200, 120, 90), (512, 256, 96, 64, 60), (2048, 1024, 320, 200, 100)]
 PANOS = {(pw, ph): [synth.synth_pano(pw, ph, 40 + i, "N") for i in range(3)] for pw, ph, *_ in GEOMS}
 errors = []
 lock = threading.Lock()
 
 
+_tls = threading.local()
+
+
 def truth(pano, yaws, pitches, fov, ow, oh, flags=0, maps_=None):
-    ctx = nat.Context(0)
+    """The same views from a fresh resident job -- on ONE context per thread, kept for the thread's life (a context
+    per call, times the threads, is what took the GPU down in round 3)."""
+    ctx = getattr(_tls, "ctx", None)
+    if ctx is None:
+        ctx = _tls.ctx = nat.Context(0)
     ph, pw = pano.shape[:2]
     job = nat.Job(ctx, pw, ph, 1, yaws, pitches, fov, ow, oh, flags=flags)
-    job.set_pano(0, pano)
-    if maps_ is not None:
-        job.set_maps(*maps_)
-    job.run()
-    out = job.get_views(0)
-    job.close(); ctx.close()
-    return out
+    try:
+        job.set_pano(0, pano)
+        if maps_ is not None:
+            job.set_maps(*maps_)
+        job.run()
+        return job.get_views(0)
+    finally:
+        job.close()
 
 
 def worker(tid):
@@ -80,6 +84,9 @@ def worker(tid):
                 errors.append((tid, call, kind, (pw, ph, ow, oh, fov), yaws, pitches, repr(e)))
         if rng.random() < 0.03:
             nat.release_cache()
+    ctx = getattr(_tls, "ctx", None)
+    if ctx is not None:
+        ctx.close()
 
 
 t0 = time.time()

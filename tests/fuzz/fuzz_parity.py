@@ -11,11 +11,15 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from _util import oracle_maps, oracle_views
 pkg = importlib.import_module("360-to-planer-images_amd"); nat = pkg._native
 synth = importlib.import_module("360-to-planer-images_amd.synth")
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2026
-only = int(sys.argv[3]) if len(sys.argv) > 3 and int(sys.argv[3]) >= 0 else None      # re-run one case, checking every yaw
-big = len(sys.argv) > 4 and sys.argv[4] == "big"
-real = len(sys.argv) > 4 and sys.argv[4] == "real"   # real-valued yaw / pitch / FOV, pitch anywhere in [0, 180]
+import _args  # named options with hard caps (tests/fuzz/_args.py)
+_p = _args.parser(__doc__, cases=100, seed=2026)
+_p.add_argument("--only", type=int, default=-1, help="re-run one case, checking every yaw")
+_p.add_argument("--mode", choices=("default", "big", "real"), default="default",
+                help="big: large geometries; real: real-valued yaw / pitch / FOV, pitch anywhere in [0, 180]")
+_a = _p.parse_args()
+n_cases, seed = _a.cases, _a.seed
+only = _a.only if _a.only >= 0 else None
+big, real = _a.mode == "big", _a.mode == "real"
 ctx = nat.Context(0)
 t0 = time.time(); bad = 0
 for case in range(int(os.environ.get("FUZZ_FIRST", "0")), n_cases):  # FUZZ_FIRST: resume a long run

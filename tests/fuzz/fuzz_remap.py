@@ -11,8 +11,9 @@ from _util import coords_to_maps
 from oracle import cpu_ref, maps
 pkg = importlib.import_module("360-to-planer-images_amd"); nat = pkg._native
 synth = importlib.import_module("360-to-planer-images_amd.synth")
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+import _args  # named options with hard caps (tests/fuzz/_args.py)
+_a = _args.parser(__doc__, cases=100, seed=5).parse_args()
+n_cases, seed = _a.cases, _a.seed
 part = os.environ.get("FUZZ_REMAP_PART", "both")  # remap | job | both: which half runs (hunting a rare fault)
 bad = 0; t0 = time.time()
 for case in range(int(os.environ.get("FUZZ_FIRST", "0")), n_cases):  # FUZZ_FIRST: resume a long run

@@ -28,6 +28,10 @@ struct p2p_stub_stream { int alive; };
 struct p2p_stub_event { int recorded; };
 
 extern "C" int p2p_stub_device_count;  // tests flip this to exercise the no-device paths
+// what the library has created and not yet destroyed (atomics in launch_stubs.cpp): the harness asserts that a context
+// and a job that nobody times own a handful of events and ONE stream
+extern "C" long p2p_stub_live(int what /* 0 events, 1 streams */);
+extern "C" void p2p_stub_count(int what, long delta);
 
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : (e == hipErrorOutOfMemory ? "out of memory" : "invalid value"); }
 static inline hipError_t hipGetLastError(void) { return hipSuccess; }
@@ -48,15 +52,15 @@ static inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, siz
     return hipSuccess;
 }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
-static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)calloc(1, sizeof(p2p_stub_stream)); return *s ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)calloc(1, sizeof(p2p_stub_stream)); if (*s) p2p_stub_count(1, 1); return *s ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipStreamSynchronize(hipStream_t s) { return s ? hipSuccess : hipErrorInvalidValue; }
-static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { if (s) p2p_stub_count(1, -1); free(s); return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) { return s && e ? hipSuccess : hipErrorInvalidValue; }
-static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)calloc(1, sizeof(p2p_stub_event)); return *e ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)calloc(1, sizeof(p2p_stub_event)); if (*e) p2p_stub_count(0, 1); return *e ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { if (!e || !s) return hipErrorInvalidValue; e->recorded = 1; return hipSuccess; }
 static inline hipError_t hipEventQuery(hipEvent_t e) { return e ? hipSuccess : hipErrorInvalidValue; }
 static inline hipError_t hipEventSynchronize(hipEvent_t e) { return e ? hipSuccess : hipErrorInvalidValue; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { if (!a || !b) return hipErrorInvalidValue; *ms = 0.125f; return hipSuccess; }
-static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { if (e) p2p_stub_count(0, -1); free(e); return hipSuccess; }
 #endif

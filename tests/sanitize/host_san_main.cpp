@@ -9,6 +9,7 @@
 #include <vector>
 
 extern "C" int p2p_stub_device_count;
+extern "C" long p2p_stub_live(int what);  // 0: events, 1: streams the library holds right now
 
 #define CHECK(cond) do { if (!(cond)) { fprintf(stderr, "CHECK failed line %d: %s (%s)\n", __LINE__, #cond, p2p_last_error()); exit(1); } } while (0)
 
@@ -56,6 +57,7 @@ int main()
     CHECK(p2p_ctx_create(0, nullptr) == P2P_ERR_INVALID && p2p_ctx_create(3, &ctx) == P2P_ERR_NO_DEVICE);
     {   // the cap on live contexts (a process that creates them without bound takes the GPU down): P2P_MAX_CONTEXTS
         setenv("P2P_MAX_CONTEXTS", "5", 1);
+        CHECK(p2p_reload_options() == P2P_OK);   // the environment is read once per process, and again on request
         std::vector<p2p_ctx*> many;   // (the one-shot calls above may have left a slot's context alive: at most 5 fit, not exactly 5)
         int refused = 0;
         for (int i = 0; i < 8; ++i) {
@@ -72,7 +74,11 @@ int main()
         many.push_back(again);
         for (p2p_ctx* c : many) p2p_ctx_destroy(c);
         unsetenv("P2P_MAX_CONTEXTS");
+        CHECK(p2p_reload_options() == P2P_OK);
     }
+    // ---- what a context and a job cost: ONE stream and a handful of events, unless timing / async copies are asked for
+    CHECK(p2p_release_cache() == P2P_OK);
+    const long ev_before = p2p_stub_live(0), st_before = p2p_stub_live(1);
     CHECK(p2p_ctx_create(0, &ctx) == P2P_OK);
     p2p_job* job = nullptr;
     p2p_job_desc d = {64, 32, 2, 3, nullptr, 2, nullptr, 90, 70, 33, P2P_FLAG_DEFAULT};
@@ -86,12 +92,26 @@ int main()
     CHECK(p2p_job_set_pano(job, 0, pano.data(), 192) == P2P_OK);
     CHECK(p2p_job_run(job) == P2P_ERR_STATE);                        // panorama 1 still missing
     CHECK(p2p_job_get_views(job, 0, views.data()) == P2P_ERR_STATE);
-    CHECK(p2p_job_set_pano_async(job, 1, pano.data(), 192) == P2P_OK);
+    CHECK(p2p_job_set_pano(job, 1, pano.data(), 192) == P2P_OK);
     CHECK(p2p_job_run(job) == P2P_OK);
+    CHECK(p2p_job_get_views(job, 0, views.data()) == P2P_OK);
+    {   // a fresh context + job + one run + one download: <= 8 events (4 of the context, 3 of the job), one stream
+        p2p_job_info info;
+        CHECK(p2p_job_get_info(job, &info) == P2P_OK && info.timing_events == 0 && info.copy_streams == 0);
+        CHECK(info.tile_w == 64 || info.tile_w == 128);
+        CHECK(p2p_stub_live(0) - ev_before <= 8 && p2p_stub_live(1) - st_before == 1);
+        float ms1 = 0.0f;
+        CHECK(p2p_job_kernel_ms(job, &ms1) == P2P_ERR_STATE);        // nobody asked for timing
+    }
+    CHECK(p2p_job_set_pano_async(job, 1, pano.data(), 192) == P2P_OK);  // the upload stream appears with its first use
+    CHECK(p2p_job_wait(job) == P2P_OK && p2p_stub_live(1) - st_before == 2);
+    CHECK(p2p_job_time_launches(job, -1) == P2P_ERR_INVALID && p2p_job_time_launches(job, 5000) == P2P_ERR_INVALID);
+    CHECK(p2p_job_time_launches(job, 256) == P2P_OK);                // 512 events, because somebody asked
     for (int i = 0; i < 300; ++i)                                    // past the ring of 256 event pairs
         CHECK(p2p_job_run(job) == P2P_OK);
     float ms[300];
     CHECK(p2p_job_kernel_ms_last(job, ms, 256) == P2P_OK && p2p_job_kernel_ms_last(job, ms, 257) == P2P_ERR_STATE);
+    CHECK(p2p_job_time_launches(job, 0) == P2P_OK && p2p_job_run(job) == P2P_OK && p2p_job_kernel_ms(job, ms) == P2P_ERR_STATE);
     CHECK(p2p_job_get_views_async(job, 1, views.data()) == P2P_OK && p2p_job_wait(job) == P2P_OK);
     std::vector<int32_t> coords((size_t)2 * 33 * 70 * 2);
     CHECK(p2p_job_get_coords(job, coords.data()) == P2P_OK);
@@ -122,13 +142,31 @@ int main()
     CHECK(p2p_job_plan_ms(job3, &pm, &tm) == P2P_ERR_STATE);          // not run yet
     CHECK(p2p_job_run(job3) == P2P_OK && p2p_job_plan_ms(job3, &pm, &tm) == P2P_OK && pm >= 0.0f && tm >= 0.0f);
     p2p_job_destroy(job2);
-    setenv("P2P_PLAN_CACHE_MB", "0", 1);                             // every unused entry goes at the next insertion
     const double y3[1] = {13.5};
     CHECK(p2p_job_set_yaws_f64(job3, y3) == P2P_OK && p2p_job_run(job3) == P2P_OK);
     std::vector<float> U3((size_t)16 * 16, 2.0f);
     CHECK(p2p_job_set_maps(job3, nullptr, U3.data(), U3.data()) == P2P_OK && p2p_job_run(job3) == P2P_OK);  // private plan
-    unsetenv("P2P_PLAN_CACHE_MB");
+    CHECK(p2p_release_cache() == P2P_OK);                            // unused entries of THIS (explicit) context go too
+    CHECK(p2p_job_run(job3) == P2P_OK);                              // ... and what a live job uses stays
     p2p_job_destroy(job3);
+    {   // a context created under a cache budget of zero: every unused entry goes at the next insertion
+        setenv("P2P_PLAN_CACHE_MB", "0", 1);
+        CHECK(p2p_reload_options() == P2P_OK);
+        p2p_ctx* c0 = nullptr;
+        CHECK(p2p_ctx_create(0, &c0) == P2P_OK);
+        unsetenv("P2P_PLAN_CACHE_MB");
+        CHECK(p2p_reload_options() == P2P_OK);
+        p2p_job *ja = nullptr, *jb = nullptr;
+        CHECK(p2p_job_create_f64(c0, &d2, &ja) == P2P_OK && p2p_job_set_pano(ja, 0, pano.data(), 192) == P2P_OK &&
+              p2p_job_set_pano(ja, 1, pano.data(), 192) == P2P_OK && p2p_job_run(ja) == P2P_OK);
+        p2p_job_destroy(ja);
+        d2.yaw_deg = y3;
+        CHECK(p2p_job_create_f64(c0, &d2, &jb) == P2P_OK && p2p_job_set_pano(jb, 0, pano.data(), 192) == P2P_OK &&
+              p2p_job_set_pano(jb, 1, pano.data(), 192) == P2P_OK && p2p_job_run(jb) == P2P_OK);
+        d2.yaw_deg = y2;
+        p2p_job_destroy(jb);
+        p2p_ctx_destroy(c0);
+    }
     p2p_job_destroy(job);
     p2p_job_destroy(nullptr);
     void* host = nullptr;

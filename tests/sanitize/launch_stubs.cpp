@@ -6,6 +6,10 @@
 #include <string.h>
 #include <vector>
 extern "C" int p2p_stub_device_count = 1;
+#include <atomic>
+static std::atomic<long> g_stub_live[2];
+extern "C" long p2p_stub_live(int what) { return g_stub_live[what & 1].load(); }
+extern "C" void p2p_stub_count(int what, long delta) { g_stub_live[what & 1].fetch_add(delta); }
 
 namespace p2p {
 hipError_t launch_yaw_tables(uint32_t* packed, float* rows, int pw, int n_yaw, const double* yaw_rad, hipStream_t)

@@ -146,7 +146,7 @@ def test_maps_cache_keys_and_shapes(gpu, pkg):
     assert (512, 16, 30) in m.yaw_mapping_cache and Uy.shape == (16, 512) and Vy[5, 7] == 5.0
 
 
-def test_oneshot_cache_reuses_buffers_without_changing_results(gpu, pkg, synth, monkeypatch):
+def test_oneshot_cache_reuses_buffers_without_changing_results(gpu, pkg, synth, monkeypatch, p2p_env):
     """The one-shot calls keep the last geometry's device buffers per thread (the reference's map caches,
     P:17-18); every sequence of calls must give what a cold library gives."""
     from _util import oracle_maps
@@ -156,12 +156,12 @@ def test_oneshot_cache_reuses_buffers_without_changing_results(gpu, pkg, synth, 
     pitches = [60, 90]
 
     def cold(pano, yaws, pit=pitches, ow=96, oh=64):
-        monkeypatch.setenv("P2P_ONESHOT_CACHE", "0")
+        p2p_env("P2P_ONESHOT_CACHE", "0")
         gpu.release_cache()
         try:
             return gpu.remap_views(pano, yaws, pit, 90, ow, oh)
         finally:
-            monkeypatch.setenv("P2P_ONESHOT_CACHE", "1")
+            p2p_env("P2P_ONESHOT_CACHE", "1")
 
     ref_a = cold(pa, [0, 77])
     ref_b = cold(pb, [13, 200])
@@ -304,10 +304,10 @@ def test_folder_walk_through_the_device_pipeline(gpu, pkg, synth, tmp_path):
                 assert np.array_equal(got, want[yi, pi]), (i, y, pt)
 
 
-def test_one_shot_pool_is_bounded_and_survives_many_threads(gpu, pkg, synth, monkeypatch):
+def test_one_shot_pool_is_bounded_and_survives_many_threads(gpu, pkg, synth, monkeypatch, p2p_env):
     """The reference's default fan-out is int(0.9 * cores) threads (P:304-306).  The one-shot entry points serve them
     from P2P_ONESHOT_SLOTS contexts per device: results identical, callers beyond the pool wait."""
-    monkeypatch.setenv("P2P_ONESHOT_SLOTS", "2")
+    p2p_env("P2P_ONESHOT_SLOTS", "2")
     pano = synth.synth_pano(1024, 512, 3400, "N")
     yaws = list(range(0, 360, 10))
     want = pkg.process_views(pano, yaws, [60, 120], 96, 64)
@@ -357,6 +357,6 @@ def test_no_device_or_host_memory_drift_over_many_images(gpu):
     import subprocess
     import sys
     root = __import__("pathlib").Path(__file__).resolve().parent.parent
-    r = subprocess.run([sys.executable, str(root / "tools" / "soak_leak.py"), "12"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, str(root / "tools" / "soak_leak.py"), "--rounds", "12"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "drift after round" in r.stdout

@@ -93,7 +93,11 @@ def test_resident_job_multi_pano(gpu, synth):
     job.run()
     for i, p in enumerate(panos):
         assert np.array_equal(job.get_views(i), oracle_views(p, yaws, pitches, ow, oh, 90))
-    assert job.kernel_ms() > 0
+    with pytest.raises(gpu.P2PError):
+        job.kernel_ms()          # launch timing is off unless asked for (no timing events, none recorded)
+    job.time_launches(2)
+    job.run()
+    assert job.kernel_ms() > 0 and job.info()["timing_events"] == 4
     job.close()
     ctx.close()
 
@@ -143,7 +147,7 @@ def test_general_caller_pitch_maps_with_border_taps(gpu, synth):
     assert np.array_equal(got[0, 0], want)
 
 
-def test_pair_chunking_across_workgroups(gpu, synth, monkeypatch):
+def test_pair_chunking_across_workgroups(gpu, synth, monkeypatch, p2p_env):
     # P2P_PAIRS_PER_BLOCK forces the (panorama, yaw) pairs of a tile to be split over several workgroups
     # (grid.z chunks, as happens by itself for small outputs and long yaw sweeps); results must not depend on it
     pw, ph, ow, oh = 512, 256, 96, 64
@@ -152,7 +156,7 @@ def test_pair_chunking_across_workgroups(gpu, synth, monkeypatch):
     rows, U, V = oracle_maps(yaws, pitches, ow, oh, pw, ph, 90)
     want = [oracle_views(p, yaws, pitches, ow, oh, 90) for p in panos]
     for ppb in ("1", "4", "7", "64"):
-        monkeypatch.setenv("P2P_PAIRS_PER_BLOCK", ppb)
+        p2p_env("P2P_PAIRS_PER_BLOCK", ppb)
         ctx = gpu.Context(0)
         job = gpu.Job(ctx, pw, ph, 2, yaws, pitches, 90, ow, oh)
         job.set_maps(rows, U, V)

@@ -32,52 +32,52 @@ def _run(gpu, panos, yaws, pitches, ow, oh, fov, maps):
 
 @pytest.mark.parametrize("tile_shape", ["64", "128"])
 @pytest.mark.parametrize("n_panos", [1, 2])
-def test_every_work_list_order_draws_the_oracles_bytes(gpu, synth, monkeypatch, n_panos, tile_shape):
+def test_every_work_list_order_draws_the_oracles_bytes(gpu, synth, monkeypatch, n_panos, tile_shape, p2p_env):
     pw, ph, ow, oh, fov = 2048, 1024, 333, 210, 90
     yaws = [0, 14.0625, 33, 90, 123.4, 180, 200, 270, 301, 359]   # whole-column, fractional and (14.0625 on 2048: none) plain ones
     pitches = [8, 60, 90, 150]                                    # pitch 8: a pole in view -> gather tiles
     panos = [synth.synth_pano(pw, ph, 4200 + i, "N") for i in range(n_panos)]
     maps = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
     want = [oracle_views(p, yaws, pitches, ow, oh, fov) for p in panos]
-    monkeypatch.setenv("P2P_PLAN_CACHE", "0")
-    monkeypatch.setenv("P2P_TILE_SHAPE", tile_shape)  # both tile shapes of the library (csrc/p2p_device.h)
-    monkeypatch.setenv("P2P_PAIRS_PER_BLOCK", "3")   # several chunks of pairs per tile
+    p2p_env("P2P_PLAN_CACHE", "0")
+    p2p_env("P2P_TILE_SHAPE", tile_shape)  # both tile shapes of the library (csrc/p2p_device.h)
+    p2p_env("P2P_PAIRS_PER_BLOCK", "3")   # several chunks of pairs per tile
     combos = list(itertools.product(("0", "1", "2"), ("1", "5", "192"), ("0", "1"), ("0", "1")))
     for main_order, group, prefetch, gather_order in combos:
-        monkeypatch.setenv("P2P_MAIN_ORDER", main_order)
-        monkeypatch.setenv("P2P_MAIN_GROUP", group)
-        monkeypatch.setenv("P2P_PREFETCH_LEAD", prefetch)
-        monkeypatch.setenv("P2P_GATHER_ORDER", gather_order)
+        p2p_env("P2P_MAIN_ORDER", main_order)
+        p2p_env("P2P_MAIN_GROUP", group)
+        p2p_env("P2P_PREFETCH_LEAD", prefetch)
+        p2p_env("P2P_GATHER_ORDER", gather_order)
         got = _run(gpu, panos, yaws, pitches, ow, oh, fov, maps)
         for i in range(n_panos):
             bad = np.argwhere(got[i] != want[i])
             assert bad.size == 0, (tile_shape, main_order, group, prefetch, gather_order, i, len(bad), bad[:3])
 
 
-def test_device_maps_job_is_the_same_in_every_order_and_tile_shape(gpu, synth, monkeypatch):
+def test_device_maps_job_is_the_same_in_every_order_and_tile_shape(gpu, synth, monkeypatch, p2p_env):
     # the default path (maps evaluated on the device): list order, grid order and both tile shapes agree byte for byte
     pw, ph, ow, oh, fov = 4096, 2048, 640, 360, 90
     yaws, pitches = list(range(0, 360, 20)), [45, 90, 135]
     pano = synth.synth_pano(pw, ph, 4300, "N")
-    monkeypatch.setenv("P2P_PLAN_CACHE", "0")
+    p2p_env("P2P_PLAN_CACHE", "0")
     outs = []
     for tile_shape in ("64", "128"):
         for main_order in ("0", "1"):
-            monkeypatch.setenv("P2P_TILE_SHAPE", tile_shape)
-            monkeypatch.setenv("P2P_MAIN_ORDER", main_order)
+            p2p_env("P2P_TILE_SHAPE", tile_shape)
+            p2p_env("P2P_MAIN_ORDER", main_order)
             outs.append(_run(gpu, [pano], yaws, pitches, ow, oh, fov, None)[0])
     for o in outs[1:]:
         assert np.array_equal(outs[0], o)
 
 
 @pytest.mark.parametrize("blocky_from", ["0", "12", "1000000"])
-def test_gather_tiles_in_rows_and_in_blocks_draw_the_same_bytes(gpu, synth, monkeypatch, blocky_from):
+def test_gather_tiles_in_rows_and_in_blocks_draw_the_same_bytes(gpu, synth, monkeypatch, blocky_from, p2p_env):
     # the gather kernel's lane layout (rows of 64 pixels / blocks of 16 x 4, csrc/p2p_views.hip: draw_gather) is chosen
     # per tile by the plan; forcing every tile into blocks (0), none (a huge threshold) or the default must not change
     # a byte: polar views (every tile gathers around the pole), a strongly minifying view set (every tile gathers),
     # view sizes that are not multiples of the tile
-    monkeypatch.setenv("P2P_PLAN_CACHE", "0")
-    monkeypatch.setenv("P2P_GATHER_BLOCKY_FROM", blocky_from)
+    p2p_env("P2P_PLAN_CACHE", "0")
+    p2p_env("P2P_GATHER_BLOCKY_FROM", blocky_from)
     for (pw, ph, ow, oh, fov, yaws, pitches) in (
             (2048, 1024, 301, 177, 90, [0, 33.3, 180, 270], [3, 90, 176]),
             (4096, 2048, 203, 150, 110, [0, 90, 200], [30, 60, 150])):
@@ -85,7 +85,7 @@ def test_gather_tiles_in_rows_and_in_blocks_draw_the_same_bytes(gpu, synth, monk
         maps = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
         want = oracle_views(pano, yaws, pitches, ow, oh, fov)
         for tile_shape in ("64", "128"):
-            monkeypatch.setenv("P2P_TILE_SHAPE", tile_shape)
+            p2p_env("P2P_TILE_SHAPE", tile_shape)
             got = _run(gpu, [pano], yaws, pitches, ow, oh, fov, maps)[0]
             bad = np.argwhere(got != want)
             assert bad.size == 0, (blocky_from, tile_shape, pw, ow, len(bad), bad[:3])

@@ -18,5 +18,5 @@ for ny in (24, 48):
     yaws=[(i*360)//ny for i in range(ny)]
     for ppb in (6, 12, 24, 48):
         if ppb>ny: continue
-        os.environ["P2P_PAIRS_PER_BLOCK"]=str(ppb)
+        os.environ["P2P_PAIRS_PER_BLOCK"]=str(ppb); nat.reload_options()
         run(yaws,[60,90,120],"%d yaws ppb %d"%(ny,ppb))

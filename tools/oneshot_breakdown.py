@@ -37,9 +37,11 @@ def main():
     npix = len(YAWS) * len(PITCHES) * OW * OH
 
     os.environ["P2P_ONESHOT_CACHE"] = "0"
+    nat.reload_options()
     nat.remap_views(pano, YAWS, PITCHES, 90, OW, OH)
     out["oneshot_pageable_nocache"] = best(lambda: nat.remap_views(pano, YAWS, PITCHES, 90, OW, OH))
     os.environ["P2P_ONESHOT_CACHE"] = "1"
+    nat.reload_options()
     nat.remap_views(pano, YAWS, PITCHES, 90, OW, OH)
     out["oneshot_pageable_cached"] = best(lambda: nat.remap_views(pano, YAWS, PITCHES, 90, OW, OH))
     nat.remap_views(pin, YAWS, PITCHES, 90, OW, OH, pinned=True)

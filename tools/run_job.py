@@ -12,6 +12,7 @@ pano = synth.synth_pano(8192, 4096, 1000, "S")
 ctx = nat.Context(0)
 job = nat.Job(ctx, 8192, 4096, 1, [(i * 360) // ny for i in range(ny)], pitches, 90, 1920, 1080)
 job.set_pano(0, pano)
+job.time_launches(8)
 for _ in range(6):
     job.run()
 ctx.synchronize()

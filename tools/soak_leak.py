@@ -9,7 +9,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("360-to-planer-images_amd"); nat = pkg._native
 drv = importlib.import_module("360-to-planer-images_amd._driver")
 synth = importlib.import_module("360-to-planer-images_amd.synth")
-rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+import argparse
+_ap = argparse.ArgumentParser(description=__doc__, allow_abbrev=False)
+_ap.add_argument("--rounds", type=int, default=30)
+rounds = _ap.parse_args().rounds
+if not 1 <= rounds <= 1000:
+    sys.exit("--rounds must be in 1..1000")
 
 
 def rss_mb():
