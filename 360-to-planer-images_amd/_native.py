@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "p2p_job_set_pano_async", "p2p_job_share_panos", "p2p_job_get_views_async", "p2p_job_wait", "p2p_job_set_maps", "p2p_job_run",
     "p2p_job_get_views", "p2p_job_kernel_ms", "p2p_job_kernel_ms_last", "p2p_job_device_out", "p2p_job_get_coords",
     "p2p_job_get_yaw_tables", "p2p_job_set_yaws", "p2p_host_alloc", "p2p_host_free", "p2p_release_cache",
-    "p2p_reload_options", "p2p_job_get_info",
+    "p2p_reload_options", "p2p_job_get_info", "p2p_job_get_view",
 )
 
 
@@ -167,6 +167,8 @@ def lib():
     L.p2p_release_cache.argtypes = []
     L.p2p_reload_options.restype = c_int
     L.p2p_reload_options.argtypes = []
+    L.p2p_job_get_view.restype = c_int
+    L.p2p_job_get_view.argtypes = [c_vp, c_int, c_int, c_int, c_vp]
     L.p2p_job_get_info.restype = c_int
     L.p2p_job_get_info.argtypes = [c_vp, ctypes.POINTER(JobInfo)]
     _lib = L
@@ -593,6 +595,12 @@ class Job:
         if out is None:
             out = np.empty(shape, dtype=np.uint8)
         check(lib().p2p_job_get_views(self._h, int(index), out.ctypes.data))
+        return out
+
+    def get_view(self, yaw_i, pitch_i, index=0):
+        """One view [oh][ow][3] of panorama `index` (p2p_job_get_view)."""
+        out = np.empty((self.oh, self.ow, 3), dtype=np.uint8)
+        check(lib().p2p_job_get_view(self._h, int(index), int(yaw_i), int(pitch_i), out.ctypes.data))
         return out
 
     def get_views_async(self, index=0, out=None, pinned=True):

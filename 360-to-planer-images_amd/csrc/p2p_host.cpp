@@ -1862,6 +1862,26 @@ static int enqueue_views_copy(p2p_job* j, int index, uint8_t* out, hipStream_t s
     return P2P_OK;
 }
 
+// ONE view (panorama `index`, yaw yaw_i, pitch pitch_i) -> the caller's contiguous [oh][ow][3] array, on `st`
+static int enqueue_view_copy(p2p_job* j, int index, int yaw_i, int pitch_i, uint8_t* out, hipStream_t st)
+{
+    const size_t view = (size_t)j->d.oh * j->out_row;
+    const uint8_t* src = j->d_out + (((size_t)index * j->d.n_yaw + yaw_i) * j->d.n_pitch + pitch_i) * view;
+    const size_t row = (size_t)3 * j->d.ow;
+    if ((size_t)j->out_row == row) {
+        HIP_TRY(hipMemcpyAsync(out, src, view, hipMemcpyDeviceToHost, st));
+    } else {
+        const size_t packed = (size_t)j->d.oh * row;
+        if (!j->d_pack) {  // sized for a whole panorama's views, as the whole-block download uses it
+            const size_t all = (size_t)j->d.n_yaw * j->d.n_pitch * packed;
+            HIP_TRY(dev_alloc((void**)&j->d_pack, (all + 3) & ~(size_t)3));
+        }
+        HIP_TRY(p2p::launch_compact_rows(j->d_pack, src, packed, (int)row, j->out_row, st));
+        HIP_TRY(hipMemcpyAsync(out, j->d_pack, packed, hipMemcpyDeviceToHost, st));
+    }
+    return P2P_OK;
+}
+
 static int get_views_check(p2p_job* j, int index, uint8_t* out)
 {
     if (!j || !out)
@@ -1888,6 +1908,25 @@ int p2p_job_get_views_async(p2p_job* j, int index, uint8_t* out)
         return rc;
     HIP_TRY(hipEventRecord(j->ev_down, down));
     j->down_pending = true;
+    return P2P_OK;
+}
+
+int p2p_job_get_view(p2p_job* j, int index, int yaw_i, int pitch_i, uint8_t* out)
+{
+    if (int rc = get_views_check(j, index, out))
+        return rc;
+    if (yaw_i < 0 || yaw_i >= j->d.n_yaw || pitch_i < 0 || pitch_i >= j->d.n_pitch)
+        return fail(P2P_ERR_INVALID, "view (yaw %d, pitch %d) out of range", yaw_i, pitch_i);
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    if (j->down_pending) {  // d_pack is shared with the asynchronous path
+        HIP_TRY(hipEventSynchronize(j->ev_down));
+        j->down_pending = false;
+    }
+    StreamSyncGuard sync_on_exit(j->ctx->stream);  // `out` is the caller's
+    if (int rc = enqueue_view_copy(j, index, yaw_i, pitch_i, out, j->ctx->stream))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+    sync_on_exit.armed = false;
     return P2P_OK;
 }
 

@@ -239,6 +239,9 @@ int p2p_job_get_views(p2p_job* job, int index, uint8_t* out);
    the context's download stream behind the job's last run; `out` is complete after p2p_job_wait /
    p2p_ctx_synchronize.  The job's next run waits for the copy on the device. */
 int p2p_job_get_views_async(p2p_job* job, int index, uint8_t* out);
+/* ONE view of panorama `index` -- yaw yaw_i, pitch pitch_i of the job's lists -- to host, uint8 [oh][ow][3]; returns
+   when `out` is complete.  (Config 4 holds 18 GB of views per panorama; a caller that wants five of them.) */
+int p2p_job_get_view(p2p_job* job, int index, int yaw_i, int pitch_i, uint8_t* out);
 /* Wait for everything the job has in flight: uploads, its last run, downloads. */
 int p2p_job_wait(p2p_job* job);
 /* Launch timing, off by default (a job that nobody times creates no timing event and records none).  n >= 1: every

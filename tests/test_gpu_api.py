@@ -319,6 +319,52 @@ def test_one_shot_pool_is_bounded_and_survives_many_threads(gpu, pkg, synth, mon
     assert np.array_equal(pkg.process_views(pano, yaws[:2], [60], 96, 64)[1, 0], want[1, 0])
 
 
+def test_reference_fan_out_of_230_threads_through_the_default_pool(gpu, pkg, synth):
+    """P:304-306: num_workers = int(0.9 * cores) -- 230 threads on a 256-core host -- each calling
+    process_yaw_and_pitchs on ONE shared panorama (P:252-265).  With the library's defaults (4 one-shot slots per
+    device, one stream each) all of them are served, every view byte for byte what a single call gives, and the process
+    ends up with the pool's four contexts, not with one per thread."""
+    pano = synth.synth_pano(1024, 512, 3500, "N")
+    yaws = list(range(0, 360, 3))          # 120 distinct yaws, each asked for by one or two of the 230 tasks
+    tasks = [yaws[i % len(yaws)] for i in range(230)]
+    want = pkg.process_views(pano, yaws, [60, 120], 96, 64)
+    gpu.release_cache()
+    with ThreadPoolExecutor(max_workers=230) as ex:
+        got = list(ex.map(lambda y: pkg.process_yaw_and_pitchs(pano, y, [60, 120], 96, 64), tasks))
+    for y, views in zip(tasks, got):
+        yi = yaws.index(y)
+        assert np.array_equal(views[0], want[yi, 0]) and np.array_equal(views[1], want[yi, 1]), y
+    gpu.release_cache()
+
+
+def test_release_cache_gives_device_memory_back(gpu, synth):
+    """p2p_release_cache: the cached one-shot jobs, the unused tables of every live context (the caller's own
+    included) and the pool's idle blocks go back to the driver -- free device memory returns to where it was."""
+    import torch
+
+    def free_mb():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info(0)[0] / 2**20
+
+    pano = synth.synth_pano(4096, 2048, 3600, "S")
+    gpu.release_cache()
+    before = free_mb()
+    ctx = gpu.Context(0)                                       # an explicit context: its caches must be reachable too
+    for pitches in ([60, 90, 120], [45, 135], [30, 150]):      # three geometries -> three cached plans
+        job = gpu.Job(ctx, 4096, 2048, 1, list(range(0, 360, 20)), pitches, 90, 1280, 720)
+        job.set_pano(0, pano)
+        job.run()
+        job.get_views(0)
+        job.close()
+    gpu.remap_views(pano, [0, 90], [60, 120], 90, 1280, 720)   # and a one-shot slot's cached job
+    held = before - free_mb()
+    assert held > 150, held                                    # panoramas, views, plans and tables are being kept
+    gpu.release_cache()
+    after = before - free_mb()
+    assert after < 32, (held, after)                           # all of it came back (the context itself holds no tables)
+    ctx.close()
+
+
 def test_process_exit_with_live_caches_from_pool_threads(gpu, tmp_path):
     """Cached one-shot jobs, streams and page-locked blocks are alive when the interpreter exits -- from pool
     threads that finished, from a daemon thread that never will, and on sys.exit from the main thread.  Nothing is

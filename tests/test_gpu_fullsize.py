@@ -81,6 +81,7 @@ def test_cfg3_one_gpu_share_of_the_64_panorama_batch(gpu, synth):
     ctx = gpu.Context(0)
     fused = gpu.Job(ctx, c["pw"], c["ph"], n, yaws, c["pitches"], c["fov"], c["ow"], c["oh"])
     exact = gpu.Job(ctx, c["pw"], c["ph"], n, yaws, c["pitches"], c["fov"], c["ow"], c["oh"])
+    assert fused.info()["tile_w"] == 128   # 1.8 GB of views from several resident panoramas: the library's rule (choose_shape)
     for i, p in enumerate(panos):
         fused.set_pano(i, p)
         exact.set_pano(i, p)
@@ -128,6 +129,7 @@ def test_cfg4_five_pitch_job_sampled_views_vs_oracle(gpu, synth):
     rows, U, V = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
     ctx = gpu.Context(0)
     job = gpu.Job(ctx, pw, ph, 1, yaws, pitches, fov, ow, oh)
+    assert job.info()["tile_w"] == 64   # 2.5 GB of views: below the 4 GB from which a job's views stream in 128-wide tiles
     job.set_pano(0, pano)
     job.set_maps(rows, U, V)
     job.run()
@@ -141,6 +143,68 @@ def test_cfg4_five_pitch_job_sampled_views_vs_oracle(gpu, synth):
         assert bad.size == 0, (pitch, len(bad), bad[:4].tolist())
     # and a whole-column shift of the same job (stage 1 is a copy: the other loop of the kernels) on the horizon view
     assert np.array_equal(got[0, 2], oracle_views_threaded(pano, [0], [90], ow, oh, fov)[0, 0])
+
+
+def test_cfg4_in_the_shape_it_ships_in_sampled_views_vs_oracle(gpu, synth):
+    """Config 4 exactly as bench.py launches it: 72 yaws x 5 pitches of a 16K noise panorama, 18 GB of views in ONE job
+    -- which makes choose_shape pick the 128-wide tiles, cuts the 72 yaws into three chunks of 24 pairs, puts the main
+    kernel's tiles in list order with 96-entry turns, and adds the table-prefetch workgroups (565 MB of plan tables).
+    The test names that shape (p2p_job_get_info) and checks six views byte for byte against the oracle: one or two per
+    chunk of pairs, both polar pitches (gather tiles), the horizon, whole-column and fractional yaws.  Views come back
+    one at a time (p2p_job_get_view): nobody holds 18 GB on the host."""
+    pw, ph, ow, oh, fov = 16384, 8192, 4096, 4096, 60
+    pano = synth.synth_pano(pw, ph, 1004, "N")
+    yaws, pitches = list(range(0, 360, 5)), [30, 60, 90, 120, 150]
+    rows, U, V = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
+    ctx = gpu.Context(0)
+    job = gpu.Job(ctx, pw, ph, 1, yaws, pitches, fov, ow, oh)
+    info = job.info()
+    assert (info["tile_w"], info["tile_h"]) == (128, 16), info
+    assert info["pair_chunks"] >= 2 and info["pairs_per_block"] * info["pair_chunks"] >= 72, info   # several chunks of pairs per tile
+    assert info["list_order"] == 1 and info["main_group"] == 96 and info["prefetch_lead"] > 0, info
+    job.set_pano(0, pano)
+    job.set_maps(rows, U, V)
+    job.run()
+    assert job.info()["n_gather_tiles"] > 0   # the pole tiles of pitch 30 / 150
+    # (yaw index, pitch index): chunk 0 = yaws 0..23, chunk 1 = 24..47, chunk 2 = 48..71; 16384 columns: 45-degree
+    # multiples are whole-column shifts (stage 1 copies), everything else blends
+    sample = [(0, 2), (7, 0), (27, 1), (31, 4), (50, 0), (71, 3)]
+    got = {v: job.get_view(*v) for v in sample}
+    job.close()
+    ctx.close()
+    for yi in sorted({y for y, _ in sample}):
+        pis = [p for y, p in sample if y == yi]
+        want = oracle_views_threaded(pano, [yaws[yi]], [pitches[p] for p in pis], ow, oh, fov)
+        for k, pi in enumerate(pis):
+            bad = np.argwhere(got[(yi, pi)] != want[0, k])
+            assert bad.size == 0, (yaws[yi], pitches[pi], len(bad), bad[:4].tolist())
+
+
+@pytest.mark.parametrize("tile_shape", ["64", "128"])
+def test_cfg3_share_in_both_tile_shapes_vs_oracle(gpu, synth, p2p_env, tile_shape):
+    """One GPU's share of config 3 (8 resident panoramas x 36 views, 1.8 GB: the library's own rule picks 128-wide tiles,
+    grid order, chunks outermost) with each tile shape forced in turn; two panoramas x two yaws x three pitches byte
+    for byte against the oracle in both."""
+    c = CFG2
+    yaws = list(range(0, 360, 30))
+    n = 8
+    p2p_env("P2P_TILE_SHAPE", tile_shape)
+    panos = [synth.synth_pano(c["pw"], c["ph"], 1000 + i, "N") for i in range(n)]
+    rows, U, V = oracle_maps(yaws, c["pitches"], c["ow"], c["oh"], c["pw"], c["ph"], c["fov"])
+    ctx = gpu.Context(0)
+    job = gpu.Job(ctx, c["pw"], c["ph"], n, yaws, c["pitches"], c["fov"], c["ow"], c["oh"])
+    assert job.info()["tile_w"] == int(tile_shape) and job.info()["list_order"] == 0
+    for i, p in enumerate(panos):
+        job.set_pano(i, p)
+    job.set_maps(rows, U, V)
+    job.run()
+    for i, ysel in ((1, [2, 9]), (6, [0, 7])):
+        want = oracle_views_threaded(panos[i], [yaws[y] for y in ysel], c["pitches"], c["ow"], c["oh"], c["fov"])
+        for k, y in enumerate(ysel):
+            for pi in range(len(c["pitches"])):
+                assert np.array_equal(job.get_view(y, pi, index=i), want[k, pi]), (tile_shape, i, yaws[y], pi)
+    job.close()
+    ctx.close()
 
 
 def test_cfg5_yaw_sweep_at_8k(gpu, pkg, pano8k):

@@ -1,13 +1,14 @@
 #!/bin/bash
-# round-3 iteration check: GPU parity tests, then the bench lines / probes that moved
+# iteration check of a round: GPU parity tests (log kept), then the bench line with its secondary configs.
+#   bash tools/gpu_check.sh <tag>   -> gpurun_out/check_<tag>/
+TAG=${1:-x}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r3_check
+OUT=$ROOT/gpurun_out/check_$TAG
 mkdir -p $OUT
 cd $ROOT
-timeout 1500 python3 -m pytest tests -m gpu -q --timeout 600 > $OUT/pytest.log 2>&1
-tail -12 $OUT/pytest.log
-python3 tools/probe_default_cli.py > $OUT/cli.log 2>&1; cat $OUT/cli.log
-python3 bench.py --no-cpu-baseline --counters none > $OUT/cfg2.json 2> $OUT/cfg2.err; tail -3 $OUT/cfg2.err
+timeout 2400 python3 -m pytest tests -m gpu -q --timeout 900 > $OUT/pytest_gpu.log 2>&1
+echo "pytest -m gpu: rc $?"; tail -12 $OUT/pytest_gpu.log
+timeout 600 python3 bench.py --no-cpu-baseline --counters none > $OUT/cfg2.json 2> $OUT/cfg2.err; tail -3 $OUT/cfg2.err
 python3 - $OUT/cfg2.json <<'PY'
 import json,sys
 j=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=j['roofline']
