@@ -9,7 +9,6 @@
 
 namespace p2p {
 
-constexpr int TILE_H = 16;          // rows of an output tile (both tile shapes)
 constexpr int PLAN_MAX_ROWS = 256;  // rot rows a tile's footprint may span (one plan thread per row)
 // Every device panorama row is followed by a copy of the row's first PANO_PAD pixels: the source pixels of two
 // neighbouring rot columns are then three contiguous pixels also where the yaw shift runs across the row's end
@@ -180,7 +179,11 @@ namespace P2P_SHAPE_NS {
 #ifndef P2P_WAVES
 #define P2P_WAVES 6
 #endif
+#ifndef P2P_TILE_ROWS
+#define P2P_TILE_ROWS 16
+#endif
 constexpr int TILE_W = P2P_TILE_W;  // output tile of one workgroup
+constexpr int TILE_H = P2P_TILE_ROWS;
 #ifndef P2P_BLOCK
 #define P2P_BLOCK 256
 #endif

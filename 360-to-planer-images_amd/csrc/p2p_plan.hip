@@ -205,7 +205,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
     // panorama width divisible by 4 (12-byte items never straddle a row end).
     // (float path: taps reach one column further)
     bool ok = any_live && !stray && (P.pw & 3) == 0 && c0 >= 0 && r0 >= 0 && c1 + 1 + P.float_path < P.pw &&
-              r1 + 1 < P.ph && nrow <= PLAN_MAX_ROWS;
+              r1 + 1 < P.ph && nrow <= PLAN_MAX_ROWS && nrow <= VIEWS_BLOCK;  // (one plan thread per rot row)
     uint32_t n_items = 0;
     if (ok) {
         // ---- per rot row: the span of columns the taps read.  A pixel's taps sit in rows iy and iy + 1: two atomics
@@ -321,7 +321,7 @@ hipError_t launch_plan(const PlanParams& P, hipStream_t st)
 // what the host calls this shape through (p2p_device.h: tile shapes)
 const ShapeOps& P2P_SHAPE_OPS_NAME()
 {
-    static const ShapeOps ops = {{P2P_SHAPE_NS::TILE_W, TILE_H, P2P_SHAPE_NS::VIEWS_BLOCK, P2P_SHAPE_NS::VIEWS_PXT, P2P_SHAPE_NS::LDS_ITEMS_CAP},
+    static const ShapeOps ops = {{P2P_SHAPE_NS::TILE_W, P2P_SHAPE_NS::TILE_H, P2P_SHAPE_NS::VIEWS_BLOCK, P2P_SHAPE_NS::VIEWS_PXT, P2P_SHAPE_NS::LDS_ITEMS_CAP},
                                  &P2P_SHAPE_NS::launch_plan, &P2P_SHAPE_NS::launch_remap_views, &P2P_SHAPE_NS::launch_float_views};
     return ops;
 }

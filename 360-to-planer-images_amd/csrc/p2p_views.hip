@@ -262,10 +262,16 @@ __device__ __forceinline__ PairCtxs pair_contexts(const ViewsParams& P, const Ya
         cw1 = ((uint32_t)(ngroups - g0) & 0xFFFFu) | (uint32_t)yi << 16;  // (masked: a garbage descriptor must not reach the yaw field)
         cw2 = 4 * g0 - yd.s;
         cw3 |= k << 26;  // n_panos < 2^26 (host check): the chunk-local pair index rides along
-        // items reach group ((c1 + 1 - c0) + 3) >> 2 past the first; beyond the row's last group they wrap
-        // (telling the two apart at compile time would save 3 instructions per item, but the prefetch of the NEXT
-        // pair crosses class boundaries: not done, only the clipped column makes a class of its own)
+        // Items reach at most group ((c1 + 2 - c0) + 7) >> 2 past the first (the taps' columns c0 .. c1 + 1, the yaw's
+        // alignment 0..3, whole groups); beyond the row's last group, ngroups - g0 groups on, they wrap to its start.
+        // A pair none of whose items can wrap loads its pieces without the wrap test (3 instructions per item less):
+        // classes 0 and 2.  The pieces are requested one pair ahead, so the loops below run a class's pairs but the last
+        // with the test-free loads (the next pair is of the same class) and the last one with the general ones.
+#ifdef P2P_NO_WRAP_CLASSES
         const bool wraps = clamp_in;
+#else
+        const bool wraps = clamp_in || (ngroups - g0) <= (((c1 + 2 - c0) + 7) >> 2);
+#endif
         cls = yd.mode != 0 ? 4 : (yd.f == 0 ? (wraps ? 1 : 0) : (wraps ? 3 : 2));
     }
     int cum[5];
@@ -292,9 +298,9 @@ __device__ __forceinline__ void decode_px(const uint32_t* __restrict__ pxw, int 
         const uint32_t dl = (wd >> PXW_UP_BITS) & ((1u << PXW_DL_BITS) - 1u);
         tap_up[j] = (wd & ((1u << PXW_UP_BITS) - 1u)) << 2;
         tap_lo[j] = tap_up[j] + (dl << 2);
-        const uint32_t fx = (wd >> 22) & 31u, fy = wd >> 27;
         // a pixel with no footprint in the panorama (NaN coordinate) gets weight 0 everywhere:
         // (0 + 512) >> 10 == 0, the BORDER_CONSTANT value
+        const uint32_t fx = (wd >> 22) & 31u, fy = wd >> 27;
         tw[j] = tap_weights(fx, fy, dl != 0);
     }
 }
@@ -322,6 +328,32 @@ __device__ __forceinline__ StoreCtx store_ctx(const ViewsParams& P, const TileGe
     s.out_off12 = s_ok ? (uint32_t)(G.y0 + srow) * (uint32_t)P.out_row + 3u * (uint32_t)(G.x0 + scol) : 0xFFFFFFFFu;
     s.stg_rd = (uint32_t)(sj * 64 + x4);
     return s;
+}
+
+// first half: the wave's pixels into its staging dwords
+__device__ __forceinline__ void stage_wave_pixels(const StoreCtx& s, const uint32_t (&pix)[VIEWS_PXT])
+{
+#pragma unroll
+    for (int j = 0; j < VIEWS_PXT; ++j)
+        s.stg[j * 64 + s.ln] = pix[j];
+}
+
+// second half: four adjacent pixels of one row back out of the staging dwords (DS operations of one wave execute in
+// order: the read sees the wave's own writes, also those of the pair before), 12 bytes, one store.  `records` = bytes
+// of the view, or 0: a descriptor of no records, every lane dropped by the hardware
+__device__ __forceinline__ uint4 read_staged_pixels(const StoreCtx& s)
+{
+    return *reinterpret_cast<const uint4*>(s.stg + s.stg_rd);
+}
+
+__device__ __forceinline__ void store_staged_pixels(const StoreCtx& s, const uint4& v, uint8_t* O, uint32_t records)
+{
+    u32x3 o;
+    o.x = __builtin_amdgcn_perm(v.y, v.x, 0x04020100u);  // B0 G0 R0 B1
+    o.y = __builtin_amdgcn_perm(v.z, v.y, 0x05040201u);  // G1 R1 B2 G2
+    o.z = __builtin_amdgcn_perm(v.w, v.z, 0x06050402u);  // R2 B3 G3 R3
+    __builtin_amdgcn_raw_buffer_store_b96(o, __builtin_amdgcn_make_buffer_rsrc(O, 0, (int)records, 0x00020000),
+                                          (int)s.out_off12, 0, P2P_STORE_AUX);
 }
 
 __device__ __forceinline__ void store_wave_pixels(const StoreCtx& s, const uint32_t (&pix)[VIEWS_PXT], uint8_t* O, size_t view_bytes)
@@ -406,8 +438,10 @@ __device__ __forceinline__ void draw_tight(
         return w;
     };
     PairWords pwc = pair_words(0);
-    auto load_pieces = [&](auto ns_c, const PairWords& W, Q16 (&qq)[VIEWS_SLOTS]) {
+    // NW (std::true_type): the pair is of class 0 or 2, none of its items wraps
+    auto load_pieces = [&](auto ns_c, auto nw_c, const PairWords& W, Q16 (&qq)[VIEWS_SLOTS]) {
         constexpr int NS = decltype(ns_c)::value;
+        constexpr bool NW = decltype(nw_c)::value;
         const uint32_t w0 = W.w0;
         const uint32_t wrap_g = W.w1 & 0xFFFFu;
         // one descriptor per panorama: an item word that points outside it loads zeros instead of faulting
@@ -417,7 +451,8 @@ __device__ __forceinline__ void draw_tight(
         for (int sl = 0; sl < NS; ++sl) {
             uint32_t off = slot_off[sl] + goff;
 #ifndef P2P_ABLATE_WRAP  // (timing experiment: what rows padded with a copy of their first columns would save)
-            off = slot_g[sl] >= wrap_g ? off - row_bytes : off;  // items past the end of the row continue at its start
+            if (!NW)
+                off = slot_g[sl] >= wrap_g ? off - row_bytes : off;  // items past the end of the row continue at its start
 #endif
 #ifdef P2P_ABLATE_LOADS2
             off &= 0x3FFFu;  // timing experiment (wrong pixels): every load issued, all of them hits in 16 KB
@@ -481,13 +516,41 @@ __device__ __forceinline__ void draw_tight(
         }
     };
     // one pair: `cur` holds its source pieces, the next pair's are requested into `nxt`
-    auto one_pair = [&](auto ns_c, auto mode_c, int k, const Q16 (&cur)[VIEWS_SLOTS], Q16 (&nxt)[VIEWS_SLOTS]) {
+    // The way out runs ONE PAIR BEHIND (unless P2P_STORE_INLINE): a pair's pixels go into the wave's staging dwords at the
+    // end of its stage 2 and stay there; they are read back, packed and stored by the NEXT pair, between its stage 1 and
+    // its barrier -- where the wave waits for its LDS writes anyway, so the staging round trip (write, read, lgkmcnt(0))
+    // no longer stands between stage 2 and the next pair.  The first pair "stores" through a descriptor of no records.
+    uint8_t* pend_O = out;
+    uint32_t pend_records = 0u;
+    auto one_pair = [&](auto ns_c, auto mode_c, auto nw_c, int k, const Q16 (&cur)[VIEWS_SLOTS], Q16 (&nxt)[VIEWS_SLOTS]) {
         {
             uint4* tl4 = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(&tile4[0][0]) + buf_bytes);
+#ifndef P2P_STORE_INLINE
+            // the read-back goes out first and is consumed after stage 1 (the scheduler would otherwise pull the whole
+            // chain up behind the previous pair's staging writes: the round trip this order exists to avoid)
+            __builtin_amdgcn_sched_barrier(0);
+            const uint4 staged = read_staged_pixels(SC);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             stage1(ns_c, mode_c, pwc, cur, tl4);
+#ifndef P2P_STORE_INLINE
+            __builtin_amdgcn_sched_barrier(0);
+            store_staged_pixels(SC, staged, pend_O, pend_records);
+#endif
             // LDS position of rot column c0 within its row's first item: 0..3, from the yaw's shift
             uint32_t soff = buf_bytes + 4u * ((pwc.w0 >> 20) & 3u);
+#ifdef P2P_TAP_ADD_SGPR
             asm volatile("" : "+s"(soff));  // one scalar: keeps the buffer base out of separate vector adds
+#else
+            // ... and that scalar in a VGPR: v_add_u32 with two vector operands issues in 2 cycles, with a scalar
+            // operand in 4 (tools/ubench/valu_rates.hip) -- one v_mov and eight fast adds per pair instead of eight slow ones
+            asm volatile("" : "+s"(soff));
+            {
+                uint32_t soff_v;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(soff_v) : "s"(soff));
+                soff = soff_v;
+            }
+#endif
 #ifndef P2P_ABLATE_BARRIER
             __syncthreads();
 #endif
@@ -506,7 +569,7 @@ __device__ __forceinline__ void draw_tight(
             // for them a whole pair earlier, before stage 1, changes nothing (92.9 vs 93.0 us): not latency-bound
             const PairWords pwn = pair_words(k + 1 < nplain ? k + 1 : k);
 #ifndef P2P_ABLATE_LOADS
-            load_pieces(ns_c, pwn, nxt);
+            load_pieces(ns_c, nw_c, pwn, nxt);
 #else
 #pragma unroll
             for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
@@ -517,30 +580,34 @@ __device__ __forceinline__ void draw_tight(
             for (int j = 0; j < PXT; ++j)
                 pix[j] = blend4_packed(ta[j][0], ta[j][1], ta[j][2], ta[j][3], tw[j]);
             const int pair = X.pair0 + (int)((uint32_t)pwc.w3 >> 26);
-#ifdef P2P_ABLATE_STORES
-            if (pix[0] == 0x12345678u && pix[PXT - 1] == 0x9ABCDEF0u)
-#endif
+#ifdef P2P_STORE_INLINE
             store_wave_pixels(SC, pix, out + ((size_t)pair * P.n_pitch + G.pitch_i) * view_bytes, view_bytes);  // [pano][yaw][pitch][oh][ow][3]
+#else
+            stage_wave_pixels(SC, pix);
+            pend_O = out + ((size_t)pair * P.n_pitch + G.pitch_i) * view_bytes;  // [pano][yaw][pitch][oh][ow][3]
+            pend_records = (uint32_t)view_bytes;
+#endif
             buf_bytes ^= (uint32_t)sizeof(tile4[0]);
             pwc = pwn;
         }
     };
     // the pieces ping-pong between two register sets (pairs two at a time), so nothing is copied per pair
-    auto tight = [&](auto ns_c, auto mode_c, int kbeg, int kend) {
+    // nw_c: the pieces requested inside the loop (those of pairs kbeg + 1 .. kend) belong to pairs without wrapping items
+    auto tight = [&](auto ns_c, auto mode_c, auto nw_c, int kbeg, int kend) {
         int k = kbeg;
         for (; k + 1 < kend; k += 2) {
-            one_pair(ns_c, mode_c, k, qc, qn);
-            one_pair(ns_c, mode_c, k + 1, qn, qc);
+            one_pair(ns_c, mode_c, nw_c, k, qc, qn);
+            one_pair(ns_c, mode_c, nw_c, k + 1, qn, qc);
         }
         if (k < kend) {
-            one_pair(ns_c, mode_c, k, qc, qn);
+            one_pair(ns_c, mode_c, nw_c, k, qc, qn);
 #pragma unroll
             for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
                 qc[sl] = qn[sl];
         }
     };
     auto run_ns = [&](auto ns_c) {
-        load_pieces(ns_c, pwc, qc);
+        load_pieces(ns_c, std::false_type{}, pwc, qc);
         // Inside the loops the pieces of pair k + 1 are followed by the store of pair k, so "pieces landed" is
         // vmcnt(1).  Entering the first loop straight after the first loads the compiler would have to assume
         // vmcnt(0) for both paths.  One store that writes nothing (a buffer store through a descriptor of zero
@@ -548,9 +615,22 @@ __device__ __forceinline__ void draw_tight(
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_raw_buffer_store_b32(0u, __builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0x00020000), 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        tight(ns_c, std::integral_constant<int, 0>{}, 0, X.n1);
-        tight(ns_c, std::integral_constant<int, 1>{}, X.n1, X.n2);
-        tight(ns_c, std::integral_constant<int, 2>{}, X.n2, X.n3);
+#ifdef P2P_NO_WRAP_CLASSES
+        tight(ns_c, std::integral_constant<int, 0>{}, std::false_type{}, 0, X.n1);
+        tight(ns_c, std::integral_constant<int, 1>{}, std::false_type{}, X.n1, X.n2);
+        tight(ns_c, std::integral_constant<int, 2>{}, std::false_type{}, X.n2, X.n3);
+#else
+        // classes 0 | 1 copy, 2 blend, 3 blend with the clipped column; 0 and 2: no item wraps
+        const int a = X.n0 > 0 ? X.n0 - 1 : 0, b = X.n2 - 1 > X.n1 ? X.n2 - 1 : X.n1;
+        tight(ns_c, std::integral_constant<int, 0>{}, std::true_type{}, 0, a);
+        tight(ns_c, std::integral_constant<int, 0>{}, std::false_type{}, a, X.n1);
+        tight(ns_c, std::integral_constant<int, 1>{}, std::true_type{}, X.n1, b);
+        tight(ns_c, std::integral_constant<int, 1>{}, std::false_type{}, b, X.n2);
+        tight(ns_c, std::integral_constant<int, 2>{}, std::false_type{}, X.n2, X.n3);
+#endif
+#ifndef P2P_STORE_INLINE
+        store_staged_pixels(SC, read_staged_pixels(SC), pend_O, pend_records);  // the last pair's pixels
+#endif
     };
     static_assert(VIEWS_SLOTS == 2 || VIEWS_SLOTS == 3, "dispatch below");
     if (ns_wave == 0)
