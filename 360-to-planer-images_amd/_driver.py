@@ -9,8 +9,8 @@ pitch) view is independent work, exactly as the reference treats i
   shard_views      the (yaw x pitch) view list of ONE image dealt round-robin to N devices, pitch-major, so that a
                    device's share falls into few (pitch, yaw subset) groups and keeps few pitch plans;
   process_views_sharded
-                   one image on several GPUs: one host thread per device, the panorama uploaded once per device
-                   (the groups of a device share it: p2p_job_share_panos), results stitched on the host.
+                   one image on several GPUs: one host thread per device, ONE job per device that draws exactly the
+                   device's (yaw, pitch) views (a view mask: p2p_job_set_view_mask), results stitched on the host.
 """
 import threading
 from concurrent.futures import ThreadPoolExecutor
@@ -94,7 +94,7 @@ class DevicePipeline:
 
 _ctx_lock = threading.Lock()  # guards the three dicts below
 _ctxs = {}
-_groups = {}  # device slot -> (geometry key, [(job, pitch index, yaw indices)]): the slot's resident jobs
+_groups = {}  # device slot -> (geometry key, [(job, page-locked staging views, None)]): the slot's resident job
 _slot_locks = {}  # device slot -> lock held for the whole of one image on that slot: two concurrent calls that name the
                   # same (rank, device) take turns instead of interleaving set_pano / run / get_views on the same jobs
 
@@ -176,35 +176,43 @@ def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0):
         if not groups:
             return
         ctx = _shared_ctx(slot)
+        # ONE job per device: the yaws and pitches that occur in the rank's share, and a view mask for the combinations
+        # that are really its own (36 views on 8 ranks: 4 or 5 of a 3 x 3 grid) -- one launch, whose pitch views share
+        # the source rows they read, instead of one job and one launch per pitch
+        yaw_idx = sorted({y for ys in groups.values() for y in ys})
+        pitch_idx = sorted(groups)
+        mine = [(y, p) for p in pitch_idx for y in groups[p]]
         if kept is None:
-            jobs, owner = [], None
+            job = _native.Job(ctx, pw, ph, 1, [yaws[y] for y in yaw_idx], [pitches[p] for p in pitch_idx], fov, ow, oh, flags=flags)
             try:
-                for pi, yis in sorted(groups.items()):
-                    job = _native.Job(ctx, pw, ph, 1, [yaws[y] for y in yis], [pitches[pi]], fov, ow, oh, flags=flags)
-                    jobs.append((job, pi, yis))
-                    if owner is None:
-                        owner = job
-                    else:
-                        job.share_panos(owner)
+                mask = np.zeros((len(yaw_idx), len(pitch_idx)), np.uint8)
+                for y, p in mine:
+                    mask[yaw_idx.index(y), pitch_idx.index(p)] = 1
+                if not mask.all():
+                    job.set_view_mask(mask)
+                try:
+                    stage = _native.pinned_empty((len(mine), int(oh), int(ow), 3))
+                except (MemoryError, _native.P2PError, OSError):
+                    stage = np.empty((len(mine), int(oh), int(ow), 3), np.uint8)
             except Exception:
-                for job, _, _ in reversed(jobs):
-                    job.close()
+                job.close()
                 raise
             with _ctx_lock:
-                _groups[slot] = (geo, jobs)
+                _groups[slot] = (geo, [(job, stage, None)])
         with _ctx_lock:
-            jobs = _groups[slot][1]
+            job, stage, _ = _groups[slot][1][0]
         try:
-            jobs[0][0].set_pano(0, pano, wait=False)  # once per device
-            pending = []
-            for job, pi, yis in jobs:
-                job.run()
-                pending.append((job.get_views_async(0), pi, yis))
-            for job, _, _ in jobs:
-                job.wait()
-            for views, pi, yis in pending:
-                for k, y in enumerate(yis):
-                    out[y, pi] = views[k, 0]
+            job.set_pano(0, pano, wait=False)  # once per device
+            job.run()
+            packed = job.ow % 4 == 0  # (odd widths go through the job's packing buffer: one view at a time)
+            for k, (y, p) in enumerate(mine):
+                if packed:
+                    job.get_view_async(yaw_idx.index(y), pitch_idx.index(p), stage[k])
+                else:
+                    stage[k] = job.get_view(yaw_idx.index(y), pitch_idx.index(p))
+            job.wait()
+            for k, (y, p) in enumerate(mine):
+                out[y, p] = stage[k]
         except Exception:
             _close_group(slot)
             raise

@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "p2p_job_set_pano_async", "p2p_job_share_panos", "p2p_job_get_views_async", "p2p_job_wait", "p2p_job_set_maps", "p2p_job_run",
     "p2p_job_get_views", "p2p_job_kernel_ms", "p2p_job_kernel_ms_last", "p2p_job_device_out", "p2p_job_get_coords",
     "p2p_job_get_yaw_tables", "p2p_job_set_yaws", "p2p_host_alloc", "p2p_host_free", "p2p_release_cache",
-    "p2p_reload_options", "p2p_job_get_info", "p2p_job_get_view",
+    "p2p_reload_options", "p2p_job_get_info", "p2p_job_get_view", "p2p_job_get_view_async", "p2p_job_set_view_mask",
 )
 
 
@@ -51,7 +51,7 @@ class JobInfo(ctypes.Structure):
         ("pair_chunks", ctypes.c_int32), ("list_order", ctypes.c_int32), ("main_group", ctypes.c_int32),
         ("prefetch_lead", ctypes.c_int32), ("n_odd_yaws", ctypes.c_int32), ("n_tiles", ctypes.c_int64),
         ("n_gather_tiles", ctypes.c_int64), ("timing_events", ctypes.c_int32), ("copy_streams", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 4),
+        ("n_views_wanted", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3),
     ]
 
 
@@ -169,6 +169,10 @@ def lib():
     L.p2p_reload_options.argtypes = []
     L.p2p_job_get_view.restype = c_int
     L.p2p_job_get_view.argtypes = [c_vp, c_int, c_int, c_int, c_vp]
+    L.p2p_job_get_view_async.restype = c_int
+    L.p2p_job_get_view_async.argtypes = [c_vp, c_int, c_int, c_int, c_vp]
+    L.p2p_job_set_view_mask.restype = c_int
+    L.p2p_job_set_view_mask.argtypes = [c_vp, c_vp]
     L.p2p_job_get_info.restype = c_int
     L.p2p_job_get_info.argtypes = [c_vp, ctypes.POINTER(JobInfo)]
     _lib = L
@@ -596,6 +600,23 @@ class Job:
             out = np.empty(shape, dtype=np.uint8)
         check(lib().p2p_job_get_views(self._h, int(index), out.ctypes.data))
         return out
+
+    def set_view_mask(self, mask):
+        """mask: bool / uint8 [n_yaw][n_pitch] of the views the job draws, or None for all (p2p_job_set_view_mask)."""
+        if mask is None:
+            check(lib().p2p_job_set_view_mask(self._h, None))
+            return
+        m = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
+        if m.shape != (self.n_yaw, self.n_pitch):
+            raise ValueError("view mask must be [n_yaw][n_pitch] = (%d, %d), got %s" % (self.n_yaw, self.n_pitch, m.shape))
+        check(lib().p2p_job_set_view_mask(self._h, m.ctypes.data))
+
+    def get_view_async(self, yaw_i, pitch_i, out, index=0):
+        """Enqueue the download of one view into `out` ([oh][ow][3] uint8, C-contiguous); complete after wait()."""
+        if out.dtype != np.uint8 or out.shape != (self.oh, self.ow, 3) or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous uint8 [oh][ow][3] array")
+        check(lib().p2p_job_get_view_async(self._h, int(index), int(yaw_i), int(pitch_i), out.ctypes.data))
+        self._inflight.append(out)
 
     def get_view(self, yaw_i, pitch_i, index=0):
         """One view [oh][ow][3] of panorama `index` (p2p_job_get_view)."""

@@ -100,6 +100,11 @@ struct ViewsParams {
     int gather_ppb;          // (panorama, yaw) pairs per workgroup of the gather / table kernels
     int n_list;              // gather kernel: gather_list is [8][n_list], one work list per XCD, ~0 = no tile (p2p_host.cpp: xcd_lists)
     int gather_all;          // 1: the gather kernel draws EVERY tile (few of the job's tiles fit the LDS scheme: one launch less)
+    // sparse view sets (p2p_job_set_view_mask; the view-sharded multi-GPU path: a rank's 4-5 views of one image in ONE
+    // launch): bit (yaw & 31) of word [pitch][yaw >> 5] = the view is drawn; nullptr: all of them.  A view that is not
+    // wanted is neither computed (main / gather kernels: a pair class of its own, skipped) nor stored.
+    const uint32_t* view_mask;
+    int mask_words;          // words per pitch: ceil(n_yaw / 32)
     float centre;            // float pixel path only: 0 = the reference's sampling convention, 0.5 = pixel centres
     uint32_t* audit;         // -DP2P_AUDIT builds: the context's violation record (see p2p_audit.h); else nullptr
 };

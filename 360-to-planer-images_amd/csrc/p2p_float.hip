@@ -125,11 +125,13 @@ __device__ __forceinline__ void draw_float(
     uint32_t cw0 = 0, cw1 = 0;
     float cwf = 0.0f;
     int cw3 = 0;
+    bool wanted = false;  // the job draws this pair's view of this pitch (p2p_job_set_view_mask)
     {
         const int k = t & 63;
         if (k < npairs) {
             cw3 = pano_of_pair(P, pair0 + k);
             const int yi = pair0 + k - cw3 * P.n_yaw;
+            wanted = view_wanted(P, G.pitch_i, yi);
             const double sh = yaw_shift(P.yaw_rad[yi], P.pw);
             int si = (int)sh;
             if (si >= P.pw)
@@ -153,6 +155,7 @@ __device__ __forceinline__ void draw_float(
     const uint32_t out_off12 = s_ok ? (uint32_t)(G.y0 + srow) * (uint32_t)P.out_row + 3u * (uint32_t)(G.x0 + scol) : 0xFFFFFFFFu;
     const uint32_t stg_rd = (uint32_t)(sj * 64 + x4);
 
+    const unsigned long long wanted_mask = __ballot(wanted);  // bit k: pair k of the chunk
     const int wave_base = __builtin_amdgcn_readfirstlane(t & ~63);
     int ns_wave = 0;
 #pragma unroll
@@ -232,6 +235,8 @@ __device__ __forceinline__ void draw_float(
                 }
             }
             uint8_t* O = out + ((size_t)(pair0 + k) * P.n_pitch + G.pitch_i) * view_bytes;  // [pano][yaw][pitch][oh][ow][3]
+            // a view the job does not draw is stored through a descriptor of no records: dropped by the hardware
+            const uint32_t records = ((wanted_mask >> k) & 1ull) ? (uint32_t)view_bytes : 0u;
 #pragma unroll
             for (int j = 0; j < PXT; ++j)
                 stg[j * 64 + ln] = pix[j];
@@ -240,7 +245,7 @@ __device__ __forceinline__ void draw_float(
             o.x = __builtin_amdgcn_perm(v4.y, v4.x, 0x04020100u);
             o.y = __builtin_amdgcn_perm(v4.z, v4.y, 0x05040201u);
             o.z = __builtin_amdgcn_perm(v4.w, v4.z, 0x06050402u);
-            __builtin_amdgcn_raw_buffer_store_b96(o, __builtin_amdgcn_make_buffer_rsrc(O, 0, (int)view_bytes, 0x00020000),
+            __builtin_amdgcn_raw_buffer_store_b96(o, __builtin_amdgcn_make_buffer_rsrc(O, 0, (int)records, 0x00020000),
                                                   (int)out_off12, 0, P2P_STORE_AUX);
 #pragma unroll
             for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
@@ -316,6 +321,8 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void float_views_rest_kernel(
         const size_t px_off = (size_t)py * P.out_row + 3 * (size_t)px;
         for (int pair = pair0; pair < pair1; ++pair) {
             const int pano = pano_of_pair(P, pair), yi = pair - pano * P.n_yaw;
+            if (!view_wanted(P, G.pitch_i, yi))
+                continue;
             uint8_t* O = out + ((size_t)pair * P.n_pitch + G.pitch_i) * view_bytes + px_off;
             if (dead) {
                 O[0] = O[1] = O[2] = 0;

@@ -626,6 +626,9 @@ struct p2p_job {
     int n_gather = 0;                    // tiles the plan marks for gathers
     int n_odd_yaws = 0;                  // yaws that are not a plain shift with one weight (YawDesc.mode != 0)
     uint16_t* d_pitch_order = nullptr;   // [n_pitch] heaviest view first
+    uint32_t* d_view_mask = nullptr;     // sparse view sets (p2p_job_set_view_mask): [n_pitch][mask_words] bits, nullptr = every view
+    int mask_words = 0;
+    int n_views_wanted = 0;              // views per panorama the job draws (n_yaw * n_pitch without a mask)
     size_t n_tiles = 0;
     int shape = 0;                       // tile shape of the job's plan and kernels (choose_shape)
     p2p::MapGeom geom{};
@@ -944,6 +947,7 @@ void p2p_job_destroy(p2p_job* j)
     (void)dev_free(j->d_rows);
     (void)dev_free(j->d_odd_pairs);
     (void)dev_free(j->d_pitch_order);
+    (void)dev_free(j->d_view_mask);
     for (hipEvent_t e : j->ev_ring)
         (void)hipEventDestroy(e);
     delete j;
@@ -1123,6 +1127,7 @@ static int job_create_core(p2p_ctx* ctx, const p2p_job_desc& d, const double* ya
     j->pitch.assign(pitch_deg, pitch_deg + d.n_pitch);
     j->fov = fov_deg;
     j->pano_set.assign(d.n_panos, 0);
+    j->n_views_wanted = d.n_yaw * d.n_pitch;
 
     j->src_pitch = (3 * (d.pw + p2p::PANO_PAD) + 15) & ~15;  // every row is followed by a copy of its first pixels
     j->pano_stride = (((size_t)j->src_pitch * d.ph + kSlack) + 255) & ~(size_t)255;
@@ -1392,6 +1397,37 @@ static int job_main_order(const p2p_job* j)
     return (j->d.n_panos == 1 && j->d.n_pitch > 1) ? 1 : 0;
 }
 
+int p2p_job_set_view_mask(p2p_job* j, const uint8_t* mask)
+{
+    if (!j)
+        return fail(P2P_ERR_INVALID, "job is NULL");
+    const p2p_job_desc& d = j->d;
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream));  // no launch in flight reads the mask that is about to change
+    if (!mask) {
+        (void)dev_free(j->d_view_mask);
+        j->d_view_mask = nullptr;
+        j->mask_words = 0;
+        j->n_views_wanted = d.n_yaw * d.n_pitch;
+        return P2P_OK;
+    }
+    const int words = (d.n_yaw + 31) / 32;
+    std::vector<uint32_t> bits((size_t)d.n_pitch * words, 0u);
+    int wanted = 0;
+    for (int y = 0; y < d.n_yaw; ++y)
+        for (int p = 0; p < d.n_pitch; ++p)
+            if (mask[(size_t)y * d.n_pitch + p]) {
+                bits[(size_t)p * words + (y >> 5)] |= 1u << (y & 31);
+                ++wanted;
+            }
+    if (!j->d_view_mask)
+        HIP_TRY(dev_alloc((void**)&j->d_view_mask, bits.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(j->d_view_mask, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    j->mask_words = words;
+    j->n_views_wanted = wanted;
+    return P2P_OK;
+}
+
 // Build the job's plan (p2p_plan.hip) for its current maps: once per job geometry, like the yaw tables.  It
 // depends on the maps only, never on pixel data -- the device counterpart of the reference's
 // pitch_mapping_cache (P:17-18, P:55-73), which lives as long as the process.
@@ -1625,6 +1661,8 @@ int p2p_job_run(p2p_job* j)
     P.oh = j->d.oh;
     P.out = j->d_out;
     P.border = j->border;
+    P.view_mask = j->d_view_mask;
+    P.mask_words = j->mask_words;
     const bool timed = j->time_launches && j->ring_pairs > 0;
     const int slot = timed ? (int)(j->runs % j->ring_pairs) : 0;
     const bool float_path = (j->d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)) != 0;
@@ -1911,6 +1949,27 @@ int p2p_job_get_views_async(p2p_job* j, int index, uint8_t* out)
     return P2P_OK;
 }
 
+int p2p_job_get_view_async(p2p_job* j, int index, int yaw_i, int pitch_i, uint8_t* out)
+{
+    if (int rc = get_views_check(j, index, out))
+        return rc;
+    if (yaw_i < 0 || yaw_i >= j->d.n_yaw || pitch_i < 0 || pitch_i >= j->d.n_pitch)
+        return fail(P2P_ERR_INVALID, "view (yaw %d, pitch %d) out of range", yaw_i, pitch_i);
+    if ((size_t)j->out_row != (size_t)3 * j->d.ow)
+        return fail(P2P_ERR_STATE, "asynchronous single-view downloads need a view width divisible by 4 (the packing buffer is shared); use p2p_job_get_view");
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    hipStream_t down = nullptr;
+    HIP_TRY(ctx_copy_stream(j->ctx, false, &down));
+    if (int rc = mark_run(j))
+        return rc;
+    HIP_TRY(hipStreamWaitEvent(down, j->ev_run, 0));
+    if (int rc = enqueue_view_copy(j, index, yaw_i, pitch_i, out, down))
+        return rc;
+    HIP_TRY(hipEventRecord(j->ev_down, down));
+    j->down_pending = true;
+    return P2P_OK;
+}
+
 int p2p_job_get_view(p2p_job* j, int index, int yaw_i, int pitch_i, uint8_t* out)
 {
     if (int rc = get_views_check(j, index, out))
@@ -2087,6 +2146,7 @@ int p2p_job_get_info(p2p_job* j, p2p_job_info* out)
     }
     out->n_gather_tiles = j->plan_ref ? (int64_t)j->plan_ref->n_gather : -1;
     out->n_odd_yaws = j->n_odd_yaws;
+    out->n_views_wanted = j->n_views_wanted;
     out->timing_events = (int32_t)j->ev_ring.size();
     out->copy_streams = (j->ctx->stream_up != nullptr) + (j->ctx->stream_down != nullptr);
     return P2P_OK;

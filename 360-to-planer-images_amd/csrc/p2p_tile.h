@@ -59,6 +59,14 @@ __device__ __forceinline__ int pano_of_pair(const ViewsParams& P, int pair)
     return P.n_yaw == 1 ? pair : (int)__umulhi((uint32_t)pair, P.n_yaw_magic);
 }
 
+// does the job draw view (yaw yi, pitch pitch_i)?  (yi < n_yaw, pitch_i < n_pitch: inside the mask by construction)
+__device__ __forceinline__ bool view_wanted(const ViewsParams& P, int pitch_i, int yi)
+{
+    if (!P.view_mask)
+        return true;
+    return ((P.view_mask[(size_t)pitch_i * P.mask_words + (yi >> 5)] >> (yi & 31)) & 1u) != 0u;
+}
+
 // pitch block of the grid -> pitch view, heaviest first; the table is the host's, its values are clamped all the same
 __device__ __forceinline__ int pitch_of_block(const ViewsParams& P, int by)
 {

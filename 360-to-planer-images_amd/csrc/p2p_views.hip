@@ -192,10 +192,11 @@ __device__ __forceinline__ bool tight_tile(const TileGeo& g, const ViewsParams& 
 //      pw - 1 lives: that one rot pixel is a copy instead
 //   4  per-column weights (a shift fraction within float noise of a rounding tie: 6 of the 360 one-degree
 //      yaws on 8192 columns) or a caller row that is not a shift -> general loop of the rest kernel
+//   5  the job does not draw this (yaw, pitch) view (p2p_job_set_view_mask): nobody's
 struct PairCtxs {
     uint32_t cw0, cw1;
     int cw2, cw3;
-    int n0, n1, n2, n3;  // pairs of class 0, of classes 0..1, 0..2, 0..3
+    int n0, n1, n2, n3, n4;  // pairs of class 0, of classes 0..1, 0..2, 0..3, 0..4
     int npairs, pair0;
 };
 
@@ -237,7 +238,7 @@ __device__ __forceinline__ int pair_of_lane(const ViewsParams& P, bool list, int
 // LIST: the chunk's pairs come from P.odd_pairs (the rest kernel drawing only the yaws left to it) instead of being
 // the contiguous run chunk * pairs_per_block ...
 template <bool LIST = false>
-__device__ __forceinline__ PairCtxs pair_contexts(const ViewsParams& P, const YawDesc* __restrict__ ydesc, int c0, int c1, int t, int chunk)
+__device__ __forceinline__ PairCtxs pair_contexts(const ViewsParams& P, const YawDesc* __restrict__ ydesc, int c0, int c1, int t, int chunk, int pitch_i)
 {
     PairCtxs X;
     pair_chunk(P, LIST, LIST ? P.rest_ppb : P.pairs_per_block, chunk, X.pair0, X.npairs);
@@ -273,13 +274,16 @@ __device__ __forceinline__ PairCtxs pair_contexts(const ViewsParams& P, const Ya
         const bool wraps = clamp_in || (ngroups - g0) <= (((c1 + 2 - c0) + 7) >> 2);
 #endif
         cls = yd.mode != 0 ? 4 : (yd.f == 0 ? (wraps ? 1 : 0) : (wraps ? 3 : 2));
+        if (!view_wanted(P, pitch_i, yi))
+            cls = 5;
     }
-    int cum[5];
-    const int r = sort_lanes_by_class<5>(k, k < X.npairs, cls, cum);
+    int cum[6];
+    const int r = sort_lanes_by_class<6>(k, k < X.npairs, cls, cum);
     X.n0 = cum[0];
     X.n1 = cum[1];
     X.n2 = cum[2];
     X.n3 = cum[3];
+    X.n4 = cum[4];
     X.cw0 = (uint32_t)__builtin_amdgcn_ds_permute(4 * r, (int)cw0);
     X.cw1 = (uint32_t)__builtin_amdgcn_ds_permute(4 * r, (int)cw1);
     X.cw2 = __builtin_amdgcn_ds_permute(4 * r, cw2);
@@ -390,7 +394,7 @@ __device__ __forceinline__ void draw_tight(
     if (!tight_tile(G, P))
         return;  // the other kernels'
     P2P_AUD_LT(P.audit, AUD_MAIN_HDR, G.n_items, LDS_ITEMS_CAP + 1);
-    const PairCtxs X = pair_contexts(P, ydesc, G.c0, G.c1, t, chunk);
+    const PairCtxs X = pair_contexts(P, ydesc, G.c0, G.c1, t, chunk, G.pitch_i);
     const int nplain = X.n3;
     if (nplain == 0)
         return;
@@ -705,7 +709,9 @@ __device__ __forceinline__ void draw_gather(
         const int yi = pair - cw3 * P.n_yaw;
         const YawDesc yd = ydesc[yi];
         cw3 |= k << 26;
-        if (yd.mode == 0 && (unsigned)yd.s < (unsigned)P.pw && (unsigned)yd.f <= 32u) {
+        if (!view_wanted(P, G.pitch_i, yi)) {
+            cls = 4;  // a view the job does not draw (p2p_job_set_view_mask)
+        } else if (yd.mode == 0 && (unsigned)yd.s < (unsigned)P.pw && (unsigned)yd.f <= 32u) {
             const bool nowrap = c1v + 1 + yd.s <= P.pw - 2, allwrap = c0v + yd.s >= P.pw;
             // (a whole-column shift has no clipped column; the seam itself still needs the wrap test)
             cls = (nowrap || allwrap) ? (yd.f == 0 ? 0 : 1) : 2;
@@ -714,10 +720,10 @@ __device__ __forceinline__ void draw_gather(
             cwC = P.pw - yd.s;  // rot columns from here on read past the row's end
         }
     }
-    int cum[4];
-    const int r = sort_lanes_by_class<4>(k, k < npairs, cls, cum);
+    int cum[5];
+    const int r = sort_lanes_by_class<5>(k, k < npairs, cls, cum);
     if (cum[2] == 0)
-        return;  // every yaw of the chunk is the table kernel's
+        return;  // every yaw of the chunk is the table kernel's, or not wanted
     cwA = __builtin_amdgcn_ds_permute(4 * r, cwA);
     cwB = __builtin_amdgcn_ds_permute(4 * r, cwB);
     cwC = __builtin_amdgcn_ds_permute(4 * r, cwC);
@@ -1002,6 +1008,8 @@ __device__ __forceinline__ void draw_rest(
             const int pair = pair_of_lane(P, list, first, k, AUD_TABLE_PAIR);
             const int pano_i = pano_of_pair(P, pair);
             const int yaw_i = pair - pano_i * P.n_yaw;
+            if (!view_wanted(P, G.pitch_i, yaw_i))
+                continue;  // (uniform: the pair is the workgroup's)
             uint32_t pix[PXT];
             direct_pixels(d, make_buf(src + (size_t)pano_i * P.pano_stride, (uint32_t)P.pano_stride), yaw_i, pix);
             store_pixels(pair, pix);
@@ -1014,10 +1022,11 @@ __device__ __forceinline__ void draw_rest(
 
     // ---- LDS scheme, general loop ----
     const bool listed = P.use_pair_list != 0;
-    const PairCtxs X = listed ? pair_contexts<true>(P, ydesc, G.c0, G.c1, t, tile_grid_chunk(P))
-                              : pair_contexts<false>(P, ydesc, G.c0, G.c1, t, tile_grid_chunk(P));
+    const PairCtxs X = listed ? pair_contexts<true>(P, ydesc, G.c0, G.c1, t, tile_grid_chunk(P), G.pitch_i)
+                              : pair_contexts<false>(P, ydesc, G.c0, G.c1, t, tile_grid_chunk(P), G.pitch_i);
     const int kfirst = main_draws_plain ? X.n3 : 0;  // the main kernel has classes 0..3 of its tiles
-    if (kfirst >= X.npairs)
+    const int klast = X.n4;                          // (class 5: views the job does not draw)
+    if (kfirst >= klast)
         return;
     uint32_t tap_up[PXT], tap_lo[PXT];
     TapWeights tw[PXT];
@@ -1079,11 +1088,11 @@ __device__ __forceinline__ void draw_rest(
     if (pc.fast)
         issue_loads(pc, make_buf(src + (size_t)pc.pano * P.pano_stride, (uint32_t)P.pano_stride), q, fw);
     int buf = 0;
-    for (int ki = kfirst; ki < X.npairs; ++ki) {
+    for (int ki = kfirst; ki < klast; ++ki) {
         const auto S = make_buf(src + (size_t)pc.pano * P.pano_stride, (uint32_t)P.pano_stride);
         const int cur_yaw = pc.yaw_i;
         const int pair = listed ? pc.pano * P.n_yaw + pc.yaw_i : X.pair0 + pc.korig;
-        const bool has_next = ki + 1 < X.npairs;
+        const bool has_next = ki + 1 < klast;
         uint32_t pix[PXT];
 
         if (pc.fast) {

@@ -448,13 +448,23 @@ def main():
         # = 4 or 5 each, a 7.2x cap); every rank uploads the panorama once, its groups share it
         groups = drv.shard_views(n_yaw, n_pitch, dist.world, dist.rank)
         npg, total_views, seeds = 1, n_yaw * n_pitch, [1000]
-        for pi, yis in sorted(groups.items()):
-            j = nat.Job(ctx, w["pw"], w["ph"], 1, [w["yaws"][y] for y in yis], [w["pitches"][pi]], w["fov"], w["ow"], w["oh"], flags=flags)
-            if jobs:
-                j.share_panos(jobs[0])
+        if groups:
+            # ONE job per rank: the yaws and pitches that occur in its share, and a view mask for the combinations that
+            # are its own (p2p_job_set_view_mask) -- one launch whose pitch views share the source rows they read
+            import numpy as np
+            yaw_idx = sorted({y for ys in groups.values() for y in ys})
+            pitch_idx = sorted(groups)
+            j = nat.Job(ctx, w["pw"], w["ph"], 1, [w["yaws"][y] for y in yaw_idx], [w["pitches"][p] for p in pitch_idx],
+                        w["fov"], w["ow"], w["oh"], flags=flags)
+            mask = np.zeros((len(yaw_idx), len(pitch_idx)), np.uint8)
+            for p, ys in groups.items():
+                for y in ys:
+                    mask[yaw_idx.index(y), pitch_idx.index(p)] = 1
+            if not mask.all():
+                j.set_view_mask(mask)
             jobs.append(j)
         views_per_rank = sum(len(v) for v in groups.values())
-        sharding = "views of one panorama dealt round-robin pitch-major, %d on this rank in %d launches, no collective" % (views_per_rank, len(jobs))
+        sharding = "views of one panorama dealt round-robin pitch-major, %d on this rank in one masked job, no collective" % views_per_rank
     else:
         npg = args.panos_per_gpu
         total_views = npg * n_yaw * n_pitch * dist.world

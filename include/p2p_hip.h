@@ -230,6 +230,13 @@ int p2p_job_set_yaws_f64(p2p_job* job, const double* yaw_deg);
 /* Optional: use caller float maps instead of in-kernel ones (see p2p_remap_views_maps_u8).  yaw_rows may be
    NULL to keep the yaw tables built from yaw_deg. */
 int p2p_job_set_maps(p2p_job* job, const float* yaw_rows, const float* U, const float* V);
+/* Sparse view sets.  mask: uint8 [n_yaw][n_pitch], non-zero = the job draws that (yaw, pitch) view of every panorama;
+   NULL = all of them again.  Views that are not wanted are neither computed nor written (their part of the output
+   block keeps whatever it held).  What it is for: the view-sharded multi-GPU path -- one task per yaw on ONE shared
+   pano_image in the reference (P:252-265); here the 36 views of an image dealt round-robin to 8 GPUs give a rank 4 or
+   5 (yaw, pitch) combinations that are no full yaw x pitch grid, and with a mask they are ONE job and one launch,
+   whose pitch views share the source rows they read. */
+int p2p_job_set_view_mask(p2p_job* job, const uint8_t* mask);
 /* Enqueue the view-synthesis kernel for all panoramas x yaws x pitches (asynchronous). */
 int p2p_job_run(p2p_job* job);
 /* Copy all views of panorama `index` to host, uint8 [n_yaw][n_pitch][oh][ow][3], on the kernel stream behind the
@@ -242,6 +249,9 @@ int p2p_job_get_views_async(p2p_job* job, int index, uint8_t* out);
 /* ONE view of panorama `index` -- yaw yaw_i, pitch pitch_i of the job's lists -- to host, uint8 [oh][ow][3]; returns
    when `out` is complete.  (Config 4 holds 18 GB of views per panorama; a caller that wants five of them.) */
 int p2p_job_get_view(p2p_job* job, int index, int yaw_i, int pitch_i, uint8_t* out);
+/* The same without waiting, on the context's download stream behind the job's last run (view widths divisible by 4);
+   `out` is complete after p2p_job_wait / p2p_ctx_synchronize. */
+int p2p_job_get_view_async(p2p_job* job, int index, int yaw_i, int pitch_i, uint8_t* out);
 /* Wait for everything the job has in flight: uploads, its last run, downloads. */
 int p2p_job_wait(p2p_job* job);
 /* Launch timing, off by default (a job that nobody times creates no timing event and records none).  n >= 1: every
@@ -283,7 +293,8 @@ typedef struct p2p_job_info {
     int64_t n_gather_tiles;        /* of those, drawn by the gather kernel (-1 before the first p2p_job_run) */
     int32_t timing_events;         /* HIP events of the launch-timing ring (0 unless p2p_job_time_launches asked) */
     int32_t copy_streams;          /* copy streams the job's context has created so far (0..2) */
-    int32_t reserved[4];
+    int32_t n_views_wanted;        /* views per panorama the job draws (n_yaw * n_pitch unless p2p_job_set_view_mask) */
+    int32_t reserved[3];
 } p2p_job_info;
 int p2p_job_get_info(p2p_job* job, p2p_job_info* out);
 

@@ -113,6 +113,16 @@ int main()
     CHECK(p2p_job_kernel_ms_last(job, ms, 256) == P2P_OK && p2p_job_kernel_ms_last(job, ms, 257) == P2P_ERR_STATE);
     CHECK(p2p_job_time_launches(job, 0) == P2P_OK && p2p_job_run(job) == P2P_OK && p2p_job_kernel_ms(job, ms) == P2P_ERR_STATE);
     CHECK(p2p_job_get_views_async(job, 1, views.data()) == P2P_OK && p2p_job_wait(job) == P2P_OK);
+    {   // a sparse view set, one view at a time, and back to all views
+        const uint8_t mask[6] = {1, 0, 0, 1, 1, 1};                  // [n_yaw = 3][n_pitch = 2]
+        p2p_job_info info;
+        CHECK(p2p_job_set_view_mask(job, mask) == P2P_OK && p2p_job_get_info(job, &info) == P2P_OK && info.n_views_wanted == 4);
+        CHECK(p2p_job_run(job) == P2P_OK);
+        std::vector<uint8_t> one((size_t)33 * 70 * 3);
+        CHECK(p2p_job_get_view(job, 1, 2, 1, one.data()) == P2P_OK && p2p_job_get_view(job, 0, 3, 0, one.data()) == P2P_ERR_INVALID);
+        CHECK(p2p_job_get_view_async(job, 0, 0, 0, one.data()) == P2P_ERR_STATE);   // 70 is not divisible by 4: packed downloads only
+        CHECK(p2p_job_set_view_mask(job, nullptr) == P2P_OK && p2p_job_get_info(job, &info) == P2P_OK && info.n_views_wanted == 6);
+    }
     std::vector<int32_t> coords((size_t)2 * 33 * 70 * 2);
     CHECK(p2p_job_get_coords(job, coords.data()) == P2P_OK);
     std::vector<uint32_t> tabs((size_t)3 * 64);
@@ -134,6 +144,7 @@ int main()
     CHECK(p2p_job_run(job2) == P2P_OK);
     std::vector<uint8_t> v2((size_t)16 * 16 * 3);
     CHECK(p2p_job_get_views(job2, 1, v2.data()) == P2P_OK);
+    CHECK(p2p_job_get_view_async(job2, 1, 0, 0, v2.data()) == P2P_OK && p2p_job_wait(job2) == P2P_OK);
     // the context's table caches: a third job of job2's geometry shares its plan and yaw tables (the build times
     // reported are those of the first build), outlives it, and survives a budget of zero
     p2p_job* job3 = nullptr;

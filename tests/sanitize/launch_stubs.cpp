@@ -12,6 +12,7 @@ extern "C" long p2p_stub_live(int what) { return g_stub_live[what & 1].load(); }
 extern "C" void p2p_stub_count(int what, long delta) { g_stub_live[what & 1].fetch_add(delta); }
 
 namespace p2p {
+constexpr int TILE_H = 16;  // rows of a tile in both shapes the library ships (p2p_device.h: P2P_TILE_ROWS)
 hipError_t launch_yaw_tables(uint32_t* packed, float* rows, int pw, int n_yaw, const double* yaw_rad, hipStream_t)
 {
     for (int y = 0; y < n_yaw; ++y)

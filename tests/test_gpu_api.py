@@ -247,6 +247,12 @@ def test_view_sharded_path_two_contexts_on_one_device(gpu, pkg, synth):
     for devices in ([0, 0], [0, 0, 0, 0, 0, 0, 0, 0], [0]):
         got = d.process_views_sharded(pano, yaws, pitches, 320, 180, 90.0, devices)
         assert np.array_equal(got, one), devices
+    # 36 views on 8 ranks: each rank's 4 or 5 views are ONE job with a view mask (a 3 x 3 grid with holes); and a view
+    # width that is not divisible by 4 (single views through the job's packing buffer)
+    one_odd = pkg.process_views(pano, yaws, pitches, 318, 180, 90)
+    got = d.process_views_sharded(pano, yaws, pitches, 318, 180, 90.0, [0] * 8)
+    assert np.array_equal(got, one_odd)
+    d.release_sharded()
     # through the tool: a single image with --devices 0 0
     m = pkg.panorama_to_plane_pitch
     m.set_devices([0, 0])
@@ -317,6 +323,47 @@ def test_one_shot_pool_is_bounded_and_survives_many_threads(gpu, pkg, synth, mon
         assert np.array_equal(got[yi][0], want[yi, 0]) and np.array_equal(got[yi][1], want[yi, 1])
     gpu.release_cache()
     assert np.array_equal(pkg.process_views(pano, yaws[:2], [60], 96, 64)[1, 0], want[1, 0])
+
+
+@pytest.mark.parametrize("flags_name", ["u8", "f16"])
+def test_view_mask_draws_exactly_the_wanted_views(gpu, synth, flags_name):
+    """p2p_job_set_view_mask: a sparse (yaw, pitch) set -- a rank's share of one image in the view-sharded path -- in
+    ONE job.  The wanted views equal the full job's bytes; the others are not touched (they keep the previous image's
+    pixels); a pole pitch (gather tiles), a flickering yaw on 8192 columns (rest / table kernels) and a cleared mask
+    are in."""
+    pw, ph, ow, oh, fov = 8192, 4096, 320, 200, 90
+    yaws, pitches = [0, 14, 33.5, 90, 200, 359], [4, 60, 90, 150]   # 14 degrees: per-column weights on 8192 columns
+    flags = {"u8": 0, "f16": gpu.FLAG_PIXELS_F16}[flags_name]
+    pa, pb = synth.synth_pano(pw, ph, 3700, "N"), synth.synth_pano(pw, ph, 3701, "N")
+    ctx = gpu.Context(0)
+    job = gpu.Job(ctx, pw, ph, 1, yaws, pitches, fov, ow, oh, flags=flags)
+    full = {}
+    for name, pano in (("a", pa), ("b", pb)):
+        job.set_pano(0, pano)
+        job.run()
+        full[name] = job.get_views(0)
+    rng = np.random.default_rng(7)
+    mask = rng.integers(0, 2, size=(len(yaws), len(pitches))).astype(np.uint8)
+    mask[1, 0] = mask[1, 2] = 1          # the flickering yaw at the pole pitch and at the horizon
+    mask[0, 1] = 0
+    job.set_pano(0, pa)
+    job.run()                            # every view holds image a
+    job.set_view_mask(mask)
+    assert job.info()["n_views_wanted"] == int(mask.sum())
+    job.set_pano(0, pb)
+    job.run()                            # the wanted views now hold image b
+    got = job.get_views(0)
+    for yi in range(len(yaws)):
+        for pi in range(len(pitches)):
+            want = full["b" if mask[yi, pi] else "a"][yi, pi]
+            assert np.array_equal(got[yi, pi], want), (flags_name, yaws[yi], pitches[pi], int(mask[yi, pi]))
+            if mask[yi, pi]:
+                assert np.array_equal(job.get_view(yi, pi), want)
+    job.set_view_mask(None)
+    job.run()
+    assert np.array_equal(job.get_views(0), full["b"])
+    job.close()
+    ctx.close()
 
 
 def test_reference_fan_out_of_230_threads_through_the_default_pool(gpu, pkg, synth):
