@@ -35,6 +35,7 @@ ABI_SYMBOLS = (
     "p2p_job_get_views", "p2p_job_kernel_ms", "p2p_job_kernel_ms_last", "p2p_job_device_out", "p2p_job_get_coords",
     "p2p_job_get_yaw_tables", "p2p_job_set_yaws", "p2p_host_alloc", "p2p_host_free", "p2p_release_cache",
     "p2p_reload_options", "p2p_job_get_info", "p2p_job_get_view", "p2p_job_get_view_async", "p2p_job_set_view_mask",
+    "p2p_device_mem_info",
 )
 
 
@@ -173,6 +174,8 @@ def lib():
     L.p2p_job_get_view_async.argtypes = [c_vp, c_int, c_int, c_int, c_vp]
     L.p2p_job_set_view_mask.restype = c_int
     L.p2p_job_set_view_mask.argtypes = [c_vp, c_vp]
+    L.p2p_device_mem_info.restype = c_int
+    L.p2p_device_mem_info.argtypes = [c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]
     L.p2p_job_get_info.restype = c_int
     L.p2p_job_get_info.argtypes = [c_vp, ctypes.POINTER(JobInfo)]
     _lib = L
@@ -186,6 +189,13 @@ def check(rc):
 
 def device_count():
     return lib().p2p_device_count()
+
+
+def device_mem_info(device=0):
+    """(free, total) bytes of device memory as the driver reports them."""
+    f, t = ctypes.c_int64(), ctypes.c_int64()
+    check(lib().p2p_device_mem_info(int(device), ctypes.byref(f), ctypes.byref(t)))
+    return f.value, t.value
 
 
 def reload_options():

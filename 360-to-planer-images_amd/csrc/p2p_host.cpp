@@ -2119,6 +2119,21 @@ int p2p_release_cache(void)
     return P2P_OK;
 }
 
+int p2p_device_mem_info(int device, int64_t* free_bytes, int64_t* total_bytes)
+{
+    if (!free_bytes || !total_bytes)
+        return fail(P2P_ERR_INVALID, "NULL argument");
+    DeviceRestore keep;
+    int rc = use_device(device);
+    if (rc != P2P_OK)
+        return rc;
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    *free_bytes = (int64_t)f;
+    *total_bytes = (int64_t)t;
+    return P2P_OK;
+}
+
 int p2p_reload_options(void)
 {
     std::lock_guard<std::mutex> lk(g_opt_mu);

@@ -331,6 +331,8 @@ int p2p_host_alloc(size_t bytes, void** out);
 int p2p_host_free(void* ptr);
 int p2p_release_cache(void);
 int p2p_reload_options(void);
+/* Free and total device memory as the driver sees them (hipMemGetInfo): what p2p_release_cache gives back shows here. */
+int p2p_device_mem_info(int device, int64_t* free_bytes, int64_t* total_bytes);
 
 #ifdef __cplusplus
 }

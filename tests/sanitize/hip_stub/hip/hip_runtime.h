@@ -39,6 +39,7 @@ static inline hipError_t hipGetDeviceCount(int* n) { *n = p2p_stub_device_count;
 static inline hipError_t hipSetDevice(int d) { return d >= 0 && d < p2p_stub_device_count ? hipSuccess : hipErrorInvalidValue; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+static inline hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = (size_t)1 << 30; *t = (size_t)2 << 30; return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }

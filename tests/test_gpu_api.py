@@ -387,11 +387,8 @@ def test_reference_fan_out_of_230_threads_through_the_default_pool(gpu, pkg, syn
 def test_release_cache_gives_device_memory_back(gpu, synth):
     """p2p_release_cache: the cached one-shot jobs, the unused tables of every live context (the caller's own
     included) and the pool's idle blocks go back to the driver -- free device memory returns to where it was."""
-    import torch
-
     def free_mb():
-        torch.cuda.synchronize()
-        return torch.cuda.mem_get_info(0)[0] / 2**20
+        return gpu.device_mem_info(0)[0] / 2**20
 
     pano = synth.synth_pano(4096, 2048, 3600, "S")
     gpu.release_cache()

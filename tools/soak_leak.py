@@ -4,7 +4,6 @@ two-slot device pipeline, view-sharded runs, job create / close) while watching 
 process's resident set: neither may drift.  Diagnostic; run on the GPU box:  python tools/soak_leak.py [rounds]"""
 import importlib, os, sys, threading, time
 import numpy as np
-import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("360-to-planer-images_amd"); nat = pkg._native
 drv = importlib.import_module("360-to-planer-images_amd._driver")
@@ -25,8 +24,8 @@ def rss_mb():
 
 
 def free_mb():
-    torch.cuda.synchronize()
-    return torch.cuda.mem_get_info(0)[0] / 2**20
+    # (every call below returns with its device work done; the driver's own figure, no second runtime in the process)
+    return nat.device_mem_info(0)[0] / 2**20
 
 
 panos = {(2048, 1024): synth.synth_pano(2048, 1024, 1, "N"), (4096, 2048): synth.synth_pano(4096, 2048, 2, "S"),
