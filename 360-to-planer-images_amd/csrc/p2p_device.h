@@ -182,7 +182,7 @@ namespace P2P_SHAPE_NS {
 #define P2P_TILE_W 64
 #endif
 #ifndef P2P_WAVES
-#define P2P_WAVES 6
+#define P2P_WAVES (P2P_TILE_W == 64 ? 7 : 6)  // 64 x 16: 7 workgroups x 22.5 KB of LDS (the staging dwords live inside the tile buffers)
 #endif
 #ifndef P2P_TILE_ROWS
 #define P2P_TILE_ROWS 16

@@ -265,7 +265,7 @@ __device__ __forceinline__ void draw_float(
 }
 
 template <bool HALF>
-__global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void float_views_kernel(
+__global__ __launch_bounds__(VIEWS_BLOCK, 6) void float_views_kernel(
     ViewsParams P, const uint8_t* __restrict__ src, uint8_t* __restrict__ out,
     const PieceHdr* __restrict__ hdr, const uint32_t* __restrict__ px, const uint32_t* __restrict__ px2,
     const uint32_t* __restrict__ items)

@@ -334,20 +334,20 @@ __device__ __forceinline__ StoreCtx store_ctx(const ViewsParams& P, const TileGe
     return s;
 }
 
-// first half: the wave's pixels into its staging dwords
-__device__ __forceinline__ void stage_wave_pixels(const StoreCtx& s, const uint32_t (&pix)[VIEWS_PXT])
+// first half: the wave's pixels into its staging dwords (stg: this wave's 64 x VIEWS_PXT dwords)
+__device__ __forceinline__ void stage_wave_pixels(const StoreCtx& s, uint32_t* stg, const uint32_t (&pix)[VIEWS_PXT])
 {
 #pragma unroll
     for (int j = 0; j < VIEWS_PXT; ++j)
-        s.stg[j * 64 + s.ln] = pix[j];
+        stg[j * 64 + s.ln] = pix[j];
 }
 
 // second half: four adjacent pixels of one row back out of the staging dwords (DS operations of one wave execute in
 // order: the read sees the wave's own writes, also those of the pair before), 12 bytes, one store.  `records` = bytes
 // of the view, or 0: a descriptor of no records, every lane dropped by the hardware
-__device__ __forceinline__ uint4 read_staged_pixels(const StoreCtx& s)
+__device__ __forceinline__ uint4 read_staged_pixels(const StoreCtx& s, const uint32_t* stg)
 {
-    return *reinterpret_cast<const uint4*>(s.stg + s.stg_rd);
+    return *reinterpret_cast<const uint4*>(stg + s.stg_rd);
 }
 
 __device__ __forceinline__ void store_staged_pixels(const StoreCtx& s, const uint4& v, uint8_t* O, uint32_t records)
@@ -524,8 +524,22 @@ __device__ __forceinline__ void draw_tight(
     // end of its stage 2 and stay there; they are read back, packed and stored by the NEXT pair, between its stage 1 and
     // its barrier -- where the wave waits for its LDS writes anyway, so the staging round trip (write, read, lgkmcnt(0))
     // no longer stands between stage 2 and the next pair.  The first pair "stores" through a descriptor of no records.
+    // The staging dwords are not a buffer of their own (unless P2P_STAGE_OWN_LDS): a wave stages into the tile buffer that
+    // is NOT being read -- it holds the pair before, which every wave has finished with at the last barrier -- and
+    // there into the 64 items (1 KB) that only this wave itself writes in stage 1 (items t + sl * VIEWS_BLOCK: slot 0 of
+    // its own lanes).  The pixels are read back at the top of the next pair, before the wave's stage-1 writes to the
+    // same addresses (DS operations of one wave execute in order).  4 KB of LDS less per workgroup: seven per CU.
     uint8_t* pend_O = out;
     uint32_t pend_records = 0u;
+    auto staging = [&](uint32_t buffer_bytes) {
+#ifdef P2P_STAGE_OWN_LDS
+        (void)buffer_bytes;
+        return SC.stg;
+#else
+        return reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(&tile4[0][0]) + buffer_bytes) + (t >> 6) * (64 * 4);
+#endif
+    };
+    static_assert(VIEWS_PXT == 4, "a wave's staging dwords are the 64 items of its lanes' first slot");
     auto one_pair = [&](auto ns_c, auto mode_c, auto nw_c, int k, const Q16 (&cur)[VIEWS_SLOTS], Q16 (&nxt)[VIEWS_SLOTS]) {
         {
             uint4* tl4 = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(&tile4[0][0]) + buf_bytes);
@@ -533,7 +547,7 @@ __device__ __forceinline__ void draw_tight(
             // the read-back goes out first and is consumed after stage 1 (the scheduler would otherwise pull the whole
             // chain up behind the previous pair's staging writes: the round trip this order exists to avoid)
             __builtin_amdgcn_sched_barrier(0);
-            const uint4 staged = read_staged_pixels(SC);
+            const uint4 staged = read_staged_pixels(SC, staging(buf_bytes));
             __builtin_amdgcn_sched_barrier(0);
 #endif
             stage1(ns_c, mode_c, pwc, cur, tl4);
@@ -587,7 +601,7 @@ __device__ __forceinline__ void draw_tight(
 #ifdef P2P_STORE_INLINE
             store_wave_pixels(SC, pix, out + ((size_t)pair * P.n_pitch + G.pitch_i) * view_bytes, view_bytes);  // [pano][yaw][pitch][oh][ow][3]
 #else
-            stage_wave_pixels(SC, pix);
+            stage_wave_pixels(SC, staging(buf_bytes ^ (uint32_t)sizeof(tile4[0])), pix);
             pend_O = out + ((size_t)pair * P.n_pitch + G.pitch_i) * view_bytes;  // [pano][yaw][pitch][oh][ow][3]
             pend_records = (uint32_t)view_bytes;
 #endif
@@ -633,7 +647,7 @@ __device__ __forceinline__ void draw_tight(
         tight(ns_c, std::integral_constant<int, 2>{}, std::false_type{}, X.n2, X.n3);
 #endif
 #ifndef P2P_STORE_INLINE
-        store_staged_pixels(SC, read_staged_pixels(SC), pend_O, pend_records);  // the last pair's pixels
+        store_staged_pixels(SC, read_staged_pixels(SC, staging(buf_bytes)), pend_O, pend_records);  // the last pair's pixels
 #endif
     };
     static_assert(VIEWS_SLOTS == 2 || VIEWS_SLOTS == 3, "dispatch below");
@@ -1181,7 +1195,11 @@ __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views
     const PieceHdr* __restrict__ hdr, const uint32_t* __restrict__ px, const uint32_t* __restrict__ items)
 {
     __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
+#if defined(P2P_STAGE_OWN_LDS) || defined(P2P_STORE_INLINE)
     __shared__ __attribute__((aligned(16))) uint32_t stage[(VIEWS_BLOCK / 64) * VIEWS_PXT * 64];  // a dword per pixel
+#else
+    uint32_t* const stage = nullptr;  // staged inside the tile buffers (draw_tight)
+#endif
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
     int tile_id, pitch_i, chunk;
     if (P.main_list) {
