@@ -1,6 +1,6 @@
 // p2p_views.hip -- the hot kernel: both cv2.remap stages of every (panorama, yaw, pitch) view in one launch
 //   cv2.remap x2       P:192-199, P:212-218 -> remap_views_kernel (both stages fused, fixed point),
-//                                            remap_views_rest_kernel and remap_views_direct_kernel (the odd
+//                                            remap_views_gather_kernel, remap_views_rest_kernel and remap_views_table_kernel (the odd
 //                                            cases), driven by the tables of the plan pass (p2p_plan.hip);
 //                                            3-channel single remaps of the legacy tool (L:179) too
 // Reference behaviour (cited, never copied):
