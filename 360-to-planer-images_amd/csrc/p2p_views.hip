@@ -540,6 +540,9 @@ __device__ __forceinline__ void draw_tight(
 #endif
     };
     static_assert(VIEWS_PXT == 4, "a wave's staging dwords are the 64 items of its lanes' first slot");
+#ifdef P2P_ABLATE_HALF_TAPS
+    uint32_t ta_keep[PXT][4] = {};  // (timing experiment, wrong pixels: every second pair re-uses the taps of the pair before)
+#endif
     auto one_pair = [&](auto ns_c, auto mode_c, auto nw_c, int k, const Q16 (&cur)[VIEWS_SLOTS], Q16 (&nxt)[VIEWS_SLOTS]) {
         {
             uint4* tl4 = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(&tile4[0][0]) + buf_bytes);
@@ -574,6 +577,9 @@ __device__ __forceinline__ void draw_tight(
 #endif
             const unsigned char* tl = reinterpret_cast<const unsigned char*>(&tile4[0][0]);
             uint32_t ta[PXT][4];
+#ifdef P2P_ABLATE_HALF_TAPS
+            if (&cur[0] == &qc[0]) {
+#endif
 #pragma unroll
             for (int j = 0; j < PXT; ++j) {
                 const uint32_t* up = reinterpret_cast<const uint32_t*>(tl + (tap_up[j] + soff));
@@ -583,6 +589,18 @@ __device__ __forceinline__ void draw_tight(
                 ta[j][2] = lo[0];
                 ta[j][3] = lo[1];
             }
+#ifdef P2P_ABLATE_HALF_TAPS
+#pragma unroll
+            for (int j = 0; j < PXT; ++j)
+                for (int q4 = 0; q4 < 4; ++q4)
+                    ta_keep[j][q4] = ta[j][q4];
+            } else {
+#pragma unroll
+            for (int j = 0; j < PXT; ++j)
+                for (int q4 = 0; q4 < 4; ++q4)
+                    ta[j][q4] = ta_keep[j][q4] + (uint32_t)k;
+            }
+#endif
             // the next pair's pieces (the last pair asks for its own again: no branch on the memory path); asking
             // for them a whole pair earlier, before stage 1, changes nothing (92.9 vs 93.0 us): not latency-bound
             const PairWords pwn = pair_words(k + 1 < nplain ? k + 1 : k);
