@@ -6,11 +6,14 @@
 A "step" is one pass of the hot path over one batch of synthetic input: every (yaw, pitch) view of
 the rank's resident panorama(s), i.e. one launch of remap_views_kernel.  Inputs are resident in HBM
 before the timed region; outputs stay in HBM.  With N > 1 (launched by torch.distributed.run, one
-rank per GPU) the (image x yaw x pitch) batch is dealt to the ranks -- by default config 3's 64
-panoramas, 64 / N resident per GPU ("strong": the batch is fixed); --scaling strong on a
-single-panorama workload deals its views instead; --scaling weak gives every rank panoramas of its
-own.  It is independent work, so there is NO data-path collective; torch.distributed (RCCL) is used
-only for the barrier and the max-over-ranks of the elapsed time.  value = pixels of the whole job / that time.
+rank per GPU) the (image x yaw x pitch) batch is dealt to the ranks at IMAGE granularity: by default
+every rank draws the metric's own configuration -- one 8K panorama of its own x 36 views, N images
+in all, "scaling": "weak" (per-GPU work fixed as N grows; the N = 1 line is the same workload).
+--workload cfg3 deals config 3's 64 panoramas instead, 64 / N resident per GPU ("strong": the batch
+is fixed); --scaling strong on a single-panorama workload deals its VIEWS (36 views on 8 GPUs: 4 or
+5 each, one masked job per rank).  It is independent work, so there is NO data-path collective;
+torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the elapsed time.
+value = pixels of the whole job / that time.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     -- algorithmic bytes of one launch / mean launch duration (HIP events around every
@@ -398,7 +401,9 @@ def main():
     if args.no_preroll:
         args.preroll_s = 0.0
     if args.workload is None:
-        args.workload = "cfg2" if args.gpus == 1 else "cfg3"
+        # the metric's configuration at every N: images dealt to the ranks, one resident panorama x 36 views each
+        # (weak scaling: the same per-GPU workload as the N = 1 line; config 3's 64-panorama batch is --workload cfg3)
+        args.workload = "cfg2"
     if args.scaling is None:
         args.scaling = "strong" if "n_panos_total" in WORKLOADS[args.workload] else "weak"
     if args.panos_per_gpu is None:

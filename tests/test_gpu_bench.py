@@ -67,12 +67,21 @@ def test_two_ranks_on_one_gpu_dry_run(gpu):
 
 
 def test_multi_rank_defaults_config3_share_and_view_sharding(gpu):
-    """--gpus N > 1 defaults to config 3 (64 panoramas dealt to the ranks, 64 / N resident per GPU, "strong");
-    --scaling strong on config 2 deals its 36 views round-robin, pitch-major.  Two gloo ranks on the one GPU."""
+    """--gpus N > 1 defaults to the metric's own configuration on every rank (one panorama x 36 views each, "weak");
+    --workload cfg3 deals config 3's 64 panoramas (64 / N resident per GPU, "strong"); --scaling strong on config 2 deals
+    its 36 views round-robin, pitch-major, one masked job per rank.  Two gloo ranks on the one GPU."""
     env = dict(os.environ, P2P_BENCH_BACKEND="gloo", P2P_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
             "--master-addr", "127.0.0.1"]
-    r = subprocess.run(base + ["--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1",
+    r = subprocess.run(base + ["--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "10", "--warmup", "2",
+                               "--kind", "N", "--preroll-s", "0.1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = _last_json(r.stdout)
+    assert line["scaling"] == "weak" and line["config"]["panos_per_gpu"] == 1 and line["config"]["views_per_gpu"] == 36
+    assert line["metric"].startswith("Mpix/s remapped, 8K equirect->1080p x36 views") and line["value"] > 0
+    # two ranks x 36 views x 1920 x 1080 per step
+    assert abs(line["value"] * line["ms_per_step"] * 1e3 - 2 * 36 * 1920 * 1080) / (2 * 36 * 1920 * 1080) < 1e-6
+    r = subprocess.run(base + ["--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--workload", "cfg3", "--steps", "3", "--warmup", "1",
                                "--kind", "N", "--preroll-s", "0.1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     line = _last_json(r.stdout)
@@ -83,6 +92,6 @@ def test_multi_rank_defaults_config3_share_and_view_sharding(gpu):
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     line = _last_json(r.stdout)
-    assert line["scaling"] == "strong" and line["config"]["views_per_gpu"] == 18 and line["config"]["launches_per_step"] == 3
+    assert line["scaling"] == "strong" and line["config"]["views_per_gpu"] == 18 and line["config"]["launches_per_step"] == 1  # one masked job
     # 36 views x 1920 x 1080 per step, whatever the number of ranks
     assert abs(line["value"] * line["ms_per_step"] * 1e3 - 36 * 1920 * 1080) / (36 * 1920 * 1080) < 1e-6
