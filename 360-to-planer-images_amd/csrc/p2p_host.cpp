@@ -1456,8 +1456,12 @@ static int job_build_plan(p2p_job* j)
     }
     auto Pl = std::make_shared<Plan>();
     Pl->device = ctx->device;
-    // declared after Pl, so it runs first: on every error return the stream is drained before the host vectors below
-    // and the plan's blocks (back to the pool, where any thread may pick them up at once) go out of scope
+    // host buffers that asynchronous copies read from or write to: declared BEFORE the guard, so that on every error
+    // return the stream is drained (the guard, destroyed first) before they and the plan's blocks -- back to the pool,
+    // where any thread may pick them up at once -- go out of scope
+    std::vector<p2p::PieceHdr> hh;
+    std::vector<uint32_t> tm, tg, ta;
+    uint32_t cnt = 0;
     StreamSyncGuard sync_on_exit(st);
     if (float_path)
         HIP_TRY(dev_alloc((void**)&Pl->d_px2, slots * S.block * S.pxt * sizeof(uint32_t)));
@@ -1502,11 +1506,9 @@ static int job_build_plan(p2p_job* j)
     HIP_TRY(hipEventRecord(ctx->ev_t0, st));
     HIP_TRY(shape_ops(j->shape).plan(Q, st));
     HIP_TRY(hipEventRecord(ctx->ev_t1, st));
-    uint32_t cnt = 0;
     HIP_TRY(hipMemcpyAsync(&cnt, Pl->d_n_gather, sizeof(cnt), hipMemcpyDeviceToHost, st));
     // the work lists are made from the plan's headers, once per geometry: they come back with the counter
     const bool want_main_order = main_order != 0;
-    std::vector<p2p::PieceHdr> hh;
     if (want_main_order) {
         hh.resize(slots);
         HIP_TRY(hipMemcpyAsync(hh.data(), Pl->d_hdr, slots * sizeof(p2p::PieceHdr), hipMemcpyDeviceToHost, st));
@@ -1523,8 +1525,7 @@ static int job_build_plan(p2p_job* j)
         HIP_TRY(hipMemcpyAsync(hh.data(), Pl->d_hdr, slots * sizeof(p2p::PieceHdr), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
-    std::vector<uint32_t> tm;  // (alive until the stream has taken the copies: synchronised below)
-    if (make_main_list) {
+    if (make_main_list) {  // (tm, tg, ta stay alive until the stream has taken the copies: synchronised below)
         tm = xcd_main_lists(hh, j->n_tiles, &Pl->main_stride);
         HIP_TRY(dev_alloc((void**)&Pl->d_main_list, tm.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpyAsync(Pl->d_main_list, tm.data(), tm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
@@ -1540,11 +1541,10 @@ static int job_build_plan(p2p_job* j)
         if (marked.size() != (size_t)cnt) {
             return fail(P2P_ERR_HIP, "the plan's headers mark %zu gather tiles, its counter %u", marked.size(), cnt);
         }
-        const std::vector<uint32_t> tg = xcd_lists(marked, hh, d.pw, by_source, opt.gather_group, &Pl->xcd_stride);
+        tg = xcd_lists(marked, hh, d.pw, by_source, opt.gather_group, &Pl->xcd_stride);
         HIP_TRY(dev_alloc((void**)&Pl->d_xcd_list, tg.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpyAsync(Pl->d_xcd_list, tg.data(), tg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         Pl->bytes += tg.size() * sizeof(uint32_t);
-        std::vector<uint32_t> ta;
         if ((slots - (size_t)cnt) * 4 <= slots) {  // the gather kernel may draw every tile (p2p_job_run: gather_all)
             all.resize(slots);
             for (size_t s = 0; s < slots; ++s)
