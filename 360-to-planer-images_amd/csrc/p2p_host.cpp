@@ -808,6 +808,14 @@ int choose_pairs_per_block(const p2p_job_desc& d, const p2p::TileShape& S, const
         const int chunks = (n_pairs + cap - 1) / cap;  // even chunks instead of full ones plus a remainder
         ppb = (n_pairs + chunks - 1) / chunks;
     }
+    // Several resident panoramas and no forced cap: whole panoramas per chunk -- about 20 pairs, a multiple of the yaw
+    // count -- so that no workgroup's pairs straddle two panoramas (8 panoramas x 12 yaws: 24 pairs 792 us, 16 pairs
+    // 803, 12 pairs 814: tools/ab_cfg3_share.sh)
+    if (d.n_panos > 1 && opt.max_pairs_per_block < 0 && d.n_yaw <= 64) {
+        const int per = std::max(1, (20 + d.n_yaw / 2) / d.n_yaw) * d.n_yaw;
+        if (per <= 64 && per <= n_pairs)
+            ppb = per;
+    }
     return ppb < 1 ? 1 : ppb;
 }
 
