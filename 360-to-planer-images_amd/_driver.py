@@ -34,6 +34,22 @@ def shard_views(n_yaw, n_pitch, world, rank):
     return groups
 
 
+def rank_view_set(n_yaw, n_pitch, world, rank):
+    """The ONE masked job a rank draws its share of an image with: (yaw_idx, pitch_idx, mask, mine).  yaw_idx and
+    pitch_idx are the image's yaw / pitch indices that occur in the rank's share (ascending: the job's own angle
+    lists), mask is uint8 [len(yaw_idx)][len(pitch_idx)] with 1 where the combination is the rank's own (the layout
+    p2p_job_set_view_mask takes), mine the share as (yaw, pitch) image indices in pitch-major order.  A rank with no
+    views gets ([], [], empty mask, [])."""
+    groups = shard_views(n_yaw, n_pitch, world, rank)
+    yaw_idx = sorted({y for ys in groups.values() for y in ys})
+    pitch_idx = sorted(groups)
+    mine = [(y, p) for p in pitch_idx for y in groups[p]]
+    mask = np.zeros((len(yaw_idx), len(pitch_idx)), np.uint8)
+    for y, p in mine:
+        mask[yaw_idx.index(y), pitch_idx.index(p)] = 1
+    return yaw_idx, pitch_idx, mask, mine
+
+
 class _Ticket:
     """One image in flight on a DevicePipeline; result() waits for its download."""
 
@@ -167,27 +183,21 @@ def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0):
             _one_device_locked(rank, slot)
 
     def _one_device_locked(rank, slot):
-        groups = shard_views(len(yaws), len(pitches), world, rank)
+        yaw_idx, pitch_idx, mask, mine = rank_view_set(len(yaws), len(pitches), world, rank)
         with _ctx_lock:
             kept = _groups.get(slot)
         if kept is not None and kept[0] != geo:
             _close_group(slot)  # (also when this geometry leaves the rank with nothing to draw)
             kept = None
-        if not groups:
+        if not mine:
             return
         ctx = _shared_ctx(slot)
         # ONE job per device: the yaws and pitches that occur in the rank's share, and a view mask for the combinations
         # that are really its own (36 views on 8 ranks: 4 or 5 of a 3 x 3 grid) -- one launch, whose pitch views share
         # the source rows they read, instead of one job and one launch per pitch
-        yaw_idx = sorted({y for ys in groups.values() for y in ys})
-        pitch_idx = sorted(groups)
-        mine = [(y, p) for p in pitch_idx for y in groups[p]]
         if kept is None:
             job = _native.Job(ctx, pw, ph, 1, [yaws[y] for y in yaw_idx], [pitches[p] for p in pitch_idx], fov, ow, oh, flags=flags)
             try:
-                mask = np.zeros((len(yaw_idx), len(pitch_idx)), np.uint8)
-                for y, p in mine:
-                    mask[yaw_idx.index(y), pitch_idx.index(p)] = 1
                 if not mask.all():
                     job.set_view_mask(mask)
                 try:

@@ -451,24 +451,17 @@ def main():
     elif args.scaling == "strong":
         # one panorama, its (yaw x pitch) views dealt round-robin, pitch-major (36 views on 8 GPUs
         # = 4 or 5 each, a 7.2x cap); every rank uploads the panorama once, its groups share it
-        groups = drv.shard_views(n_yaw, n_pitch, dist.world, dist.rank)
+        yaw_idx, pitch_idx, mask, mine_views = drv.rank_view_set(n_yaw, n_pitch, dist.world, dist.rank)
         npg, total_views, seeds = 1, n_yaw * n_pitch, [1000]
-        if groups:
+        if mine_views:
             # ONE job per rank: the yaws and pitches that occur in its share, and a view mask for the combinations that
             # are its own (p2p_job_set_view_mask) -- one launch whose pitch views share the source rows they read
-            import numpy as np
-            yaw_idx = sorted({y for ys in groups.values() for y in ys})
-            pitch_idx = sorted(groups)
             j = nat.Job(ctx, w["pw"], w["ph"], 1, [w["yaws"][y] for y in yaw_idx], [w["pitches"][p] for p in pitch_idx],
                         w["fov"], w["ow"], w["oh"], flags=flags)
-            mask = np.zeros((len(yaw_idx), len(pitch_idx)), np.uint8)
-            for p, ys in groups.items():
-                for y in ys:
-                    mask[yaw_idx.index(y), pitch_idx.index(p)] = 1
             if not mask.all():
                 j.set_view_mask(mask)
             jobs.append(j)
-        views_per_rank = sum(len(v) for v in groups.values())
+        views_per_rank = len(mine_views)
         sharding = "views of one panorama dealt round-robin pitch-major, %d on this rank in one masked job, no collective" % views_per_rank
     else:
         npg = args.panos_per_gpu

@@ -65,3 +65,44 @@ def test_round_robin_edge_cases():
     assert sum(len(bench.shard_round_robin(36, 8, r)) for r in range(8)) == 36
     w = bench.WORKLOADS["cfg2"]
     assert bench.algorithmic_bytes(w, 1) == 3 * 8192 * 4096 + 3 * 1920 * 1080 * 36 == 324612096
+
+
+@pytest.mark.parametrize("n_yaw,n_pitch,world", [(12, 3, 8), (12, 3, 2), (12, 3, 1), (4, 1, 3), (1, 1, 4), (5, 7, 6), (360, 1, 8)])
+def test_rank_view_sets_cover_every_view_exactly_once(n_yaw, n_pitch, world):
+    """The masked job of each rank (what bench.py --scaling strong and process_views_sharded build): the ranks' masks,
+    mapped back to the image's view indices, are a partition of the yaw x pitch grid, sized within one of each other."""
+    import importlib
+
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    drv = importlib.import_module("360-to-planer-images_amd._driver")
+    seen = np.zeros((n_yaw, n_pitch), np.int32)
+    sizes = []
+    for rank in range(world):
+        yaw_idx, pitch_idx, mask, mine = drv.rank_view_set(n_yaw, n_pitch, world, rank)
+        assert mask.shape == (len(yaw_idx), len(pitch_idx)) and mask.dtype == np.uint8
+        assert yaw_idx == sorted(set(yaw_idx)) and pitch_idx == sorted(set(pitch_idx))
+        assert int(mask.sum()) == len(mine) == len(set(mine))
+        if mine:  # every yaw and pitch the job is created with draws at least one view
+            assert mask.any(axis=1).all() and mask.any(axis=0).all()
+        for a, y in enumerate(yaw_idx):
+            for b, p in enumerate(pitch_idx):
+                assert bool(mask[a, b]) == ((y, p) in mine)
+                seen[y, p] += int(mask[a, b])
+        assert mine == sorted(mine, key=lambda v: (v[1], v[0]))  # pitch-major: the order the views are downloaded in
+        sizes.append(len(mine))
+    assert (seen == 1).all()
+    assert max(sizes) - min(sizes) <= 1 and sum(sizes) == n_yaw * n_pitch
+
+
+def test_rank_view_set_of_config_2_on_8_gpus():
+    import importlib
+
+    sys.path.insert(0, ROOT)
+    drv = importlib.import_module("360-to-planer-images_amd._driver")
+    yaw_idx, pitch_idx, mask, mine = drv.rank_view_set(12, 3, 8, 0)  # views 0, 8, 16, 24, 32 of the pitch-major list
+    assert mine == [(0, 0), (8, 0), (4, 1), (0, 2), (8, 2)]
+    assert yaw_idx == [0, 4, 8] and pitch_idx == [0, 1, 2]
+    assert mask.tolist() == [[1, 0, 1], [0, 1, 0], [1, 0, 1]]     # 5 of a 3 x 3 grid
+    assert drv.rank_view_set(2, 1, 4, 3)[3] == []                # more ranks than views
