@@ -72,6 +72,8 @@ struct ViewsParams {
     const uint32_t* main_list;  // main kernel: [8][main_stride] the LDS-scheme tiles dealt to the XCDs in source order (p2p_host.cpp:
     int main_stride;            // xcd_main_lists), ~0 = none; nullptr: the grid's own (tile, chunk, pitch view) order
     int main_group, main_chunks;  // list entries an XCD draws for one chunk of pairs before it turns to the next chunk; chunks of pairs
+                                  // (main_chunks counts workgroups per tile: chunks of pairs / main_span, rounded up)
+    int main_span;           // main kernel: chunks of pairs ONE workgroup draws, one after the other (>= 1)
     int pf_lead;             // main kernel: > 0 = every (PF_GROUP + 1)-th workgroup of an XCD's run draws nothing and touches the plan
                              // tables of the PF_GROUP tiles that start pf_lead groups later (p2p_tile.h: main_block_role)
     int chunk_outer;         // tile grids: 0 = (tile, chunk, pitch view), 1 = (tile, pitch view, chunk) -- see pair_chunk

@@ -76,6 +76,7 @@ struct Options {
     int chunk_outer = -1;             // P2P_CHUNK_OUTER
     int main_order = -1;              // P2P_MAIN_ORDER: 0 grid order, 1 list order, 2 list order also with several panoramas; -1 = by job
     int main_group = -1;              // P2P_MAIN_GROUP
+    int main_span = -1;               // P2P_MAIN_SPAN: chunks of pairs one main-kernel workgroup draws (-1: the library's rule)
     int prefetch_lead = -1;           // P2P_PREFETCH_LEAD
     int force_rest = 0;               // P2P_FORCE_REST
     int gather_ppb = 16;              // P2P_GATHER_PPB
@@ -108,6 +109,7 @@ void options_load_locked()
     o.chunk_outer = env_int("P2P_CHUNK_OUTER", o.chunk_outer);
     o.main_order = env_int("P2P_MAIN_ORDER", o.main_order);
     o.main_group = env_int("P2P_MAIN_GROUP", o.main_group);
+    o.main_span = env_int("P2P_MAIN_SPAN", o.main_span);
     o.prefetch_lead = env_int("P2P_PREFETCH_LEAD", o.prefetch_lead);
     o.force_rest = env_int("P2P_FORCE_REST", o.force_rest);
     o.gather_ppb = env_int("P2P_GATHER_PPB", o.gather_ppb);
@@ -817,6 +819,43 @@ int choose_pairs_per_block(const p2p_job_desc& d, const p2p::TileShape& S, const
             ppb = per;
     }
     return ppb < 1 ? 1 : ppb;
+}
+
+// bytes of plan tables one launch reads (per-pixel words and item lists of every tile of every pitch view)
+size_t plan_table_bytes(const p2p_job_desc& d, const p2p::TileShape& S)
+{
+    const size_t tiles = (size_t)((d.ow + S.tile_w - 1) / S.tile_w) * ((d.oh + S.tile_h - 1) / S.tile_h);
+    return tiles * (size_t)d.n_pitch * (S.block * S.pxt + S.cap) * sizeof(uint32_t);
+}
+
+// Chunks of pairs ONE main-kernel workgroup draws, one after the other.  1 as long as a launch's plan tables stay in the
+// Infinity Cache: every chunk then has its own workgroup, and more of them are in flight.  Beyond that (config 4: 565 MB
+// of tables per launch) every chunk's workgroup would pull the tile's words and items in again behind the launch's
+// own write stream; one workgroup then draws all the chunks of its tile and reads them once.
+int choose_main_span(const p2p_job_desc& d, const p2p::TileShape& S, const Options& opt, int pairs_per_block)
+{
+    const int chunks = (d.n_panos * d.n_yaw + pairs_per_block - 1) / pairs_per_block;
+    int span = 1;
+    if (S.tile_w != 128)
+        return 1;  // (only the 128-wide kernel has the loop: p2p_views.hip, draw_tight)
+    if (opt.main_span >= 1)
+        span = opt.main_span;
+    else if (d.n_panos == 1 && plan_table_bytes(d, S) > ((size_t)128 << 20))
+        span = chunks;
+    return std::max(1, std::min(span, chunks));
+}
+
+// List order: entries of an XCD's list that are drawn for one chunk of pairs before the next chunk (about the
+// workgroups the XCD holds at a time: their tables and source rows are still in its L2 for the next chunk).  When one
+// workgroup draws ALL the chunks of its tile the number only spaces the table-prefetch workgroups -- one per group,
+// touching the tables of the group two further on: config 4 with 96 / 48 / 24 entries 6.39 / 6.37 / 6.34 ms.
+int choose_main_group(const Options& opt, int shape, int span, int chunks)
+{
+    if (opt.main_group >= 0)
+        return opt.main_group;
+    if (span > 1 && span >= chunks)
+        return 24;
+    return shape ? 96 : 192;
 }
 
 }  // namespace
@@ -1695,16 +1734,18 @@ int p2p_job_run(p2p_job* j)
     const int main_order = job_main_order(j);
     P.main_list = (main_order == 2 || (main_order == 1 && j->d.n_panos == 1)) ? j->d_main_list : nullptr;
     P.main_stride = j->main_stride;
-    P.main_chunks = (j->d.n_panos * j->d.n_yaw + P.pairs_per_block - 1) / P.pairs_per_block;
+    P.main_span = choose_main_span(j->d, shape_ops(j->shape).shape, opt, P.pairs_per_block);
+    const int pair_chunks = (j->d.n_panos * j->d.n_yaw + P.pairs_per_block - 1) / P.pairs_per_block;
+    P.main_chunks = (pair_chunks + P.main_span - 1) / P.main_span;
     // entries drawn for one chunk of pairs before the next chunk: with ONE panorama a short run (the entries' plan tables
     // and source rows are still in L2 for the next chunk), with several all of them (a chunk's panoramas serve every
     // tile before the next ones are touched: see pair_chunk)
-    P.main_group = P.chunk_outer ? std::max(1, j->main_stride) : std::max(1, std::min(j->main_stride, opt.main_group >= 0 ? opt.main_group : (j->shape ? 96 : 192)));  // the workgroups an XCD holds at a time
+    P.main_group = P.chunk_outer ? std::max(1, j->main_stride)
+                                 : std::max(1, std::min(j->main_stride, choose_main_group(opt, j->shape, P.main_span, pair_chunks)));
     // table-prefetch workgroups (p2p_tile.h: main_block_role) when one launch's plan tables cannot stay in the Infinity
     // Cache next to the panorama (config 4: 565 MB): 2 groups = 64 tiles of lead per XCD
     {
-        const p2p::TileShape& S = shape_ops(j->shape).shape;
-        const size_t table_bytes = j->n_tiles * (size_t)j->d.n_pitch * (S.block * S.pxt + S.cap) * sizeof(uint32_t);
+        const size_t table_bytes = plan_table_bytes(j->d, shape_ops(j->shape).shape);
         P.pf_lead = opt.prefetch_lead >= 0 ? opt.prefetch_lead : (table_bytes > ((size_t)128 << 20) ? 2 : 0);
     }
     P.pitch_order = j->d_pitch_order;
@@ -2162,11 +2203,10 @@ int p2p_job_get_info(p2p_job* j, p2p_job_info* out)
     out->pair_chunks = (j->d.n_panos * j->d.n_yaw + out->pairs_per_block - 1) / out->pairs_per_block;
     const int mo = job_main_order(j);
     out->list_order = (mo == 2 || (mo == 1 && j->d.n_panos == 1)) ? 1 : 0;
-    out->main_group = j->opt.main_group >= 0 ? j->opt.main_group : (j->shape ? 96 : 192);
-    {
-        const size_t table_bytes = j->n_tiles * (size_t)j->d.n_pitch * (S.block * S.pxt + S.cap) * sizeof(uint32_t);
-        out->prefetch_lead = j->opt.prefetch_lead >= 0 ? j->opt.prefetch_lead : (table_bytes > ((size_t)128 << 20) ? 2 : 0);
-    }
+
+    out->prefetch_lead = j->opt.prefetch_lead >= 0 ? j->opt.prefetch_lead : (plan_table_bytes(j->d, S) > ((size_t)128 << 20) ? 2 : 0);
+    out->chunks_per_workgroup = choose_main_span(j->d, S, j->opt, out->pairs_per_block);
+    out->main_group = choose_main_group(j->opt, j->shape, out->chunks_per_workgroup, out->pair_chunks);
     out->n_gather_tiles = j->plan_ref ? (int64_t)j->plan_ref->n_gather : -1;
     out->n_odd_yaws = j->n_odd_yaws;
     out->n_views_wanted = j->n_views_wanted;
@@ -2207,7 +2247,7 @@ static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride
     auto same_options = [&](const Options& a) {
         return a.plan_cache == now.plan_cache && a.tile_shape == now.tile_shape && a.pairs_per_block == now.pairs_per_block &&
                a.max_pairs_per_block == now.max_pairs_per_block && a.chunk_outer == now.chunk_outer && a.main_order == now.main_order &&
-               a.main_group == now.main_group && a.prefetch_lead == now.prefetch_lead && a.force_rest == now.force_rest &&
+               a.main_group == now.main_group && a.main_span == now.main_span && a.prefetch_lead == now.prefetch_lead && a.force_rest == now.force_rest &&
                a.gather_ppb == now.gather_ppb && a.gather_all == now.gather_all && a.gather_blocky_from == now.gather_blocky_from &&
                a.gather_order == now.gather_order && a.gather_group == now.gather_group && a.scramble_plan == now.scramble_plan;
     };

@@ -94,8 +94,18 @@ __device__ __forceinline__ int tile_of_block(const ViewsParams& P, int bx, int g
 // tiles that the same XCD starts pf_lead groups later (workgroups are dispatched to an XCD in index order), so those
 // find them in L2.  gridDim.x == 8 * groups * (PF_GROUP + 1), groups = ceil(ceil(tiles / 8) / PF_GROUP).
 constexpr int PF_GROUP = 32;
+#ifdef P2P_ABLATE_HALF_PX
+constexpr int PF_PX_LINES = VIEWS_BLOCK * VIEWS_PXT * 4 / 256;
+#else
 constexpr int PF_PX_LINES = VIEWS_BLOCK * VIEWS_PXT * 4 / 128;  // 128-byte lines of a tile's per-pixel words
+#endif
+#ifdef P2P_ABLATE_ITEMS_WINDOW
+constexpr int PF_ITEM_LINES = 0;
+#elif defined(P2P_PF_ITEM_LINES)
+constexpr int PF_ITEM_LINES = P2P_PF_ITEM_LINES;
+#else
 constexpr int PF_ITEM_LINES = 12;                               // ... of its item list that are touched (384 items)
+#endif
 struct BlockRole {
     int tile_id;             // >= 0: draw this tile
     int pf_first, pf_count;  // pf_count > 0: touch the tables of tiles pf_first .. pf_first + pf_count - 1

@@ -298,7 +298,11 @@ __device__ __forceinline__ void decode_px(const uint32_t* __restrict__ pxw, int 
 {
 #pragma unroll
     for (int j = 0; j < PXT; ++j) {
+#ifdef P2P_ABLATE_HALF_PX  // timing experiment (wrong pixels): half the lines of the per-pixel words -- what 2-byte words would read
+        const uint32_t wd = pxw[(j >> 1) * VIEWS_BLOCK + t];
+#else
         const uint32_t wd = pxw[j * VIEWS_BLOCK + t];
+#endif
         const uint32_t dl = (wd >> PXW_UP_BITS) & ((1u << PXW_DL_BITS) - 1u);
         tap_up[j] = (wd & ((1u << PXW_UP_BITS) - 1u)) << 2;
         tap_lo[j] = tap_up[j] + (dl << 2);
@@ -394,9 +398,15 @@ __device__ __forceinline__ void draw_tight(
     if (!tight_tile(G, P))
         return;  // the other kernels'
     P2P_AUD_LT(P.audit, AUD_MAIN_HDR, G.n_items, LDS_ITEMS_CAP + 1);
-    const PairCtxs X = pair_contexts(P, ydesc, G.c0, G.c1, t, chunk, G.pitch_i);
-    const int nplain = X.n3;
-    if (nplain == 0)
+    // A workgroup draws P.main_span consecutive chunks of pairs (1 unless the plan tables are too big to stay cached:
+    // the tile's words and items are then read and decoded once for all of them instead of once per chunk).
+    // Only the 128-wide shape has the loop: the 64-wide kernel sits at its 72 registers (seven workgroups per CU), and
+    // the loop's live values cost it 5 spilled ones; the host asks for spans with 128-wide tiles only.
+    constexpr bool SPAN_LOOP = TILE_W == 128;
+    const int chunk_end = chunk + (SPAN_LOOP && P.main_span > 1 ? P.main_span : 1);
+    PairCtxs X = pair_contexts(P, ydesc, G.c0, G.c1, t, chunk, G.pitch_i);
+    int nplain = X.n3;
+    if (nplain == 0 && chunk + 1 == chunk_end)
         return;
     uint32_t tap_up[PXT], tap_lo[PXT];
     TapWeights tw[PXT];
@@ -459,7 +469,10 @@ __device__ __forceinline__ void draw_tight(
                 off = slot_g[sl] >= wrap_g ? off - row_bytes : off;  // items past the end of the row continue at its start
 #endif
 #ifdef P2P_ABLATE_LOADS2
-            off &= 0x3FFFu;  // timing experiment (wrong pixels): every load issued, all of them hits in 16 KB
+#ifndef P2P_ABLATE_LOADS2_MASK
+#define P2P_ABLATE_LOADS2_MASK 0x3FFFu
+#endif
+            off &= P2P_ABLATE_LOADS2_MASK;  // timing experiment (wrong pixels): every load issued, all of them hits in 16 KB (or the window asked for)
 #endif
             P2P_AUD_RANGE(P.audit, AUD_MAIN_SRC, off, 16u, P.pano_stride);
             const bu32x4 q = __builtin_amdgcn_raw_buffer_load_b128(S, (int)off, 0, 0);
@@ -669,14 +682,28 @@ __device__ __forceinline__ void draw_tight(
 #endif
     };
     static_assert(VIEWS_SLOTS == 2 || VIEWS_SLOTS == 3, "dispatch below");
-    if (ns_wave == 0)
-        run_ns(std::integral_constant<int, 0>{});
-    else if (ns_wave == 1)
-        run_ns(std::integral_constant<int, 1>{});
-    else if (VIEWS_SLOTS == 2 || ns_wave == 2)
-        run_ns(std::integral_constant<int, 2>{});
-    else
-        run_ns(std::integral_constant<int, VIEWS_SLOTS>{});
+    for (int ch = chunk;;) {
+        if (nplain > 0) {  // (the same for every wave of the workgroup: the loops' barriers stay uniform)
+            if (ns_wave == 0)
+                run_ns(std::integral_constant<int, 0>{});
+            else if (ns_wave == 1)
+                run_ns(std::integral_constant<int, 1>{});
+            else if (VIEWS_SLOTS == 2 || ns_wave == 2)
+                run_ns(std::integral_constant<int, 2>{});
+            else
+                run_ns(std::integral_constant<int, VIEWS_SLOTS>{});
+        }
+        if (!SPAN_LOOP || ++ch >= chunk_end)
+            break;
+        // the next chunk of this tile: new pair contexts, everything else stands.  The tile buffers keep alternating
+        // (the last pair's taps are still being read by slower waves from the buffer this wave does NOT write next).
+        X = pair_contexts(P, ydesc, G.c0, G.c1, t, ch, G.pitch_i);
+        nplain = X.n3;
+        if (X.npairs == 0)
+            break;  // past the job's last chunk
+        pwc = pair_words(0);
+        pend_records = 0u;  // (the chunk's last pair has been flushed)
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1299,8 +1326,13 @@ __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views
     const PieceHdr h = hdr[(size_t)pitch_i * tiles + tile_id];
     const TileGeo G = tile_geo(P, h, pitch_i, tile_id, (int)threadIdx.x);
 #endif
+#ifdef P2P_ABLATE_ITEMS_WINDOW  // timing experiment (wrong pixels): the item lists of 64 tiles serve all -- what item lists of no size would give
+    draw_tight(P, src, ydesc, out, G, px + (size_t)G.slot * (VIEWS_BLOCK * VIEWS_PXT), items + (size_t)(G.slot & 63u) * LDS_ITEMS_CAP,
+               tile4, stage, chunk * (TILE_W == 128 && P.main_span > 1 ? P.main_span : 1));
+#else
     draw_tight(P, src, ydesc, out, G, px + (size_t)G.slot * (VIEWS_BLOCK * VIEWS_PXT), items + (size_t)G.slot * LDS_ITEMS_CAP,
-               tile4, stage, chunk);
+               tile4, stage, chunk * (TILE_W == 128 && P.main_span > 1 ? P.main_span : 1));
+#endif
 }
 
 __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_rest_kernel(
@@ -1397,6 +1429,8 @@ hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
     if (which == 1 && P.use_pair_list)
         zblocks = (P.n_odd_pairs + P.rest_ppb - 1) / P.rest_ppb;
     // 8 XCDs, each a contiguous run of tiles; (tile, chunk, pitch view): see pair_chunk
+    if (which == 0 && TILE_W == 128 && P.main_span > 1)  // a main-kernel workgroup loops over main_span chunks
+        zblocks = (zblocks + P.main_span - 1) / P.main_span;
     dim3 grid(8 * ((tiles + 7) / 8), P.chunk_outer ? P.n_pitch : zblocks, P.chunk_outer ? zblocks : P.n_pitch);
     if (which == 0 && P.main_list)  // list order: (blocks of main_group entries) x chunks, per XCD
         grid = dim3(8 * ((P.main_stride + P.main_group - 1) / P.main_group) * (P.main_group * P.main_chunks + (P.pf_lead > 0 ? 1 : 0)), 1, 1);

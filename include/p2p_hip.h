@@ -284,7 +284,7 @@ int p2p_job_get_yaw_tables(p2p_job* job, uint32_t* packed);
 typedef struct p2p_job_info {
     int32_t tile_w, tile_h;        /* output tile of one workgroup: 64 x 16 or 128 x 16 */
     int32_t pairs_per_block;       /* (panorama, yaw) pairs one workgroup loops over */
-    int32_t pair_chunks;           /* workgroups per tile = ceil(n_panos * n_yaw / pairs_per_block) */
+    int32_t pair_chunks;           /* chunks of pairs = ceil(n_panos * n_yaw / pairs_per_block) */
     int32_t list_order;            /* 1: the main kernel's tiles are drawn in source-band order from per-XCD lists */
     int32_t main_group;            /* list entries an XCD draws for one chunk before it turns to the next chunk */
     int32_t prefetch_lead;         /* > 0: table-prefetch workgroups, this many groups ahead */
@@ -294,7 +294,9 @@ typedef struct p2p_job_info {
     int32_t timing_events;         /* HIP events of the launch-timing ring (0 unless p2p_job_time_launches asked) */
     int32_t copy_streams;          /* copy streams the job's context has created so far (0..2) */
     int32_t n_views_wanted;        /* views per panorama the job draws (n_yaw * n_pitch unless p2p_job_set_view_mask) */
-    int32_t reserved[3];
+    int32_t chunks_per_workgroup;  /* chunks of pairs one main-kernel workgroup draws in turn (1 unless the plan tables
+                                      of a launch are too big to stay cached: config 4) */
+    int32_t reserved[2];
 } p2p_job_info;
 int p2p_job_get_info(p2p_job* job, p2p_job_info* out);
 

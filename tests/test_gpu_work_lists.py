@@ -54,6 +54,51 @@ def test_every_work_list_order_draws_the_oracles_bytes(gpu, synth, monkeypatch, 
             assert bad.size == 0, (tile_shape, main_order, group, prefetch, gather_order, i, len(bad), bad[:3])
 
 
+@pytest.mark.parametrize("n_panos", [1, 2])
+def test_workgroups_that_draw_several_chunks_of_pairs_draw_the_oracles_bytes(gpu, synth, monkeypatch, n_panos, p2p_env):
+    """P2P_MAIN_SPAN: one workgroup of the 128-wide main kernel draws 2, 3 ... all chunks of pairs of its tile in turn
+    (what config 4 ships with: its plan tables are read once per tile instead of once per chunk) -- in grid and list
+    order, with and without the table-prefetch workgroups, with a view mask that empties whole chunks."""
+    pw, ph, ow, oh, fov = 2048, 1024, 333, 210, 90
+    yaws = [0, 14.0625, 33, 90, 123.4, 180, 200, 270, 301, 359]
+    pitches = [8, 60, 90, 150]
+    panos = [synth.synth_pano(pw, ph, 4300 + i, "N") for i in range(n_panos)]
+    maps = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
+    want = [oracle_views(p, yaws, pitches, ow, oh, fov) for p in panos]
+    p2p_env("P2P_PLAN_CACHE", "0")
+    p2p_env("P2P_TILE_SHAPE", "128")
+    p2p_env("P2P_PAIRS_PER_BLOCK", "3")   # 4 chunks of pairs per panorama's 10 yaws (7 for two panoramas)
+    for span, main_order, prefetch in itertools.product(("2", "3", "4", "64"), ("0", "1", "2"), ("0", "1")):
+        p2p_env("P2P_MAIN_SPAN", span)
+        p2p_env("P2P_MAIN_ORDER", main_order)
+        p2p_env("P2P_PREFETCH_LEAD", prefetch)
+        got = _run(gpu, panos, yaws, pitches, ow, oh, fov, maps)
+        for i in range(n_panos):
+            bad = np.argwhere(got[i] != want[i])
+            assert bad.size == 0, (span, main_order, prefetch, i, len(bad), bad[:3])
+    # a view mask that leaves the second chunk (yaws 3..5) without a wanted view at pitch 60, and the first at pitch 90
+    p2p_env("P2P_MAIN_SPAN", "4")
+    p2p_env("P2P_MAIN_ORDER", "1")
+    mask = np.ones((len(yaws), len(pitches)), np.uint8)
+    mask[3:6, 1] = 0
+    mask[0:3, 2] = 0
+    ctx = gpu.Context(0)
+    try:
+        job = gpu.Job(ctx, pw, ph, 1, yaws, pitches, fov, ow, oh)
+        job.set_maps(*maps)
+        job.set_view_mask(mask)
+        job.set_pano(0, panos[0])
+        assert job.info()["chunks_per_workgroup"] == 4 and job.info()["pair_chunks"] == 4
+        job.run()
+        got = job.get_views(0)
+        job.close()
+    finally:
+        ctx.close()
+    for y, p in itertools.product(range(len(yaws)), range(len(pitches))):
+        if mask[y, p]:
+            assert np.array_equal(got[y, p], want[0][y, p]), (y, p)
+
+
 def test_device_maps_job_is_the_same_in_every_order_and_tile_shape(gpu, synth, monkeypatch, p2p_env):
     # the default path (maps evaluated on the device): list order, grid order and both tile shapes agree byte for byte
     pw, ph, ow, oh, fov = 4096, 2048, 640, 360, 90
