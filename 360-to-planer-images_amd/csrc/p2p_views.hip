@@ -299,7 +299,8 @@ __device__ __forceinline__ void decode_px(const uint32_t* __restrict__ pxw, int 
 #pragma unroll
     for (int j = 0; j < PXT; ++j) {
 #ifdef P2P_ABLATE_HALF_PX  // timing experiment (wrong pixels): half the lines of the per-pixel words -- what 2-byte words would read
-        const uint32_t wd = pxw[(j >> 1) * VIEWS_BLOCK + t];
+        uint32_t wd = pxw[(j >> 1) * VIEWS_BLOCK + t];
+        asm volatile("" : "+v"(wd));  // (two pixels with one word: without this the compiler draws them once -- "8 % faster")
 #else
         const uint32_t wd = pxw[j * VIEWS_BLOCK + t];
 #endif
