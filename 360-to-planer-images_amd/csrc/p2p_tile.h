@@ -17,6 +17,19 @@ __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cas
 #ifndef P2P_STORE_AUX
 #define P2P_STORE_AUX 2  // cache policy of the view stores: 2 = nt
 #endif
+// ... of the main kernel's (store_staged_pixels), per tile shape: 18 = nt sc1 for the 64-wide kernel, whose launches
+// mostly stay inside the Infinity Cache (config 2 86.4 -> 84.7 us, config 5 743 -> 729 / 739 -> 735); the 128-wide
+// kernel's streams lose 1-4 % with it, and so does the gather kernel (60.3 -> 69.1 us): both keep nt
+// (profiles/r04_main_kernel_store_policy_all_configs.txt)
+#ifndef P2P_MAIN_STORE_AUX_W64
+#define P2P_MAIN_STORE_AUX_W64 18
+#endif
+#ifndef P2P_MAIN_STORE_AUX_W128
+#define P2P_MAIN_STORE_AUX_W128 P2P_STORE_AUX
+#endif
+#ifndef P2P_SRC_LOAD_AUX
+#define P2P_SRC_LOAD_AUX 0  // cache policy of the main kernel's source pieces (experiments)
+#endif
 
 constexpr int TILE_LW = TILE_W == 128 ? 7 : (TILE_W == 64 ? 6 : (TILE_W == 32 ? 5 : 4));
 static_assert((1 << TILE_LW) == TILE_W, "TILE_W must be 16, 32, 64 or 128");

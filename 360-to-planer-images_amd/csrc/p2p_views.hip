@@ -362,7 +362,7 @@ __device__ __forceinline__ void store_staged_pixels(const StoreCtx& s, const uin
     o.y = __builtin_amdgcn_perm(v.z, v.y, 0x05040201u);  // G1 R1 B2 G2
     o.z = __builtin_amdgcn_perm(v.w, v.z, 0x06050402u);  // R2 B3 G3 R3
     __builtin_amdgcn_raw_buffer_store_b96(o, __builtin_amdgcn_make_buffer_rsrc(O, 0, (int)records, 0x00020000),
-                                          (int)s.out_off12, 0, P2P_STORE_AUX);
+                                          (int)s.out_off12, 0, TILE_W == 128 ? P2P_MAIN_STORE_AUX_W128 : P2P_MAIN_STORE_AUX_W64);
 }
 
 __device__ __forceinline__ void store_wave_pixels(const StoreCtx& s, const uint32_t (&pix)[VIEWS_PXT], uint8_t* O, size_t view_bytes)
@@ -476,7 +476,7 @@ __device__ __forceinline__ void draw_tight(
             off &= P2P_ABLATE_LOADS2_MASK;  // timing experiment (wrong pixels): every load issued, all of them hits in 16 KB (or the window asked for)
 #endif
             P2P_AUD_RANGE(P.audit, AUD_MAIN_SRC, off, 16u, P.pano_stride);
-            const bu32x4 q = __builtin_amdgcn_raw_buffer_load_b128(S, (int)off, 0, 0);
+            const bu32x4 q = __builtin_amdgcn_raw_buffer_load_b128(S, (int)off, 0, P2P_SRC_LOAD_AUX);
             qq[sl].d[0] = q.x; qq[sl].d[1] = q.y; qq[sl].d[2] = q.z; qq[sl].d[3] = q.w;
         }
     };
