@@ -27,6 +27,9 @@ __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cas
 #ifndef P2P_MAIN_STORE_AUX_W128
 #define P2P_MAIN_STORE_AUX_W128 P2P_STORE_AUX
 #endif
+#ifndef P2P_GATHER_LOAD_AUX
+#define P2P_GATHER_LOAD_AUX 0  // ... of the gather kernel's taps (experiments)
+#endif
 #ifndef P2P_SRC_LOAD_AUX
 #define P2P_SRC_LOAD_AUX 0  // cache policy of the main kernel's source pieces (experiments)
 #endif

@@ -862,8 +862,8 @@ __device__ __forceinline__ void draw_gather(
             R.al[j] = a;  // its two low bits are the alignment
             a &= ~3u;
             P2P_AUD_RANGE(P.audit, AUD_GATHER_SRC, a + d_lo[j], 12u, P.pano_stride);
-            R.U[j] = __builtin_amdgcn_raw_buffer_load_b96(S, (int)a, 0, 0);
-            R.L[j] = __builtin_amdgcn_raw_buffer_load_b96(S, (int)(a + d_lo[j]), 0, 0);
+            R.U[j] = __builtin_amdgcn_raw_buffer_load_b96(S, (int)a, 0, P2P_GATHER_LOAD_AUX);
+            R.L[j] = __builtin_amdgcn_raw_buffer_load_b96(S, (int)(a + d_lo[j]), 0, P2P_GATHER_LOAD_AUX);
         }
     };
     // the two rot taps of one row from its three source pixels (bytes o .. o + 8 of the load)
