@@ -775,9 +775,11 @@ int choose_shape(const p2p_job_desc& d, const Options& opt)
         return forced == 128;
     const size_t out_row = 12 * (((size_t)d.ow + 3) / 4);
     const size_t bytes = (size_t)d.n_panos * d.n_yaw * d.n_pitch * d.oh * out_row;
-    // (several resident panoramas stream from HBM as well: 16 of config 2's, 3.6 GB of views, 1.59 against 1.64 ms; 8 of
-    // them, 1.8 GB, 0.785 against 0.80; ONE panorama and 2.2 GB, config 5, 768 against 750 us)
-    const size_t from = d.n_panos > 1 ? (size_t)3 << 29 : (size_t)4 << 30;
+    // (several resident panoramas stream from HBM as well, and the 64-wide kernel's nt sc1 stores are for launches that
+    // stay in the Infinity Cache: of config 2's panoramas 3, 0.67 GB of views, 253 us with 64-wide tiles against 267; 4,
+    // 0.9 GB, 413 against 401; 8 0.83 against 0.79 ms; 16 1.64 against 1.56; ONE panorama and 2.2 GB, config 5, 720
+    // against 768 us: tools/ab_shape_threshold.sh)
+    const size_t from = d.n_panos > 1 ? (size_t)3 << 28 : (size_t)4 << 30;
     // (a strongly minifying view set is drawn by the gather kernel, which gains nothing from wide tiles: 16K -> 2048^2
     // at FOV 110, 4.5 GB, 5.28 ms with 64-wide tiles against 5.49)
     const double src_px_per_out_px = (double)d.pw * d.fov_deg / (360.0 * d.ow);
