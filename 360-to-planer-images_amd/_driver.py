@@ -6,7 +6,7 @@ pitch) view is independent work, exactly as the reference treats i
   DevicePipeline   one GPU, two resident jobs used alternately: while image k is resampled, image k+1 is already
                    uploading (its own stream) and the views of image k-1 are downloading (a third stream)
                    -- the cv2.imread (P:244) / cv2.imwrite (P:277) boundary of the reference, overlapped;
-  shard_views      the (yaw x pitch) view list of ONE image dealt round-robin to N devices, pitch-major, so that a
+  shard_views      the (yaw x pitch) view list of ONE image cut into N contiguous runs, pitch-major, so that a
                    device's share falls into few (pitch, yaw subset) groups and keeps few pitch plans;
   process_views_sharded
                    one image on several GPUs: one host thread per device, ONE job per device that draws exactly the
@@ -25,22 +25,37 @@ def shard_round_robin(n_items, world, rank):
     return list(range(rank, n_items, world))
 
 
-def shard_views(n_yaw, n_pitch, world, rank):
-    """This rank's views of one image as {pitch index: [yaw indices]}: the pitch-major list
-    (p0,y0), (p0,y1) ... (p1,y0) ... dealt round-robin, so consecutive ranks get consecutive yaws of one pitch."""
+def shard_blocks(n_items, world, rank):
+    """Items 0..n-1 cut into `world` contiguous runs whose lengths differ by at most one (the longer ones first)."""
+    base, rem = divmod(int(n_items), int(world))
+    first = rank * base + min(rank, rem)
+    return list(range(first, first + base + (1 if rank < rem else 0)))
+
+
+def shard_views(n_yaw, n_pitch, world, rank, how="auto"):
+    """This rank's views of one image as {pitch index: [yaw indices]}.  The pitch-major list (p0,y0), (p0,y1) ...
+    (p1,y0) ... is cut into contiguous runs, one per rank ("blocks"): consecutive yaws of ONE pitch view (of two where
+    a run crosses a pitch boundary), so that the rank's masked job sets every tile of that pitch view up once for all
+    its yaws.  Config 2's 36 views, slowest rank's launch: 3 ranks 38.0 us (dealt round-robin: 40.0), 6 ranks 23.4
+    (28.5), 8 ranks 23.6 (28.0), 12 ranks 17.0 (23.7) -- tools/sharded_rank_times.py.  With fewer ranks than pitch
+    views and a yaw count they divide ("auto" then deals round-robin) every rank gets the same yaws of EVERY pitch
+    view, a full grid without a mask: 2 ranks 50.4 us against 54.6 in blocks."""
+    if how == "auto":
+        how = "round_robin" if (world < n_pitch and n_yaw % world == 0) else "blocks"
+    deal = shard_round_robin if how == "round_robin" else shard_blocks
     groups = {}
-    for v in shard_round_robin(n_yaw * n_pitch, world, rank):
+    for v in deal(n_yaw * n_pitch, world, rank):
         groups.setdefault(v // n_yaw, []).append(v % n_yaw)
     return groups
 
 
-def rank_view_set(n_yaw, n_pitch, world, rank):
+def rank_view_set(n_yaw, n_pitch, world, rank, how="auto"):
     """The ONE masked job a rank draws its share of an image with: (yaw_idx, pitch_idx, mask, mine).  yaw_idx and
     pitch_idx are the image's yaw / pitch indices that occur in the rank's share (ascending: the job's own angle
     lists), mask is uint8 [len(yaw_idx)][len(pitch_idx)] with 1 where the combination is the rank's own (the layout
     p2p_job_set_view_mask takes), mine the share as (yaw, pitch) image indices in pitch-major order.  A rank with no
     views gets ([], [], empty mask, [])."""
-    groups = shard_views(n_yaw, n_pitch, world, rank)
+    groups = shard_views(n_yaw, n_pitch, world, rank, how)
     yaw_idx = sorted({y for ys in groups.values() for y in ys})
     pitch_idx = sorted(groups)
     mine = [(y, p) for p in pitch_idx for y in groups[p]]
@@ -156,7 +171,7 @@ def release_sharded():
 
 
 def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0):
-    """Every (yaw, pitch) view of ONE panorama drawn by several GPUs: views dealt round-robin, pitch-major
+    """Every (yaw, pitch) view of ONE panorama drawn by several GPUs: the pitch-major view list in contiguous runs
     (shard_views); each device uploads the panorama once, draws its (pitch, yaw subset) groups and downloads them;
     the host stitches [n_yaw][n_pitch][oh][ow][3].  `devices` may name a device twice (two contexts on one GPU).
     A device slot keeps its jobs (device buffers, plan, yaw tables) for the next image of the same geometry, as the

@@ -250,7 +250,7 @@ def process_single_image(
 
 def _views_of(input_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg, device=None):
     """Every view of one image.  With several devices selected (set_devices) and this single image to draw, the
-    (yaw x pitch) views are dealt round-robin, pitch-major, to all of them; otherwise one device."""
+    (yaw x pitch) views are cut, pitch-major, into one run per device; otherwise one device."""
     if device is None and _DEVICES and len(_DEVICES) > 1:
         return _driver.process_views_sharded(input_image, [_angle(y, "yaw angle") for y in yaw_angles],
                                              [_angle(p, "pitch angle") for p in pitch_angles], output_width,
@@ -438,7 +438,7 @@ def main(
                 pipe.close()
 
         if _DEVICES and len(_DEVICES) > 1 and len(all_images) < len(_DEVICES):
-            # fewer images than GPUs: every image is drawn by all of them, its views dealt round-robin
+            # fewer images than GPUs: every image is drawn by all of them, each its run of the view list
             logging.info(f"Dealing the views of each of {len(all_images)} images to devices {_DEVICES}")
             for image_file in all_images:
                 process_single_image(input_image_path=image_file, **common)

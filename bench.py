@@ -375,7 +375,7 @@ def main():
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="weak: every rank gets --panos-per-gpu panoramas of its own (default for cfg2 / cfg4 / cfg5); "
                          "strong: the workload's total is split -- cfg3's 64 panoramas dealt to the ranks (its default), "
-                         "or, for a single-panorama workload, its (yaw x pitch) views dealt round-robin, pitch-major")
+                         "or, for a single-panorama workload, its (yaw x pitch) views in pitch-major runs")
     ap.add_argument("--maps", default="fused", choices=["fused", "caller"],
                     help="fused: coordinate maps computed in-kernel (default, the product path); "
                          "caller: float maps handed in (the bit-exact mode)")
@@ -449,8 +449,8 @@ def main():
             jobs.append(nat.Job(ctx, w["pw"], w["ph"], npg, w["yaws"], w["pitches"], w["fov"], w["ow"], w["oh"], flags=flags))
         views_per_rank = npg * n_yaw * n_pitch
     elif args.scaling == "strong":
-        # one panorama, its (yaw x pitch) views dealt round-robin, pitch-major (36 views on 8 GPUs
-        # = 4 or 5 each, a 7.2x cap); every rank uploads the panorama once, its groups share it
+        # one panorama, its pitch-major view list cut into one contiguous run per rank (36 views on 8 GPUs
+        # = 5 or 4 consecutive yaws of one pitch view each); every rank uploads the panorama once
         yaw_idx, pitch_idx, mask, mine_views = drv.rank_view_set(n_yaw, n_pitch, dist.world, dist.rank)
         npg, total_views, seeds = 1, n_yaw * n_pitch, [1000]
         if mine_views:
@@ -462,7 +462,7 @@ def main():
                 j.set_view_mask(mask)
             jobs.append(j)
         views_per_rank = len(mine_views)
-        sharding = "views of one panorama dealt round-robin pitch-major, %d on this rank in one masked job, no collective" % views_per_rank
+        sharding = "views of one panorama, pitch-major runs, %d on this rank in one job, no collective" % views_per_rank
     else:
         npg = args.panos_per_gpu
         total_views = npg * n_yaw * n_pitch * dist.world

@@ -67,8 +67,9 @@ def test_round_robin_edge_cases():
     assert bench.algorithmic_bytes(w, 1) == 3 * 8192 * 4096 + 3 * 1920 * 1080 * 36 == 324612096
 
 
+@pytest.mark.parametrize("how", ["auto", "blocks", "round_robin"])
 @pytest.mark.parametrize("n_yaw,n_pitch,world", [(12, 3, 8), (12, 3, 2), (12, 3, 1), (4, 1, 3), (1, 1, 4), (5, 7, 6), (360, 1, 8)])
-def test_rank_view_sets_cover_every_view_exactly_once(n_yaw, n_pitch, world):
+def test_rank_view_sets_cover_every_view_exactly_once(n_yaw, n_pitch, world, how):
     """The masked job of each rank (what bench.py --scaling strong and process_views_sharded build): the ranks' masks,
     mapped back to the image's view indices, are a partition of the yaw x pitch grid, sized within one of each other."""
     import importlib
@@ -80,7 +81,7 @@ def test_rank_view_sets_cover_every_view_exactly_once(n_yaw, n_pitch, world):
     seen = np.zeros((n_yaw, n_pitch), np.int32)
     sizes = []
     for rank in range(world):
-        yaw_idx, pitch_idx, mask, mine = drv.rank_view_set(n_yaw, n_pitch, world, rank)
+        yaw_idx, pitch_idx, mask, mine = drv.rank_view_set(n_yaw, n_pitch, world, rank, how)
         assert mask.shape == (len(yaw_idx), len(pitch_idx)) and mask.dtype == np.uint8
         assert yaw_idx == sorted(set(yaw_idx)) and pitch_idx == sorted(set(pitch_idx))
         assert int(mask.sum()) == len(mine) == len(set(mine))
@@ -101,8 +102,13 @@ def test_rank_view_set_of_config_2_on_8_gpus():
 
     sys.path.insert(0, ROOT)
     drv = importlib.import_module("360-to-planer-images_amd._driver")
-    yaw_idx, pitch_idx, mask, mine = drv.rank_view_set(12, 3, 8, 0)  # views 0, 8, 16, 24, 32 of the pitch-major list
-    assert mine == [(0, 0), (8, 0), (4, 1), (0, 2), (8, 2)]
-    assert yaw_idx == [0, 4, 8] and pitch_idx == [0, 1, 2]
-    assert mask.tolist() == [[1, 0, 1], [0, 1, 0], [1, 0, 1]]     # 5 of a 3 x 3 grid
-    assert drv.rank_view_set(2, 1, 4, 3)[3] == []                # more ranks than views
+    yaw_idx, pitch_idx, mask, mine = drv.rank_view_set(12, 3, 8, 0)  # views 0..4 of the pitch-major list
+    assert mine == [(0, 0), (1, 0), (2, 0), (3, 0), (4, 0)]
+    assert yaw_idx == [0, 1, 2, 3, 4] and pitch_idx == [0] and mask.all()    # five yaws of one pitch view: no mask needed
+    yaw_idx, pitch_idx, mask, mine = drv.rank_view_set(12, 3, 8, 2)  # the run that crosses from pitch 0 to pitch 1
+    assert mine == [(10, 0), (11, 0), (0, 1), (1, 1), (2, 1)]
+    assert yaw_idx == [0, 1, 2, 10, 11] and pitch_idx == [0, 1]
+    assert mask.tolist() == [[0, 1], [0, 1], [0, 1], [1, 0], [1, 0]]         # 5 of a 5 x 2 grid
+    yaw_idx, pitch_idx, mask, mine = drv.rank_view_set(12, 3, 8, 0, "round_robin")  # (the dealing before: 5 of a 3 x 3 grid)
+    assert mine == [(0, 0), (8, 0), (4, 1), (0, 2), (8, 2)] and mask.tolist() == [[1, 0, 1], [0, 1, 0], [1, 0, 1]]
+    assert drv.rank_view_set(2, 1, 4, 3)[3] == []                            # more ranks than views

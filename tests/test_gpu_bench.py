@@ -69,7 +69,7 @@ def test_two_ranks_on_one_gpu_dry_run(gpu):
 def test_multi_rank_defaults_config3_share_and_view_sharding(gpu):
     """--gpus N > 1 defaults to the metric's own configuration on every rank (one panorama x 36 views each, "weak");
     --workload cfg3 deals config 3's 64 panoramas (64 / N resident per GPU, "strong"); --scaling strong on config 2 deals
-    its 36 views round-robin, pitch-major, one masked job per rank.  Two gloo ranks on the one GPU."""
+    its 36 views (pitch-major runs; on two ranks every other yaw of all pitch views), one job per rank.  Two gloo ranks on the one GPU."""
     env = dict(os.environ, P2P_BENCH_BACKEND="gloo", P2P_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
             "--master-addr", "127.0.0.1"]

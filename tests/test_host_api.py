@@ -219,22 +219,30 @@ def test_multi_device_round_robin_of_a_folder(pkg, tmp_path, monkeypatch):
     assert len(list((tmp_path / "out").iterdir())) == 7
 
 
-def test_view_sharding_pitch_major_round_robin(pkg):
-    """with fewer images than GPUs the (yaw x pitch) views of an image are dealt round-robin,
-    pitch-major; every view exactly once, shares differ by at most one view, few pitch groups per device."""
+def test_view_sharding_pitch_major_runs(pkg):
+    """with fewer images than GPUs the (yaw x pitch) views of an image are cut, pitch-major, into one
+    contiguous run per device (round-robin where that gives every device a full grid: fewer devices than pitch views);
+    every view exactly once, shares differ by at most one view, at most two pitch views per device in runs."""
     d = importlib.import_module("360-to-planer-images_amd._driver")
-    for n_yaw, n_pitch, world in ((12, 3, 8), (12, 3, 2), (4, 5, 8), (1, 1, 8), (360, 1, 8), (7, 3, 5)):
-        seen, sizes = set(), []
-        for r in range(world):
-            g = d.shard_views(n_yaw, n_pitch, world, r)
-            views = [(p, y) for p, ys in g.items() for y in ys]
-            assert not (seen & set(views))
-            seen |= set(views)
-            sizes.append(len(views))
-        assert seen == {(p, y) for p in range(n_pitch) for y in range(n_yaw)}
-        assert max(sizes) - min(sizes) <= 1
-    # config 2 on 8 GPUs: 36 views -> 4 or 5 per device; the 7.2x cap of SURVEY 8(e)
-    assert sorted(sum(len(v) for v in d.shard_views(12, 3, 8, r).values()) for r in range(8)) == [4] * 4 + [5] * 4
+    for n_yaw, n_pitch, world in ((12, 3, 8), (12, 3, 2), (4, 5, 8), (1, 1, 8), (360, 1, 8), (7, 3, 5), (12, 3, 3), (12, 3, 6)):
+        for how in ("auto", "blocks", "round_robin"):
+            seen, sizes = set(), []
+            for r in range(world):
+                g = d.shard_views(n_yaw, n_pitch, world, r, how)
+                views = [(p, y) for p, ys in g.items() for y in ys]
+                assert not (seen & set(views))
+                seen |= set(views)
+                sizes.append(len(views))
+                if how == "blocks" and n_yaw >= len(views):
+                    assert len(g) <= 2, (n_yaw, n_pitch, world, r, g)   # one pitch view, or a run across one boundary
+            assert seen == {(p, y) for p in range(n_pitch) for y in range(n_yaw)}
+            assert max(sizes) - min(sizes) <= 1
+    # config 2 on 8 GPUs: 36 views -> 5 or 4 per device (the 7.2x cap of SURVEY 8(e)), consecutive yaws of one pitch view
+    assert [sum(len(v) for v in d.shard_views(12, 3, 8, r).values()) for r in range(8)] == [5] * 4 + [4] * 4
+    assert d.shard_views(12, 3, 8, 0) == {0: [0, 1, 2, 3, 4]} and d.shard_views(12, 3, 8, 2) == {0: [10, 11], 1: [0, 1, 2]}
+    # on 2 GPUs: every other yaw of all three pitch views -- a full 6 x 3 grid per device
+    assert d.shard_views(12, 3, 2, 1) == {0: [1, 3, 5, 7, 9, 11], 1: [1, 3, 5, 7, 9, 11], 2: [1, 3, 5, 7, 9, 11]}
+    assert d.shard_blocks(10, 4, 0) == [0, 1, 2] and d.shard_blocks(10, 4, 3) == [8, 9] and d.shard_blocks(2, 4, 3) == []
 
 
 def test_integration_stubs_compile_and_bind_exported_entry_points(nat):
