@@ -796,9 +796,12 @@ int choose_pairs_per_block(const p2p_job_desc& d, const p2p::TileShape& S, const
         forced = 64;  // the kernel keeps one pair context per lane of a wave
     if (forced > 0)
         return forced > n_pairs ? n_pairs : forced;
-    // keep >= ~8 workgroups per CU in flight, otherwise amortise the map maths over many pairs
+    // about 8 workgroups per CU in flight, otherwise amortise the tile's set-up over many pairs.  Rounded to the nearest
+    // count, not up: one pitch view of 1920 x 1080 is 2040 tiles, and two workgroups per tile instead of one cost a
+    // 5-yaw job 22.4 us instead of 19.9, a 4-yaw job 20.1 instead of 17.1 (tools/ab_small_job_ppb.sh) -- the shares of
+    // the view-sharded multi-GPU path
     const long long target = 256LL * 8;
-    long long z = (target + base - 1) / base;
+    long long z = (target + base / 2) / base;
     if (z < 1) z = 1;
     if (z > n_pairs) z = n_pairs;
     int ppb = (int)((n_pairs + z - 1) / z);
