@@ -805,6 +805,10 @@ int choose_pairs_per_block(const p2p_job_desc& d, const p2p::TileShape& S, const
     if (z < 1) z = 1;
     if (z > n_pairs) z = n_pairs;
     int ppb = (int)((n_pairs + z - 1) / z);
+    // (never fewer than 3 pairs behind one set-up, however few the tiles: 640 x 360, 230 tiles, 12 yaws: 1 / 2 / 3 / 4 / 6
+    // pairs per workgroup 10.7 / 8.5 / 7.7 / 7.7 / 8.1 us)
+    if (ppb < 3)
+        ppb = n_pairs < 3 ? n_pairs : 3;
     // measured on the plan-driven kernel (config 5, 360 yaws): 16 pairs per workgroup 0.885 ms, 30: 0.843, 45: 0.835,
     // 60: 0.832 -- the per-workgroup set-up is small now.  Chunks that run across several panoramas are another
     // matter (8 resident panoramas: 16 pairs 0.843 ms, 48 pairs 0.894): their sources compete for the caches
