@@ -74,6 +74,9 @@ struct ViewsParams {
     int main_group, main_chunks;  // list entries an XCD draws for one chunk of pairs before it turns to the next chunk; chunks of pairs
                                   // (main_chunks counts workgroups per tile: chunks of pairs / main_span, rounded up)
     int main_span;           // main kernel: chunks of pairs ONE workgroup draws, one after the other (>= 1)
+    int main_tail;           // list order, one chunk of pairs: the last main_tail entries of every XCD's list are drawn by
+    int main_tail_parts;     // main_tail_parts workgroups each, a part of the pairs each (0 = off)
+    int main_count[8];       // entries of each XCD's list
     int pf_lead;             // main kernel: > 0 = every (PF_GROUP + 1)-th workgroup of an XCD's run draws nothing and touches the plan
                              // tables of the PF_GROUP tiles that start pf_lead groups later (p2p_tile.h: main_block_role)
     int chunk_outer;         // tile grids: 0 = (tile, chunk, pitch view), 1 = (tile, pitch view, chunk) -- see pair_chunk

@@ -76,6 +76,8 @@ struct Options {
     int chunk_outer = -1;             // P2P_CHUNK_OUTER
     int main_order = -1;              // P2P_MAIN_ORDER: 0 grid order, 1 list order, 2 list order also with several panoramas; -1 = by job
     int main_group = -1;              // P2P_MAIN_GROUP
+    int main_tail = -1;               // P2P_MAIN_TAIL: list entries per XCD, at the end of its list, drawn by several workgroups each (-1: rule)
+    int main_tail_parts = 2;          // P2P_MAIN_TAIL_PARTS: ... by how many (2..4)
     int main_span = -1;               // P2P_MAIN_SPAN: chunks of pairs one main-kernel workgroup draws (-1: the library's rule)
     int prefetch_lead = -1;           // P2P_PREFETCH_LEAD
     int force_rest = 0;               // P2P_FORCE_REST
@@ -110,6 +112,8 @@ void options_load_locked()
     o.main_order = env_int("P2P_MAIN_ORDER", o.main_order);
     o.main_group = env_int("P2P_MAIN_GROUP", o.main_group);
     o.main_span = env_int("P2P_MAIN_SPAN", o.main_span);
+    o.main_tail = env_int("P2P_MAIN_TAIL", o.main_tail);
+    o.main_tail_parts = std::min(4, std::max(2, env_int("P2P_MAIN_TAIL_PARTS", o.main_tail_parts)));
     o.prefetch_lead = env_int("P2P_PREFETCH_LEAD", o.prefetch_lead);
     o.force_rest = env_int("P2P_FORCE_REST", o.force_rest);
     o.gather_ppb = env_int("P2P_GATHER_PPB", o.gather_ppb);
@@ -347,6 +351,7 @@ struct Plan {  // the plan pass's tables (p2p_plan.hip)
     uint32_t* d_xcd_all = nullptr;       // [8][xcd_all_stride] every tile, likewise (only when most tiles gather: ViewsParams::gather_all)
     uint32_t* d_main_list = nullptr;     // [8][main_stride] the LDS-scheme tiles, dealt to the XCDs in source order (xcd_main_lists)
     int xcd_stride = 0, xcd_all_stride = 0, main_stride = 0;
+    int main_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // entries of each XCD's main list (the rest of its main_stride is empty)
     int n_gather = 0;
     bool built = false;
     float plan_ms = 0.0f;                // device time of the plan pass
@@ -623,6 +628,7 @@ struct p2p_job {
     int xcd_stride = 0, xcd_all_stride = 0;
     uint32_t* d_main_list = nullptr;     // the main kernel's per-XCD work lists (see Plan)
     int main_stride = 0;
+    int main_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t* d_odd_pairs = nullptr;     // (panorama, yaw) pairs whose yaw is not a plain shift with one weight
     int n_odd_pairs = 0;
     int n_gather = 0;                    // tiles the plan marks for gathers
@@ -1583,6 +1589,12 @@ static int job_build_plan(p2p_job* j)
     }
     if (make_main_list) {  // (tm, tg, ta stay alive until the stream has taken the copies: synchronised below)
         tm = xcd_main_lists(hh, j->n_tiles, &Pl->main_stride);
+        for (int x = 0; x < 8; ++x) {
+            int c = 0;
+            while (c < Pl->main_stride && tm[(size_t)x * Pl->main_stride + c] != ~0u)
+                ++c;
+            Pl->main_count[x] = c;
+        }
         HIP_TRY(dev_alloc((void**)&Pl->d_main_list, tm.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpyAsync(Pl->d_main_list, tm.data(), tm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         Pl->bytes += tm.size() * sizeof(uint32_t);
@@ -1735,6 +1747,8 @@ int p2p_job_run(p2p_job* j)
         j->d_gather_list = Pl.d_gather_list; j->d_xcd_list = Pl.d_xcd_list; j->d_xcd_all = Pl.d_xcd_all;
         j->xcd_stride = Pl.xcd_stride; j->xcd_all_stride = Pl.xcd_all_stride; j->n_gather = Pl.n_gather;
         j->d_main_list = Pl.d_main_list; j->main_stride = Pl.main_stride;
+        for (int x = 0; x < 8; ++x)
+            j->main_count[x] = Pl.main_count[x];
     }
     const Options& opt = j->opt;
     P.pairs_per_block = choose_pairs_per_block(j->d, shape_ops(j->shape).shape, opt);
@@ -1749,6 +1763,8 @@ int p2p_job_run(p2p_job* j)
     // entries drawn for one chunk of pairs before the next chunk: with ONE panorama a short run (the entries' plan tables
     // and source rows are still in L2 for the next chunk), with several all of them (a chunk's panoramas serve every
     // tile before the next ones are touched: see pair_chunk)
+    for (int x = 0; x < 8; ++x)
+        P.main_count[x] = j->main_count[x];
     P.main_group = P.chunk_outer ? std::max(1, j->main_stride)
                                  : std::max(1, std::min(j->main_stride, choose_main_group(opt, j->shape, P.main_span, pair_chunks)));
     // table-prefetch workgroups (p2p_tile.h: main_block_role) when one launch's plan tables cannot stay in the Infinity
@@ -1756,6 +1772,16 @@ int p2p_job_run(p2p_job* j)
     {
         const size_t table_bytes = plan_table_bytes(j->d, shape_ops(j->shape).shape);
         P.pf_lead = opt.prefetch_lead >= 0 ? opt.prefetch_lead : (table_bytes > ((size_t)128 << 20) ? 2 : 0);
+    }
+    // The last entries of every XCD's list as two workgroups of half the pairs each: when the list runs out, the
+    // workgroups in flight end over a whole workgroup's life (25 us on config 2) with ever fewer of them left -- half
+    // of that is lost.  Shorter workgroups at the end shorten it.  Only where one workgroup draws ALL pairs of its tile.
+    P.main_tail = 0;
+    P.main_tail_parts = opt.main_tail_parts;
+    if (P.main_list && pair_chunks == 1 && P.main_span == 1 && P.pf_lead == 0 && j->d.n_panos * j->d.n_yaw >= 4) {
+        const int in_flight = 32 * (j->shape ? 3 : 7);  // workgroups an XCD holds at a time
+        P.main_tail = opt.main_tail >= 0 ? opt.main_tail : in_flight / 5;
+        P.main_tail = std::min(P.main_tail, j->main_stride);
     }
     P.pitch_order = j->d_pitch_order;
     P.coords = j->d_coords;
@@ -2256,7 +2282,7 @@ static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride
     auto same_options = [&](const Options& a) {
         return a.plan_cache == now.plan_cache && a.tile_shape == now.tile_shape && a.pairs_per_block == now.pairs_per_block &&
                a.max_pairs_per_block == now.max_pairs_per_block && a.chunk_outer == now.chunk_outer && a.main_order == now.main_order &&
-               a.main_group == now.main_group && a.main_span == now.main_span && a.prefetch_lead == now.prefetch_lead && a.force_rest == now.force_rest &&
+               a.main_group == now.main_group && a.main_span == now.main_span && a.main_tail == now.main_tail && a.main_tail_parts == now.main_tail_parts && a.prefetch_lead == now.prefetch_lead && a.force_rest == now.force_rest &&
                a.gather_ppb == now.gather_ppb && a.gather_all == now.gather_all && a.gather_blocky_from == now.gather_blocky_from &&
                a.gather_order == now.gather_order && a.gather_group == now.gather_group && a.scramble_plan == now.scramble_plan;
     };

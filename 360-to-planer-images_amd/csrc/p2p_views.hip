@@ -238,10 +238,11 @@ __device__ __forceinline__ int pair_of_lane(const ViewsParams& P, bool list, int
 // LIST: the chunk's pairs come from P.odd_pairs (the rest kernel drawing only the yaws left to it) instead of being
 // the contiguous run chunk * pairs_per_block ...
 template <bool LIST = false>
-__device__ __forceinline__ PairCtxs pair_contexts(const ViewsParams& P, const YawDesc* __restrict__ ydesc, int c0, int c1, int t, int chunk, int pitch_i)
+__device__ __forceinline__ PairCtxs pair_contexts(const ViewsParams& P, const YawDesc* __restrict__ ydesc, int c0, int c1, int t, int chunk, int pitch_i,
+                                                  int ppb = 0)
 {
     PairCtxs X;
-    pair_chunk(P, LIST, LIST ? P.rest_ppb : P.pairs_per_block, chunk, X.pair0, X.npairs);
+    pair_chunk(P, LIST, LIST ? P.rest_ppb : (ppb > 0 ? ppb : P.pairs_per_block), chunk, X.pair0, X.npairs);
     const int ngroups = P.pw >> 2;
     uint32_t cw0 = 0, cw1 = 0;
     int cw2 = 0, cw3 = 0, cls = 4;
@@ -392,7 +393,7 @@ __device__ __forceinline__ void store_wave_pixels(const StoreCtx& s, const uint3
 __device__ __forceinline__ void draw_tight(
     const ViewsParams& P, const uint8_t* __restrict__ src, const YawDesc* __restrict__ ydesc,
     uint8_t* __restrict__ out, const TileGeo& G, const uint32_t* __restrict__ pxw, const uint32_t* __restrict__ itw,
-    uint4 (*tile4)[LDS_ITEMS_CAP], uint32_t* stage, int chunk)
+    uint4 (*tile4)[LDS_ITEMS_CAP], uint32_t* stage, int chunk, int ppb = 0)
 {
     constexpr int PXT = VIEWS_PXT;
     const int t = threadIdx.x;
@@ -405,7 +406,7 @@ __device__ __forceinline__ void draw_tight(
     // the loop's live values cost it 5 spilled ones; the host asks for spans with 128-wide tiles only.
     constexpr bool SPAN_LOOP = TILE_W == 128;
     const int chunk_end = chunk + (SPAN_LOOP && P.main_span > 1 ? P.main_span : 1);
-    PairCtxs X = pair_contexts(P, ydesc, G.c0, G.c1, t, chunk, G.pitch_i);
+    PairCtxs X = pair_contexts(P, ydesc, G.c0, G.c1, t, chunk, G.pitch_i, ppb);
     int nplain = X.n3;
     if (nplain == 0 && chunk + 1 == chunk_end)
         return;
@@ -698,7 +699,7 @@ __device__ __forceinline__ void draw_tight(
             break;
         // the next chunk of this tile: new pair contexts, everything else stands.  The tile buffers keep alternating
         // (the last pair's taps are still being read by slower waves from the buffer this wave does NOT write next).
-        X = pair_contexts(P, ydesc, G.c0, G.c1, t, ch, G.pitch_i);
+        X = pair_contexts(P, ydesc, G.c0, G.c1, t, ch, G.pitch_i, ppb);
         nplain = X.n3;
         if (X.npairs == 0)
             break;  // past the job's last chunk
@@ -1247,8 +1248,32 @@ __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views
     uint32_t* const stage = nullptr;  // staged inside the tile buffers (draw_tight)
 #endif
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
-    int tile_id, pitch_i, chunk;
-    if (P.main_list) {
+    int tile_id, pitch_i, chunk, ppb = 0;
+    if (P.main_list && P.main_tail > 0) {
+        // List order, ONE chunk of pairs, no prefetch workgroups (the host's rule): entry q of the XCD's list -- but its
+        // last main_tail entries are drawn by main_tail_parts workgroups each, a part of the pairs each (p2p_host.cpp: main_tail).
+        const uint32_t q = blockIdx.x >> 3, L = (uint32_t)P.main_count[blockIdx.x & 7u];
+        const uint32_t K = (uint32_t)P.main_tail < L ? (uint32_t)P.main_tail : L;
+        uint32_t e = q;
+        chunk = 0;
+        if (q >= L - K) {
+            const uint32_t i = q - (L - K), parts = (uint32_t)P.main_tail_parts;
+            if (i >= parts * K)
+                return;
+            e = L - K + i / parts;
+            chunk = (int)(i - (i / parts) * parts);
+            ppb = (P.n_panos * P.n_yaw + (int)parts - 1) / (int)parts;
+        }
+        if (e >= (uint32_t)P.main_stride)
+            return;
+        uint32_t slot = P.main_list[(blockIdx.x & 7u) * (uint32_t)P.main_stride + e];
+        if (slot == ~0u)
+            return;
+        P2P_AUD_LT(P.audit, AUD_MAIN_PITCH, slot, (uint32_t)(tiles * P.n_pitch));
+        slot = slot < (uint32_t)(tiles * P.n_pitch) ? slot : 0u;  // (a garbage list draws a valid tile)
+        pitch_i = (int)(slot / (uint32_t)tiles);
+        tile_id = (int)(slot - (uint32_t)pitch_i * (uint32_t)tiles);
+    } else if (P.main_list) {
         // List order (p2p_host.cpp: xcd_main_lists): workgroup b runs on XCD b & 7 and is that XCD's q-th, q = b >> 3.
         // The XCD draws main_group entries of its list for one chunk of pairs, the same entries for the next chunk
         // (their plan tables and source rows are still in its L2), and so on, then the next main_group entries.
@@ -1329,10 +1354,10 @@ __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views
 #endif
 #ifdef P2P_ABLATE_ITEMS_WINDOW  // timing experiment (wrong pixels): the item lists of 64 tiles serve all -- what item lists of no size would give
     draw_tight(P, src, ydesc, out, G, px + (size_t)G.slot * (VIEWS_BLOCK * VIEWS_PXT), items + (size_t)(G.slot & 63u) * LDS_ITEMS_CAP,
-               tile4, stage, chunk * (TILE_W == 128 && P.main_span > 1 ? P.main_span : 1));
+               tile4, stage, chunk * (TILE_W == 128 && P.main_span > 1 ? P.main_span : 1), ppb);
 #else
     draw_tight(P, src, ydesc, out, G, px + (size_t)G.slot * (VIEWS_BLOCK * VIEWS_PXT), items + (size_t)G.slot * LDS_ITEMS_CAP,
-               tile4, stage, chunk * (TILE_W == 128 && P.main_span > 1 ? P.main_span : 1));
+               tile4, stage, chunk * (TILE_W == 128 && P.main_span > 1 ? P.main_span : 1), ppb);
 #endif
 }
 
@@ -1433,7 +1458,9 @@ hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
     if (which == 0 && TILE_W == 128 && P.main_span > 1)  // a main-kernel workgroup loops over main_span chunks
         zblocks = (zblocks + P.main_span - 1) / P.main_span;
     dim3 grid(8 * ((tiles + 7) / 8), P.chunk_outer ? P.n_pitch : zblocks, P.chunk_outer ? zblocks : P.n_pitch);
-    if (which == 0 && P.main_list)  // list order: (blocks of main_group entries) x chunks, per XCD
+    if (which == 0 && P.main_list && P.main_tail > 0)  // list order, one chunk: every entry once, the last main_tail of every XCD twice
+        grid = dim3(8 * (P.main_stride + (P.main_tail_parts - 1) * P.main_tail), 1, 1);
+    else if (which == 0 && P.main_list)  // list order: (blocks of main_group entries) x chunks, per XCD
         grid = dim3(8 * ((P.main_stride + P.main_group - 1) / P.main_group) * (P.main_group * P.main_chunks + (P.pf_lead > 0 ? 1 : 0)), 1, 1);
     else if (which == 0 && P.pf_lead > 0)  // one table-prefetch workgroup in PF_GROUP + 1 (p2p_tile.h: main_block_role)
         grid.x = 8 * (((tiles + 7) / 8 + PF_GROUP - 1) / PF_GROUP) * (PF_GROUP + 1);

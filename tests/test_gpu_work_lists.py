@@ -99,6 +99,47 @@ def test_workgroups_that_draw_several_chunks_of_pairs_draw_the_oracles_bytes(gpu
             assert np.array_equal(got[y, p], want[0][y, p]), (y, p)
 
 
+@pytest.mark.parametrize("tile_shape", ["64", "128"])
+def test_tail_entries_drawn_by_several_workgroups_draw_the_oracles_bytes(gpu, synth, monkeypatch, tile_shape, p2p_env):
+    """P2P_MAIN_TAIL / P2P_MAIN_TAIL_PARTS: the last entries of every XCD's main list are drawn by 2..4 workgroups, a
+    part of the job's pairs each (what config 2 ships with: 44 entries, two workgroups) -- no tail, one entry, more
+    entries than the lists hold; odd pair counts; a view mask that empties one part."""
+    pw, ph, ow, oh, fov = 2048, 1024, 333, 210, 90
+    pitches = [8, 60, 90, 150]
+    for yaws in ([0, 14.0625, 33, 90, 123.4, 180, 200, 270, 301, 359], [0, 33, 90, 200, 301]):
+        pano = synth.synth_pano(pw, ph, 4400 + len(yaws), "N")
+        maps = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
+        want = oracle_views(pano, yaws, pitches, ow, oh, fov)
+        p2p_env("P2P_PLAN_CACHE", "0")
+        p2p_env("P2P_TILE_SHAPE", tile_shape)
+        p2p_env("P2P_MAIN_ORDER", "1")
+        for tail, parts in itertools.product(("0", "1", "7", "100000"), ("2", "3", "4")):
+            p2p_env("P2P_MAIN_TAIL", tail)
+            p2p_env("P2P_MAIN_TAIL_PARTS", parts)
+            got = _run(gpu, [pano], yaws, pitches, ow, oh, fov, maps)[0]
+            bad = np.argwhere(got != want)
+            assert bad.size == 0, (tile_shape, len(yaws), tail, parts, len(bad), bad[:3])
+    # the mask leaves the second half of the yaws without a wanted view at pitch 60
+    p2p_env("P2P_MAIN_TAIL", "100000")
+    p2p_env("P2P_MAIN_TAIL_PARTS", "2")
+    mask = np.ones((len(yaws), len(pitches)), np.uint8)
+    mask[3:, 1] = 0
+    ctx = gpu.Context(0)
+    try:
+        job = gpu.Job(ctx, pw, ph, 1, yaws, pitches, fov, ow, oh)
+        job.set_maps(*maps)
+        job.set_view_mask(mask)
+        job.set_pano(0, pano)
+        job.run()
+        got = job.get_views(0)
+        job.close()
+    finally:
+        ctx.close()
+    for y, p in itertools.product(range(len(yaws)), range(len(pitches))):
+        if mask[y, p]:
+            assert np.array_equal(got[y, p], want[y, p]), (y, p)
+
+
 def test_device_maps_job_is_the_same_in_every_order_and_tile_shape(gpu, synth, monkeypatch, p2p_env):
     # the default path (maps evaluated on the device): list order, grid order and both tile shapes agree byte for byte
     pw, ph, ow, oh, fov = 4096, 2048, 640, 360, 90
