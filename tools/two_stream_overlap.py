@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Do two resident jobs on two contexts (two HIP streams) overlap at the ends of their launches?  A launch of config 2 costs
-about 16 us + 11.3 ns per tile: the 16 us are its start and its drain.  Launches of ONE stream run one after the other;
+"""Do two resident jobs on two contexts (two HIP streams) overlap at the ends of their launches?  About 8 us of a launch of config 2
+do not scale with its tiles: its start and its drain.  Launches of ONE stream run one after the other;
 launches of two streams may run side by side.
     python tools/two_stream_overlap.py [--launches 2000]"""
 import argparse, importlib, os, sys, time
