@@ -356,14 +356,24 @@ __device__ __forceinline__ uint4 read_staged_pixels(const StoreCtx& s, const uin
     return *reinterpret_cast<const uint4*>(stg + s.stg_rd);
 }
 
-__device__ __forceinline__ void store_staged_pixels(const StoreCtx& s, const uint4& v, uint8_t* O, uint32_t records)
+__device__ __forceinline__ u32x3 pack_staged_pixels(const uint4& v)
 {
     u32x3 o;
     o.x = __builtin_amdgcn_perm(v.y, v.x, 0x04020100u);  // B0 G0 R0 B1
     o.y = __builtin_amdgcn_perm(v.z, v.y, 0x05040201u);  // G1 R1 B2 G2
     o.z = __builtin_amdgcn_perm(v.w, v.z, 0x06050402u);  // R2 B3 G3 R3
+    return o;
+}
+
+__device__ __forceinline__ void store_packed_pixels(const StoreCtx& s, const u32x3& o, uint8_t* O, uint32_t records)
+{
     __builtin_amdgcn_raw_buffer_store_b96(o, __builtin_amdgcn_make_buffer_rsrc(O, 0, (int)records, 0x00020000),
                                           (int)s.out_off12, 0, TILE_W == 128 ? P2P_MAIN_STORE_AUX_W128 : P2P_MAIN_STORE_AUX_W64);
+}
+
+__device__ __forceinline__ void store_staged_pixels(const StoreCtx& s, const uint4& v, uint8_t* O, uint32_t records)
+{
+    store_packed_pixels(s, pack_staged_pixels(v), O, records);
 }
 
 __device__ __forceinline__ void store_wave_pixels(const StoreCtx& s, const uint32_t (&pix)[VIEWS_PXT], uint8_t* O, size_t view_bytes)
@@ -571,7 +581,11 @@ __device__ __forceinline__ void draw_tight(
             stage1(ns_c, mode_c, pwc, cur, tl4);
 #ifndef P2P_STORE_INLINE
             __builtin_amdgcn_sched_barrier(0);
+#ifdef P2P_STORE_AFTER_LOADS
+            const u32x3 packed = pack_staged_pixels(staged);  // (stored behind the next pair's loads, below)
+#else
             store_staged_pixels(SC, staged, pend_O, pend_records);
+#endif
 #endif
             // LDS position of rot column c0 within its row's first item: 0..3, from the yaw's shift
             uint32_t soff = buf_bytes + 4u * ((pwc.w0 >> 20) & 3u);
@@ -625,6 +639,13 @@ __device__ __forceinline__ void draw_tight(
 #pragma unroll
             for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
                 nxt[sl] = cur[sl];
+#endif
+#if defined(P2P_STORE_AFTER_LOADS) && !defined(P2P_STORE_INLINE)
+            // the store BEHIND the loads: the wait for those pieces (vmcnt counts in issue order) then does not include
+            // this store's acknowledgement, only the one of the pair before
+            __builtin_amdgcn_sched_barrier(0);
+            store_packed_pixels(SC, packed, pend_O, pend_records);
+            __builtin_amdgcn_sched_barrier(0);
 #endif
             uint32_t pix[PXT];
 #pragma unroll

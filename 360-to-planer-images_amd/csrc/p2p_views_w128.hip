@@ -10,4 +10,11 @@
 #define P2P_BLOCK 512
 #define P2P_CAP 1408
 #define P2P_SHAPE_NS w128
+// the main kernel's store goes out BEHIND the next pair's loads in this shape (draw_tight): its launches stream 4-18 GB of
+// views to HBM, and a pair's wait for its pieces then does not include the acknowledgement of the store issued just
+// before them -- config 4 6.22 -> 6.15 / 6.13 -> 6.08 ms, config 3's 64 panoramas 6.02 -> 6.00 / 6.11 -> 6.06; the 64-wide
+// shape, whose views mostly stay in the Infinity Cache, loses 0.3-0.7 % with it (profiles/r04_store_after_loads.txt)
+#ifndef P2P_STORE_BEFORE_LOADS
+#define P2P_STORE_AFTER_LOADS 1
+#endif
 #include "p2p_views.hip"
