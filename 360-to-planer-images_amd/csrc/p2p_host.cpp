@@ -1843,7 +1843,9 @@ int p2p_job_run(p2p_job* j)
                     opt.gather_all != 0) ? 1 : 0;
     // (the gather kernel of a big job on a side stream, forked and joined by events, so that its cache waits overlap
     // the main kernel's arithmetic: config 4's pitch 30 1647 vs 1621 us, all five pitches 8021 vs 7988 -- the two
-    // kernels do not interleave, not kept)
+    // kernels do not interleave, not kept.  Round 4 once more, the side stream at the LOWEST priority and the gather
+    // kernel enqueued behind the main kernel, to fill the slots its last workgroups leave: config 4 6.301 / 6.312 /
+    // 6.303 -> 6.286 / 6.311 / 6.293 ms, five 1080p pitch views x 12 yaws 170.6 -> 174.2 us: not kept either)
     if (j->n_gather > 0) {
         if (gather_ok) {
             P.use_pair_list = 0;
