@@ -100,6 +100,19 @@ static hipError_t stub_views(const ViewsParams& P, int which, hipStream_t)
     if (which == 0 && P.main_list && (P.main_stride < 1 || P.main_group < 1 || P.main_chunks < 1 ||
                                       !list_covers(P.main_list, P.main_stride, P.hdr, slots, true, false)))
         return hipErrorInvalidValue;
+    if (which == 0 && P.main_list) {
+        // what the kernel's tail path indexes with: the count of every XCD's list, and a tail that fits
+        for (int x = 0; x < 8; ++x) {
+            int c = 0;
+            while (c < P.main_stride && P.main_list[(size_t)x * P.main_stride + c] != ~0u)
+                ++c;
+            if (P.main_count[x] != c)
+                return hipErrorInvalidValue;
+        }
+        if (P.main_span < 1 || P.main_tail < 0 || P.main_tail > P.main_stride ||
+            (P.main_tail > 0 && (P.main_tail_parts < 2 || P.main_tail_parts > 4 || P.main_chunks != 1 || P.main_span != 1 || P.pf_lead != 0)))
+            return hipErrorInvalidValue;
+    }
     if (which == 3 && (P.n_list < 1 || !list_covers(P.gather_list, P.n_list, P.hdr, slots, P.gather_all != 0, true)))
         return hipErrorInvalidValue;
     if ((which == 2 || which == 1) && P.n_gather > 0)
