@@ -1449,14 +1449,22 @@ int p2p_job_set_maps(p2p_job* j, const float* yaw_rows, const float* U, const fl
 }
 
 // List order for the main kernel (xcd_main_lists): 1 = jobs with ONE resident panorama, 2 = also with several, 0 = the
-// grid's own order.  By default: one panorama AND several pitch views -- the order exists to make views that read the
-// same source rows neighbours on an XCD; a single pitch view gains nothing from it and pays its index arithmetic
-// (config 5: 0.742 ms in list order against 0.713).
+// grid's own order.  By default: one panorama AND (several pitch views OR all pairs in one workgroup per tile).  The
+// order exists to make views that read the same source rows neighbours on an XCD; a single pitch view drawn in several
+// chunks of pairs gains nothing from it and pays its index arithmetic (config 5, 8 chunks: 0.742 ms in list order
+// against 0.713).  With ONE chunk the lists' equal WORK per XCD (the grid gives every XCD the same number of tiles)
+// and their split tail pay for a single pitch view too: 12 yaws of one 1080p view 37.5 -> 33.0 us, 5 yaws 19.4 -> 19.1
+// (tools/ab_single_pitch_order.sh) -- the shares of the view-sharded path.
 static int job_main_order(const p2p_job* j)
 {
     if (j->opt.main_order >= 0)
         return j->opt.main_order;
-    return (j->d.n_panos == 1 && j->d.n_pitch > 1) ? 1 : 0;
+    if (j->d.n_panos != 1)
+        return 0;
+    if (j->d.n_pitch > 1)
+        return 1;
+    const int ppb = choose_pairs_per_block(j->d, shape_ops(j->shape).shape, j->opt);
+    return (j->d.n_yaw + ppb - 1) / ppb == 1 ? 1 : 0;
 }
 
 int p2p_job_set_view_mask(p2p_job* j, const uint8_t* mask)
