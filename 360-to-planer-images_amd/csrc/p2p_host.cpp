@@ -422,9 +422,15 @@ std::vector<uint32_t> xcd_main_lists(const std::vector<p2p::PieceHdr>& hh, size_
     // every XCD's list has the longest one's length, the shorter ones end in empty entries (spreading those over the
     // list instead: nothing on config 2, 7.31 against 7.02 ms on config 4)
     std::vector<uint32_t> table(8 * per, ~0u);
-    for (int x = 0; x < 8; ++x)
-        for (size_t i = first[x]; i < first[x + 1]; ++i)
-            table[x * per + (i - first[x])] = order[i].second;
+    for (int x = 0; x < 8; ++x) {
+        // an XCD draws its bands from the costlier end (towards a pole) to the cheaper one: the workgroups in flight when
+        // its list runs out are then its shortest (config 2 84.3 / 83.8 / 83.6 -> 82.9 / 83.1 / 83.5 us, config 4 6.10 ->
+        // 6.02 ms, 12 yaws of one 1080p view at pitch 60 33.6 -> 33.2 us)
+        const size_t a = first[x], b = first[x + 1], q = (b - a) / 4;
+        const bool reversed = q > 0 && (upto[b] - upto[b - q]) > (upto[a + q] - upto[a]);
+        for (size_t i = a; i < b; ++i)
+            table[x * per + (i - a)] = order[reversed ? (b - 1 - (i - a)) : i].second;
+    }
     *stride = (int)per;
     return table;
 }
