@@ -387,7 +387,7 @@ uint64_t source_order_key(const p2p::PieceHdr& h)
 // a contiguous part of that order: the tiles of two views that read the same rows follow each other on one XCD and
 // find them in its L2 (117 MB; config 2 -2 ... -3.5 %, config 4 -4.5 %).  Used for jobs with ONE resident panorama:
 // with several, streamed from HBM, the grid's own order is faster.
-std::vector<uint32_t> xcd_main_lists(const std::vector<p2p::PieceHdr>& hh, size_t tiles, int* stride)
+std::vector<uint32_t> xcd_main_lists(const std::vector<p2p::PieceHdr>& hh, size_t tiles, int* stride, int tile_w)
 {
     // (band, view, raster position): the slots come in (view, raster) order, so a counting sort by band does it
     (void)tiles;
@@ -405,10 +405,14 @@ std::vector<uint32_t> xcd_main_lists(const std::vector<p2p::PieceHdr>& hh, size_
     // equal WORK per XCD, not equal counts: a tile costs about 600 + its footprint's items (stage 2 and the way out,
     // plus stage 1 per item), and the footprints grow towards the poles -- with equal counts the two XCDs that hold the
     // polar bands finish last (config 3's share: 7.6 ms against 6.5 in grid order)
+    // (the constant, swept: config 2, 64-wide tiles, is flat from 200 to 1400 -- 84.6 ... 85.1 us, 86.9 at 0, 86.0 at 3000;
+    // config 4, 128-wide tiles of twice the pixels, has a sharp optimum: 450 / 525 / 600 / 675 / 750 / 850 / 1000 give
+    // 6.32 / 6.26 / 6.22 / 6.17 / 6.25 / 6.32 / 6.45 ms)
+    const uint32_t cost_base = tile_w == 128 ? 675u : 600u;
     const size_t n = order.size();
     std::vector<uint64_t> upto(n + 1, 0);
     for (size_t i = 0; i < n; ++i)
-        upto[i + 1] = upto[i] + 600u + (hh[order[i].second].mode_items >> 8);
+        upto[i + 1] = upto[i] + cost_base + (hh[order[i].second].mode_items >> 8);
     size_t first[9];
     first[0] = 0;
     for (int x = 1; x < 8; ++x)
@@ -1602,7 +1606,7 @@ static int job_build_plan(p2p_job* j)
         HIP_TRY(hipStreamSynchronize(st));
     }
     if (make_main_list) {  // (tm, tg, ta stay alive until the stream has taken the copies: synchronised below)
-        tm = xcd_main_lists(hh, j->n_tiles, &Pl->main_stride);
+        tm = xcd_main_lists(hh, j->n_tiles, &Pl->main_stride, shape_ops(j->shape).shape.tile_w);
         for (int x = 0; x < 8; ++x) {
             int c = 0;
             while (c < Pl->main_stride && tm[(size_t)x * Pl->main_stride + c] != ~0u)
