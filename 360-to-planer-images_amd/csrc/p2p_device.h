@@ -35,6 +35,61 @@ struct PieceHdr {
                           // (the order of the gather lists), never by a kernel
 };
 static_assert(sizeof(PieceHdr) == 16, "PieceHdr is read as one s_load_dwordx4");
+// mode 3 (band plans only): the tile's pixels are drawn from source-band tiles (below), the header carries nothing else.
+
+// ---- source-band tiles.  The dual of the tiles above: a tile is a RECTANGLE of the yaw-resampled panorama (a band of
+// rot rows x a run of columns) and the set of 4-pixel output groups -- of ANY pitch view -- whose taps fall into it.
+// Views whose footprints overlap (config 2's 60 / 90 / 120 degree views by half) share stage 1, a strongly minifying
+// view set (the reference CLI's defaults) gets LDS tiles at all, and a lane draws the 4 adjacent pixels it stores: no
+// staging.  Built on the device by the band passes (p2p_plan.hip): groups -> cells of the source (counting sort) -> a
+// greedy cut of every band's cell row into tiles of <= VIEWS_BLOCK groups and <= LDS_ITEMS_CAP items -> per tile the
+// groups in (pitch view, row, column) order, one per lane.
+// A band tile's header is a PieceHdr: mode_items = 3 | n_items << 8 (n_items = rows * row_items, a rectangle: no item
+// list), c0 / c1 as above, rows = first rot row | items per row << 16.  Per pixel word: as above with the distance
+// field reduced to a live flag (the lower tap is one LDS row further: 4 * row_items dwords).  Per group one word: byte
+// offset of its 12 bytes inside the n_pitch views of a (panorama, yaw) pair, ~0 = lane without a group.
+struct BandGeom {
+    int bh, cw;        // cell of the source: bh rot rows x cw columns (a group belongs to the cell of its upper-left tap)
+    int ncx, n_bands;  // cells per band, bands
+    int maxw, maxh;    // a group whose taps span more columns / rows than this sends its tile to the gather kernel
+};
+struct BandTileRec {   // what the cut knows about a tile (24 bytes)
+    uint32_t gstart, gcount;  // its groups: a run of the cell-sorted group list
+    int32_t c0, cmax1;        // columns its taps may read: c0 .. cmax1 (conservative: the cells' extents)
+    int32_t r0, rmax1;        // rows r0 .. rmax1
+};
+struct BandInfo {      // device-side summary, read back once per geometry
+    uint32_t n_tiles, n_groups;
+    uint32_t first[9];     // XCD x draws tiles first[x] .. first[x + 1] - 1 (equal work, at most per_cap each)
+    uint32_t reversed[8];  // ... from the far end (its costlier end first)
+    uint32_t pad[5];
+};
+struct BandParams {
+    int pw, ph, ow, oh, n_pitch;
+    BandGeom g;
+    const int2* coords;       // the plan pass's quantised coordinates
+    uint32_t* cell_count;     // [n_bands * ncx] groups per cell
+    int* cell_cmin;           //   ... their leftmost tap column
+    int* cell_cmax1;          //   ... rightmost tap column
+    int* cell_rmax1;          //   ... lowest tap row
+    uint32_t* cell_off;       //   ... first position in the sorted list
+    uint32_t* cell_cur;       //   ... scatter cursor
+    uint32_t* gcell;          // [n_pitch * oh * ceil(ow / 4)] cell of every group, ~0: its tile gathers
+    uint32_t* band_tiles;     // [n_bands] tiles of the band, then (scan) its first tile
+    uint32_t* band_groups;    // [n_bands] groups of the band, then its first position in the sorted list
+    unsigned long long* band_cost;  // [n_bands] the cut's cost estimate of the band's tiles (band_xcd_kernel)
+    BandInfo* info;
+    BandTileRec* recs;        // [n_tiles]
+    uint32_t* sorted;         // [n_groups] group indices, by cell
+    PieceHdr* hdr;            // [n_tiles] band tile headers
+    uint32_t* px;             // [n_tiles][VIEWS_BLOCK * 4]
+    uint32_t* grp;            // [n_tiles][VIEWS_BLOCK]
+    int n_tiles, n_groups;    // host copies (after the read-back)
+    int out_row;
+    size_t view_bytes;
+    int per_cap;              // tiles per XCD the view kernel's grid provides for
+    uint32_t cost_base;
+};
 // per-pixel word: tap_up (dwords into an LDS buffer, PXW_UP_BITS) | (tap_lo - tap_up) << 12 (PXW_DL_BITS, 0 = the
 // pixel has no footprint: NaN coordinate) | fx << 22 | fy << 27
 // item word: rot row << 16 | 4-pixel group relative to the group of column c0
@@ -112,6 +167,16 @@ struct ViewsParams {
     int mask_words;          // words per pitch: ceil(n_yaw / 32)
     float centre;            // float pixel path only: 0 = the reference's sampling convention, 0.5 = pixel centres
     uint32_t* audit;         // -DP2P_AUDIT builds: the context's violation record (see p2p_audit.h); else nullptr
+    // source-band tiles (band plans): the band kernel draws them for every plain-shift yaw instead of the main kernel
+    const PieceHdr* band_hdr;
+    const uint32_t* band_px;
+    const uint32_t* band_grp;
+    const BandInfo* band_info;
+    int band_tiles;          // tiles (host copy); 0: no band plan
+    int band_per;            // list entries per XCD the grid provides for (>= every first[x + 1] - first[x])
+    int band_tail;           // like main_tail: the last band_tail tiles of every XCD's run are drawn by main_tail_parts workgroups
+    const uint32_t* band_gather_list;  // != nullptr: the plan's gather tiles ([8][band_gather_n] per-XCD lists, as gather_list / n_list)
+    int band_gather_n;                 // are drawn by the first 8 * band_gather_n * (chunks of gather_ppb pairs) workgroups of the band kernel
 };
 
 struct PlanParams {
@@ -130,6 +195,9 @@ struct PlanParams {
     int blocky_from;         // a tile with an output row of 64 pixels across this many source rows is drawn in 16 x 4 blocks (GATHER_BLOCKY_FROM)
     uint32_t* n_gather;      // [0] tiles marked for gathers
     uint32_t* gather_list;   // [n_pitch * tiles] the tiles marked for gathers (pitch * tiles + tile), in no particular order
+    // band plan (band.gcell != nullptr): a tile all of whose groups can go into source-band tiles gets mode 3 and no
+    // tables (px / items are nullptr); its groups are counted into the cells of the source.  The other tiles gather.
+    BandParams band;
 };
 
 struct RemapParams {
@@ -174,6 +242,9 @@ struct ShapeOps {
     hipError_t (*plan)(const PlanParams& P, hipStream_t st);
     hipError_t (*views)(const ViewsParams& P, int which, hipStream_t st);
     hipError_t (*float_views)(const ViewsParams& P, bool half, int which, hipStream_t st);
+    // the band passes after the plan pass: 0 = cut count + scan (then the host reads BandInfo back and allocates),
+    // 1 = cut, scatter, tile build, XCD runs
+    hipError_t (*band)(const BandParams& B, int stage, hipStream_t st);
 };
 const ShapeOps& shape_ops_w64();
 const ShapeOps& shape_ops_w128();
@@ -215,6 +286,7 @@ constexpr int VIEWS_WAVES_PER_SIMD = P2P_WAVES;  // __launch_bounds__ of the mai
 hipError_t launch_plan(const PlanParams& P, hipStream_t st);
 hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st);
 hipError_t launch_float_views(const ViewsParams& P, bool half, int which, hipStream_t st);
+hipError_t launch_band(const BandParams& B, int stage, hipStream_t st);
 }  // namespace P2P_SHAPE_NS
 using namespace P2P_SHAPE_NS;
 #define P2P_SHAPE_OPS_NAME2(ns) shape_ops_##ns

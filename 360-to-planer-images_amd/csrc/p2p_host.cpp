@@ -87,6 +87,10 @@ struct Options {
     int gather_order = 1;             // P2P_GATHER_ORDER
     int gather_group = 3;             // P2P_GATHER_GROUP
     int scramble_plan = 0;            // P2P_SCRAMBLE_PLAN (robustness self-test only)
+    int band = -1;                    // P2P_BAND: 1 = source-band tiles wherever they apply, 0 = never, -1 = the library's rule (choose_band)
+    int band_bh = 16, band_cw = 8;    // P2P_BAND_BH / P2P_BAND_CW: cell of the source, rows x columns
+    int band_maxw = 27, band_maxh = 7;  // P2P_BAND_MAXW / P2P_BAND_MAXH: tap extent of a group beyond which its tile gathers
+    int band_merge = 1;               // P2P_BAND_MERGE: 1 = a band plan's gather tiles are drawn by the first workgroups of the band kernel's launch
 };
 
 void pool_set_budget(size_t bytes);  // (the pool is defined below)
@@ -122,6 +126,12 @@ void options_load_locked()
     o.gather_order = env_int("P2P_GATHER_ORDER", o.gather_order);
     o.gather_group = std::min(8, std::max(0, env_int("P2P_GATHER_GROUP", o.gather_group)));
     o.scramble_plan = env_int("P2P_SCRAMBLE_PLAN", o.scramble_plan);
+    o.band = env_int("P2P_BAND", o.band);
+    o.band_bh = std::min(256, std::max(1, env_int("P2P_BAND_BH", o.band_bh)));
+    o.band_cw = std::min(256, std::max(1, env_int("P2P_BAND_CW", o.band_cw)));
+    o.band_maxw = std::min(255, std::max(3, env_int("P2P_BAND_MAXW", o.band_maxw)));
+    o.band_maxh = std::min(63, std::max(1, env_int("P2P_BAND_MAXH", o.band_maxh)));
+    o.band_merge = env_int("P2P_BAND_MERGE", o.band_merge);
     g_opt = o;
     g_opt_loaded = true;
     pool_set_budget((size_t)o.pool_mb << 20);
@@ -319,12 +329,12 @@ struct PlanKey {  // the reference's key (ow, oh, pitch, pw, ph, fov), for the w
     double fov;
     std::vector<double> pitch;
     int shape;  // tile shape of the tables (0: 64 x 16, 1: 128 x 16)
-    int knobs[4];  // the options that change the tables: gather_blocky_from (header bit), main_order (whether the main
-                   // list exists), gather_order / gather_group (the XCD lists) -- a plan built under one setting is
-                   // never served under another
+    int knobs[9];  // the options that change the tables: gather_blocky_from (header bit), main_order (whether the main
+                   // list exists), gather_order / gather_group (the XCD lists), band plan or not and its cell / extent
+                   // parameters -- a plan built under one setting is never served under another
     bool operator<(const PlanKey& o) const
     {
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 9; ++i)
             if (knobs[i] != o.knobs[i]) return knobs[i] < o.knobs[i];
         if (shape != o.shape) return shape < o.shape;
         if (pw != o.pw) return pw < o.pw;
@@ -353,8 +363,15 @@ struct Plan {  // the plan pass's tables (p2p_plan.hip)
     int xcd_stride = 0, xcd_all_stride = 0, main_stride = 0;
     int main_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // entries of each XCD's main list (the rest of its main_stride is empty)
     int n_gather = 0;
+    // band plan (source-band tiles, p2p_device.h): no px / items tables; the band kernel draws band_tiles tiles
+    bool band = false;
+    p2p::PieceHdr* d_band_hdr = nullptr;
+    uint32_t* d_band_px = nullptr;
+    uint32_t* d_band_grp = nullptr;
+    p2p::BandInfo* d_band_info = nullptr;
+    int band_tiles = 0, band_groups = 0, band_per = 0;
     bool built = false;
-    float plan_ms = 0.0f;                // device time of the plan pass
+    float plan_ms = 0.0f;                // device time of the plan pass (band plans: with the band passes)
     size_t bytes = 0;
     unsigned long long stamp = 0;        // last use (eviction order)
     ~Plan()
@@ -363,6 +380,7 @@ struct Plan {  // the plan pass's tables (p2p_plan.hip)
         (void)hipSetDevice(device);
         (void)dev_free(d_coords); (void)dev_free(d_hdr); (void)dev_free(d_px); (void)dev_free(d_items);
         (void)dev_free(d_px2); (void)dev_free(d_n_gather); (void)dev_free(d_gather_list); (void)dev_free(d_xcd_list); (void)dev_free(d_xcd_all); (void)dev_free(d_main_list);
+        (void)dev_free(d_band_hdr); (void)dev_free(d_band_px); (void)dev_free(d_band_grp); (void)dev_free(d_band_info);
     }
 };
 
@@ -1465,6 +1483,54 @@ int p2p_job_set_maps(p2p_job* j, const float* yaw_rows, const float* U, const fl
 // against 0.713).  With ONE chunk the lists' equal WORK per XCD (the grid gives every XCD the same number of tiles)
 // and their split tail pay for a single pitch view too: 12 yaws of one 1080p view 37.5 -> 33.0 us, 5 yaws 19.4 -> 19.1
 // (tools/ab_single_pitch_order.sh) -- the shares of the view-sharded path.
+// Source-band tiles (p2p_device.h) instead of the main kernel's per-view tiles: where they apply at all -- the uint8
+// path, BORDER_CONSTANT, every yaw a plain shift (no rest kernel), panorama width divisible by 4, the n_pitch views of a
+// pair within one 32-bit descriptor -- and, unless P2P_BAND forces them, where they pay (choose_band's rule).
+static bool job_band_applies(const p2p_job* j)
+{
+    const p2p_job_desc& d = j->d;
+    const p2p::TileShape& S = shape_ops(j->shape).shape;
+    const Options& o = j->opt;
+    if (d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16))
+        return false;
+    if (j->border != 0 || j->n_odd_yaws > 0 || (d.pw & 3) != 0 || o.force_rest != 0)
+        return false;
+    if ((unsigned long long)d.n_pitch * d.oh * j->out_row >= (1ull << 32))
+        return false;
+    if ((unsigned long long)d.n_pitch * d.oh * ((d.ow + 3) / 4) >= (1ull << 32) - 1ull)
+        return false;
+    // a single cell must fit a tile's LDS buffer, whatever its groups look like
+    const long rows = o.band_bh + o.band_maxh + 1, ri = ((o.band_cw + o.band_maxw + 3) >> 2) + 1;
+    if (rows * ri > S.cap || rows > 65535)
+        return false;
+    if ((d.pw + o.band_cw - 1) / o.band_cw > 4096)  // (p2p_plan.hip: BAND_MAX_NCX, the cut's cells in LDS)
+        return false;
+    return true;
+}
+
+static bool job_wants_band(const p2p_job* j)
+{
+    if (j->opt.band == 0 || !job_band_applies(j))
+        return false;
+    if (j->opt.band > 0)
+        return true;
+    // The library's rule (tools/band_rule.py, profiles/r05_band_rule_sweep.txt).  Band tiles do MORE arithmetic per
+    // output pixel than the gather kernel (stage 1 for the whole source rectangle, not for the taps alone) and win where
+    // that kernel waits for its scattered lines: view sets that minify enough for the per-view tiles' footprints to
+    // overflow the LDS (about 1.25 source pixels per output pixel) but not so much that the rectangle is mostly gaps
+    // (3.2), with enough (panorama, yaw) pairs per tile to pay its set-up -- 8, or 4 when five pitch views share every
+    // source rectangle, as in the reference CLI's defaults -- and views small enough for the write-back stores their
+    // ragged edges need (p2p_tile.h: P2P_BAND_STORE_AUX): 128 MB per launch.  Config 2 (1.07) stays with the per-view tiles.
+    const p2p_job_desc& d = j->d;
+    const double r = (double)d.pw * j->fov / (360.0 * d.ow);
+    const long long pairs = (long long)d.n_panos * d.n_yaw;
+    if (r < 1.25 || r > 3.2 || j->d_view_mask)
+        return false;
+    if (!(pairs >= 8 || (pairs >= 4 && d.n_pitch >= 5)))
+        return false;
+    return j->out_bytes <= ((size_t)128 << 20);
+}
+
 static int job_main_order(const p2p_job* j)
 {
     if (j->opt.main_order >= 0)
@@ -1520,9 +1586,11 @@ static int job_build_plan(p2p_job* j)
     const size_t slots = j->n_tiles * d.n_pitch;
     // device maps: the plan is a function of the key alone -- the context may have it already
     const Options& opt = j->opt;
-    const int main_order = job_main_order(j);
+    const bool band = job_wants_band(j);
+    const int main_order = band ? 0 : job_main_order(j);
     PlanKey key{d.pw, d.ph, d.ow, d.oh, d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16 | P2P_FLAG_PIXEL_CENTRES), j->border,
-                j->fov, j->pitch, j->shape, {opt.gather_blocky_from, main_order != 0, opt.gather_order, opt.gather_group}};
+                j->fov, j->pitch, j->shape, {opt.gather_blocky_from, main_order != 0, opt.gather_order, opt.gather_group,
+                                             band ? 1 : 0, band ? opt.band_bh : 0, band ? opt.band_cw : 0, band ? opt.band_maxw : 0, band ? opt.band_maxh : 0}};
     const p2p::TileShape& S = shape_ops(j->shape).shape;
     const bool cached = !j->host_maps && opt.plan_cache != 0 && opt.scramble_plan == 0;
     if (cached) {
@@ -1542,17 +1610,28 @@ static int job_build_plan(p2p_job* j)
     std::vector<p2p::PieceHdr> hh;
     std::vector<uint32_t> tm, tg, ta;
     uint32_t cnt = 0;
+    p2p::BandInfo binfo{};
+    // the band passes' scratch (cells, the groups' cells, the cut's records, the sorted group list): freed on every
+    // path, after the stream has been drained (declared before the guard: destroyed after it)
+    struct Scratch {
+        std::vector<void*> blocks;
+        ~Scratch() { for (void* b : blocks) (void)dev_free(b); }
+        hipError_t get(void** out, size_t bytes) { hipError_t e = dev_alloc(out, bytes); if (e == hipSuccess) blocks.push_back(*out); return e; }
+    } scratch;
     StreamSyncGuard sync_on_exit(st);
+    Pl->band = band;
     if (float_path)
         HIP_TRY(dev_alloc((void**)&Pl->d_px2, slots * S.block * S.pxt * sizeof(uint32_t)));
     HIP_TRY(dev_alloc((void**)&Pl->d_coords, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2)));
     HIP_TRY(dev_alloc((void**)&Pl->d_hdr, slots * sizeof(p2p::PieceHdr)));
-    HIP_TRY(dev_alloc((void**)&Pl->d_px, slots * S.block * S.pxt * sizeof(uint32_t)));
-    HIP_TRY(dev_alloc((void**)&Pl->d_items, slots * S.cap * sizeof(uint32_t)));
+    if (!band) {
+        HIP_TRY(dev_alloc((void**)&Pl->d_px, slots * S.block * S.pxt * sizeof(uint32_t)));
+        HIP_TRY(dev_alloc((void**)&Pl->d_items, slots * S.cap * sizeof(uint32_t)));
+    }
     HIP_TRY(dev_alloc((void**)&Pl->d_n_gather, sizeof(uint32_t)));
     HIP_TRY(dev_alloc((void**)&Pl->d_gather_list, slots * sizeof(uint32_t)));
     Pl->bytes = (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2) +
-                slots * (sizeof(p2p::PieceHdr) + (S.block * S.pxt * (float_path ? 2 : 1) + S.cap + 1) * sizeof(uint32_t));
+                slots * (sizeof(p2p::PieceHdr) + ((band ? 0 : S.block * S.pxt * (float_path ? 2 : 1) + S.cap) + 1) * sizeof(uint32_t));
     p2p::PlanParams Q{};
     Q.pw = d.pw; Q.ph = d.ph; Q.ow = d.ow; Q.oh = d.oh; Q.n_pitch = d.n_pitch; Q.border = j->border;
     Q.geom = j->geom;
@@ -1569,8 +1648,35 @@ static int job_build_plan(p2p_job* j)
     Q.float_path = float_path;
     Q.centre = (d.flags & P2P_FLAG_PIXEL_CENTRES) ? 0.5f : 0.0f;
     Q.px2 = Pl->d_px2;
+    p2p::BandParams& B = Q.band;
+    const size_t n_groups_all = (size_t)d.n_pitch * d.oh * ((d.ow + 3) / 4);
+    if (band) {
+        B.pw = d.pw; B.ph = d.ph; B.ow = d.ow; B.oh = d.oh; B.n_pitch = d.n_pitch;
+        B.g.bh = opt.band_bh; B.g.cw = opt.band_cw;
+        B.g.ncx = (d.pw + B.g.cw - 1) / B.g.cw;
+        B.g.n_bands = (d.ph + B.g.bh - 1) / B.g.bh;
+        B.g.maxw = opt.band_maxw; B.g.maxh = opt.band_maxh;
+        B.coords = Pl->d_coords;
+        B.out_row = j->out_row;
+        B.view_bytes = (size_t)d.oh * j->out_row;
+        B.cost_base = S.tile_w == 128 ? 675u : 600u;  // (xcd_main_lists' cost model)
+        const size_t cells = (size_t)B.g.n_bands * B.g.ncx;
+        uint32_t* cellblk = nullptr;  // count, cmax1, rmax1, cur (zeroed), cmin (0x7F..), off
+        HIP_TRY(scratch.get((void**)&cellblk, cells * 6 * sizeof(uint32_t)));
+        B.cell_count = cellblk; B.cell_cmax1 = (int*)(cellblk + cells); B.cell_rmax1 = (int*)(cellblk + 2 * cells);
+        B.cell_cur = cellblk + 3 * cells; B.cell_cmin = (int*)(cellblk + 4 * cells); B.cell_off = cellblk + 5 * cells;
+        HIP_TRY(scratch.get((void**)&B.gcell, n_groups_all * sizeof(uint32_t)));
+        HIP_TRY(scratch.get((void**)&B.band_cost, (size_t)B.g.n_bands * (sizeof(unsigned long long) + 2 * sizeof(uint32_t))));
+        B.band_tiles = (uint32_t*)(B.band_cost + B.g.n_bands);
+        B.band_groups = B.band_tiles + B.g.n_bands;
+        HIP_TRY(dev_alloc((void**)&Pl->d_band_info, sizeof(p2p::BandInfo)));
+        B.info = Pl->d_band_info;
+        HIP_TRY(hipMemsetAsync(cellblk, 0, cells * 4 * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(B.cell_cmin, 0x7F, cells * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(B.info, 0, sizeof(p2p::BandInfo), st));
+    }
 #ifdef P2P_AUDIT
-    {
+    if (!band) {
         // every pool poisoned: a kernel that reads a slot the plan pass did not write gets 0xFF.. and the audit sees it
         HIP_TRY(hipMemsetAsync(Pl->d_hdr, 0xFF, slots * sizeof(p2p::PieceHdr), st));
         HIP_TRY(hipMemsetAsync(Pl->d_px, 0xFF, slots * S.block * S.pxt * sizeof(uint32_t), st));
@@ -1585,6 +1691,34 @@ static int job_build_plan(p2p_job* j)
     HIP_TRY(hipMemsetAsync(Pl->d_n_gather, 0, sizeof(uint32_t), st));
     HIP_TRY(hipEventRecord(ctx->ev_t0, st));
     HIP_TRY(shape_ops(j->shape).plan(Q, st));
+    if (band) {
+        // the band passes: count the tiles, read the count back (the tables are sized by it), cut, sort, build
+        HIP_TRY(shape_ops(j->shape).band(B, 0, st));
+        HIP_TRY(hipMemcpyAsync(&binfo, B.info, sizeof(binfo), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&cnt, Pl->d_n_gather, sizeof(cnt), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if ((size_t)binfo.n_groups > n_groups_all || (size_t)binfo.n_tiles > n_groups_all)
+            return fail(P2P_ERR_HIP, "the band passes counted %u tiles, %u groups of %zu", binfo.n_tiles, binfo.n_groups, n_groups_all);
+        B.n_tiles = (int)binfo.n_tiles;
+        B.n_groups = (int)binfo.n_groups;
+        Pl->band_tiles = B.n_tiles;
+        Pl->band_groups = B.n_groups;
+        // list entries per XCD the view kernel's grid provides for: a quarter more than an equal share (the runs are of
+        // equal WORK; band_xcd_kernel keeps every run within this)
+        Pl->band_per = (B.n_tiles + 7) / 8 + (B.n_tiles + 31) / 32 + 16;
+        B.per_cap = Pl->band_per;
+        if (B.n_tiles > 0) {
+            const size_t nt = (size_t)B.n_tiles;
+            HIP_TRY(scratch.get((void**)&B.recs, nt * sizeof(p2p::BandTileRec)));
+            HIP_TRY(scratch.get((void**)&B.sorted, (size_t)std::max(1, B.n_groups) * sizeof(uint32_t)));
+            HIP_TRY(dev_alloc((void**)&Pl->d_band_hdr, nt * sizeof(p2p::PieceHdr)));
+            HIP_TRY(dev_alloc((void**)&Pl->d_band_px, nt * S.block * S.pxt * sizeof(uint32_t)));
+            HIP_TRY(dev_alloc((void**)&Pl->d_band_grp, nt * S.block * sizeof(uint32_t)));
+            Pl->bytes += nt * (sizeof(p2p::PieceHdr) + (S.block * S.pxt + S.block) * sizeof(uint32_t));
+            B.hdr = Pl->d_band_hdr; B.px = Pl->d_band_px; B.grp = Pl->d_band_grp;
+            HIP_TRY(shape_ops(j->shape).band(B, 1, st));
+        }
+    }
     HIP_TRY(hipEventRecord(ctx->ev_t1, st));
     HIP_TRY(hipMemcpyAsync(&cnt, Pl->d_n_gather, sizeof(cnt), hipMemcpyDeviceToHost, st));
     // the work lists are made from the plan's headers, once per geometry: they come back with the counter
@@ -1651,8 +1785,15 @@ static int job_build_plan(p2p_job* j)
         // through an exact-extent buffer descriptor (csrc/p2p_audit.h).  Such a plan is never entered in the cache.
         const uint32_t sd = (uint32_t)seed;
         HIP_TRY(p2p::launch_scramble(Pl->d_hdr, slots * sizeof(p2p::PieceHdr), sd + 1, st));
-        HIP_TRY(p2p::launch_scramble(Pl->d_px, slots * S.block * S.pxt * sizeof(uint32_t), sd + 2, st));
-        HIP_TRY(p2p::launch_scramble(Pl->d_items, slots * S.cap * sizeof(uint32_t), sd + 3, st));
+        HIP_TRY(p2p::launch_scramble(Pl->d_px, Pl->d_px ? slots * S.block * S.pxt * sizeof(uint32_t) : 0, sd + 2, st));
+        HIP_TRY(p2p::launch_scramble(Pl->d_items, Pl->d_items ? slots * S.cap * sizeof(uint32_t) : 0, sd + 3, st));
+        if (Pl->band_tiles > 0) {
+            const size_t nt = (size_t)Pl->band_tiles;
+            HIP_TRY(p2p::launch_scramble(Pl->d_band_hdr, nt * sizeof(p2p::PieceHdr), sd + 13, st));
+            HIP_TRY(p2p::launch_scramble(Pl->d_band_px, nt * S.block * S.pxt * sizeof(uint32_t), sd + 14, st));
+            HIP_TRY(p2p::launch_scramble(Pl->d_band_grp, nt * S.block * sizeof(uint32_t), sd + 15, st));
+            HIP_TRY(p2p::launch_scramble(Pl->d_band_info, sizeof(p2p::BandInfo), sd + 16, st));
+        }
         HIP_TRY(p2p::launch_scramble(Pl->d_gather_list, slots * sizeof(uint32_t), sd + 4, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_xcd_list, Pl->d_xcd_list ? 8 * (size_t)Pl->xcd_stride * sizeof(uint32_t) : 0, sd + 10, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_main_list, Pl->d_main_list ? 8 * (size_t)Pl->main_stride * sizeof(uint32_t) : 0, sd + 12, st));
@@ -1675,8 +1816,8 @@ static int job_build_plan(p2p_job* j)
     }
     sync_on_exit.armed = false;  // every path above has synchronised the stream
     if (opt.verbose)
-        fprintf(stderr, "p2p plan: %u of %zu tiles gather (%dx%d views, %d pitches), %.1f us\n", cnt, slots, d.ow, d.oh, d.n_pitch,
-                Pl->plan_ms * 1e3);
+        fprintf(stderr, "p2p plan: %u of %zu tiles gather (%dx%d views, %d pitches), %.1f us; band tiles %d (%d groups)\n", cnt, slots, d.ow, d.oh, d.n_pitch,
+                Pl->plan_ms * 1e3, Pl->band_tiles, Pl->band_groups);
     if (cached) {
         std::lock_guard<std::mutex> lk(ctx->cache_mu);
         Pl->stamp = ++ctx->cache_clock;
@@ -1754,11 +1895,17 @@ int p2p_job_run(p2p_job* j)
     const bool float_path = (j->d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)) != 0;
     if (float_path && j->host_maps)
         return fail(P2P_ERR_STATE, "the float pixel path evaluates its own maps; caller maps are not supported");
+    if (j->plan_ref && j->plan_ref->band != job_wants_band(j)) {
+        // (the yaws changed under a band plan, or away from one: p2p_job_set_yaws / p2p_job_set_maps)
+        HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+        j->plan_ref.reset();
+    }
     if (!j->plan_ref) {
         int rc = job_build_plan(j);
         if (rc != P2P_OK)
             return rc;
     }
+    const bool band = j->plan_ref->band;
     {   // the job's view of its plan
         const Plan& Pl = *j->plan_ref;
         j->d_coords = Pl.d_coords; j->d_hdr = Pl.d_hdr; j->d_px = Pl.d_px; j->d_items = Pl.d_items; j->d_px2 = Pl.d_px2;
@@ -1772,7 +1919,7 @@ int p2p_job_run(p2p_job* j)
     P.pairs_per_block = choose_pairs_per_block(j->d, shape_ops(j->shape).shape, opt);
     P.chunk_outer = opt.chunk_outer >= 0 ? opt.chunk_outer : (j->d.n_panos > 1 ? 1 : 0);
     // the main kernel's grid: list order (source bands, all pitch views together) unless the plan has no list
-    const int main_order = job_main_order(j);
+    const int main_order = band ? 0 : job_main_order(j);
     P.main_list = (main_order == 2 || (main_order == 1 && j->d.n_panos == 1)) ? j->d_main_list : nullptr;
     P.main_stride = j->main_stride;
     P.main_span = choose_main_span(j->d, shape_ops(j->shape).shape, opt, P.pairs_per_block);
@@ -1800,6 +1947,20 @@ int p2p_job_run(p2p_job* j)
         const int in_flight = 32 * (j->shape ? 3 : 7);  // workgroups an XCD holds at a time
         P.main_tail = opt.main_tail >= 0 ? opt.main_tail : in_flight / 5;
         P.main_tail = std::min(P.main_tail, j->main_stride);
+    }
+    if (band) {
+        const Plan& Pl = *j->plan_ref;
+        P.band_hdr = Pl.d_band_hdr; P.band_px = Pl.d_band_px; P.band_grp = Pl.d_band_grp; P.band_info = Pl.d_band_info;
+        P.band_tiles = Pl.band_tiles;
+        P.band_per = Pl.band_per;
+        P.pf_lead = 0;
+        // the split tail (see main_tail): one chunk of pairs, no span loop
+        P.band_tail = 0;
+        if (pair_chunks == 1 && P.main_span == 1 && j->d.n_panos * j->d.n_yaw >= 4) {
+            const int in_flight = 32 * (j->shape ? 3 : 7);
+            P.band_tail = opt.main_tail >= 0 ? opt.main_tail : in_flight / 5;
+            P.band_tail = std::min(P.band_tail, std::max(0, Pl.band_tiles / 8));
+        }
     }
     P.pitch_order = j->d_pitch_order;
     P.coords = j->d_coords;
@@ -1857,13 +2018,17 @@ int p2p_job_run(p2p_job* j)
     // Few tiles left for the LDS scheme (the edge tiles of a strongly minifying view set): the gather kernel, which
     // needs nothing but the coordinates, draws those too, and the main kernel's launch (6 us for a handful of
     // tiles) is saved.  The odd pairs of those tiles stay the rest kernel's.
-    P.gather_all = (gather_ok && j->n_gather > 0 && j->d_xcd_all && (slots - (size_t)j->n_gather) * 4 <= slots &&
+    P.gather_all = (gather_ok && !band && j->n_gather > 0 && j->d_xcd_all && (slots - (size_t)j->n_gather) * 4 <= slots &&
                     opt.gather_all != 0) ? 1 : 0;
     // (the gather kernel of a big job on a side stream, forked and joined by events, so that its cache waits overlap
     // the main kernel's arithmetic: config 4's pitch 30 1647 vs 1621 us, all five pitches 8021 vs 7988 -- the two
     // kernels do not interleave, not kept.  Round 4 once more, the side stream at the LOWEST priority and the gather
     // kernel enqueued behind the main kernel, to fill the slots its last workgroups leave: config 4 6.301 / 6.312 /
     // 6.303 -> 6.286 / 6.311 / 6.293 ms, five 1080p pitch views x 12 yaws 170.6 -> 174.2 us: not kept either)
+    // Band plans: the gather kernel's few, long workgroups (the tiles around a pole) leave most of the GPU idle while the
+    // band kernel behind them on the same stream waits for the last one (CLI default set: 17 us of 52; on a side stream,
+    // forked and joined by events: 63.5 us) -- they become the first workgroups of the band kernel's own launch.
+    const bool merged = band && j->n_gather > 0 && gather_ok && opt.band_merge != 0 && j->n_odd_pairs == 0 && j->plan_ref->band_tiles > 0;
     if (j->n_gather > 0) {
         if (gather_ok) {
             P.use_pair_list = 0;
@@ -1874,8 +2039,12 @@ int p2p_job_run(p2p_job* j)
             }
             P.gather_list = P.gather_all ? j->d_xcd_all : j->d_xcd_list;
             P.n_list = P.gather_all ? j->xcd_all_stride : j->xcd_stride;
-            if (P.gather_list && P.n_list > 0)
+            if (P.gather_list && P.n_list > 0 && !merged)
                 HIP_TRY(shape_ops(j->shape).views(P, 3, j->ctx->stream));
+            if (merged) {
+                P.band_gather_list = P.gather_list;
+                P.band_gather_n = P.n_list;
+            }
             P.gather_list = j->d_gather_list;
         }
         // the table kernel: every pair where the gather kernel does not apply, else the odd pairs
@@ -1883,12 +2052,15 @@ int p2p_job_run(p2p_job* j)
         if (!gather_ok || j->n_odd_pairs > 0)
             HIP_TRY(shape_ops(j->shape).views(P, 2, j->ctx->stream));
     }
-    if (need_rest) {
+    if (need_rest && !band) {
         P.use_pair_list = (fast_width && j->n_odd_pairs > 0) ? 1 : 0;
         HIP_TRY(shape_ops(j->shape).views(P, 1, j->ctx->stream));
     }
     P.use_pair_list = 0;
-    if (fast_width && any_lds && !P.gather_all)
+    if (band) {
+        if (P.band_tiles > 0)
+            HIP_TRY(shape_ops(j->shape).views(P, 4, j->ctx->stream));
+    } else if (fast_width && any_lds && !P.gather_all)
         HIP_TRY(shape_ops(j->shape).views(P, 0, j->ctx->stream));
     if (timed)
         HIP_TRY(hipEventRecord(j->ev_ring[2 * slot + 1], j->ctx->stream));
@@ -2267,6 +2439,7 @@ int p2p_job_get_info(p2p_job* j, p2p_job_info* out)
     out->n_views_wanted = j->n_views_wanted;
     out->timing_events = (int32_t)j->ev_ring.size();
     out->copy_streams = (j->ctx->stream_up != nullptr) + (j->ctx->stream_down != nullptr);
+    out->band_tiles = j->plan_ref ? (j->plan_ref->band ? j->plan_ref->band_tiles : 0) : (job_wants_band(j) ? -1 : 0);
     return P2P_OK;
 }
 

@@ -201,10 +201,59 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
     }
     const bool any_live = (fl & 1) != 0, stray = (fl & 2) != 0;
     const int nrow = any_live ? r1 - r0 + 2 : 0;
+    // ---- band plan: the tile's 4-pixel groups (lanes 4k .. 4k + 3 of a wave are four neighbours of one row) go into
+    // source-band tiles if every one of them can: some live pixel, no tap on the panorama's border, taps within
+    // maxw x maxh of each other.  One bad group sends the whole tile to the gather kernel (as a pole does above).
+    const bool band = P.band.gcell != nullptr;
+    int gq_x0[PXT], gq_y0[PXT], gq_x1[PXT], gq_y1[PXT];
+    bool band_ok = false;
+    if (band) {
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) {
+            const int py = y0 + ty0 + j * ROWSTEP;
+            const bool exists = (px & ~3) < P.ow && py < P.oh;
+            int qx0 = inrange[j] ? ix[j] : INT32_MAX, qx1 = inrange[j] ? ix[j] : INT32_MIN;
+            int qy0 = inrange[j] ? iy[j] : INT32_MAX, qy1 = inrange[j] ? iy[j] : INT32_MIN;
+#define P2P_QUAD_STEP(ctrl)                                                                          \
+            qx0 = min(qx0, __builtin_amdgcn_update_dpp(qx0, qx0, ctrl, 0xf, 0xf, false));            \
+            qx1 = max(qx1, __builtin_amdgcn_update_dpp(qx1, qx1, ctrl, 0xf, 0xf, false));            \
+            qy0 = min(qy0, __builtin_amdgcn_update_dpp(qy0, qy0, ctrl, 0xf, 0xf, false));            \
+            qy1 = max(qy1, __builtin_amdgcn_update_dpp(qy1, qy1, ctrl, 0xf, 0xf, false));
+            P2P_QUAD_STEP(0xB1)  // quad_perm:[1,0,3,2]
+            P2P_QUAD_STEP(0x4E)  // quad_perm:[2,3,0,1]
+#undef P2P_QUAD_STEP
+            gq_x0[j] = qx0; gq_x1[j] = qx1; gq_y0[j] = qy0; gq_y1[j] = qy1;
+            const bool edge = inrange[j] && (ix[j] < 0 || ix[j] + 1 >= P.pw || iy[j] < 0 || iy[j] + 1 >= P.ph);
+            const bool dead = exists && qx1 < qx0;
+            const bool wide = exists && qx1 >= qx0 && (qx1 - qx0 > P.band.g.maxw || qy1 - qy0 > P.band.g.maxh);
+            bad |= edge || dead || wide;
+        }
+        band_ok = __syncthreads_or(bad) == 0 && any_live && !stray && (P.pw & 3) == 0 && !P.float_path;
+        // its groups into the cells of the source (or marked: the tile gathers)
+        if ((t & 3) == 0) {
+            const size_t gxn = (size_t)((P.ow + 3) >> 2);
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) {
+                const int py = y0 + ty0 + j * ROWSTEP;
+                if (px < P.ow && py < P.oh) {
+                    uint32_t cell = ~0u;
+                    if (band_ok) {
+                        cell = (uint32_t)(gq_y0[j] / P.band.g.bh) * (uint32_t)P.band.g.ncx + (uint32_t)(gq_x0[j] / P.band.g.cw);
+                        atomicAdd(&P.band.cell_count[cell], 1u);
+                        atomicMin(&P.band.cell_cmin[cell], gq_x0[j]);
+                        atomicMax(&P.band.cell_cmax1[cell], gq_x1[j] + 1);
+                        atomicMax(&P.band.cell_rmax1[cell], gq_y1[j] + 1);
+                    }
+                    P.band.gcell[((size_t)pitch_i * P.oh + py) * gxn + (size_t)(px >> 2)] = cell;
+                }
+            }
+        }
+    }
     // The LDS scheme needs the whole footprint strictly inside the panorama (no tap is a border tap) and a
     // panorama width divisible by 4 (12-byte items never straddle a row end).
     // (float path: taps reach one column further)
-    bool ok = any_live && !stray && (P.pw & 3) == 0 && c0 >= 0 && r0 >= 0 && c1 + 1 + P.float_path < P.pw &&
+    bool ok = !band && any_live && !stray && (P.pw & 3) == 0 && c0 >= 0 && r0 >= 0 && c1 + 1 + P.float_path < P.pw &&
               r1 + 1 < P.ph && nrow <= PLAN_MAX_ROWS && nrow <= VIEWS_BLOCK;  // (one plan thread per rot row)
     uint32_t n_items = 0;
     if (ok) {
@@ -268,6 +317,19 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
             ok = __syncthreads_or(far) == 0;
         }
     }
+    if (band) {  // no tables: mode 3 tiles are drawn from the band tiles, the others from the coordinates
+        if (t == 0) {
+            if (!band_ok)
+                P.gather_list[atomicAdd(P.n_gather, 1u)] = slot;
+            PieceHdr h;
+            h.mode_items = (band_ok ? 3u : 2u) | (uint32_t)(fl & 4);
+            h.c0 = any_live ? c0 : 0;
+            h.c1 = any_live ? c1 : -1;
+            h.rows = any_live ? ((uint32_t)(r0 + 1) & 0xFFFFu) | (uint32_t)(r1 + 1) << 16 : 0u;
+            P.hdr[slot] = h;
+        }
+        return;
+    }
     uint32_t* pxw = P.px + (size_t)slot * (VIEWS_BLOCK * PXT);
     uint32_t* px2w = P.float_path ? P.px2 + (size_t)slot * (VIEWS_BLOCK * PXT) : nullptr;
     uint32_t* itw = P.items + (size_t)slot * LDS_ITEMS_CAP;
@@ -306,6 +368,393 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Source-band tiles (p2p_device.h: BandGeom ...).  The plan pass above has counted every group of every mode-3 tile into
+// the cell of its upper-left tap (cell_count, and the cell's tap extents) and written each group's cell (gcell).
+//   band_cut_kernel      one wave per band: walks the band's cells from left to right and cuts the row into tiles --
+//                        a tile takes cells (the last one possibly in part) until it holds VIEWS_BLOCK groups or one
+//                        more cell would push its rectangle (first cell's leftmost tap .. rightmost tap, band top ..
+//                        lowest tap) beyond LDS_ITEMS_CAP items.  Run twice: count, then (bases known) write.
+//   band_scan_kernel     one workgroup: exclusive scan of the bands' tile and group counts.
+//   band_scatter_kernel  every group to its cell's run of the sorted list (order inside a cell: as the atomics fall).
+//   band_build_kernel    one workgroup per tile: its groups sorted by index = (pitch view, row, column), one per lane;
+//                        the exact rectangle of their taps, the per-pixel words, the group words, the header.
+//   band_xcd_kernel      one workgroup: the tiles (band order = source order) cut into eight runs of equal work.
+// ---------------------------------------------------------------------------------------------
+constexpr int BAND_MAX_NCX = 4096;  // cells per band the cut keeps in LDS (64 KB): panoramas up to 32766 wide in cells of >= 8 columns
+
+// inclusive scans over the 64 lanes of a wave
+// (DPP: Hillis-Steele inside each row of 16 lanes, then the rows' totals handed on -- a ds_bpermute per step would cost
+// an LDS round trip each, and the cut is a chain of such scans.)  Values are >= 0: lanes a step gives no source add / max 0.
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v, int)
+{
+#define P2P_DPP_ADD(ctrl, row_mask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, row_mask, 0xf, false);
+    P2P_DPP_ADD(0x111, 0xf) P2P_DPP_ADD(0x112, 0xf) P2P_DPP_ADD(0x114, 0xf) P2P_DPP_ADD(0x118, 0xf)
+    P2P_DPP_ADD(0x142, 0xa) P2P_DPP_ADD(0x143, 0xc)
+#undef P2P_DPP_ADD
+    return v;
+}
+__device__ __forceinline__ int wave_scan_max(int v, int)
+{
+#define P2P_DPP_MAX(ctrl, row_mask) v = max(v, __builtin_amdgcn_update_dpp(0, v, ctrl, row_mask, 0xf, false));
+    P2P_DPP_MAX(0x111, 0xf) P2P_DPP_MAX(0x112, 0xf) P2P_DPP_MAX(0x114, 0xf) P2P_DPP_MAX(0x118, 0xf)
+    P2P_DPP_MAX(0x142, 0xa) P2P_DPP_MAX(0x143, 0xc)
+#undef P2P_DPP_MAX
+    return v;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void band_cut_kernel(BandParams B)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int r0 = b * B.g.bh;
+    const size_t cbase = (size_t)b * B.g.ncx;
+    const uint32_t tbase = WRITE ? B.band_tiles[b] : 0u, gbase = WRITE ? B.band_groups[b] : 0u;
+    // the open tile (carried from window to window): its groups, first column, rightmost column, lowest row
+    uint32_t ng = 0u, tiles = 0u, placed = 0u, tile_gstart = 0u;
+    unsigned long long cost = 0ull;
+    int cs = 0, cm = 0, rm = 0;
+    auto close = [&]() {
+        if (WRITE && lane == 0) {
+            BandTileRec r;
+            r.gstart = gbase + tile_gstart; r.gcount = ng; r.c0 = cs; r.cmax1 = cm; r.r0 = r0; r.rmax1 = rm;
+            B.recs[tbase + tiles] = r;
+        }
+        cost += B.cost_base + (uint32_t)((((3 + cm - cs) >> 2) + 1) * (rm - r0 + 1));
+        ++tiles;
+        tile_gstart += ng;
+        ng = 0u;
+    };
+    // One window of 64 cells at a time; inside it one step per TILE (not per cell): prefix sums / maxima from the
+    // tile's first cell say in which lane the tile ends -- the first whose cell would push the rectangle beyond the LDS
+    // buffer (the tile ends before it), or the first in which the groups reach VIEWS_BLOCK (the tile takes part of it).
+    // (the band's cells into LDS first, all loads in flight at once: the walk itself is a chain of short steps)
+    __shared__ uint4 s_cell[BAND_MAX_NCX];
+    for (int ci = lane; ci < B.g.ncx && ci < BAND_MAX_NCX; ci += 64) {
+        uint4 v;
+        v.x = B.cell_count[cbase + ci];
+        v.y = (uint32_t)B.cell_cmin[cbase + ci];
+        v.z = (uint32_t)B.cell_cmax1[cbase + ci];
+        v.w = (uint32_t)B.cell_rmax1[cbase + ci];
+        s_cell[ci] = v;
+    }
+    __syncthreads();
+    for (int c0i = 0; c0i < B.g.ncx; c0i += 64) {
+        const int ci = c0i + lane;
+        const uint4 cv = ci < B.g.ncx && ci < BAND_MAX_NCX ? s_cell[ci] : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t n = cv.x;
+        const int a = (int)cv.y, mx = (int)cv.z, rx = (int)cv.w;
+        const uint32_t incl = wave_scan_add(n, lane);
+        if (WRITE && ci < B.g.ncx)
+            B.cell_off[cbase + ci] = gbase + placed + incl - n;
+        placed += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        int at = 0;              // first lane not consumed yet
+        uint32_t left = 0u;      // groups of lane `at` still to place (0: all of them)
+        for (;;) {
+            const uint32_t nn = lane < at ? 0u : (lane == at && left ? left : n);
+            const unsigned long long nz = __ballot(nn != 0u);
+            if (!nz)
+                break;  // window exhausted; an open tile is carried on
+            const int f = __ffsll((long long)nz) - 1;
+            const int cs_t = ng ? cs : __builtin_amdgcn_readlane(a, f);
+            const uint32_t C = wave_scan_add(nn, lane) + ng;
+            const int M = max(wave_scan_max(nn ? mx : 0, lane), ng ? cm : 0);
+            const int R = max(wave_scan_max(nn ? rx : 0, lane), ng ? rm : 0);
+            const int items = (((3 + M - cs_t) >> 2) + 1) * (R - r0 + 1);
+            const unsigned long long over = __ballot(nn != 0u && items > LDS_ITEMS_CAP);
+            const unsigned long long full = __ballot(nn != 0u && C >= (uint32_t)VIEWS_BLOCK);
+            const int e_cap = over ? __ffsll((long long)over) - 1 : 64, e_cnt = full ? __ffsll((long long)full) - 1 : 64;
+            if (e_cap <= e_cnt && e_cap < 64) {
+                // the cell of lane e_cap does not fit: the tile ends before it (it holds something: one cell always fits)
+                if (e_cap == f && ng == 0u) {
+                    // (one cell alone always fits -- the host checks the parameters; whatever the arrays hold, the walk moves on)
+                    const uint32_t nf = (uint32_t)__builtin_amdgcn_readlane((int)nn, f);
+                    ng = min(nf, (uint32_t)VIEWS_BLOCK);
+                    cs = cs_t;
+                    cm = __builtin_amdgcn_readlane(M, f);
+                    rm = __builtin_amdgcn_readlane(R, f);
+                    const uint32_t rest = nf - ng;
+                    close();
+                    left = rest;
+                    at = rest ? f : f + 1;
+                    continue;
+                }
+                if (e_cap > f) {
+                    // the last cell with groups before e_cap
+                    const unsigned long long before = nz & ((1ull << e_cap) - 1ull);
+                    const int p = 63 - __builtin_clzll(before);
+                    ng = (uint32_t)__builtin_amdgcn_readlane((int)C, p);
+                    cm = __builtin_amdgcn_readlane(M, p);
+                    rm = __builtin_amdgcn_readlane(R, p);
+                    cs = cs_t;
+                }
+                close();
+                at = e_cap;
+                left = (uint32_t)__builtin_amdgcn_readlane((int)nn, e_cap);
+            } else if (e_cnt < 64) {
+                // lane e_cnt fills the tile: it takes what is missing, the rest of the cell opens the next tile
+                const uint32_t c_e = (uint32_t)__builtin_amdgcn_readlane((int)C, e_cnt);
+                cm = __builtin_amdgcn_readlane(M, e_cnt);
+                rm = __builtin_amdgcn_readlane(R, e_cnt);
+                cs = cs_t;
+                ng = (uint32_t)VIEWS_BLOCK;
+                close();
+                left = c_e - (uint32_t)VIEWS_BLOCK;
+                at = left ? e_cnt : e_cnt + 1;
+            } else {
+                // everything left in the window joins the open tile
+                ng = (uint32_t)__builtin_amdgcn_readlane((int)C, 63);
+                cm = __builtin_amdgcn_readlane(M, 63);
+                rm = __builtin_amdgcn_readlane(R, 63);
+                cs = cs_t;
+                break;
+            }
+        }
+    }
+    if (ng)
+        close();
+    if (!WRITE && lane == 0) {
+        B.band_tiles[b] = tiles;
+        B.band_groups[b] = placed;
+        B.band_cost[b] = cost;
+    }
+}
+
+__global__ __launch_bounds__(1024) void band_scan_kernel(BandParams B)
+{
+    // exclusive running sums over the bands: tiles, groups, and the cut's cost (for band_xcd_kernel)
+    __shared__ uint32_t s_t[1024], s_g[1024];
+    __shared__ unsigned long long s_c[1024];
+    const int t = threadIdx.x;
+    uint32_t run_t = 0u, run_g = 0u;
+    unsigned long long run_c = 0ull;
+    for (int base = 0; base < B.g.n_bands; base += 1024) {
+        const int i = base + t;
+        const uint32_t vt = i < B.g.n_bands ? B.band_tiles[i] : 0u, vg = i < B.g.n_bands ? B.band_groups[i] : 0u;
+        const unsigned long long vc = i < B.g.n_bands ? B.band_cost[i] : 0ull;
+        s_t[t] = vt; s_g[t] = vg; s_c[t] = vc;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const uint32_t at = t >= d ? s_t[t - d] : 0u, ag = t >= d ? s_g[t - d] : 0u;
+            const unsigned long long ac = t >= d ? s_c[t - d] : 0ull;
+            __syncthreads();
+            s_t[t] += at; s_g[t] += ag; s_c[t] += ac;
+            __syncthreads();
+        }
+        if (i < B.g.n_bands) {
+            B.band_tiles[i] = run_t + s_t[t] - vt;
+            B.band_groups[i] = run_g + s_g[t] - vg;
+            B.band_cost[i] = run_c + s_c[t] - vc;
+        }
+        run_t += s_t[1023]; run_g += s_g[1023]; run_c += s_c[1023];
+        __syncthreads();
+    }
+    if (t == 0) {
+        B.info->n_tiles = run_t;
+        B.info->n_groups = run_g;
+        B.info->pad[0] = (uint32_t)run_c;
+        B.info->pad[1] = (uint32_t)(run_c >> 32);
+    }
+}
+
+__global__ __launch_bounds__(256) void band_scatter_kernel(BandParams B, uint32_t n_all)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= n_all)
+        return;
+    const uint32_t cell = B.gcell[g];
+    if (cell == ~0u)
+        return;
+    const uint32_t pos = B.cell_off[cell] + atomicAdd(&B.cell_cur[cell], 1u);
+    if (pos < (uint32_t)B.n_groups)
+        B.sorted[pos] = g;
+}
+
+__global__ __launch_bounds__(VIEWS_BLOCK) void band_build_kernel(BandParams B)
+{
+    __shared__ uint32_t s_key[VIEWS_BLOCK];
+    __shared__ int s_red[4][VIEWS_BLOCK / 64];
+    const int t = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    const BandTileRec rec = B.recs[tile];
+    uint32_t cnt = rec.gcount < (uint32_t)VIEWS_BLOCK ? rec.gcount : (uint32_t)VIEWS_BLOCK;
+    if (rec.gstart >= (uint32_t)B.n_groups)
+        cnt = 0u;
+    else if (rec.gstart + cnt > (uint32_t)B.n_groups)
+        cnt = (uint32_t)B.n_groups - rec.gstart;
+    s_key[t] = (uint32_t)t < cnt ? B.sorted[rec.gstart + t] : ~0u;
+    __syncthreads();
+    // bitonic sort, ascending: (pitch view, row, column) order, lanes without a group last
+    for (int k = 2; k <= VIEWS_BLOCK; k <<= 1)
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            const int o = t ^ jj;
+            if (o > t) {
+                const uint32_t x = s_key[t], y = s_key[o];
+                const bool up = (t & k) == 0;
+                if ((x > y) == up) {
+                    s_key[t] = y;
+                    s_key[o] = x;
+                }
+            }
+            __syncthreads();
+        }
+    const uint32_t g = s_key[t];
+    const uint32_t gxn = (uint32_t)((B.ow + 3) >> 2), per_view = gxn * (uint32_t)B.oh;
+    const bool has = g < per_view * (uint32_t)B.n_pitch;
+    uint32_t pitch_i = 0u, y = 0u, x4 = 0u;
+    int ix[4], iy[4];
+    uint32_t fx[4], fy[4];
+    bool live[4];
+    int bx0 = INT32_MAX, bx1 = INT32_MIN, by0 = INT32_MAX, by1 = INT32_MIN;
+    if (has) {
+        pitch_i = g / per_view;
+        const uint32_t rem = g - pitch_i * per_view;
+        y = rem / gxn;
+        x4 = rem - y * gxn;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        live[i] = false;
+        ix[i] = iy[i] = 0;
+        fx[i] = fy[i] = 0u;
+        const int x = (int)(4u * x4) + i;
+        if (has && x < B.ow) {
+            const int2 c = B.coords[((size_t)pitch_i * B.oh + y) * B.ow + x];
+            ix[i] = sat_short(c.x >> 5);
+            iy[i] = sat_short(c.y >> 5);
+            fx[i] = (uint32_t)c.x & 31u;
+            fy[i] = (uint32_t)c.y & 31u;
+            // all four taps inside the panorama (the plan pass has checked that for the tile): a pixel that is not, is dead
+            live[i] = ix[i] >= 0 && iy[i] >= 0 && ix[i] + 1 < B.pw && iy[i] + 1 < B.ph;
+            if (live[i]) {
+                bx0 = min(bx0, ix[i]); bx1 = max(bx1, ix[i] + 1);
+                by0 = min(by0, iy[i]); by1 = max(by1, iy[i] + 1);
+            }
+        }
+    }
+    bx0 = wave_reduce<false>(bx0); bx1 = wave_reduce<true>(bx1);
+    by0 = wave_reduce<false>(by0); by1 = wave_reduce<true>(by1);
+    if ((t & 63) == 0) {
+        s_red[0][t >> 6] = bx0; s_red[1][t >> 6] = bx1; s_red[2][t >> 6] = by0; s_red[3][t >> 6] = by1;
+    }
+    __syncthreads();
+    int c0 = INT32_MAX, cmax1 = INT32_MIN, r0 = INT32_MAX, rmax1 = INT32_MIN;
+#pragma unroll
+    for (int w = 0; w < VIEWS_BLOCK / 64; ++w) {
+        c0 = min(c0, s_red[0][w]); cmax1 = max(cmax1, s_red[1][w]);
+        r0 = min(r0, s_red[2][w]); rmax1 = max(rmax1, s_red[3][w]);
+    }
+    const bool any = cmax1 >= c0;
+    uint32_t row_items = any ? (uint32_t)(((3 + cmax1 - c0) >> 2) + 1) : 1u;
+    uint32_t rows = any ? (uint32_t)(rmax1 - r0 + 1) : 1u;
+    // (the cut's conservative rectangle fits, so this one does; a garbage table must not make an oversized tile)
+    const bool fits = row_items * rows <= (uint32_t)LDS_ITEMS_CAP && row_items < 65536u && r0 < 65536;
+    if (!fits) {
+        row_items = 1u;
+        rows = 1u;
+    }
+    uint32_t* pxw = B.px + (size_t)tile * (VIEWS_BLOCK * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t word = 0u;
+        if (live[i] && fits && any)
+            word = (4u * row_items * (uint32_t)(iy[i] - r0) + (uint32_t)(ix[i] - c0)) | 1u << PXW_UP_BITS | fx[i] << 22 | fy[i] << 27;
+        pxw[i * VIEWS_BLOCK + t] = word;
+    }
+    B.grp[(size_t)tile * VIEWS_BLOCK + t] =
+        has ? (uint32_t)((size_t)pitch_i * B.view_bytes + (size_t)y * (size_t)B.out_row + 12u * (size_t)x4) : ~0u;
+    if (t == 0) {
+        PieceHdr h;
+        h.mode_items = 3u | (any && fits ? row_items * rows : 0u) << 8;
+        h.c0 = any ? c0 : 0;
+        h.c1 = any ? cmax1 - 1 : -1;
+        h.rows = (any ? (uint32_t)r0 : 0u) | row_items << 16;
+        B.hdr[tile] = h;
+    }
+}
+
+// The tiles (band order = source order) cut into eight runs of equal work, one per XCD: by the bands' costs (the cut's
+// estimate: cost_base + the rectangle's items per tile), then tile by tile inside the band a boundary falls into.
+__global__ __launch_bounds__(64) void band_xcd_kernel(BandParams B)
+{
+    const int lane = threadIdx.x;
+    const uint32_t n = (uint32_t)B.n_tiles;
+    const unsigned long long total = (unsigned long long)B.info->pad[0] | (unsigned long long)B.info->pad[1] << 32;
+    if (lane >= 1 && lane < 8) {
+        // band_cost[] holds the cost of the bands BEFORE each band (band_scan_kernel): binary search for the band the
+        // boundary falls into, then a share of its tiles in proportion (a band's tiles cost about the same)
+        const unsigned long long want = total * (unsigned long long)lane / 8ull;
+        int lo = 0, hi = B.g.n_bands - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (B.band_cost[mid] <= want)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        const unsigned long long before = B.band_cost[lo], after = lo + 1 < B.g.n_bands ? B.band_cost[lo + 1] : total;
+        const uint32_t t0 = B.band_tiles[lo], t1 = lo + 1 < B.g.n_bands ? B.band_tiles[lo + 1] : n;
+        uint32_t first = t0;
+        if (after > before)
+            first = t0 + (uint32_t)((unsigned long long)(t1 - t0) * (want - before) / (after - before));
+        B.info->first[lane] = total ? first : n * (uint32_t)lane / 8u;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        // no run longer than the view kernel's grid provides for
+        uint32_t f[9];
+        f[0] = 0u;
+        f[8] = n;
+        const uint32_t cap = (uint32_t)B.per_cap;
+        for (uint32_t x = 1; x < 8; ++x) {
+            uint32_t v = min(B.info->first[x], n);
+            v = max(v, f[x - 1]);
+            v = min(v, f[x - 1] + cap);
+            const uint32_t need = (8u - x) * cap;  // tiles the XCDs from x on can still take
+            if (n > need)
+                v = max(v, n - need);
+            f[x] = v;
+        }
+        for (uint32_t x = 0; x < 9; ++x)
+            B.info->first[x] = f[x];
+    }
+    __syncthreads();
+    // an XCD draws its run from the costlier end (towards a pole): the workgroups in flight when it runs out are its
+    // cheapest -- compare the rectangles of the run's first and last tiles
+    if (lane < 8) {
+        const uint32_t a = B.info->first[lane], e = B.info->first[lane + 1];
+        uint32_t rev = 0u;
+        if (e > a + 8u) {
+            unsigned long long head = 0ull, tail = 0ull;
+            for (uint32_t i = 0; i < 4u; ++i) {
+                const BandTileRec r = B.recs[a + i], q = B.recs[e - 1u - i];
+                head += (uint32_t)((((3 + r.cmax1 - r.c0) >> 2) + 1) * (r.rmax1 - r.r0 + 1));
+                tail += (uint32_t)((((3 + q.cmax1 - q.c0) >> 2) + 1) * (q.rmax1 - q.r0 + 1));
+            }
+            rev = tail > head ? 1u : 0u;
+        }
+        B.info->reversed[lane] = rev;
+    }
+}
+
+hipError_t launch_band(const BandParams& B, int stage, hipStream_t st)
+{
+    if (stage == 0) {
+        hipLaunchKernelGGL(band_cut_kernel<false>, dim3(B.g.n_bands), dim3(64), 0, st, B);
+        hipLaunchKernelGGL(band_scan_kernel, dim3(1), dim3(1024), 0, st, B);
+        return hipGetLastError();
+    }
+    if (B.n_tiles <= 0)
+        return hipSuccess;
+    const uint32_t n_all = (uint32_t)B.n_pitch * (uint32_t)B.oh * (uint32_t)((B.ow + 3) >> 2);
+    hipLaunchKernelGGL(band_cut_kernel<true>, dim3(B.g.n_bands), dim3(64), 0, st, B);
+    hipLaunchKernelGGL(band_scatter_kernel, dim3((n_all + 255u) / 256u), dim3(256), 0, st, B, n_all);
+    hipLaunchKernelGGL(band_build_kernel, dim3(B.n_tiles), dim3(VIEWS_BLOCK), 0, st, B);
+    hipLaunchKernelGGL(band_xcd_kernel, dim3(1), dim3(64), 0, st, B);
+    return hipGetLastError();
+}
+
 hipError_t launch_plan(const PlanParams& P, hipStream_t st)
 {
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
@@ -322,7 +771,7 @@ hipError_t launch_plan(const PlanParams& P, hipStream_t st)
 const ShapeOps& P2P_SHAPE_OPS_NAME()
 {
     static const ShapeOps ops = {{P2P_SHAPE_NS::TILE_W, P2P_SHAPE_NS::TILE_H, P2P_SHAPE_NS::VIEWS_BLOCK, P2P_SHAPE_NS::VIEWS_PXT, P2P_SHAPE_NS::LDS_ITEMS_CAP},
-                                 &P2P_SHAPE_NS::launch_plan, &P2P_SHAPE_NS::launch_remap_views, &P2P_SHAPE_NS::launch_float_views};
+                                 &P2P_SHAPE_NS::launch_plan, &P2P_SHAPE_NS::launch_remap_views, &P2P_SHAPE_NS::launch_float_views, &P2P_SHAPE_NS::launch_band};
     return ops;
 }
 

@@ -27,6 +27,13 @@ __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cas
 #ifndef P2P_MAIN_STORE_AUX_W128
 #define P2P_MAIN_STORE_AUX_W128 P2P_STORE_AUX
 #endif
+// Cache policy of the band kernel's stores: the default one (write-back).  A band tile's region of a view is cut where
+// the SOURCE rectangle ends, at any 12-byte group: most 64-byte sectors of its rows are shared with the neighbouring
+// tile, and under the streaming policies of the per-view tiles (nt, nt sc1: whole sectors there) every such sector goes
+// out twice, half written -- config 2 235 us (nt sc1) / 215 (nt) / 131 (default); the L2 merges the two halves.
+#ifndef P2P_BAND_STORE_AUX
+#define P2P_BAND_STORE_AUX 0
+#endif
 #ifndef P2P_GATHER_LOAD_AUX
 #define P2P_GATHER_LOAD_AUX 0  // ... of the gather kernel's taps (experiments)
 #endif
@@ -47,6 +54,7 @@ struct TileGeo {
     int c0, c1;
     int col, row0;  // this thread's column and first row inside the tile
     uint32_t slot;  // pitch_i * tiles + tile: index of the tile's header, per-pixel words and item list
+    int band_r0, band_row_items;  // band tiles: first rot row and items per row of the footprint rectangle
 };
 
 __device__ __forceinline__ TileGeo tile_geo(const ViewsParams& P, const PieceHdr& h, int pitch_i, int tile_id, int t)
@@ -78,7 +86,7 @@ __device__ __forceinline__ int pano_of_pair(const ViewsParams& P, int pair)
 // does the job draw view (yaw yi, pitch pitch_i)?  (yi < n_yaw, pitch_i < n_pitch: inside the mask by construction)
 __device__ __forceinline__ bool view_wanted(const ViewsParams& P, int pitch_i, int yi)
 {
-    if (!P.view_mask)
+    if (!P.view_mask || pitch_i < 0)  // (pitch_i < 0: a band tile's pair contexts -- its lanes test their own pitch views)
         return true;
     return ((P.view_mask[(size_t)pitch_i * P.mask_words + (yi >> 5)] >> (yi & 31)) & 1u) != 0u;
 }

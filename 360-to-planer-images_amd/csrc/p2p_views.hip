@@ -293,9 +293,10 @@ __device__ __forceinline__ PairCtxs pair_contexts(const ViewsParams& P, const Ya
 }
 
 // per-pixel words of the plan -> tap offsets (bytes inside one LDS buffer) and packed weights
+// band_row_bytes > 0: a band tile's words -- the distance field is a live flag, the lower tap sits one LDS row further
 template <int PXT>
 __device__ __forceinline__ void decode_px(const uint32_t* __restrict__ pxw, int t, uint32_t (&tap_up)[PXT],
-                                          uint32_t (&tap_lo)[PXT], TapWeights (&tw)[PXT])
+                                          uint32_t (&tap_lo)[PXT], TapWeights (&tw)[PXT], uint32_t band_row_bytes = 0u)
 {
 #pragma unroll
     for (int j = 0; j < PXT; ++j) {
@@ -307,7 +308,7 @@ __device__ __forceinline__ void decode_px(const uint32_t* __restrict__ pxw, int 
 #endif
         const uint32_t dl = (wd >> PXW_UP_BITS) & ((1u << PXW_DL_BITS) - 1u);
         tap_up[j] = (wd & ((1u << PXW_UP_BITS) - 1u)) << 2;
-        tap_lo[j] = tap_up[j] + (dl << 2);
+        tap_lo[j] = tap_up[j] + (band_row_bytes ? band_row_bytes : dl << 2);
         // a pixel with no footprint in the panorama (NaN coordinate) gets weight 0 everywhere:
         // (0 + 512) >> 10 == 0, the BORDER_CONSTANT value
         const uint32_t fx = (wd >> 22) & 31u, fy = wd >> 27;
@@ -400,14 +401,18 @@ __device__ __forceinline__ void store_wave_pixels(const StoreCtx& s, const uint3
 // s_waitcnt vmcnt stay counted (with a conditional load or store in the loop it falls back to vmcnt(0), and every
 // pair then waits for the previous pair's stores to be acknowledged: loads and stores retire in issue order).
 // ---------------------------------------------------------------------------------------------
+// BAND: a source-band tile (p2p_device.h).  Its footprint is a rectangle (G.band_r0, G.band_row_items: no item list,
+// itw unused), lane t draws the 4 adjacent pixels of group t and stores them itself (no staging): grpw[t] is the byte
+// offset of its 12 bytes inside the n_pitch views of a (panorama, yaw) pair.
+template <bool BAND = false, bool MASKED = false>
 __device__ __forceinline__ void draw_tight(
     const ViewsParams& P, const uint8_t* __restrict__ src, const YawDesc* __restrict__ ydesc,
     uint8_t* __restrict__ out, const TileGeo& G, const uint32_t* __restrict__ pxw, const uint32_t* __restrict__ itw,
-    uint4 (*tile4)[LDS_ITEMS_CAP], uint32_t* stage, int chunk, int ppb = 0)
+    uint4 (*tile4)[LDS_ITEMS_CAP], uint32_t* stage, int chunk, int ppb = 0, const uint32_t* __restrict__ grpw = nullptr)
 {
     constexpr int PXT = VIEWS_PXT;
     const int t = threadIdx.x;
-    if (!tight_tile(G, P))
+    if (!BAND && !tight_tile(G, P))
         return;  // the other kernels'
     P2P_AUD_LT(P.audit, AUD_MAIN_HDR, G.n_items, LDS_ITEMS_CAP + 1);
     // A workgroup draws P.main_span consecutive chunks of pairs (1 unless the plan tables are too big to stay cached:
@@ -416,13 +421,30 @@ __device__ __forceinline__ void draw_tight(
     // the loop's live values cost it 5 spilled ones; the host asks for spans with 128-wide tiles only.
     constexpr bool SPAN_LOOP = TILE_W == 128;
     const int chunk_end = chunk + (SPAN_LOOP && P.main_span > 1 ? P.main_span : 1);
-    PairCtxs X = pair_contexts(P, ydesc, G.c0, G.c1, t, chunk, G.pitch_i, ppb);
+    // (band tiles: lanes of several pitch views -- no pair is skipped as a whole; unwanted views are dropped per lane below)
+    PairCtxs X = pair_contexts(P, ydesc, G.c0, G.c1, t, chunk, BAND ? -1 : G.pitch_i, ppb);
     int nplain = X.n3;
     if (nplain == 0 && chunk + 1 == chunk_end)
         return;
     uint32_t tap_up[PXT], tap_lo[PXT];
     TapWeights tw[PXT];
-    decode_px<PXT>(pxw, t, tap_up, tap_lo, tw);
+    const uint32_t band_row_bytes = BAND ? 16u * (uint32_t)G.band_row_items : 0u;
+    // band tiles: where this lane's 12 bytes go inside a pair's n_pitch views (~0: no group, the hardware drops the
+    // store).  Does this wave hold any group?  A footprint-limited tile -- a minifying view set -- fills only its first
+    // waves; the others produce their items, skip stage 2 and need no per-pixel words.
+    uint32_t grp_off = 0xFFFFFFFFu;
+    if (BAND)
+        grp_off = grpw[t];
+    const bool wave_draws = !BAND || __ballot(grp_off != 0xFFFFFFFFu) != 0ull;
+    if (wave_draws) {
+        decode_px<PXT>(pxw, t, tap_up, tap_lo, tw, band_row_bytes);
+    } else {
+#pragma unroll
+        for (int jj = 0; jj < PXT; ++jj) {
+            tap_up[jj] = tap_lo[jj] = 0u;
+            tw[jj].w_up = tw[jj].w_lo = 0u;
+        }
+    }
 #ifdef P2P_AUDIT
 #pragma unroll
     for (int j = 0; j < PXT; ++j)
@@ -437,10 +459,46 @@ __device__ __forceinline__ void draw_tight(
     }
 #endif
     uint32_t slot_off[VIEWS_SLOTS], slot_g[VIEWS_SLOTS];
-    decode_items(itw, t, G.n_items, P.src_pitch, slot_off, slot_g);
+    if (BAND) {
+        // the footprint is a rectangle: item i = (row i / row_items, group i % row_items); surplus lanes redo item 0
+        const uint32_t ri = (uint32_t)G.band_row_items;
+        const float ri_inv = 1.0f / (float)ri;
+#pragma unroll
+        for (int k = 0; k < VIEWS_SLOTS; ++k) {
+            uint32_t item = (uint32_t)(t + k * VIEWS_BLOCK);
+            item = item < (uint32_t)G.n_items && item < (uint32_t)LDS_ITEMS_CAP ? item : 0u;
+            uint32_t row = (uint32_t)((float)item * ri_inv);  // item < 2^11: the quotient is off by one at most
+            row -= row * ri > item ? 1u : 0u;
+            row += (row + 1u) * ri <= item ? 1u : 0u;
+            slot_g[k] = item - row * ri;
+            slot_off[k] = ((uint32_t)G.band_r0 + row) * (uint32_t)P.src_pitch + 12u * slot_g[k];
+        }
+    } else {
+        decode_items(itw, t, G.n_items, P.src_pitch, slot_off, slot_g);
+    }
     const uint32_t row_bytes = 3u * (uint32_t)P.pw;
     const size_t view_bytes = P.view_bytes;
-    const StoreCtx SC = store_ctx(P, G, stage, t);
+    StoreCtx SC{};
+    if (!BAND)
+        SC = store_ctx(P, G, stage, t);
+    // band tiles, sparse view sets only: which of the chunk's pairs this lane's pitch view wants
+    unsigned long long lane_want = ~0ull;
+    int lane_pitch = 0;
+    auto lane_wants = [&]() {  // (per chunk of pairs)
+        lane_want = 0ull;
+        for (int k = 0; k < X.npairs; ++k) {
+            const int pair = X.pair0 + k;
+            const int yi = pair - pano_of_pair(P, pair) * P.n_yaw;
+            lane_want |= (unsigned long long)view_wanted(P, lane_pitch, yi) << k;
+        }
+    };
+    if (BAND) {
+        if (MASKED) {
+            // (one integer division per workgroup, sparse view sets only)
+            lane_pitch = grp_off == 0xFFFFFFFFu ? 0 : (int)min((uint32_t)(P.n_pitch - 1), grp_off / (uint32_t)view_bytes);
+            lane_wants();
+        }
+    }
 
     const int wave_base = __builtin_amdgcn_readfirstlane(t & ~63);
     int ns_wave = 0;  // items this wave produces per pair (wave-uniform)
@@ -568,8 +626,61 @@ __device__ __forceinline__ void draw_tight(
 #ifdef P2P_ABLATE_HALF_TAPS
     uint32_t ta_keep[PXT][4] = {};  // (timing experiment, wrong pixels: every second pair re-uses the taps of the pair before)
 #endif
-    auto one_pair = [&](auto ns_c, auto mode_c, auto nw_c, int k, const Q16 (&cur)[VIEWS_SLOTS], Q16 (&nxt)[VIEWS_SLOTS]) {
-        {
+    auto one_pair = [&](auto ns_c, auto mode_c, auto nw_c, auto draws_c, int k, const Q16 (&cur)[VIEWS_SLOTS], Q16 (&nxt)[VIEWS_SLOTS]) {
+        if constexpr (BAND) {
+            // stage 1 -> barrier -> taps -> the next pair's pieces -> stage 2 -> 12 bytes per lane, stored from registers
+            constexpr bool DRAWS = decltype(draws_c)::value;
+            uint4* tl4 = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(&tile4[0][0]) + buf_bytes);
+            stage1(ns_c, mode_c, pwc, cur, tl4);
+            // (the lower taps: one LDS row further for every pixel of a band tile -- a second scalar, no second offset per pixel)
+            uint32_t soff = buf_bytes + 4u * ((pwc.w0 >> 20) & 3u), soff_lo = soff + band_row_bytes;
+            asm volatile("" : "+s"(soff), "+s"(soff_lo));
+            {
+                uint32_t soff_v, soff_lo_v;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(soff_v) : "s"(soff));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(soff_lo_v) : "s"(soff_lo));
+                soff = soff_v;
+                soff_lo = soff_lo_v;
+            }
+            __syncthreads();
+            const unsigned char* tl = reinterpret_cast<const unsigned char*>(&tile4[0][0]);
+            uint32_t ta[PXT][4];
+            if (DRAWS) {
+#pragma unroll
+                for (int j = 0; j < PXT; ++j) {
+                    const uint32_t* up = reinterpret_cast<const uint32_t*>(tl + (tap_up[j] + soff));
+                    const uint32_t* lo = reinterpret_cast<const uint32_t*>(tl + (tap_up[j] + soff_lo));
+                    ta[j][0] = up[0];
+                    ta[j][1] = up[1];
+                    ta[j][2] = lo[0];
+                    ta[j][3] = lo[1];
+                }
+            }
+            const PairWords pwn = pair_words(k + 1 < nplain ? k + 1 : k);
+            load_pieces(ns_c, nw_c, pwn, nxt);
+            if (DRAWS) {
+                uint4 v;
+                v.x = blend4_packed(ta[0][0], ta[0][1], ta[0][2], ta[0][3], tw[0]);
+                v.y = blend4_packed(ta[1][0], ta[1][1], ta[1][2], ta[1][3], tw[1]);
+                v.z = blend4_packed(ta[2][0], ta[2][1], ta[2][2], ta[2][3], tw[2]);
+                v.w = blend4_packed(ta[3][0], ta[3][1], ta[3][2], ta[3][3], tw[3]);
+                const uint32_t korig = (uint32_t)pwc.w3 >> 26;
+                const int pair = X.pair0 + (int)korig;
+                uint32_t off = grp_off;
+                if (MASKED)
+                    off = (lane_want >> korig) & 1ull ? off : 0xFFFFFFFFu;
+                const uint32_t pair_bytes = (uint32_t)P.n_pitch * (uint32_t)view_bytes;  // < 2^32 (host check)
+                const u32x3 o3 = pack_staged_pixels(v);
+#ifdef P2P_ABLATE_STORES2  // (timing experiment: the store instruction alone skipped)
+                if ((o3.x ^ o3.y ^ o3.z) == 0x12345678u)
+#endif
+                __builtin_amdgcn_raw_buffer_store_b96(o3,
+                                                      __builtin_amdgcn_make_buffer_rsrc(out + (size_t)pair * pair_bytes, 0, (int)pair_bytes, 0x00020000),
+                                                      (int)off, 0, P2P_BAND_STORE_AUX);
+            }
+            buf_bytes ^= (uint32_t)sizeof(tile4[0]);
+            pwc = pwn;
+        } else {
             uint4* tl4 = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(&tile4[0][0]) + buf_bytes);
 #ifndef P2P_STORE_INLINE
             // the read-back goes out first and is consumed after stage 1 (the scheduler would otherwise pull the whole
@@ -665,20 +776,20 @@ __device__ __forceinline__ void draw_tight(
     };
     // the pieces ping-pong between two register sets (pairs two at a time), so nothing is copied per pair
     // nw_c: the pieces requested inside the loop (those of pairs kbeg + 1 .. kend) belong to pairs without wrapping items
-    auto tight = [&](auto ns_c, auto mode_c, auto nw_c, int kbeg, int kend) {
+    auto tight = [&](auto ns_c, auto mode_c, auto nw_c, auto draws_c, int kbeg, int kend) {
         int k = kbeg;
         for (; k + 1 < kend; k += 2) {
-            one_pair(ns_c, mode_c, nw_c, k, qc, qn);
-            one_pair(ns_c, mode_c, nw_c, k + 1, qn, qc);
+            one_pair(ns_c, mode_c, nw_c, draws_c, k, qc, qn);
+            one_pair(ns_c, mode_c, nw_c, draws_c, k + 1, qn, qc);
         }
         if (k < kend) {
-            one_pair(ns_c, mode_c, nw_c, k, qc, qn);
+            one_pair(ns_c, mode_c, nw_c, draws_c, k, qc, qn);
 #pragma unroll
             for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
                 qc[sl] = qn[sl];
         }
     };
-    auto run_ns = [&](auto ns_c) {
+    auto run_ns_d = [&](auto ns_c, auto draws_c) {
         load_pieces(ns_c, std::false_type{}, pwc, qc);
         // Inside the loops the pieces of pair k + 1 are followed by the store of pair k, so "pieces landed" is
         // vmcnt(1).  Entering the first loop straight after the first loads the compiler would have to assume
@@ -688,21 +799,28 @@ __device__ __forceinline__ void draw_tight(
         __builtin_amdgcn_raw_buffer_store_b32(0u, __builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0x00020000), 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
 #ifdef P2P_NO_WRAP_CLASSES
-        tight(ns_c, std::integral_constant<int, 0>{}, std::false_type{}, 0, X.n1);
-        tight(ns_c, std::integral_constant<int, 1>{}, std::false_type{}, X.n1, X.n2);
-        tight(ns_c, std::integral_constant<int, 2>{}, std::false_type{}, X.n2, X.n3);
+        tight(ns_c, std::integral_constant<int, 0>{}, std::false_type{}, draws_c, 0, X.n1);
+        tight(ns_c, std::integral_constant<int, 1>{}, std::false_type{}, draws_c, X.n1, X.n2);
+        tight(ns_c, std::integral_constant<int, 2>{}, std::false_type{}, draws_c, X.n2, X.n3);
 #else
         // classes 0 | 1 copy, 2 blend, 3 blend with the clipped column; 0 and 2: no item wraps
         const int a = X.n0 > 0 ? X.n0 - 1 : 0, b = X.n2 - 1 > X.n1 ? X.n2 - 1 : X.n1;
-        tight(ns_c, std::integral_constant<int, 0>{}, std::true_type{}, 0, a);
-        tight(ns_c, std::integral_constant<int, 0>{}, std::false_type{}, a, X.n1);
-        tight(ns_c, std::integral_constant<int, 1>{}, std::true_type{}, X.n1, b);
-        tight(ns_c, std::integral_constant<int, 1>{}, std::false_type{}, b, X.n2);
-        tight(ns_c, std::integral_constant<int, 2>{}, std::false_type{}, X.n2, X.n3);
+        tight(ns_c, std::integral_constant<int, 0>{}, std::true_type{}, draws_c, 0, a);
+        tight(ns_c, std::integral_constant<int, 0>{}, std::false_type{}, draws_c, a, X.n1);
+        tight(ns_c, std::integral_constant<int, 1>{}, std::true_type{}, draws_c, X.n1, b);
+        tight(ns_c, std::integral_constant<int, 1>{}, std::false_type{}, draws_c, b, X.n2);
+        tight(ns_c, std::integral_constant<int, 2>{}, std::false_type{}, draws_c, X.n2, X.n3);
 #endif
 #ifndef P2P_STORE_INLINE
-        store_staged_pixels(SC, read_staged_pixels(SC, staging(buf_bytes)), pend_O, pend_records);  // the last pair's pixels
+        if (!BAND)
+            store_staged_pixels(SC, read_staged_pixels(SC, staging(buf_bytes)), pend_O, pend_records);  // the last pair's pixels
 #endif
+    };
+    auto run_ns = [&](auto ns_c) {
+        if (!BAND || wave_draws)
+            run_ns_d(ns_c, std::true_type{});
+        else if constexpr (BAND)
+            run_ns_d(ns_c, std::false_type{});
     };
     static_assert(VIEWS_SLOTS == 2 || VIEWS_SLOTS == 3, "dispatch below");
     for (int ch = chunk;;) {
@@ -720,10 +838,12 @@ __device__ __forceinline__ void draw_tight(
             break;
         // the next chunk of this tile: new pair contexts, everything else stands.  The tile buffers keep alternating
         // (the last pair's taps are still being read by slower waves from the buffer this wave does NOT write next).
-        X = pair_contexts(P, ydesc, G.c0, G.c1, t, ch, G.pitch_i, ppb);
+        X = pair_contexts(P, ydesc, G.c0, G.c1, t, ch, BAND ? -1 : G.pitch_i, ppb);
         nplain = X.n3;
         if (X.npairs == 0)
             break;  // past the job's last chunk
+        if (BAND && MASKED)
+            lane_wants();
         pwc = pair_words(0);
         pend_records = 0u;  // (the chunk's last pair has been flushed)
     }
@@ -745,7 +865,7 @@ __device__ __forceinline__ void draw_tight(
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void draw_gather(
     const ViewsParams& P, const uint8_t* __restrict__ src, const YawDesc* __restrict__ ydesc, uint8_t* __restrict__ out,
-    const TileGeo& G, uint32_t* stage)
+    const TileGeo& G, uint32_t* stage, int chunk = -1)
 {
     constexpr int PXT = VIEWS_PXT;
     const int t = threadIdx.x;
@@ -782,7 +902,7 @@ __device__ __forceinline__ void draw_gather(
 
     // ---- pair contexts (lane k), sorted by class ----
     int pair0, npairs;
-    pair_chunk(P, false, P.gather_ppb, list_grid_chunk(), pair0, npairs);
+    pair_chunk(P, false, P.gather_ppb, chunk >= 0 ? chunk : list_grid_chunk(), pair0, npairs);
     int cwA = 0, cwB = 0, cwC = 0, cw3 = 0, cls = 3;
     const int k = t & 63;
     if (k < npairs) {
@@ -1405,12 +1525,13 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_rest_kernel(
 // the SOURCE so that tiles of different pitch views that read the same part of the panorama meet in one L2
 // (p2p_host.cpp: xcd_lists); gridDim.x == 8 * n_list, ~0 = no tile (returns false).
 template <bool XCD_LISTS>
-__device__ __forceinline__ bool tile_of_list(const ViewsParams& P, const uint32_t* __restrict__ list, uint32_t site, int& pitch_i, int& tile_id)
+__device__ __forceinline__ bool tile_of_list(const ViewsParams& P, const uint32_t* __restrict__ list, uint32_t site, int& pitch_i, int& tile_id,
+                                             uint32_t bx = blockIdx.x, int n_list = -1)
 {
     const uint32_t tiles = (uint32_t)(((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H));
-    uint32_t idx = blockIdx.x;
+    uint32_t idx = bx;
     if (XCD_LISTS)
-        idx = (blockIdx.x & 7u) * (uint32_t)P.n_list + (blockIdx.x >> 3);
+        idx = (bx & 7u) * (uint32_t)(n_list >= 0 ? n_list : P.n_list) + (bx >> 3);
     uint32_t slot = list[idx];
     if (XCD_LISTS && slot == ~0u)
         return false;
@@ -1442,6 +1563,86 @@ __global__ __launch_bounds__(VIEWS_BLOCK, P2P_GATHER_WAVES) void remap_views_gat
     draw_gather(P, src, ydesc, out, G, stage);
 }
 
+// The band kernel: source-band tiles (p2p_device.h) for every plain-shift yaw.  The tiles are in source order (band by
+// band); XCD x = blockIdx.x & 7 draws the run first[x] .. first[x + 1] - 1 of them (equal work, cut on the device:
+// band_xcd_kernel), from its costlier end if the run says so, and the last band_tail tiles of the run by
+// main_tail_parts workgroups each, a part of the pairs each (one chunk of pairs only: see main_tail).
+#ifndef P2P_BAND_WAVES
+#define P2P_BAND_WAVES 6  // (at 7 waves per SIMD, 72 registers, the three-item loops spill)
+#endif
+// MERGED: the launch's first 8 * band_gather_n * (chunks of gather_ppb pairs) workgroups draw the plan's gather tiles (the
+// gather kernel's body: few, long workgroups around a pole, which a launch of their own would leave alone on the GPU).
+#ifndef P2P_BAND_MERGED_WAVES
+#define P2P_BAND_MERGED_WAVES 5
+#endif
+template <bool MASKED, bool MERGED>
+__global__ __launch_bounds__(VIEWS_BLOCK, MERGED ? P2P_BAND_MERGED_WAVES : P2P_BAND_WAVES) void remap_views_band_kernel(
+    ViewsParams P, const uint8_t* __restrict__ src, const YawDesc* __restrict__ ydesc, uint8_t* __restrict__ out,
+    const PieceHdr* __restrict__ hdr, const uint32_t* __restrict__ px, const uint32_t* __restrict__ grp, const BandInfo* __restrict__ info)
+{
+    __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
+    uint32_t bx = blockIdx.x;
+    if (MERGED) {
+        const uint32_t per_chunk = 8u * (uint32_t)P.band_gather_n;
+        const uint32_t n_pairs = (uint32_t)(P.n_panos * P.n_yaw);
+        const uint32_t gchunks = (n_pairs + (uint32_t)P.gather_ppb - 1u) / (uint32_t)P.gather_ppb;
+        const uint32_t gw = per_chunk * gchunks;
+        if (bx < gw) {
+            if (blockIdx.y != 0)
+                return;
+            const uint32_t gchunk = bx / per_chunk;
+            int pitch_i, tile_id;
+            if (!tile_of_list<true>(P, P.band_gather_list, AUD_GATHER_LIST, pitch_i, tile_id, bx - gchunk * per_chunk, P.band_gather_n))
+                return;
+            const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
+            const PieceHdr h = P.hdr[(size_t)pitch_i * tiles + tile_id];
+            const TileGeo G = tile_geo(P, h, pitch_i, tile_id, (int)threadIdx.x);
+            if (G.mode != 2)
+                return;
+            static_assert(sizeof(tile4) >= (VIEWS_BLOCK / 64) * VIEWS_PXT * 64 * sizeof(uint32_t), "the gather body's staging dwords");
+            draw_gather(P, src, ydesc, out, G, reinterpret_cast<uint32_t*>(&tile4[0][0]), (int)gchunk);
+            return;
+        }
+        bx -= gw;
+    }
+    const uint32_t xcd = bx & 7u, q = bx >> 3;
+    const uint32_t n_tiles = (uint32_t)P.band_tiles;
+    uint32_t first = info->first[xcd], last = info->first[xcd + 1];
+    const bool rev = info->reversed[xcd] != 0u;
+    last = last < n_tiles ? last : n_tiles;  // (whatever the table holds, a valid tile is drawn)
+    first = first < last ? first : last;
+    const uint32_t L = last - first;
+    int chunk = (int)blockIdx.y, ppb = 0;
+    uint32_t e = q;
+    if (P.band_tail > 0) {
+        const uint32_t K = (uint32_t)P.band_tail < L ? (uint32_t)P.band_tail : L;
+        if (q >= L - K) {
+            const uint32_t i = q - (L - K), parts = (uint32_t)P.main_tail_parts;
+            if (i >= parts * K)
+                return;
+            e = L - K + i / parts;
+            chunk = (int)(i - (i / parts) * parts);
+            ppb = (P.n_panos * P.n_yaw + (int)parts - 1) / (int)parts;
+        }
+    }
+    if (e >= L)
+        return;
+    const uint32_t tile = rev ? last - 1u - e : first + e;
+    const PieceHdr h = hdr[tile];
+    TileGeo G{};
+    G.mode = 1;
+    G.n_items = (int)(h.mode_items >> 8);
+    G.c0 = h.c0;
+    G.c1 = h.c1;
+    G.band_r0 = (int)(h.rows & 0xFFFFu);
+    G.band_row_items = (int)(h.rows >> 16);
+    G.band_row_items = G.band_row_items > 0 ? G.band_row_items : 1;
+    G.slot = tile;
+    P2P_AUD_LT(P.audit, AUD_MAIN_HDR, G.n_items, LDS_ITEMS_CAP + 1);
+    draw_tight<true, MASKED>(P, src, ydesc, out, G, px + (size_t)tile * (VIEWS_BLOCK * VIEWS_PXT), nullptr, tile4, nullptr,
+                     chunk * (TILE_W == 128 && P.main_span > 1 ? P.main_span : 1), ppb, grp + (size_t)tile * VIEWS_BLOCK);
+}
+
 #ifndef P2P_DIRECT_WAVES
 #define P2P_DIRECT_WAVES 4
 #endif
@@ -1469,6 +1670,24 @@ hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
             hipLaunchKernelGGL(remap_views_table_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.out, P.hdr, P.gather_list);
         else
             hipLaunchKernelGGL(remap_views_gather_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.hdr, P.gather_list);
+        return hipGetLastError();
+    }
+    if (which == 4) {  // the band kernel: per XCD band_per list entries (+ the split tail), x chunks of pairs
+        int zb = (n_pairs + P.pairs_per_block - 1) / P.pairs_per_block;
+        if (TILE_W == 128 && P.main_span > 1)
+            zb = (zb + P.main_span - 1) / P.main_span;
+        const bool merged = P.band_gather_list != nullptr && P.band_gather_n > 0;
+        const int gw = merged ? 8 * P.band_gather_n * ((n_pairs + P.gather_ppb - 1) / P.gather_ppb) : 0;
+        const dim3 grid(gw + 8 * (P.band_per + (P.band_tail > 0 ? (P.main_tail_parts - 1) * P.band_tail : 0)), P.band_tail > 0 ? 1 : zb, 1);
+#define P2P_LAUNCH_BAND(MASKED, MERGED)                                                                                         \
+        hipLaunchKernelGGL((remap_views_band_kernel<MASKED, MERGED>), grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, \
+                           P.band_hdr, P.band_px, P.band_grp, P.band_info)
+        if (P.view_mask) {
+            if (merged) P2P_LAUNCH_BAND(true, true); else P2P_LAUNCH_BAND(true, false);
+        } else {
+            if (merged) P2P_LAUNCH_BAND(false, true); else P2P_LAUNCH_BAND(false, false);
+        }
+#undef P2P_LAUNCH_BAND
         return hipGetLastError();
     }
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);

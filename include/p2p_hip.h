@@ -296,7 +296,9 @@ typedef struct p2p_job_info {
     int32_t n_views_wanted;        /* views per panorama the job draws (n_yaw * n_pitch unless p2p_job_set_view_mask) */
     int32_t chunks_per_workgroup;  /* chunks of pairs one main-kernel workgroup draws in turn (1 unless the plan tables
                                       of a launch are too big to stay cached: config 4) */
-    int32_t reserved[2];
+    int32_t band_tiles;            /* > 0: the job is drawn from source-band tiles (this many) instead of the main
+                                      kernel's per-view tiles; -1: it will be, the plan is not built yet; 0: no */
+    int32_t reserved[1];
 } p2p_job_info;
 int p2p_job_get_info(p2p_job* job, p2p_job_info* out);
 
