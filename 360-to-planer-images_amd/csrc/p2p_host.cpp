@@ -1524,7 +1524,7 @@ static bool job_wants_band(const p2p_job* j)
     const p2p_job_desc& d = j->d;
     const double r = (double)d.pw * j->fov / (360.0 * d.ow);
     const long long pairs = (long long)d.n_panos * d.n_yaw;
-    if (r < 1.25 || r > 3.2 || j->d_view_mask)
+    if (r < 1.25 || r > 3.2 || j->d_view_mask || j->host_maps)  // (caller maps: their minification is not the FOV's)
         return false;
     if (!(pairs >= 8 || (pairs >= 4 && d.n_pitch >= 5)))
         return false;
