@@ -90,7 +90,6 @@ struct Options {
     int band = -1;                    // P2P_BAND: 1 = source-band tiles wherever they apply, 0 = never, -1 = the library's rule (choose_band)
     int band_bh = 16, band_cw = 8;    // P2P_BAND_BH / P2P_BAND_CW: cell of the source, rows x columns
     int band_maxw = 27, band_maxh = 7;  // P2P_BAND_MAXW / P2P_BAND_MAXH: tap extent of a group beyond which its tile gathers
-    int band_merge = 1;               // P2P_BAND_MERGE: 1 = a band plan's gather tiles are drawn by the first workgroups of the band kernel's launch
 };
 
 void pool_set_budget(size_t bytes);  // (the pool is defined below)
@@ -131,7 +130,6 @@ void options_load_locked()
     o.band_cw = std::min(256, std::max(1, env_int("P2P_BAND_CW", o.band_cw)));
     o.band_maxw = std::min(255, std::max(3, env_int("P2P_BAND_MAXW", o.band_maxw)));
     o.band_maxh = std::min(63, std::max(1, env_int("P2P_BAND_MAXH", o.band_maxh)));
-    o.band_merge = env_int("P2P_BAND_MERGE", o.band_merge);
     g_opt = o;
     g_opt_loaded = true;
     pool_set_budget((size_t)o.pool_mb << 20);
@@ -2025,10 +2023,6 @@ int p2p_job_run(p2p_job* j)
     // kernels do not interleave, not kept.  Round 4 once more, the side stream at the LOWEST priority and the gather
     // kernel enqueued behind the main kernel, to fill the slots its last workgroups leave: config 4 6.301 / 6.312 /
     // 6.303 -> 6.286 / 6.311 / 6.293 ms, five 1080p pitch views x 12 yaws 170.6 -> 174.2 us: not kept either)
-    // Band plans: the gather kernel's few, long workgroups (the tiles around a pole) leave most of the GPU idle while the
-    // band kernel behind them on the same stream waits for the last one (CLI default set: 17 us of 52; on a side stream,
-    // forked and joined by events: 63.5 us) -- they become the first workgroups of the band kernel's own launch.
-    const bool merged = band && j->n_gather > 0 && gather_ok && opt.band_merge != 0 && j->n_odd_pairs == 0 && j->plan_ref->band_tiles > 0;
     if (j->n_gather > 0) {
         if (gather_ok) {
             P.use_pair_list = 0;
@@ -2039,12 +2033,8 @@ int p2p_job_run(p2p_job* j)
             }
             P.gather_list = P.gather_all ? j->d_xcd_all : j->d_xcd_list;
             P.n_list = P.gather_all ? j->xcd_all_stride : j->xcd_stride;
-            if (P.gather_list && P.n_list > 0 && !merged)
+            if (P.gather_list && P.n_list > 0)
                 HIP_TRY(shape_ops(j->shape).views(P, 3, j->ctx->stream));
-            if (merged) {
-                P.band_gather_list = P.gather_list;
-                P.band_gather_n = P.n_list;
-            }
             P.gather_list = j->d_gather_list;
         }
         // the table kernel: every pair where the gather kernel does not apply, else the odd pairs

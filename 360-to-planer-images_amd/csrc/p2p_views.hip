@@ -619,7 +619,7 @@ __device__ __forceinline__ void draw_tight(
         (void)buffer_bytes;
         return SC.stg;
 #else
-        return reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(&tile4[0][0]) + buffer_bytes) + (t >> 6) * (64 * 4);
+        return reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(&tile4[0][0]) + buffer_bytes) + __builtin_amdgcn_readfirstlane(t >> 6) * (64 * 4);
 #endif
     };
     static_assert(VIEWS_PXT == 4, "a wave's staging dwords are the 64 items of its lanes' first slot");
@@ -1570,41 +1570,13 @@ __global__ __launch_bounds__(VIEWS_BLOCK, P2P_GATHER_WAVES) void remap_views_gat
 #ifndef P2P_BAND_WAVES
 #define P2P_BAND_WAVES 6  // (at 7 waves per SIMD, 72 registers, the three-item loops spill)
 #endif
-// MERGED: the launch's first 8 * band_gather_n * (chunks of gather_ppb pairs) workgroups draw the plan's gather tiles (the
-// gather kernel's body: few, long workgroups around a pole, which a launch of their own would leave alone on the GPU).
-#ifndef P2P_BAND_MERGED_WAVES
-#define P2P_BAND_MERGED_WAVES 5
-#endif
-template <bool MASKED, bool MERGED>
-__global__ __launch_bounds__(VIEWS_BLOCK, MERGED ? P2P_BAND_MERGED_WAVES : P2P_BAND_WAVES) void remap_views_band_kernel(
+template <bool MASKED>
+__global__ __launch_bounds__(VIEWS_BLOCK, P2P_BAND_WAVES) void remap_views_band_kernel(
     ViewsParams P, const uint8_t* __restrict__ src, const YawDesc* __restrict__ ydesc, uint8_t* __restrict__ out,
     const PieceHdr* __restrict__ hdr, const uint32_t* __restrict__ px, const uint32_t* __restrict__ grp, const BandInfo* __restrict__ info)
 {
     __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
-    uint32_t bx = blockIdx.x;
-    if (MERGED) {
-        const uint32_t per_chunk = 8u * (uint32_t)P.band_gather_n;
-        const uint32_t n_pairs = (uint32_t)(P.n_panos * P.n_yaw);
-        const uint32_t gchunks = (n_pairs + (uint32_t)P.gather_ppb - 1u) / (uint32_t)P.gather_ppb;
-        const uint32_t gw = per_chunk * gchunks;
-        if (bx < gw) {
-            if (blockIdx.y != 0)
-                return;
-            const uint32_t gchunk = bx / per_chunk;
-            int pitch_i, tile_id;
-            if (!tile_of_list<true>(P, P.band_gather_list, AUD_GATHER_LIST, pitch_i, tile_id, bx - gchunk * per_chunk, P.band_gather_n))
-                return;
-            const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
-            const PieceHdr h = P.hdr[(size_t)pitch_i * tiles + tile_id];
-            const TileGeo G = tile_geo(P, h, pitch_i, tile_id, (int)threadIdx.x);
-            if (G.mode != 2)
-                return;
-            static_assert(sizeof(tile4) >= (VIEWS_BLOCK / 64) * VIEWS_PXT * 64 * sizeof(uint32_t), "the gather body's staging dwords");
-            draw_gather(P, src, ydesc, out, G, reinterpret_cast<uint32_t*>(&tile4[0][0]), (int)gchunk);
-            return;
-        }
-        bx -= gw;
-    }
+    const uint32_t bx = blockIdx.x;
     const uint32_t xcd = bx & 7u, q = bx >> 3;
     const uint32_t n_tiles = (uint32_t)P.band_tiles;
     uint32_t first = info->first[xcd], last = info->first[xcd + 1];
@@ -1676,18 +1648,13 @@ hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
         int zb = (n_pairs + P.pairs_per_block - 1) / P.pairs_per_block;
         if (TILE_W == 128 && P.main_span > 1)
             zb = (zb + P.main_span - 1) / P.main_span;
-        const bool merged = P.band_gather_list != nullptr && P.band_gather_n > 0;
-        const int gw = merged ? 8 * P.band_gather_n * ((n_pairs + P.gather_ppb - 1) / P.gather_ppb) : 0;
-        const dim3 grid(gw + 8 * (P.band_per + (P.band_tail > 0 ? (P.main_tail_parts - 1) * P.band_tail : 0)), P.band_tail > 0 ? 1 : zb, 1);
-#define P2P_LAUNCH_BAND(MASKED, MERGED)                                                                                         \
-        hipLaunchKernelGGL((remap_views_band_kernel<MASKED, MERGED>), grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, \
-                           P.band_hdr, P.band_px, P.band_grp, P.band_info)
-        if (P.view_mask) {
-            if (merged) P2P_LAUNCH_BAND(true, true); else P2P_LAUNCH_BAND(true, false);
-        } else {
-            if (merged) P2P_LAUNCH_BAND(false, true); else P2P_LAUNCH_BAND(false, false);
-        }
-#undef P2P_LAUNCH_BAND
+        const dim3 grid(8 * (P.band_per + (P.band_tail > 0 ? (P.main_tail_parts - 1) * P.band_tail : 0)), P.band_tail > 0 ? 1 : zb, 1);
+        if (P.view_mask)
+            hipLaunchKernelGGL(remap_views_band_kernel<true>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.band_hdr, P.band_px,
+                               P.band_grp, P.band_info);
+        else
+            hipLaunchKernelGGL(remap_views_band_kernel<false>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.band_hdr, P.band_px,
+                               P.band_grp, P.band_info);
         return hipGetLastError();
     }
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
