@@ -184,6 +184,8 @@ struct PlanParams {
     const float* mapU;       // caller maps [n_pitch][oh][ow] or nullptr (then pitch_map_eval)
     const float* mapV;
     int2* coords;
+    int coords_all;          // 1: the coordinates of every pixel are written; 0: only those of the tiles that gather
+    int coords_only;         // 1: launch_plan runs coords_kernel instead (every pixel's coordinates into an existing plan)
     PieceHdr* hdr;
     uint32_t* px;
     uint32_t* items;

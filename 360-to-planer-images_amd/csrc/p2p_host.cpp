@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <condition_variable>
 #include <cmath>
 #include <cstdarg>
@@ -87,6 +88,9 @@ struct Options {
     int gather_order = 1;             // P2P_GATHER_ORDER
     int gather_group = 3;             // P2P_GATHER_GROUP
     int scramble_plan = 0;            // P2P_SCRAMBLE_PLAN (robustness self-test only)
+    int coords_all = 0;               // P2P_COORDS_ALL: 1 = the plan pass writes every pixel's quantised coordinates (0: the gather tiles')
+    int early_main = 1;               // P2P_EARLY_MAIN: 1 = a job's first launch sends the main kernel out right behind the plan pass
+    int defer_lists = 1;              // P2P_DEFER_LISTS: 1 = a plan without gather tiles makes its main lists at its second launch (0: at once)
     int band = -1;                    // P2P_BAND: 1 = source-band tiles wherever they apply, 0 = never, -1 = the library's rule (choose_band)
     int band_bh = 16, band_cw = 8;    // P2P_BAND_BH / P2P_BAND_CW: cell of the source, rows x columns
     int band_maxw = 27, band_maxh = 7;  // P2P_BAND_MAXW / P2P_BAND_MAXH: tap extent of a group beyond which its tile gathers
@@ -125,6 +129,9 @@ void options_load_locked()
     o.gather_order = env_int("P2P_GATHER_ORDER", o.gather_order);
     o.gather_group = std::min(8, std::max(0, env_int("P2P_GATHER_GROUP", o.gather_group)));
     o.scramble_plan = env_int("P2P_SCRAMBLE_PLAN", o.scramble_plan);
+    o.defer_lists = env_int("P2P_DEFER_LISTS", o.defer_lists);
+    o.early_main = env_int("P2P_EARLY_MAIN", o.early_main);
+    o.coords_all = env_int("P2P_COORDS_ALL", o.coords_all);
     o.band = env_int("P2P_BAND", o.band);
     o.band_bh = std::min(256, std::max(1, env_int("P2P_BAND_BH", o.band_bh)));
     o.band_cw = std::min(256, std::max(1, env_int("P2P_BAND_CW", o.band_cw)));
@@ -348,6 +355,7 @@ struct PlanKey {  // the reference's key (ow, oh, pitch, pw, ph, fov), for the w
 
 struct Plan {  // the plan pass's tables (p2p_plan.hip)
     int device = 0;
+    void* d_block = nullptr;             // the one allocation the next seven pointers are parts of
     int2* d_coords = nullptr;            // [n_pitch][oh][ow] quantised coordinates
     p2p::PieceHdr* d_hdr = nullptr;      // [n_pitch][tiles]
     uint32_t* d_px = nullptr;            // [n_pitch][tiles][256 * VIEWS_PXT]
@@ -368,6 +376,16 @@ struct Plan {  // the plan pass's tables (p2p_plan.hip)
     uint32_t* d_band_grp = nullptr;
     p2p::BandInfo* d_band_info = nullptr;
     int band_tiles = 0, band_groups = 0, band_per = 0;
+    // The main kernel's per-XCD lists are made from the headers on the host (xcd_main_lists).  A plan with no gather
+    // tile does not need them to draw: its FIRST launch goes out in the grid's own order right behind the plan pass, and
+    // the lists are made when a second launch asks for the plan (one image through a fresh context -- the tool on one
+    // file -- never pays the read-back, the sort and the upload: bench.py's cold figures).
+    // the quantised coordinates of every pixel (else: of the gather tiles only; ensure_full_coords completes them)
+    std::atomic<bool> coords_full{false};
+    std::atomic<bool> lists_pending{false};
+    std::mutex lists_mu;
+    std::atomic<int> launches{0};
+    int tile_w = 64;
     bool built = false;
     float plan_ms = 0.0f;                // device time of the plan pass (band plans: with the band passes)
     size_t bytes = 0;
@@ -376,8 +394,8 @@ struct Plan {  // the plan pass's tables (p2p_plan.hip)
     {
         DeviceRestore keep;
         (void)hipSetDevice(device);
-        (void)dev_free(d_coords); (void)dev_free(d_hdr); (void)dev_free(d_px); (void)dev_free(d_items);
-        (void)dev_free(d_px2); (void)dev_free(d_n_gather); (void)dev_free(d_gather_list); (void)dev_free(d_xcd_list); (void)dev_free(d_xcd_all); (void)dev_free(d_main_list);
+        (void)dev_free(d_block);  // coords, hdr, px, items, px2, n_gather, gather_list: parts of it
+        (void)dev_free(d_xcd_list); (void)dev_free(d_xcd_all); (void)dev_free(d_main_list);
         (void)dev_free(d_band_hdr); (void)dev_free(d_band_px); (void)dev_free(d_band_grp); (void)dev_free(d_band_info);
     }
 };
@@ -1575,7 +1593,10 @@ int p2p_job_set_view_mask(p2p_job* j, const uint8_t* mask)
 // Build the job's plan (p2p_plan.hip) for its current maps: once per job geometry, like the yaw tables.  It
 // depends on the maps only, never on pixel data -- the device counterpart of the reference's
 // pitch_mapping_cache (P:17-18, P:55-73), which lives as long as the process.
-static int job_build_plan(p2p_job* j)
+// after_plan_pass: called once the plan pass is enqueued and before anything waits for it (per-view plans only) --
+// p2p_job_run launches the main kernel in grid order there, so that one image through a fresh context has its pixels
+// under way while the host reads the gather count back.
+static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& after_plan_pass = nullptr)
 {
     const p2p_job_desc& d = j->d;
     p2p_ctx* ctx = j->ctx;
@@ -1618,16 +1639,29 @@ static int job_build_plan(p2p_job* j)
     } scratch;
     StreamSyncGuard sync_on_exit(st);
     Pl->band = band;
-    if (float_path)
-        HIP_TRY(dev_alloc((void**)&Pl->d_px2, slots * S.block * S.pxt * sizeof(uint32_t)));
-    HIP_TRY(dev_alloc((void**)&Pl->d_coords, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2)));
-    HIP_TRY(dev_alloc((void**)&Pl->d_hdr, slots * sizeof(p2p::PieceHdr)));
-    if (!band) {
-        HIP_TRY(dev_alloc((void**)&Pl->d_px, slots * S.block * S.pxt * sizeof(uint32_t)));
-        HIP_TRY(dev_alloc((void**)&Pl->d_items, slots * S.cap * sizeof(uint32_t)));
+    {
+        // ONE block for the plan pass's tables (the device is idle while a fresh geometry's blocks are mapped: six
+        // allocations were a third of the first image's device-side time), carved at 256-byte boundaries
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t b_px2 = float_path ? up(slots * S.block * S.pxt * sizeof(uint32_t)) : 0;
+        const size_t b_coords = up((size_t)d.n_pitch * d.oh * d.ow * sizeof(int2));
+        const size_t b_hdr = up(slots * sizeof(p2p::PieceHdr));
+        const size_t b_px = band ? 0 : up(slots * S.block * S.pxt * sizeof(uint32_t));
+        const size_t b_items = band ? 0 : up(slots * S.cap * sizeof(uint32_t));
+        const size_t b_cnt = 256, b_list = up(slots * sizeof(uint32_t));
+        unsigned char* blk = nullptr;
+        HIP_TRY(dev_alloc((void**)&blk, b_px2 + b_coords + b_hdr + b_px + b_items + b_cnt + b_list));
+        Pl->d_block = blk;
+        size_t off = 0;
+        auto take = [&](size_t b) { unsigned char* p = b ? blk + off : nullptr; off += b; return p; };
+        Pl->d_px2 = (uint32_t*)take(b_px2);
+        Pl->d_coords = (int2*)take(b_coords);
+        Pl->d_hdr = (p2p::PieceHdr*)take(b_hdr);
+        Pl->d_px = (uint32_t*)take(b_px);
+        Pl->d_items = (uint32_t*)take(b_items);
+        Pl->d_n_gather = (uint32_t*)take(b_cnt);
+        Pl->d_gather_list = (uint32_t*)take(b_list);
     }
-    HIP_TRY(dev_alloc((void**)&Pl->d_n_gather, sizeof(uint32_t)));
-    HIP_TRY(dev_alloc((void**)&Pl->d_gather_list, slots * sizeof(uint32_t)));
     Pl->bytes = (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2) +
                 slots * (sizeof(p2p::PieceHdr) + ((band ? 0 : S.block * S.pxt * (float_path ? 2 : 1) + S.cap) + 1) * sizeof(uint32_t));
     p2p::PlanParams Q{};
@@ -1637,6 +1671,8 @@ static int job_build_plan(p2p_job* j)
     Q.mapU = j->host_maps ? j->d_mapU : nullptr;
     Q.mapV = j->host_maps ? j->d_mapV : nullptr;
     Q.coords = Pl->d_coords;
+    Q.coords_all = (band || float_path || opt.coords_all != 0) ? 1 : 0;
+    Pl->coords_full = Q.coords_all != 0;
     Q.hdr = Pl->d_hdr;
     Q.px = Pl->d_px;
     Q.items = Pl->d_items;
@@ -1689,6 +1725,11 @@ static int job_build_plan(p2p_job* j)
     HIP_TRY(hipMemsetAsync(Pl->d_n_gather, 0, sizeof(uint32_t), st));
     HIP_TRY(hipEventRecord(ctx->ev_t0, st));
     HIP_TRY(shape_ops(j->shape).plan(Q, st));
+    if (!band && after_plan_pass) {
+        HIP_TRY(hipEventRecord(ctx->ev_t1, st));
+        if (int rc = after_plan_pass(*Pl))
+            return rc;
+    }
     if (band) {
         // the band passes: count the tiles, read the count back (the tables are sized by it), cut, sort, build
         HIP_TRY(shape_ops(j->shape).band(B, 0, st));
@@ -1717,11 +1758,15 @@ static int job_build_plan(p2p_job* j)
             HIP_TRY(shape_ops(j->shape).band(B, 1, st));
         }
     }
-    HIP_TRY(hipEventRecord(ctx->ev_t1, st));
+    if (band || !after_plan_pass)
+        HIP_TRY(hipEventRecord(ctx->ev_t1, st));
     HIP_TRY(hipMemcpyAsync(&cnt, Pl->d_n_gather, sizeof(cnt), hipMemcpyDeviceToHost, st));
-    // the work lists are made from the plan's headers, once per geometry: they come back with the counter
+    // the work lists are made from the plan's headers, once per geometry: they come back with the counter -- unless the
+    // plan turns out to have no gather tile and may draw its first launch in grid order (Plan::lists_pending)
     const bool want_main_order = main_order != 0;
-    if (want_main_order) {
+    const bool may_defer = want_main_order && opt.defer_lists != 0 && opt.main_order < 0 && opt.scramble_plan == 0;
+    Pl->tile_w = shape_ops(j->shape).shape.tile_w;
+    if (want_main_order && !may_defer) {
         hh.resize(slots);
         HIP_TRY(hipMemcpyAsync(hh.data(), Pl->d_hdr, slots * sizeof(p2p::PieceHdr), hipMemcpyDeviceToHost, st));
     }
@@ -1731,8 +1776,12 @@ static int job_build_plan(p2p_job* j)
         return fail(P2P_ERR_HIP, "the plan pass listed %u gather tiles of %zu", cnt, slots);
     Pl->n_gather = (int)cnt;
     Pl->built = true;
-    const bool make_main_list = want_main_order && (size_t)cnt < slots;
-    if (cnt > 0 && hh.empty()) {
+    bool make_main_list = want_main_order && (size_t)cnt < slots;
+    if (make_main_list && may_defer && cnt == 0) {
+        Pl->lists_pending = true;
+        make_main_list = false;
+    }
+    if ((cnt > 0 || make_main_list) && hh.empty()) {
         hh.resize(slots);
         HIP_TRY(hipMemcpyAsync(hh.data(), Pl->d_hdr, slots * sizeof(p2p::PieceHdr), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -1842,6 +1891,65 @@ static int audit_check(p2p_ctx* ctx, const char* what)
 }
 #endif
 
+// Every pixel's quantised coordinates into a plan that kept only its gather tiles' (PlanParams::coords_all): for
+// p2p_job_get_coords, for a gather kernel that is about to draw every tile, for yaw rows that are not a shift.
+static int ensure_full_coords(p2p_job* j)
+{
+    Plan& Pl = *j->plan_ref;
+    std::lock_guard<std::mutex> lk(Pl.lists_mu);
+    if (Pl.coords_full)
+        return P2P_OK;
+    p2p::PlanParams Q{};
+    Q.pw = j->d.pw; Q.ph = j->d.ph; Q.ow = j->d.ow; Q.oh = j->d.oh; Q.n_pitch = j->d.n_pitch; Q.border = j->border;
+    Q.geom = j->geom;
+    Q.pitch = j->d_pitch;
+    Q.mapU = j->host_maps ? j->d_mapU : nullptr;
+    Q.mapV = j->host_maps ? j->d_mapV : nullptr;
+    Q.coords = Pl.d_coords;
+    Q.coords_only = 1;
+    HIP_TRY(shape_ops(j->shape).plan(Q, j->ctx->stream));
+    Pl.coords_full = true;
+    return P2P_OK;
+}
+
+// the deferred half of job_build_plan: the main kernel's per-XCD lists of a plan that has been launched once
+static int plan_make_main_lists(p2p_job* j, Plan& Pl)
+{
+    std::lock_guard<std::mutex> lk(Pl.lists_mu);
+    if (!Pl.lists_pending)
+        return P2P_OK;
+    hipStream_t st = j->ctx->stream;
+    const size_t slots = j->n_tiles * j->d.n_pitch;
+    std::vector<p2p::PieceHdr> hh(slots);
+    std::vector<uint32_t> tm;
+    StreamSyncGuard sync_on_exit(st);
+    HIP_TRY(hipMemcpyAsync(hh.data(), Pl.d_hdr, slots * sizeof(p2p::PieceHdr), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    int stride = 0;
+    tm = xcd_main_lists(hh, j->n_tiles, &stride, Pl.tile_w);
+    uint32_t* d_list = nullptr;
+    HIP_TRY(dev_alloc((void**)&d_list, tm.size() * sizeof(uint32_t)));
+    hipError_t e = hipMemcpyAsync(d_list, tm.data(), tm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        (void)dev_free(d_list);
+        return fail(P2P_ERR_HIP, "main lists: %s", hipGetErrorString(e));
+    }
+    sync_on_exit.armed = false;
+    for (int x = 0; x < 8; ++x) {
+        int c = 0;
+        while (c < stride && tm[(size_t)x * stride + c] != ~0u)
+            ++c;
+        Pl.main_count[x] = c;
+    }
+    Pl.main_stride = stride;
+    Pl.d_main_list = d_list;
+    Pl.bytes += tm.size() * sizeof(uint32_t);
+    Pl.lists_pending = false;
+    return P2P_OK;
+}
+
 int p2p_job_run(p2p_job* j)
 {
     if (!j)
@@ -1893,17 +2001,60 @@ int p2p_job_run(p2p_job* j)
     const bool float_path = (j->d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)) != 0;
     if (float_path && j->host_maps)
         return fail(P2P_ERR_STATE, "the float pixel path evaluates its own maps; caller maps are not supported");
+    const Options& opt = j->opt;
+    // what does not depend on the plan's lists
+    auto plan_params = [&](const Plan& Pl) {
+        P.coords = Pl.d_coords; P.hdr = Pl.d_hdr; P.px = Pl.d_px; P.items = Pl.d_items; P.px2 = Pl.d_px2;
+        P.pairs_per_block = choose_pairs_per_block(j->d, shape_ops(j->shape).shape, opt);
+        P.chunk_outer = opt.chunk_outer >= 0 ? opt.chunk_outer : (j->d.n_panos > 1 ? 1 : 0);
+        P.main_span = choose_main_span(j->d, shape_ops(j->shape).shape, opt, P.pairs_per_block);
+        const int pair_chunks = (j->d.n_panos * j->d.n_yaw + P.pairs_per_block - 1) / P.pairs_per_block;
+        P.main_chunks = (pair_chunks + P.main_span - 1) / P.main_span;
+        // table-prefetch workgroups (p2p_tile.h: main_block_role) when one launch's plan tables cannot stay in the Infinity
+        // Cache next to the panorama (config 4: 565 MB): 2 groups = 64 tiles of lead per XCD
+        const size_t table_bytes = plan_table_bytes(j->d, shape_ops(j->shape).shape);
+        P.pf_lead = opt.prefetch_lead >= 0 ? opt.prefetch_lead : (table_bytes > ((size_t)128 << 20) ? 2 : 0);
+        P.pitch_order = j->d_pitch_order;
+        P.main_tail = 0;
+        P.main_tail_parts = opt.main_tail_parts;
+        P.odd_pairs = j->d_odd_pairs;
+        P.n_odd_pairs = j->n_odd_pairs;
+        P.rest_ppb = std::min(16, std::max(1, j->n_odd_pairs));
+        P.use_pair_list = 0;
+    };
+    bool early_main = false;
     if (j->plan_ref && j->plan_ref->band != job_wants_band(j)) {
         // (the yaws changed under a band plan, or away from one: p2p_job_set_yaws / p2p_job_set_maps)
         HIP_TRY(hipStreamSynchronize(j->ctx->stream));
         j->plan_ref.reset();
     }
     if (!j->plan_ref) {
-        int rc = job_build_plan(j);
+        // One image through a fresh geometry: the main kernel goes out in grid order right behind the plan pass (it draws
+        // the LDS-scheme tiles, whichever they turn out to be); the gather tiles' count, the lists and the other kernels
+        // follow below.  The kernels write disjoint pixels, in any order.
+        std::function<int(const Plan&)> launch_main;
+        if (!float_path && opt.force_rest == 0 && opt.early_main != 0 && opt.scramble_plan == 0)
+            launch_main = [&](const Plan& Pl) -> int {
+                plan_params(Pl);
+                P.main_list = nullptr;
+                P.main_stride = 0;
+                P.main_group = 1;
+                if (timed)
+                    HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
+                HIP_TRY(shape_ops(j->shape).views(P, 0, j->ctx->stream));
+                early_main = true;
+                return P2P_OK;
+            };
+        int rc = job_build_plan(j, launch_main);
         if (rc != P2P_OK)
             return rc;
     }
     const bool band = j->plan_ref->band;
+    if (j->plan_ref->lists_pending && j->plan_ref->launches > 0) {
+        int rc = plan_make_main_lists(j, *j->plan_ref);
+        if (rc != P2P_OK)
+            return rc;
+    }
     {   // the job's view of its plan
         const Plan& Pl = *j->plan_ref;
         j->d_coords = Pl.d_coords; j->d_hdr = Pl.d_hdr; j->d_px = Pl.d_px; j->d_items = Pl.d_items; j->d_px2 = Pl.d_px2;
@@ -1913,7 +2064,6 @@ int p2p_job_run(p2p_job* j)
         for (int x = 0; x < 8; ++x)
             j->main_count[x] = Pl.main_count[x];
     }
-    const Options& opt = j->opt;
     P.pairs_per_block = choose_pairs_per_block(j->d, shape_ops(j->shape).shape, opt);
     P.chunk_outer = opt.chunk_outer >= 0 ? opt.chunk_outer : (j->d.n_panos > 1 ? 1 : 0);
     // the main kernel's grid: list order (source bands, all pitch views together) unless the plan has no list
@@ -2005,7 +2155,7 @@ int p2p_job_run(p2p_job* j)
         j->ran = true;
         return P2P_OK;
     }
-    if (timed)
+    if (timed && !early_main)
         HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
     // The main kernel draws every LDS-scheme tile for every yaw that is a plain shift, the gather kernel every other
     // tile for those yaws -- on the reference's own workloads that is everything.  The other two kernels are launched
@@ -2016,13 +2166,16 @@ int p2p_job_run(p2p_job* j)
     // Few tiles left for the LDS scheme (the edge tiles of a strongly minifying view set): the gather kernel, which
     // needs nothing but the coordinates, draws those too, and the main kernel's launch (6 us for a handful of
     // tiles) is saved.  The odd pairs of those tiles stay the rest kernel's.
-    P.gather_all = (gather_ok && !band && j->n_gather > 0 && j->d_xcd_all && (slots - (size_t)j->n_gather) * 4 <= slots &&
+    P.gather_all = (gather_ok && !band && !early_main && j->n_gather > 0 && j->d_xcd_all && (slots - (size_t)j->n_gather) * 4 <= slots &&
                     opt.gather_all != 0) ? 1 : 0;
     // (the gather kernel of a big job on a side stream, forked and joined by events, so that its cache waits overlap
     // the main kernel's arithmetic: config 4's pitch 30 1647 vs 1621 us, all five pitches 8021 vs 7988 -- the two
     // kernels do not interleave, not kept.  Round 4 once more, the side stream at the LOWEST priority and the gather
     // kernel enqueued behind the main kernel, to fill the slots its last workgroups leave: config 4 6.301 / 6.312 /
     // 6.303 -> 6.286 / 6.311 / 6.293 ms, five 1080p pitch views x 12 yaws 170.6 -> 174.2 us: not kept either)
+    if (P.gather_all && !j->plan_ref->coords_full)
+        if (int rc = ensure_full_coords(j))
+            return rc;
     if (j->n_gather > 0) {
         if (gather_ok) {
             P.use_pair_list = 0;
@@ -2043,6 +2196,14 @@ int p2p_job_run(p2p_job* j)
             HIP_TRY(shape_ops(j->shape).views(P, 2, j->ctx->stream));
     }
     if (need_rest && !band) {
+        // (a yaw row that is not a shift is gathered per pixel from the coordinates, also on the LDS-scheme tiles)
+        bool not_a_shift = !fast_width;
+        if (j->yaw_ref)
+            for (const auto& yd : j->yaw_ref->desc)
+                not_a_shift = not_a_shift || yd.mode == 2;
+        if (not_a_shift && !j->plan_ref->coords_full)
+            if (int rc = ensure_full_coords(j))
+                return rc;
         P.use_pair_list = (fast_width && j->n_odd_pairs > 0) ? 1 : 0;
         HIP_TRY(shape_ops(j->shape).views(P, 1, j->ctx->stream));
     }
@@ -2050,7 +2211,7 @@ int p2p_job_run(p2p_job* j)
     if (band) {
         if (P.band_tiles > 0)
             HIP_TRY(shape_ops(j->shape).views(P, 4, j->ctx->stream));
-    } else if (fast_width && any_lds && !P.gather_all)
+    } else if (fast_width && any_lds && !P.gather_all && !early_main)
         HIP_TRY(shape_ops(j->shape).views(P, 0, j->ctx->stream));
     if (timed)
         HIP_TRY(hipEventRecord(j->ev_ring[2 * slot + 1], j->ctx->stream));
@@ -2059,6 +2220,7 @@ int p2p_job_run(p2p_job* j)
         return rc;
 #endif
     // (the event that orders copies behind this run is recorded when a copy asks for it: mark_run)
+    j->plan_ref->launches++;
     j->run_unmarked = true;
     if (!j->owns_src)
         j->src_owner->run_unmarked = true;  // uploads into the shared panoramas wait for this run too
@@ -2310,6 +2472,9 @@ int p2p_job_get_coords(p2p_job* j, int32_t* sxsy)
     if (!j->ran)
         return fail(P2P_ERR_STATE, "p2p_job_run has not been called");
     HIP_TRY(hipSetDevice(j->ctx->device));
+    if (j->plan_ref && !j->plan_ref->coords_full)
+        if (int rc = ensure_full_coords(j))
+            return rc;
     const size_t n = (size_t)j->d.n_pitch * j->d.oh * j->d.ow * 2 * sizeof(int32_t);
     HIP_TRY(hipMemcpyAsync(sxsy, (const void*)j->d_coords, n, hipMemcpyDeviceToHost, j->ctx->stream));
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));

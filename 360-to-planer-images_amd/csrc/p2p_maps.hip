@@ -88,7 +88,8 @@ __device__ __forceinline__ int yaw_delta(uint32_t te, int c, int s, int pw)
     return -1;
 }
 
-__global__ __launch_bounds__(256) void yaw_desc_kernel(YawDesc* __restrict__ desc, uint32_t* __restrict__ f4tab,
+// (1024 threads per yaw: the two passes over the table are chains of dependent loads, 8 rounds each at 8192 columns)
+__global__ __launch_bounds__(1024) void yaw_desc_kernel(YawDesc* __restrict__ desc, uint32_t* __restrict__ f4tab,
                                                        const uint32_t* __restrict__ packed, int pw)
 {
     __shared__ int bad[2];
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void yaw_desc_kernel(YawDesc* __restrict__ des
     __syncthreads();
     const int s_a = i0, s_b = (i0 + pw - 1) % pw;
     int nb_a = 0, nb_b = 0;
-    for (int c = t; c < pw; c += 256) {
+    for (int c = t; c < pw; c += 1024) {
         uint32_t te = T[c];
         nb_a += yaw_delta(te, c, s_a, pw) < 0;
         nb_b += yaw_delta(te, c, s_b, pw) < 0;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void yaw_desc_kernel(YawDesc* __restrict__ des
     const bool ok_a = bad[0] == 0, ok_b = bad[1] == 0;
     const int s = ok_a ? s_a : s_b;
     if (!ok_a && !ok_b) {
-        for (int c = t; c < pw; c += 256)
+        for (int c = t; c < pw; c += 1024)
             F4[c] = 0u;
         if (t == 0)
             desc[yi] = YawDesc{0, 2, 0, -1};
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void yaw_desc_kernel(YawDesc* __restrict__ des
     }
     const int c_last = (pw - 1 - s + pw) % pw;  // the rot column whose source column is pw-1
     int lmin = 64, lmax = -1;
-    for (int c = t; c < pw; c += 256) {
+    for (int c = t; c < pw; c += 1024) {
         uint32_t w = 0;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -271,7 +272,7 @@ hipError_t launch_yaw_pack(uint32_t* packed, const float* rows, size_t n, hipStr
 hipError_t launch_yaw_desc(YawDesc* desc, uint32_t* f4tab, const uint32_t* packed, int pw, int n_yaw,
                            hipStream_t st)
 {
-    hipLaunchKernelGGL(yaw_desc_kernel, dim3(n_yaw), dim3(256), 0, st, desc, f4tab, packed, pw);
+    hipLaunchKernelGGL(yaw_desc_kernel, dim3(n_yaw), dim3(1024), 0, st, desc, f4tab, packed, pw);
     return hipGetLastError();
 }
 

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
     const uint32_t slot = (uint32_t)(pitch_i * tiles_x * tiles_y + tile_id);
 
     // ---- the pitch-stage coordinate of every pixel of the tile, quantised as cv::remap does ----
-    int ix[PXT], iy[PXT];
+    int ix[PXT], iy[PXT], qsx[PXT], qsy[PXT];
     uint32_t fx[PXT], fy[PXT], frac16[PXT];
     bool inside[PXT], inrange[PXT];
 #pragma unroll
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
             // fractional shift is added per yaw by the kernel and may carry into the next column, so the row spans
             // are one column wider.  The bottom row is folded onto (ph - 2, fraction 1) so that the lower tap exists.
             ix[j] = iy[j] = -32768;
+            qsx[j] = qsy[j] = INT32_MIN;
             fx[j] = fy[j] = 0u;
             inrange[j] = false;
             if (inside[j]) {
@@ -150,8 +151,11 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
             }
             sx = cv_round_f32(U * 32.0f);
             sy = cv_round_f32(V * 32.0f);
-            P.coords[k] = make_int2(sx, sy);
+            if (P.coords_all)
+                P.coords[k] = make_int2(sx, sy);
         }
+        qsx[j] = sx;
+        qsy[j] = sy;
         ix[j] = sat_short(sx >> 5);
         iy[j] = sat_short(sy >> 5);
         fx[j] = (uint32_t)sx & 31u;
@@ -329,6 +333,16 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
             P.hdr[slot] = h;
         }
         return;
+    }
+    // The quantised coordinates are what the gather and table kernels draw from: kept for the tiles that are theirs (and
+    // for all tiles when the host asks: band plans, the float path, p2p_job_get_coords -- coords_kernel fills them in
+    // later otherwise).  A plan none of whose tiles gathers writes none: 8 bytes per output pixel, config 2's plan pass
+    // wrote 100 MB of them next to 42 MB of tables.
+    if (!P.coords_all && !ok && !P.float_path) {
+#pragma unroll
+        for (int j = 0; j < PXT; ++j)
+            if (inside[j])
+                P.coords[((size_t)pitch_i * P.oh + (y0 + ty0 + j * ROWSTEP)) * P.ow + px] = make_int2(qsx[j], qsy[j]);
     }
     uint32_t* pxw = P.px + (size_t)slot * (VIEWS_BLOCK * PXT);
     uint32_t* px2w = P.float_path ? P.px2 + (size_t)slot * (VIEWS_BLOCK * PXT) : nullptr;
@@ -755,8 +769,36 @@ hipError_t launch_band(const BandParams& B, int stage, hipStream_t st)
     return hipGetLastError();
 }
 
+// The quantised coordinates of EVERY pixel (plan_kernel with coords_all == 0 keeps only the gather tiles'): the same
+// evaluation, the same rounding.
+template <bool CALLER_MAPS>
+__global__ __launch_bounds__(256) void coords_kernel(PlanParams P)
+{
+    const int px = blockIdx.x * 256 + threadIdx.x, py = blockIdx.y, pitch_i = blockIdx.z;
+    if (px >= P.ow)
+        return;
+    const size_t k = ((size_t)pitch_i * P.oh + py) * P.ow + px;
+    float U, V;
+    if (CALLER_MAPS) {
+        U = P.mapU[k];
+        V = P.mapV[k];
+    } else {
+        const PitchConst pc = P.pitch[pitch_i];
+        pitch_map_eval((float)px, (float)py, P.geom, pc.c, pc.s, U, V);
+    }
+    P.coords[k] = make_int2(cv_round_f32(U * 32.0f), cv_round_f32(V * 32.0f));
+}
+
 hipError_t launch_plan(const PlanParams& P, hipStream_t st)
 {
+    if (P.coords_only) {
+        const dim3 grid((P.ow + 255) / 256, P.oh, P.n_pitch);
+        if (P.mapU)
+            hipLaunchKernelGGL(coords_kernel<true>, grid, dim3(256), 0, st, P);
+        else
+            hipLaunchKernelGGL(coords_kernel<false>, grid, dim3(256), 0, st, P);
+        return hipGetLastError();
+    }
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
     if (P.mapU)
         hipLaunchKernelGGL(plan_kernel<true>, dim3(tiles, P.n_pitch), dim3(VIEWS_BLOCK), 0, st, P);

@@ -6,8 +6,9 @@ yaw + pitch rotation per view and a single cv2.remap with BORDER_REFLECT.
     precompute_mapping(W, H, FOV_rad, yaw, ...)  L:47-157   p2p_build_rot_map (rot_map_kernel), lru_cache'd like L:47
     interpolate_color(U, V, img, method)         L:159-180  p2p_remap_maps_interp_u8 (nearest / bilinear / bicubic, BORDER_REFLECT)
     panorama_to_plane(pano_array, U, V)          L:182-194  interpolate_color(U, V, pano_array)
-    check_pitch / check_yaw                      L:196-237  same messages
-    process_image_batch / parse_arguments / main L:239-388  same flags, defaults, file names and logging
+    the command line                             L:196-388  same flags, defaults, value ranges and file names -- the DRIVER is
+                                                            this build's own: images decoded ahead on a thread pool, one upload
+                                                            and ONE launch per image for all its yaws, encoders on a second pool
 
 Image files go through Pillow (cv2 is not a dependency here).  The reference converts BGR -> RGB after
 imread and back before imwrite (L:254, L:275); remap is channel-agnostic, so the files are the same.
@@ -17,10 +18,10 @@ import argparse
 import logging
 import os
 import sys
-from concurrent.futures import ThreadPoolExecutor, as_completed
+from concurrent.futures import ThreadPoolExecutor
 from functools import lru_cache
 from pathlib import Path
-from typing import List, Tuple
+from typing import Iterable, Tuple
 
 import numpy as np
 
@@ -68,157 +69,159 @@ def panorama_to_plane(pano_array: np.ndarray, U: np.ndarray, V: np.ndarray) -> n
     return interpolate_color(U, V, pano_array)
 
 
-def check_pitch(value: str) -> int:
-    """L:196-216."""
+# ------------------------------------------------------------------------------------------------
+# Command line.  SURVEY 8(f)3 asks for the maps and the interpolation methods above; the folder tool around them keeps the
+# reference's flags, defaults, value ranges and output names (L:196-237, L:268, L:285-304) and is otherwise built like
+# this package's current tool (panorama_to_plane_pitch.py): decode ahead -> one device stage -> encode behind.
+# ------------------------------------------------------------------------------------------------
+_SUFFIXES = (".jpg", ".jpeg", ".png")  # the patterns the reference globs for (L:325)
+
+# flag -> argparse keywords, the reference's table (L:285-299)
+_FLAGS = (
+    ("--input_path", dict(type=str, required=True, help="Path to the input panorama images")),
+    ("--output_path", dict(type=str, default="output_images", help="Path to save the output images")),
+    ("--output_format", dict(type=str, choices=["png", "jpg", "jpeg"], help="Output image format (png, jpg, jpeg)")),
+    ("--FOV", dict(type=int, default=90, help="Field of View in degrees")),
+    ("--output_width", dict(type=int, default=1000, help="Width of the output image in pixels")),
+    ("--output_height", dict(type=int, default=1500, help="Height of the output image in pixels")),
+    ("--pitch", dict(default=90, help="Pitch angle in degrees (1-179)")),
+    ("--yaw_angles", dict(nargs="+", type=int, default=[0, 60, 120, 180, 240, 300],
+                          help="List of yaw angles in degrees (0-360). Example: --yaw_angles 0 60 120 180 240 300")),
+    ("--num_workers", dict(type=int, default=None,
+                           help="Number of worker threads. Defaults to 90%% of CPU cores if not specified.")),
+)
+
+
+def check_pitch(value) -> int:
+    """argparse type of --pitch: an integer in 1..179 (the range and the two messages of L:196-216)."""
     try:
-        ivalue = int(value)
-    except ValueError:
-        raise argparse.ArgumentTypeError("Pitch value must be an integer between 1 and 179.")
-    if not (1 <= ivalue <= 179):
-        raise argparse.ArgumentTypeError(f"{ivalue} is an invalid pitch value. It must be between 1 and 179.")
-    return ivalue
+        pitch = int(value)
+    except (TypeError, ValueError):
+        raise argparse.ArgumentTypeError("Pitch value must be an integer between 1 and 179.") from None
+    if pitch < 1 or pitch > 179:
+        raise argparse.ArgumentTypeError(f"{pitch} is an invalid pitch value. It must be between 1 and 179.")
+    return pitch
 
 
-def check_yaw(yaw_angles: List[int]) -> List[int]:
-    """L:218-237: validated, de-duplicated, sorted."""
-    unique_yaws = set()
-    for val in yaw_angles:
-        if not (0 <= val <= 360):
-            raise argparse.ArgumentTypeError(f"{val} is an invalid yaw value. It must be between 0 and 360.")
-        unique_yaws.add(val)
-    return sorted(unique_yaws)
-
-
-def _imread_rgb(path):
-    """cv2.imread + COLOR_BGR2RGB (L:249-254); None when the file cannot be decoded."""
-    try:
-        from PIL import Image, ImageOps
-
-        with Image.open(str(path)) as im:
-            im = ImageOps.exif_transpose(im)
-            return np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
-    except Exception:
-        return None
-
-
-def _imwrite_rgb(path, image):
-    """COLOR_RGB2BGR + cv2.imwrite (L:275-278) with cv2's defaults (JPEG quality 95)."""
-    from PIL import Image
-
-    im = Image.fromarray(np.ascontiguousarray(image))
-    if Path(path).suffix.lower() in (".jpg", ".jpeg"):
-        im.save(str(path), format="JPEG", quality=95)
-    else:
-        im.save(str(path), format="PNG", compress_level=1)
-
-
-def process_image_batch(image_path: Path, args: argparse.Namespace, output_path: Path, precomputed_mappings: dict):
-    """L:239-283: every yaw of one image; errors are logged and swallowed."""
-    logging.info(f"Processing {image_path}...")
-    try:
-        pano_array = _imread_rgb(image_path)
-        if pano_array is None:
-            logging.error(f"Failed to read image {image_path}. Skipping.")
-            return
-        file_name = image_path.stem
-        # every yaw of the image in ONE call: the image is uploaded once and all maps are drawn by one launch
-        # (the reference calls panorama_to_plane once per yaw, L:259-265; same pixels)
-        yaws = list(args.yaw_angles)
-        if pano_array.ndim == 3 and pano_array.shape[2] == 3 and yaws:
-            views = _native.remap_maps_batch(pano_array, np.stack([precomputed_mappings[y][0] for y in yaws]),
-                                             np.stack([precomputed_mappings[y][1] for y in yaws]),
-                                             border=_native.BORDER_REFLECT, device=_DEVICE)
-        else:
-            views = None
-        for k, yaw in enumerate(yaws):
-            logging.debug(f"Processing {image_path} with yaw {yaw}°...")
-            U, V = precomputed_mappings[yaw]
-            output_image_array = views[k] if views is not None else panorama_to_plane(pano_array, U, V)
-            output_format = args.output_format if args.output_format else image_path.suffix[1:]
-            output_image_name = f"{file_name}_pitch{args.pitch}_yaw{yaw}_fov{args.FOV}.{output_format}"
-            output_image_path = output_path / output_image_name
-            _imwrite_rgb(output_image_path, output_image_array)
-            logging.info(f"Saved output image to {output_image_path}")
-    except Exception as e:
-        logging.error(f"Failed to process {image_path}: {e}")
+def check_yaw(yaw_angles: Iterable[int]) -> list:
+    """The yaw list as the reference uses it (L:218-237): every value in 0..360, each once, ascending."""
+    wanted = sorted(set(yaw_angles))
+    for yaw in wanted:
+        if yaw < 0 or yaw > 360:
+            raise argparse.ArgumentTypeError(f"{yaw} is an invalid yaw value. It must be between 0 and 360.")
+    return wanted
 
 
 def build_arg_parser() -> argparse.ArgumentParser:
-    """The flags of L:285-304."""
-    parser = argparse.ArgumentParser(
-        description="Convert panorama images to plane projections based on FOV, yaw, and pitch."
-    )
-    parser.add_argument("--input_path", type=str, help="Path to the input panorama images", required=True)
-    parser.add_argument("--output_path", type=str, default="output_images", help="Path to save the output images")
-    parser.add_argument("--output_format", type=str, choices=["png", "jpg", "jpeg"],
-                        help="Output image format (png, jpg, jpeg)")
-    parser.add_argument("--FOV", type=int, default=90, help="Field of View in degrees")
-    parser.add_argument("--output_width", type=int, default=1000, help="Width of the output image in pixels")
-    parser.add_argument("--output_height", type=int, default=1500, help="Height of the output image in pixels")
-    parser.add_argument("--pitch", type=check_pitch, default=90, help="Pitch angle in degrees (1-179)")
-    parser.add_argument("--yaw_angles", nargs="+", type=int, default=[0, 60, 120, 180, 240, 300],
-                        help="List of yaw angles in degrees (0-360). Example: --yaw_angles 0 60 120 180 240 300")
-    parser.add_argument("--num_workers", type=int, default=None,
-                        help="Number of worker threads. Defaults to 90%% of CPU cores if not specified.")
+    parser = argparse.ArgumentParser(description="Convert panorama images to plane projections based on FOV, yaw, and pitch.")
+    for flag, kw in _FLAGS:
+        parser.add_argument(flag, **(dict(kw, type=check_pitch) if flag == "--pitch" else kw))
     return parser
 
 
 def parse_arguments(argv=None) -> argparse.Namespace:
     args = build_arg_parser().parse_args(argv)
-    args.yaw_angles = check_yaw(args.yaw_angles)  # L:301
+    args.yaw_angles = check_yaw(args.yaw_angles)
     return args
 
 
-def main(argv=None):
-    """L:306-388."""
-    logging.basicConfig(level=logging.INFO, format="%(asctime)s [%(levelname)s] %(message)s",
-                        handlers=[logging.StreamHandler()])
-    from tqdm import tqdm
+def _decode_rgb(path):
+    """The file as an RGB uint8 array (what cv2.imread + COLOR_BGR2RGB give the reference, L:249-254), or None."""
+    try:
+        from PIL import Image, ImageOps
 
-    args = parse_arguments(argv)
-    input_path = Path(args.input_path)
-    output_path = Path(args.output_path)
-    if not input_path.is_dir():
-        logging.error(f"Input path {input_path} is not a directory or does not exist.")
-        return
-    if output_path.exists():
-        logging.info(f"Output directory {output_path} already exists.")
+        with Image.open(str(path)) as im:
+            return np.ascontiguousarray(np.asarray(ImageOps.exif_transpose(im).convert("RGB"), dtype=np.uint8))
+    except Exception:
+        return None
+
+
+def _encode_rgb(path, image):
+    """cv2.imwrite's defaults (L:275-278): JPEG quality 95, PNG otherwise."""
+    from PIL import Image
+
+    if Path(path).suffix.lower() in (".jpg", ".jpeg"):
+        Image.fromarray(image).save(str(path), format="JPEG", quality=95)
     else:
-        output_path.mkdir(parents=True, exist_ok=True)
-        logging.info(f"Created output directory {output_path}.")
+        Image.fromarray(image).save(str(path), format="PNG", compress_level=1)
+    logging.info(f"Saved output image to {path}")
 
-    image_extensions = ["*.jpg", "*.jpeg", "*.png"]
-    image_paths = []
-    for ext in image_extensions:
-        image_paths.extend(input_path.glob(ext))
-    if not image_paths:
-        logging.warning(f"No images found in {input_path} with extensions {image_extensions}.")
-        return
 
-    max_workers = args.num_workers if args.num_workers is not None else max(1, int(os.cpu_count() * 0.9))
-    logging.info(f"Using {max_workers} worker(s) for processing.")
+def views_of_image(pano, maps_by_yaw):
+    """Every yaw's view of one image: the image goes to the device once and all maps are drawn by one launch
+    (p2p_remap_maps_batch_u8; the reference calls panorama_to_plane once per yaw, L:259-265 -- the same pixels).
+    Anything but a 3-channel image takes the one-map entry point."""
+    yaws = list(maps_by_yaw)
+    if not yaws:
+        return {}
+    if pano.ndim == 3 and pano.shape[2] == 3:
+        batch = _native.remap_maps_batch(pano, np.stack([maps_by_yaw[y][0] for y in yaws]),
+                                         np.stack([maps_by_yaw[y][1] for y in yaws]), border=_native.BORDER_REFLECT, device=_DEVICE)
+        return dict(zip(yaws, batch))
+    return {y: panorama_to_plane(pano, *maps_by_yaw[y]) for y in yaws}
 
-    # maps for every yaw, from the first image's size (L:341-363)
-    precomputed_mappings = {}
-    FOV_rad = np.radians(args.FOV)
-    pitch_rad = np.radians(args.pitch)
-    sample_pano = _imread_rgb(image_paths[0])
-    if sample_pano is None:
-        logging.error(f"Failed to read sample image {image_paths[0]} for precomputing mappings.")
-        return
-    pano_height, pano_width, _ = sample_pano.shape
-    for yaw in args.yaw_angles:
-        precomputed_mappings[yaw] = precompute_mapping(
-            W=args.output_width, H=args.output_height, FOV_rad=FOV_rad, yaw_radian=np.radians(yaw),
-            pitch_radian=pitch_rad, pano_width=pano_width, pano_height=pano_height,
-        )
 
-    logging.info(f"Starting processing of {len(image_paths)} images with {len(args.yaw_angles)} yaw angles each.")
-    with ThreadPoolExecutor(max_workers=max_workers) as executor:
-        futures = [executor.submit(process_image_batch, p, args, output_path, precomputed_mappings) for p in image_paths]
-        for _ in tqdm(as_completed(futures), total=len(futures), desc="Processing images", unit="image"):
+def convert_folder(input_path, output_path, yaw_angles, pitch=90, FOV=90, output_width=1000, output_height=1500,
+                   output_format=None, num_workers=None) -> int:
+    """The legacy tool's job (L:306-388) for one folder; returns the number of files written.  Images are decoded
+    ahead of the device on `num_workers` threads and encoded behind it on as many; the device stage itself -- one upload
+    and one launch per image -- runs on the calling thread.  A file that cannot be read, or a view that cannot be
+    written, is logged and skipped, as the reference's per-image try / except does (L:282-283)."""
+    src, dst = Path(input_path), Path(output_path)
+    if not src.is_dir():
+        logging.error(f"Input path {src} is not a directory or does not exist.")
+        return 0
+    files = sorted(p for p in src.iterdir() if p.is_file() and p.suffix in _SUFFIXES)
+    if not files:
+        logging.warning(f"No images found in {src} with extensions {['*' + e for e in _SUFFIXES]}.")
+        return 0
+    dst.mkdir(parents=True, exist_ok=True)
+    workers = num_workers if num_workers else max(1, int((os.cpu_count() or 1) * 0.9))
+    logging.info(f"Using {workers} worker(s) for processing.")
+    logging.info(f"Starting processing of {len(files)} images with {len(yaw_angles)} yaw angles each.")
+    written, maps_for = [], {}
+    with ThreadPoolExecutor(max_workers=workers) as readers, ThreadPoolExecutor(max_workers=workers) as writers:
+        decoded = [(f, readers.submit(_decode_rgb, f)) for f in files]
+        try:
+            from tqdm import tqdm
+
+            decoded = tqdm(decoded, desc="Processing images", unit="image")
+        except ImportError:
             pass
+        for f, fut in decoded:
+            pano = fut.result()
+            if pano is None:
+                logging.error(f"Failed to read image {f}. Skipping.")
+                continue
+            logging.info(f"Processing {f}...")
+            try:
+                # the maps belong to a panorama SIZE (the reference builds them once, from its first image, L:341-363)
+                size = pano.shape[:2]
+                if size not in maps_for:
+                    maps_for[size] = {y: precompute_mapping(W=output_width, H=output_height, FOV_rad=float(np.radians(FOV)),
+                                                            yaw_radian=float(np.radians(y)), pitch_radian=float(np.radians(pitch)),
+                                                            pano_width=size[1], pano_height=size[0]) for y in yaw_angles}
+                fmt = output_format or f.suffix[1:]
+                for yaw, view in views_of_image(pano, maps_for[size]).items():
+                    written.append(writers.submit(_encode_rgb, dst / f"{f.stem}_pitch{pitch}_yaw{yaw}_fov{FOV}.{fmt}", view))
+            except Exception as e:
+                logging.error(f"Failed to process {f}: {e}")
+        done = 0
+        for w in written:
+            try:
+                w.result()
+                done += 1
+            except Exception as e:
+                logging.error(f"Failed to write a view: {e}")
     logging.info("Processing completed.")
+    return done
+
+
+def main(argv=None):
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s [%(levelname)s] %(message)s", handlers=[logging.StreamHandler()])
+    a = parse_arguments(argv)
+    convert_folder(a.input_path, a.output_path, a.yaw_angles, a.pitch, a.FOV, a.output_width, a.output_height,
+                   a.output_format, a.num_workers)
 
 
 if __name__ == "__main__":

@@ -223,11 +223,98 @@ def secondary_lines(nat, ctx, pano8k, device):
                          "Gpix_s": views * w["ow"] * w["oh"] / ms / 1e6, "algorithmic_bytes": b_alg,
                          "frac_of_hbm_peak": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "plan_ms": plan_ms, "yaw_tables_ms": tables_ms,
-                         "kernels": "float_views_kernel" if flags else "remap_views_kernel + remap_views_gather_kernel (tiles that do not fit the LDS scheme)"}
+                         "kernels": "float_views_kernel" if flags else
+                                    ("remap_views_band_kernel (source-band tiles, %d) + remap_views_gather_kernel (%d tiles around the poles)"
+                                     % (job.info()["band_tiles"], job.info()["n_gather_tiles"]) if job.info()["band_tiles"] > 0 else
+                                     "remap_views_kernel + remap_views_gather_kernel (tiles that do not fit the LDS scheme)")}
             job.close()
             del pano
         except Exception as e:  # a secondary line never takes the headline down
             out[name] = {"error": repr(e)}
+    return out
+
+
+def host_to_host_lines(pkg, nat, drv, pano8k, device):
+    """What a caller with HOST buffers gets (end-to-end, H2D of the source and D2H of the views stated
+    separately) on the metric's configuration -- never `value`, which has everything resident:
+      e2e_host_to_host   _driver.DevicePipeline, the folder walk's device stage (decode / encode left out): two resident
+                         jobs used alternately, the upload of image k + 1 and the download of image k - 1 under kernel k;
+      oneshot            one p2p_remap_views_u8 call per image from page-locked memory: upload, kernel, download in turn;
+      legacy_reflect_3ch SURVEY 8(f)3: panorama_to_plane(pano, U, V), one cv2.remap with BORDER_REFLECT (L:179) -- the
+                         3-channel table kernel -- for one 1080p view of the 8K panorama, host to host.
+    Wall-clock on this process's thread; the copies' own rates come from event-timed copies of the same buffers."""
+    import numpy as np
+
+    w = WORKLOADS["cfg2"]
+    yaws, pitches, fov, ow, oh = w["yaws"], w["pitches"], w["fov"], w["ow"], w["oh"]
+    out = {}
+    up_b = int(pano8k.nbytes)
+    down_b = len(yaws) * len(pitches) * ow * oh * 3
+    try:
+        panos = []
+        for i in range(2):  # page-locked, as the tool's decoder produces them
+            a = nat.pinned_empty(pano8k.shape)
+            a[...] = np.roll(pano8k, 97 * i, axis=1)
+            panos.append(a)
+        # the copies alone, each way (one job, synchronous calls)
+        ctx = nat.Context(device)
+        job = nat.Job(ctx, w["pw"], w["ph"], 1, yaws, pitches, fov, ow, oh)
+        job.set_pano(0, panos[0]); job.run(); v = job.get_views(0, pinned=True); del v
+        ts = []
+        for _ in range(4):
+            t0 = time.perf_counter(); job.set_pano(0, panos[1]); ts.append(time.perf_counter() - t0)
+        h2d_ms = min(ts) * 1e3
+        ts = []
+        for _ in range(4):
+            t0 = time.perf_counter(); v = job.get_views(0, pinned=True); ts.append(time.perf_counter() - t0); del v
+        d2h_ms = min(ts) * 1e3
+        job.close(); ctx.close()
+        n = 10
+        pipe = drv.DevicePipeline(device)
+        for t in [pipe.submit(panos[i % 2], yaws, pitches, float(fov), ow, oh) for i in range(4)]:
+            t.result()
+        t0 = time.perf_counter()
+        tickets = []
+        for i in range(n):
+            tickets.append(pipe.submit(panos[i % 2], yaws, pitches, float(fov), ow, oh))
+            if len(tickets) > 2:
+                tickets.pop(0).result()
+        for t in tickets:
+            t.result()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        pipe.close()
+        out["e2e_host_to_host"] = {
+            "workload": w["name"] + ", page-locked host buffers in and out, two-slot device pipeline (no decode / encode)",
+            "images": n, "ms_per_image": ms, "Gpix_s": len(yaws) * len(pitches) * ow * oh / ms / 1e6,
+            "h2d_bytes": up_b, "d2h_bytes": down_b, "h2d_ms_alone": h2d_ms, "d2h_ms_alone": d2h_ms,
+            "h2d_GBs_alone": up_b / h2d_ms / 1e6, "d2h_GBs_alone": down_b / d2h_ms / 1e6,
+            "GBs_both_ways_in_pipeline": (up_b + down_b) / ms / 1e6,
+            "bound": "the download of %.0f MB of uncompressed views (the kernel is %.1f %% of an image's time)" % (down_b / 1e6, 100 * 0.085 / ms)}
+        nat.remap_views(panos[0], yaws, pitches, fov, ow, oh, device=device, pinned=True)
+        ts = []
+        for i in range(5):
+            t0 = time.perf_counter()
+            v = nat.remap_views(panos[i % 2], yaws, pitches, fov, ow, oh, device=device, pinned=True)
+            ts.append(time.perf_counter() - t0)
+            del v
+        out["oneshot"] = {"workload": w["name"] + ", one p2p_remap_views_u8 call per image (upload, kernel, download in turn; geometry cached)",
+                          "calls": len(ts), "ms_per_call_min": min(ts) * 1e3, "ms_per_call_median": sorted(ts)[len(ts) // 2] * 1e3,
+                          "Gpix_s": len(yaws) * len(pitches) * ow * oh / (min(ts) * 1e3) / 1e6}
+        nat.release_cache()
+        U, V = pkg.get_pitch_mapping(ow, oh, 60, w["pw"], w["ph"], fov)
+        pkg.panorama_to_plane(pano8k, U, V)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter(); v = pkg.panorama_to_plane(pano8k, U, V); ts.append(time.perf_counter() - t0); del v
+        out["legacy_reflect_3ch"] = {
+            "workload": "legacy panorama_to_plane(pano, U, V) (L:159-194): one cv2.remap, BORDER_REFLECT, 8192x4096 -> one 1920x1080 view "
+                        "(pitch 60), pageable host arrays in and out, maps uploaded per call",
+            "calls": len(ts), "ms_per_call_min": min(ts) * 1e3, "ms_per_call_median": sorted(ts)[len(ts) // 2] * 1e3,
+            "Mpix_s": ow * oh / (min(ts) * 1e3) / 1e3,
+            "bytes_per_call": {"source_up": up_b, "maps_up": 2 * 4 * ow * oh, "view_down": 3 * ow * oh},
+            "bound": "the upload of the %.0f MB panorama on every call (the reference's signature hands it over each time)" % (up_b / 1e6)}
+    except Exception as e:  # never takes the headline down
+        out["host_to_host_error"] = repr(e)
     return out
 
 
@@ -249,9 +336,9 @@ def cold_first_image(nat, w, pano, device):
         job.close()
         return {"plan_ms": plan_ms, "yaw_tables_ms": tables_ms, "first_run_ms": first, "view_kernel_ms_in_first_run": k,
                 "cold_one_image_ms": tables_ms + first,
-                "how": "fresh context and job; first_run_ms = HIP events around the first p2p_job_run (plan pass, host "
-                       "read-back of its counter and headers, the per-XCD work lists, view kernel); yaw tables are built "
-                       "at job creation"}
+                "how": "fresh context and job; first_run_ms = HIP events around the first p2p_job_run (one allocation for the "
+                       "plan's tables, plan pass, the main kernel in grid order right behind it, the gather count read back; "
+                       "the per-XCD work lists are made when a second launch asks for them); yaw tables are built at job creation"}
     finally:
         ctx.close()
 
@@ -397,7 +484,16 @@ def main():
                          "per counter group, before this process touches the GPU); file = profiles/traffic.json; "
                          "auto = measure at --gpus 1 when rocprofv3 is on PATH and this process is not itself running "
                          "under a profiler, else file")
+    ap.add_argument("--host-to-host-only", action="store_true",
+                    help="print the host-buffer secondary lines (e2e_host_to_host, oneshot, legacy_reflect_3ch) as one JSON "
+                         "object and exit: what the default run starts as a child process")
     args = ap.parse_args()
+    if args.host_to_host_only:
+        pkg = importlib.import_module(PKG)
+        synth = importlib.import_module(PKG + ".synth")
+        drv = importlib.import_module(PKG + "._driver")
+        print(json.dumps(host_to_host_lines(pkg, pkg._native, drv, synth.synth_pano(8192, 4096, 1000, args.kind), 0)))
+        return
     if args.no_preroll:
         args.preroll_s = 0.0
     if args.workload is None:
@@ -415,6 +511,15 @@ def main():
                              and not under_profiler()) else "file"
     if mode == "measure":
         counters = measure_counters(args)  # child processes; nothing in THIS process has touched the GPU yet
+    h2h = None
+    if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.workload == "cfg2" and not args.no_secondary and \
+            args.pixel_path == "u8" and args.maps == "fused" and args.scaling == "weak" and args.panos_per_gpu == 1 and not under_profiler():
+        try:  # the host-to-host secondary lines, in a fresh process (see below)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--host-to-host-only", "--kind", args.kind],
+                               capture_output=True, text=True, timeout=180, env=clean_child_env(tempfile.gettempdir()))
+            h2h = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception:
+            h2h = None
 
     import torch
 
@@ -609,6 +714,11 @@ def main():
         pano8k = synth.synth_pano(8192, 4096, 1000, args.kind)
         out["cold"] = cold_first_image(nat, w, pano8k, dist.local_rank)
         out["secondary"] = secondary_lines(nat, ctx, pano8k, dist.local_rank)
+        # the host-buffer lines come from a process of their own, run before this one touched the GPU (h2h below): in
+        # THIS process -- torch initialised, a dozen streams created and destroyed by now -- the pipeline's three
+        # streams no longer overlap (9.3 ms per image against 4.5: the runtime maps streams onto a handful of
+        # hardware queues); in-process only when no child could be started
+        out["secondary"].update(h2h if h2h else host_to_host_lines(pkg, nat, drv, pano8k, dist.local_rank))
         del pano8k
     if dist.rank == 0 and dist.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w)

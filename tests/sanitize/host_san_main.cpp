@@ -134,6 +134,27 @@ int main()
     CHECK(p2p_job_set_maps(job, rows.data(), U.data(), V.data()) == P2P_ERR_INVALID);
     rows[7] = 63.0f;
     CHECK(p2p_job_set_maps(job, rows.data(), U.data(), V.data()) == P2P_OK && p2p_job_run(job) == P2P_OK);
+    {   // a band plan (source-band tiles): its scratch, its two-stage build with the read-back in between, the launch, a
+        // view mask on top, and the way back to a per-view plan when P2P_BAND goes away
+        setenv("P2P_BAND", "1", 1);
+        CHECK(p2p_reload_options() == P2P_OK);
+        p2p_job* jb = nullptr;
+        const int32_t yb[2] = {0, 90}, pb[2] = {60, 120};
+        p2p_job_desc db = {64, 32, 1, 2, yb, 2, pb, 90, 70, 33, P2P_FLAG_DEFAULT};
+        CHECK(p2p_job_create(ctx, &db, &jb) == P2P_OK);
+        CHECK(p2p_job_set_pano(jb, 0, pano.data(), 192) == P2P_OK && p2p_job_run(jb) == P2P_OK && p2p_job_run(jb) == P2P_OK);
+        p2p_job_info ib;
+        CHECK(p2p_job_get_info(jb, &ib) == P2P_OK && ib.band_tiles > 0);
+        const uint8_t mb[4] = {1, 0, 0, 1};
+        CHECK(p2p_job_set_view_mask(jb, mb) == P2P_OK && p2p_job_run(jb) == P2P_OK);
+        std::vector<uint8_t> vb((size_t)4 * 33 * 70 * 3);
+        CHECK(p2p_job_get_views(jb, 0, vb.data()) == P2P_OK);
+        std::vector<int32_t> cb((size_t)2 * 33 * 70 * 2);
+        CHECK(p2p_job_get_coords(jb, cb.data()) == P2P_OK);
+        p2p_job_destroy(jb);
+        unsetenv("P2P_BAND");
+        CHECK(p2p_reload_options() == P2P_OK);
+    }
     // a second job borrowing the first one's panoramas
     p2p_job* job2 = nullptr;
     p2p_job_desc_f64 d2 = {64, 32, 2, 1, nullptr, 1, nullptr, 60.5, 16, 16, 0};

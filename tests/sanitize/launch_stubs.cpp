@@ -51,6 +51,32 @@ static hipError_t stub_plan(const PlanParams& P, hipStream_t)
 {
     constexpr int PXT = TILE_W * TILE_H / BLOCK;
     const size_t tiles = (size_t)((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
+    if (P.coords_only) {  // ensure_full_coords: every pixel's coordinates into an existing plan
+        memset(P.coords, 0, (size_t)P.n_pitch * P.oh * P.ow * sizeof(int2));
+        return hipSuccess;
+    }
+    if (P.band.gcell) {  // band plan: no px / items tables; every group gets a cell (or ~0), the cells their counts
+        const size_t gxn = (size_t)((P.ow + 3) / 4), n_groups = (size_t)P.n_pitch * P.oh * gxn;
+        const size_t cells = (size_t)P.band.g.n_bands * P.band.g.ncx;
+        uint32_t n_gather = 0;
+        for (size_t s = 0; s < tiles * P.n_pitch; ++s) {
+            const bool gathers = s % 5 == 0;
+            P.hdr[s] = PieceHdr{gathers ? 2u : 3u, 0, 7, 0x00020001u};
+            if (gathers)
+                P.gather_list[n_gather++] = (uint32_t)s;
+        }
+        for (size_t g = 0; g < n_groups; ++g) {
+            const uint32_t cell = g % 7 == 0 ? ~0u : (uint32_t)(g % cells);
+            P.band.gcell[g] = cell;
+            if (cell != ~0u)
+                P.band.cell_count[cell]++;
+        }
+        P.band.cell_cmin[cells - 1] = 0; P.band.cell_cmax1[cells - 1] = 1; P.band.cell_rmax1[cells - 1] = 1;
+        P.band.cell_cur[cells - 1] = 0; P.band.cell_off[cells - 1] = 0;
+        memset(P.coords, 0, (size_t)P.n_pitch * P.oh * P.ow * sizeof(int2));
+        P.n_gather[0] = n_gather;
+        return hipSuccess;
+    }
     // a mix of LDS-scheme and gather tiles with pseudo-random footprints (wild ones too: the host's work-list builders
     // must cope with whatever the headers say), so that xcd_main_lists / xcd_lists run under the sanitizers
     uint32_t n_gather = 0, h = 12345u + (uint32_t)(P.ow * 131 + P.oh);
@@ -67,6 +93,33 @@ static hipError_t stub_plan(const PlanParams& P, hipStream_t)
     }
     memset(P.coords, 0, (size_t)P.n_pitch * P.oh * P.ow * sizeof(int2));
     P.n_gather[0] = n_gather;
+    return hipSuccess;
+}
+// the band passes: stage 0 counts (a few tiles, every banded group), stage 1 touches the last word of every table
+template <int BLOCK>
+static hipError_t stub_band(const BandParams& B, int stage, hipStream_t)
+{
+    if (stage == 0) {
+        uint32_t groups = 0;
+        const size_t n_all = (size_t)B.n_pitch * B.oh * ((B.ow + 3) / 4);
+        for (size_t g = 0; g < n_all; ++g)
+            groups += B.gcell[g] != ~0u;
+        B.band_tiles[B.g.n_bands - 1] = 0; B.band_groups[B.g.n_bands - 1] = 0; B.band_cost[B.g.n_bands - 1] = 0;
+        B.info->n_groups = groups;
+        B.info->n_tiles = (groups + BLOCK - 1) / BLOCK;
+        return hipSuccess;
+    }
+    const size_t nt = (size_t)B.n_tiles;
+    B.recs[nt - 1] = BandTileRec{0, 0, 0, 1, 0, 1};
+    B.sorted[B.n_groups > 0 ? B.n_groups - 1 : 0] = 0;
+    for (size_t t = 0; t < nt; ++t)
+        B.hdr[t] = PieceHdr{3u | 4u << 8, 0, 3, 2u << 16};
+    B.px[nt * BLOCK * 4 - 1] = 0;
+    B.grp[nt * BLOCK - 1] = ~0u;
+    if ((int)((nt + 7) / 8) > B.per_cap)
+        return hipErrorInvalidValue;
+    for (int x = 0; x <= 8; ++x)
+        B.info->first[x] = (uint32_t)(nt * x / 8);
     return hipSuccess;
 }
 hipError_t launch_scramble(void*, size_t, uint32_t, hipStream_t) { return hipSuccess; }
@@ -97,6 +150,12 @@ template <int TILE_W>
 static hipError_t stub_views(const ViewsParams& P, int which, hipStream_t)
 {
     const size_t slots = (size_t)((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H) * P.n_pitch;
+    if (which == 4) {  // the band kernel: its tables, and a grid that provides for every XCD's run
+        if (P.band_tiles < 1 || !P.band_hdr || !P.band_px || !P.band_grp || !P.band_info || P.band_per < (P.band_tiles + 7) / 8)
+            return hipErrorInvalidValue;
+        if (P.band_hdr[P.band_tiles - 1].mode_items == 0u || P.band_info->first[8] != (uint32_t)P.band_tiles)
+            return hipErrorInvalidValue;
+    }
     if (which == 0 && P.main_list && (P.main_stride < 1 || P.main_group < 1 || P.main_chunks < 1 ||
                                       !list_covers(P.main_list, P.main_stride, P.hdr, slots, true, false)))
         return hipErrorInvalidValue;
@@ -139,12 +198,12 @@ static hipError_t stub_float_views(const ViewsParams& P, bool, int, hipStream_t)
 }
 const ShapeOps& shape_ops_w64()
 {
-    static const ShapeOps ops = {{64, TILE_H, 256, 4, 704}, &stub_plan<64, 256, 704>, &stub_views<64>, &stub_float_views};
+    static const ShapeOps ops = {{64, TILE_H, 256, 4, 704}, &stub_plan<64, 256, 704>, &stub_views<64>, &stub_float_views, &stub_band<256>};
     return ops;
 }
 const ShapeOps& shape_ops_w128()
 {
-    static const ShapeOps ops = {{128, TILE_H, 512, 4, 1408}, &stub_plan<128, 512, 1408>, &stub_views<128>, &stub_float_views};
+    static const ShapeOps ops = {{128, TILE_H, 512, 4, 1408}, &stub_plan<128, 512, 1408>, &stub_views<128>, &stub_float_views, &stub_band<512>};
     return ops;
 }
 }  // namespace p2p
