@@ -32,7 +32,59 @@ def shard_blocks(n_items, world, rank):
     return list(range(first, first + base + (1 if rank < rem else 0)))
 
 
-def shard_views(n_yaw, n_pitch, world, rank, how="auto"):
+# A rank's job sets every tile of a pitch view up once for all the rank's yaws of that view: in units of one view's
+# drawing, 2.8 (csrc: a workgroup's set-up against one (panorama, yaw) pair; measured on config 2: 8 ranks, tools/sharded_rank_times.py).  A view's own weight
+# grows with its footprint in the panorama, 1 / sin(pitch).
+_SETUP_PER_PITCH_GROUP = 2.8
+
+
+def _run_cost(first, last, n_yaw, weights):
+    """Cost of the views first .. last - 1 of the pitch-major list as ONE rank's job."""
+    cost, v = 0.0, first
+    while v < last:
+        p = v // n_yaw
+        end = min(last, (p + 1) * n_yaw)
+        cost += _SETUP_PER_PITCH_GROUP + (end - v) * weights[p]
+        v = end
+    return cost
+
+
+def shard_cost_runs(n_yaw, n_pitch, world, pitch_deg=None):
+    """The pitch-major view list cut into `world` contiguous runs [(first, last)] that minimise the costliest run
+    (_run_cost): a run that crosses from one pitch view to the next pays two set-ups and gets fewer views for it.  36
+    views on 8 ranks by count are 5 5 5 5 4 4 4 4 -- and the third run, two views of one pitch and three of the next,
+    is the slowest by a quarter; by cost they are 5 5 3 5 5 4 5 4 ... (tools/sharded_rank_times.py)."""
+    import math
+
+    n = n_yaw * n_pitch
+    w = [1.0] * n_pitch
+    if pitch_deg is not None:
+        w = [1.0 / max(0.2, math.sin(math.radians(float(p)))) for p in pitch_deg]
+
+    def greedy(bound):
+        runs, a = [], 0
+        while a < n:
+            b = a + 1
+            while b < n and _run_cost(a, b + 1, n_yaw, w) <= bound:
+                b += 1
+            runs.append((a, b))
+            a = b
+        return runs
+
+    # the optimum is the cost of some run: try them in ascending order (n <= a few hundred views)
+    bounds = sorted({_run_cost(a, b, n_yaw, w) for a in range(n) for b in range(a + 1, min(n, a + 2 * (n // world + n_yaw)) + 1)})
+    lo, hi = 0, len(bounds) - 1
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if len(greedy(bounds[mid] + 1e-9)) <= world:
+            hi = mid
+        else:
+            lo = mid + 1
+    runs = greedy(bounds[lo] + 1e-9)
+    return runs + [(n, n)] * (world - len(runs))
+
+
+def shard_views(n_yaw, n_pitch, world, rank, how="auto", pitch_deg=None):
     """This rank's views of one image as {pitch index: [yaw indices]}.  The pitch-major list (p0,y0), (p0,y1) ...
     (p1,y0) ... is cut into contiguous runs, one per rank ("blocks"): consecutive yaws of ONE pitch view (of two where
     a run crosses a pitch boundary), so that the rank's masked job sets every tile of that pitch view up once for all
@@ -41,21 +93,26 @@ def shard_views(n_yaw, n_pitch, world, rank, how="auto"):
     views and a yaw count they divide ("auto" then deals round-robin) every rank gets the same yaws of EVERY pitch
     view, a full grid without a mask: 2 ranks 50.4 us against 54.6 in blocks."""
     if how == "auto":
-        how = "round_robin" if (world < n_pitch and n_yaw % world == 0) else "blocks"
-    deal = shard_round_robin if how == "round_robin" else shard_blocks
+        how = "round_robin" if (world < n_pitch and n_yaw % world == 0) else ("cost" if n_yaw * n_pitch <= 4096 else "blocks")
+    if how == "cost":
+        # ("blocks" cuts by view COUNT; "cost" by what a run costs its rank: shard_cost_runs)
+        first, last = shard_cost_runs(n_yaw, n_pitch, world, pitch_deg)[rank]
+        mine = range(first, last)
+    else:
+        mine = (shard_round_robin if how == "round_robin" else shard_blocks)(n_yaw * n_pitch, world, rank)
     groups = {}
-    for v in deal(n_yaw * n_pitch, world, rank):
+    for v in mine:
         groups.setdefault(v // n_yaw, []).append(v % n_yaw)
     return groups
 
 
-def rank_view_set(n_yaw, n_pitch, world, rank, how="auto"):
+def rank_view_set(n_yaw, n_pitch, world, rank, how="auto", pitch_deg=None):
     """The ONE masked job a rank draws its share of an image with: (yaw_idx, pitch_idx, mask, mine).  yaw_idx and
     pitch_idx are the image's yaw / pitch indices that occur in the rank's share (ascending: the job's own angle
     lists), mask is uint8 [len(yaw_idx)][len(pitch_idx)] with 1 where the combination is the rank's own (the layout
     p2p_job_set_view_mask takes), mine the share as (yaw, pitch) image indices in pitch-major order.  A rank with no
     views gets ([], [], empty mask, [])."""
-    groups = shard_views(n_yaw, n_pitch, world, rank, how)
+    groups = shard_views(n_yaw, n_pitch, world, rank, how, pitch_deg)
     yaw_idx = sorted({y for ys in groups.values() for y in ys})
     pitch_idx = sorted(groups)
     mine = [(y, p) for p in pitch_idx for y in groups[p]]
@@ -123,11 +180,32 @@ class DevicePipeline:
         self.ctx.close()
 
 
+# A device slot = (device, k): the k-th use of that device inside one call's `devices` list (a device may be named twice:
+# two contexts on one GPU).  Slots do NOT depend on the rank a device has in a call: a caller whose device list changes
+# order or length from image to image keeps at most (devices x multiplicity) contexts alive, not one per (rank, device)
+# pair it has ever used (round 4's keying: 64 possible slots on 8 GPUs, each a HIP stream, cached plans and one of the
+# P2P_MAX_CONTEXTS).
 _ctx_lock = threading.Lock()  # guards the three dicts below
 _ctxs = {}
-_groups = {}  # device slot -> (geometry key, [(job, page-locked staging views, None)]): the slot's resident job
+_groups = {}  # device slot -> (geometry key incl. rank and world, [(job, page-locked staging views, None)]): the slot's resident job
 _slot_locks = {}  # device slot -> lock held for the whole of one image on that slot: two concurrent calls that name the
-                  # same (rank, device) take turns instead of interleaving set_pano / run / get_views on the same jobs
+                  # same device take turns instead of interleaving set_pano / run / get_views on the same jobs
+
+
+def device_slots(devices):
+    """[(device, k)] for a call's device list: k counts the earlier occurrences of the same device."""
+    seen, out = {}, []
+    for d in devices:
+        d = int(d)
+        out.append((d, seen.get(d, 0)))
+        seen[d] = seen.get(d, 0) + 1
+    return out
+
+
+def live_sharded_contexts():
+    """How many contexts the sharded path keeps right now (tests: bounded by the devices in use, whatever their order)."""
+    with _ctx_lock:
+        return len(_ctxs)
 
 
 def _slot_lock(slot):
@@ -153,7 +231,7 @@ def _shared_ctx(slot):
     with _ctx_lock:
         c = _ctxs.get(slot)
         if c is None:
-            c = _ctxs[slot] = _native.Context(slot[1])
+            c = _ctxs[slot] = _native.Context(slot[0])
         return c
 
 
@@ -181,24 +259,34 @@ def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0):
     yaws, pitches = [float(y) for y in yaws], [float(p) for p in pitches]
     out = np.empty((len(yaws), len(pitches), int(oh), int(ow), 3), dtype=np.uint8)
     world = len(devices)
-    geo = (pw, ph, tuple(yaws), tuple(pitches), float(fov), int(ow), int(oh), int(flags), world)
+    slots = device_slots(devices)
 
-    # slots of earlier calls that this call does not use (other devices, a larger world): their jobs would hold
-    # panoramas and views until release_sharded()
-    mine = {(r, int(devices[r])) for r in range(world)}
+    # slots of earlier calls that this call does not use (other devices, a second context on one device): their jobs
+    # hold panoramas and views, their contexts a stream and cached plans -- both go, unless another call is inside the
+    # slot right now (its lock is taken: that call's own sweep, or release_sharded(), gets it later)
     with _ctx_lock:
-        stale = [s for s in _groups if s not in mine]
+        stale = [s for s in set(_groups) | set(_ctxs) if s not in slots]
     for slot in stale:
-        with _slot_lock(slot):
+        lk = _slot_lock(slot)
+        if not lk.acquire(blocking=False):
+            continue
+        try:
             _close_group(slot)
+            with _ctx_lock:
+                c = _ctxs.pop(slot, None)
+            if c is not None:
+                c.close()
+        finally:
+            lk.release()
 
     def one_device(rank):
-        slot = (rank, int(devices[rank]))
+        slot = slots[rank]
         with _slot_lock(slot):
             _one_device_locked(rank, slot)
 
     def _one_device_locked(rank, slot):
-        yaw_idx, pitch_idx, mask, mine = rank_view_set(len(yaws), len(pitches), world, rank)
+        geo = (pw, ph, tuple(yaws), tuple(pitches), float(fov), int(ow), int(oh), int(flags), world, rank)
+        yaw_idx, pitch_idx, mask, mine = rank_view_set(len(yaws), len(pitches), world, rank, pitch_deg=pitches)
         with _ctx_lock:
             kept = _groups.get(slot)
         if kept is not None and kept[0] != geo:

@@ -74,26 +74,26 @@ struct Options {
     int tile_shape = 0;               // P2P_TILE_SHAPE: 64 | 128 | 0 = choose_shape's rule
     int pairs_per_block = 0;          // P2P_PAIRS_PER_BLOCK
     int max_pairs_per_block = -1;     // P2P_MAX_PAIRS_PER_BLOCK
-    int chunk_outer = -1;             // P2P_CHUNK_OUTER
+    int chunk_outer = -1;             // (no environment knob)
     int main_order = -1;              // P2P_MAIN_ORDER: 0 grid order, 1 list order, 2 list order also with several panoramas; -1 = by job
     int main_group = -1;              // P2P_MAIN_GROUP
     int main_tail = -1;               // P2P_MAIN_TAIL: list entries per XCD, at the end of its list, drawn by several workgroups each (-1: rule)
     int main_tail_parts = 2;          // P2P_MAIN_TAIL_PARTS: ... by how many (2..4)
     int main_span = -1;               // P2P_MAIN_SPAN: chunks of pairs one main-kernel workgroup draws (-1: the library's rule)
     int prefetch_lead = -1;           // P2P_PREFETCH_LEAD
-    int force_rest = 0;               // P2P_FORCE_REST
+    int force_rest = 0;               // (no environment knob)
     int gather_ppb = 16;              // P2P_GATHER_PPB
-    int gather_all = 1;               // P2P_GATHER_ALL
+    int gather_all = 1;               // (no environment knob)
     int gather_blocky_from = p2p::GATHER_BLOCKY_FROM;  // P2P_GATHER_BLOCKY_FROM
     int gather_order = 1;             // P2P_GATHER_ORDER
-    int gather_group = 3;             // P2P_GATHER_GROUP
+    int gather_group = 3;             // (no environment knob)
     int scramble_plan = 0;            // P2P_SCRAMBLE_PLAN (robustness self-test only)
-    int coords_all = 0;               // P2P_COORDS_ALL: 1 = the plan pass writes every pixel's quantised coordinates (0: the gather tiles')
+    int coords_all = 0;               // (no environment knob) 1 = the plan pass writes every pixel's quantised coordinates (0: the gather tiles')
     int early_main = 1;               // P2P_EARLY_MAIN: 1 = a job's first launch sends the main kernel out right behind the plan pass
     int defer_lists = 1;              // P2P_DEFER_LISTS: 1 = a plan without gather tiles makes its main lists at its second launch (0: at once)
     int band = -1;                    // P2P_BAND: 1 = source-band tiles wherever they apply, 0 = never, -1 = the library's rule (choose_band)
     int band_bh = 16, band_cw = 8;    // P2P_BAND_BH / P2P_BAND_CW: cell of the source, rows x columns
-    int band_maxw = 27, band_maxh = 7;  // P2P_BAND_MAXW / P2P_BAND_MAXH: tap extent of a group beyond which its tile gathers
+    int band_maxw = 27, band_maxh = 7;  // (no environment knob) tap extent of a group beyond which its tile gathers
 };
 
 void pool_set_budget(size_t bytes);  // (the pool is defined below)
@@ -115,28 +115,21 @@ void options_load_locked()
     o.tile_shape = env_int("P2P_TILE_SHAPE", o.tile_shape);
     o.pairs_per_block = env_int("P2P_PAIRS_PER_BLOCK", o.pairs_per_block);
     o.max_pairs_per_block = env_int("P2P_MAX_PAIRS_PER_BLOCK", o.max_pairs_per_block);
-    o.chunk_outer = env_int("P2P_CHUNK_OUTER", o.chunk_outer);
     o.main_order = env_int("P2P_MAIN_ORDER", o.main_order);
     o.main_group = env_int("P2P_MAIN_GROUP", o.main_group);
     o.main_span = env_int("P2P_MAIN_SPAN", o.main_span);
     o.main_tail = env_int("P2P_MAIN_TAIL", o.main_tail);
     o.main_tail_parts = std::min(4, std::max(2, env_int("P2P_MAIN_TAIL_PARTS", o.main_tail_parts)));
     o.prefetch_lead = env_int("P2P_PREFETCH_LEAD", o.prefetch_lead);
-    o.force_rest = env_int("P2P_FORCE_REST", o.force_rest);
     o.gather_ppb = env_int("P2P_GATHER_PPB", o.gather_ppb);
-    o.gather_all = env_int("P2P_GATHER_ALL", o.gather_all);
     o.gather_blocky_from = std::max(0, env_int("P2P_GATHER_BLOCKY_FROM", o.gather_blocky_from));
     o.gather_order = env_int("P2P_GATHER_ORDER", o.gather_order);
-    o.gather_group = std::min(8, std::max(0, env_int("P2P_GATHER_GROUP", o.gather_group)));
     o.scramble_plan = env_int("P2P_SCRAMBLE_PLAN", o.scramble_plan);
     o.defer_lists = env_int("P2P_DEFER_LISTS", o.defer_lists);
     o.early_main = env_int("P2P_EARLY_MAIN", o.early_main);
-    o.coords_all = env_int("P2P_COORDS_ALL", o.coords_all);
     o.band = env_int("P2P_BAND", o.band);
     o.band_bh = std::min(256, std::max(1, env_int("P2P_BAND_BH", o.band_bh)));
     o.band_cw = std::min(256, std::max(1, env_int("P2P_BAND_CW", o.band_cw)));
-    o.band_maxw = std::min(255, std::max(3, env_int("P2P_BAND_MAXW", o.band_maxw)));
-    o.band_maxh = std::min(63, std::max(1, env_int("P2P_BAND_MAXH", o.band_maxh)));
     g_opt = o;
     g_opt_loaded = true;
     pool_set_budget((size_t)o.pool_mb << 20);
@@ -872,9 +865,11 @@ int choose_pairs_per_block(const p2p_job_desc& d, const p2p::TileShape& S, const
     // Several resident panoramas and no forced cap: whole panoramas per chunk -- about 20 pairs, a multiple of the yaw
     // count -- so that no workgroup's pairs straddle two panoramas (8 panoramas x 12 yaws: 24 pairs 792 us, 16 pairs
     // 803, 12 pairs 814: tools/ab_cfg3_share.sh)
-    if (d.n_panos > 1 && opt.max_pairs_per_block < 0 && d.n_yaw <= 64) {
+    // (only up to 24 pairs -- what has been measured: 12 yaws at 12 / 16 / 24 pairs; 48 pairs across panoramas was slower
+    // than 16 above, so a job of 33..64 yaws keeps the capped chunks)
+    if (d.n_panos > 1 && opt.max_pairs_per_block < 0 && d.n_yaw <= 24) {
         const int per = std::max(1, (20 + d.n_yaw / 2) / d.n_yaw) * d.n_yaw;
-        if (per <= 64 && per <= n_pairs)
+        if (per <= 24 && per <= n_pairs)
             ppb = per;
     }
     return ppb < 1 ? 1 : ppb;
@@ -921,7 +916,7 @@ int choose_main_group(const Options& opt, int shape, int span, int chunks)
 
 extern "C" {
 
-const char* p2p_version(void) { return "0.1.0-gfx950"; }
+const char* p2p_version(void) { return "0.2.0-gfx950"; }
 const char* p2p_last_error(void) { return g_err; }
 
 int p2p_device_count(void)
@@ -1399,6 +1394,13 @@ int p2p_job_set_pano(p2p_job* j, int index, const uint8_t* pano, int64_t row_str
     // in order on the kernel stream (behind every launch that reads the panoramas, ahead of the next one): no second
     // hardware queue for callers that never overlap copies with kernels
     StreamSyncGuard sync_on_exit(j->ctx->stream);  // the caller may release `pano` when we return, also on an error
+    // (behind an asynchronous upload of the same job that is still in flight on the upload stream: two writers of
+    // one panorama in unknown order otherwise)
+    if (j->up_pending) {
+        if (hipEventQuery(j->ev_up) != hipSuccess)
+            HIP_TRY(hipStreamWaitEvent(j->ctx->stream, j->ev_up, 0));
+        j->up_pending = false;
+    }
     if (int rc = enqueue_pano_copy(j, index, pano, row_stride, j->ctx->stream))
         return rc;
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));
@@ -1584,7 +1586,13 @@ int p2p_job_set_view_mask(p2p_job* j, const uint8_t* mask)
             }
     if (!j->d_view_mask)
         HIP_TRY(dev_alloc((void**)&j->d_view_mask, bits.size() * sizeof(uint32_t)));
-    HIP_TRY(hipMemcpy(j->d_view_mask, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    {
+        // on the stream the kernels that read the mask run on, like every other upload of this file (`bits` outlives it)
+        StreamSyncGuard sync_on_exit(j->ctx->stream);
+        HIP_TRY(hipMemcpyAsync(j->d_view_mask, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice, j->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+        sync_on_exit.armed = false;
+    }
     j->mask_words = words;
     j->n_views_wanted = wanted;
     return P2P_OK;

@@ -556,7 +556,7 @@ def main():
     elif args.scaling == "strong":
         # one panorama, its pitch-major view list cut into one contiguous run per rank (36 views on 8 GPUs
         # = 5 or 4 consecutive yaws of one pitch view each); every rank uploads the panorama once
-        yaw_idx, pitch_idx, mask, mine_views = drv.rank_view_set(n_yaw, n_pitch, dist.world, dist.rank)
+        yaw_idx, pitch_idx, mask, mine_views = drv.rank_view_set(n_yaw, n_pitch, dist.world, dist.rank, pitch_deg=w["pitches"])
         npg, total_views, seeds = 1, n_yaw * n_pitch, [1000]
         if mine_views:
             # ONE job per rank: the yaws and pitches that occur in its share, and a view mask for the combinations that
@@ -720,6 +720,31 @@ def main():
         # hardware queues); in-process only when no child could be started
         out["secondary"].update(h2h if h2h else host_to_host_lines(pkg, nat, drv, pano8k, dist.local_rank))
         del pano8k
+    if dist.world > 1 and args.workload == "cfg2" and args.scaling == "weak" and not args.no_secondary and args.pixel_path == "u8":
+        # One number about the SHARDING code next to the weak-scaling headline (which is N x the one-GPU workload by
+        # construction): BASELINE config 3, the 64-panorama batch dealt round-robin, 64 / N resident per GPU, a few
+        # launches bracketed like the headline (barrier, device sync, max over ranks).  Every rank takes part.
+        w3 = WORKLOADS["cfg3"]
+        mine3 = shard_round_robin(w3["n_panos_total"], dist.world, dist.rank)
+        sec = {"workload": w3["name"], "scaling": "strong", "panos_per_gpu": len(mine3)}
+        try:
+            job3 = nat.Job(ctx, w3["pw"], w3["ph"], max(1, len(mine3)), w3["yaws"], w3["pitches"], w3["fov"], w3["ow"], w3["oh"]) if mine3 else None
+            if job3 is not None:
+                pano3 = synth.synth_pano(w3["pw"], w3["ph"], 1000 + dist.rank, args.kind)  # (content does not enter the timing)
+                for i in range(len(mine3)):
+                    job3.set_pano(i, pano3)
+                job3.time_launches(False)
+            k3 = 6
+            el3 = run_timed((lambda: job3.run()) if job3 is not None else (lambda: None), device_sync, dist, k3, 2)
+            views3 = w3["n_panos_total"] * len(w3["yaws"]) * len(w3["pitches"])
+            sec.update({"steps": k3, "ms_per_step": el3 / k3 * 1e3, "value_Mpix_s": views3 * w3["ow"] * w3["oh"] * k3 / el3 / 1e6,
+                        "algorithmic_bytes_per_gpu": algorithmic_bytes(w3, len(mine3)),
+                        "frac_of_hbm_peak_per_gpu": algorithmic_bytes(w3, len(mine3)) / (el3 / k3) / 1e9 / HBM_PEAK_GBS})
+            if job3 is not None:
+                job3.close()
+        except Exception as e:  # never takes the headline down (every rank still reaches the barriers inside run_timed
+            sec["error"] = repr(e)  # unless it failed before them: then the other ranks' barrier times out, loudly)
+        out.setdefault("secondary", {})["cfg3_strong"] = sec
     if dist.rank == 0 and dist.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w)
     elif dist.rank == 0:

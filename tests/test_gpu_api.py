@@ -252,7 +252,15 @@ def test_view_sharded_path_two_contexts_on_one_device(gpu, pkg, synth):
     one_odd = pkg.process_views(pano, yaws, pitches, 318, 180, 90)
     got = d.process_views_sharded(pano, yaws, pitches, 318, 180, 90.0, [0] * 8)
     assert np.array_equal(got, one_odd)
+    # a caller whose device list changes length from image to image: the contexts kept are those of the LAST call's
+    # slots (device, k) -- never one per (rank, device) pair ever used (round 4's advisor finding)
+    assert d.live_sharded_contexts() == 8
+    for world in (3, 1, 5, 2, 8, 4):
+        got = d.process_views_sharded(pano, yaws, pitches, 320, 180, 90.0, [0] * world)
+        assert np.array_equal(got, one), world
+        assert d.live_sharded_contexts() == world, (world, d.live_sharded_contexts())
     d.release_sharded()
+    assert d.live_sharded_contexts() == 0
     # through the tool: a single image with --devices 0 0
     m = pkg.panorama_to_plane_pitch
     m.set_devices([0, 0])

@@ -81,6 +81,10 @@ def test_multi_rank_defaults_config3_share_and_view_sharding(gpu):
     assert line["metric"].startswith("Mpix/s remapped, 8K equirect->1080p x36 views") and line["value"] > 0
     # two ranks x 36 views x 1920 x 1080 per step
     assert abs(line["value"] * line["ms_per_step"] * 1e3 - 2 * 36 * 1920 * 1080) / (2 * 36 * 1920 * 1080) < 1e-6
+    # ... and, next to the weak-scaling headline, one number about the sharding code: config 3's 64 panoramas dealt to the ranks
+    s3 = line["secondary"]["cfg3_strong"]
+    assert "error" not in s3 and s3["scaling"] == "strong" and s3["panos_per_gpu"] == 32 and s3["value_Mpix_s"] > 0
+    assert abs(s3["value_Mpix_s"] * s3["ms_per_step"] * 1e3 - 64 * 36 * 1920 * 1080) / (64 * 36 * 1920 * 1080) < 1e-6
     r = subprocess.run(base + ["--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--workload", "cfg3", "--steps", "3", "--warmup", "1",
                                "--kind", "N", "--preroll-s", "0.1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]

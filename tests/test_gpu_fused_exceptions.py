@@ -66,7 +66,9 @@ def test_the_pole_pixel_case_has_its_pole_pixel(gpu, synth):
     _, pw, ow, oh, fov, yaws, pitches, seed = CASES[0]
     ph = pw // 2
     rows, U, V = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
-    assert pole_pixels(U[0], V[0], ow, ph).sum() == 1 and pole_pixels(U[1], V[1], ow, ph).sum() == 0
+    # (pitch 9: the column x = W / 2 passes within a source row of the pole on three output rows -- V = 0.82, 0.06, 0.90 --
+    # and the middle one is the pixel whose azimuth hangs on the sign of a residue; pitch 54 is nowhere near a pole)
+    assert 1 <= pole_pixels(U[0], V[0], ow, ph).sum() <= 3 and pole_pixels(U[1], V[1], ow, ph).sum() == 0
     pano = synth.synth_pano(pw, ph, seed, "S")
     exact = gpu.remap_views_maps(pano, rows, U, V)
     assert np.array_equal(exact, oracle_views(pano, yaws, pitches, ow, oh, fov))

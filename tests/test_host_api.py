@@ -222,10 +222,12 @@ def test_multi_device_round_robin_of_a_folder(pkg, tmp_path, monkeypatch):
 def test_view_sharding_pitch_major_runs(pkg):
     """with fewer images than GPUs the (yaw x pitch) views of an image are cut, pitch-major, into one
     contiguous run per device (round-robin where that gives every device a full grid: fewer devices than pitch views);
-    every view exactly once, shares differ by at most one view, at most two pitch views per device in runs."""
+    every view exactly once; cut by count ("blocks") the shares differ by at most one view, cut by COST ("cost", the
+    default) a run that crosses from one pitch view to the next -- two set-ups -- gets fewer; at most two pitch views per
+    device in runs."""
     d = importlib.import_module("360-to-planer-images_amd._driver")
     for n_yaw, n_pitch, world in ((12, 3, 8), (12, 3, 2), (4, 5, 8), (1, 1, 8), (360, 1, 8), (7, 3, 5), (12, 3, 3), (12, 3, 6)):
-        for how in ("auto", "blocks", "round_robin"):
+        for how in ("auto", "blocks", "round_robin", "cost"):
             seen, sizes = set(), []
             for r in range(world):
                 g = d.shard_views(n_yaw, n_pitch, world, r, how)
@@ -233,13 +235,20 @@ def test_view_sharding_pitch_major_runs(pkg):
                 assert not (seen & set(views))
                 seen |= set(views)
                 sizes.append(len(views))
-                if how == "blocks" and n_yaw >= len(views):
+                if how in ("blocks", "cost") and n_yaw >= len(views):
                     assert len(g) <= 2, (n_yaw, n_pitch, world, r, g)   # one pitch view, or a run across one boundary
             assert seen == {(p, y) for p in range(n_pitch) for y in range(n_yaw)}
-            assert max(sizes) - min(sizes) <= 1
-    # config 2 on 8 GPUs: 36 views -> 5 or 4 per device (the 7.2x cap of SURVEY 8(e)), consecutive yaws of one pitch view
-    assert [sum(len(v) for v in d.shard_views(12, 3, 8, r).values()) for r in range(8)] == [5] * 4 + [4] * 4
-    assert d.shard_views(12, 3, 8, 0) == {0: [0, 1, 2, 3, 4]} and d.shard_views(12, 3, 8, 2) == {0: [10, 11], 1: [0, 1, 2]}
+            if how in ("blocks", "round_robin"):
+                assert max(sizes) - min(sizes) <= 1
+    # config 2 on 8 GPUs: 36 views -> at most 5 per device (the 7.2x cap of SURVEY 8(e)), consecutive yaws of one pitch
+    # view; the two runs that cross a pitch boundary hold 3 views, not 5 (by count: 5 5 5 5 4 4 4 4, the third the slowest)
+    assert [sum(len(v) for v in d.shard_views(12, 3, 8, r, "blocks").values()) for r in range(8)] == [5] * 4 + [4] * 4
+    assert d.shard_views(12, 3, 8, 2, "blocks") == {0: [10, 11], 1: [0, 1, 2]}
+    assert [sum(len(v) for v in d.shard_views(12, 3, 8, r, pitch_deg=[60, 90, 120]).values()) for r in range(8)] == [5, 5, 3, 5, 5, 3, 5, 5]
+    assert d.shard_views(12, 3, 8, 0) == {0: [0, 1, 2, 3, 4]} and d.shard_views(12, 3, 8, 2, pitch_deg=[60, 90, 120]) == {0: [10, 11], 1: [0]}
+    runs = d.shard_cost_runs(12, 3, 8, [60, 90, 120])
+    w = [1 / 0.8660254, 1.0, 1 / 0.8660254]
+    assert max(d._run_cost(a, b, 12, w) for a, b in runs) < max(d._run_cost(r[0], r[-1] + 1, 12, w) for r in (d.shard_blocks(36, 8, k) for k in range(8)))
     # on 2 GPUs: every other yaw of all three pitch views -- a full 6 x 3 grid per device
     assert d.shard_views(12, 3, 2, 1) == {0: [1, 3, 5, 7, 9, 11], 1: [1, 3, 5, 7, 9, 11], 2: [1, 3, 5, 7, 9, 11]}
     assert d.shard_blocks(10, 4, 0) == [0, 1, 2] and d.shard_blocks(10, 4, 3) == [8, 9] and d.shard_blocks(2, 4, 3) == []

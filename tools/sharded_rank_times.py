@@ -12,7 +12,7 @@ synth = importlib.import_module("360-to-planer-images_amd.synth")
 ap = argparse.ArgumentParser(description=__doc__, allow_abbrev=False)
 ap.add_argument("--world", type=int, nargs="+", default=[1, 2, 4, 8])
 ap.add_argument("--launches", type=int, default=600)
-ap.add_argument("--how", default="auto", choices=["auto", "blocks", "round_robin"], help="how the pitch-major view list is dealt")
+ap.add_argument("--how", default="auto", choices=["auto", "blocks", "round_robin", "cost"], help="how the pitch-major view list is dealt")
 a = ap.parse_args()
 pw, ph, ow, oh, fov = 8192, 4096, 1920, 1080, 90
 yaws, pitches = list(range(0, 360, 30)), [60, 90, 120]
@@ -22,7 +22,7 @@ base = None
 for world in a.world:
     times = []
     for rank in range(world):
-        yi, pi, mask, mine = drv.rank_view_set(len(yaws), len(pitches), world, rank, a.how)
+        yi, pi, mask, mine = drv.rank_view_set(len(yaws), len(pitches), world, rank, a.how, pitches)
         if not mine:
             times.append(0.0)
             continue
@@ -41,6 +41,6 @@ for world in a.world:
     worst = max(times)
     base = base or worst
     print(a.how + " world %d: views per rank %s, us per launch %s -> slowest %.1f us, %.2f x the one-GPU launch" %
-          (world, [len(drv.rank_view_set(len(yaws), len(pitches), world, r, a.how)[3]) for r in range(world)],
+          (world, [len(drv.rank_view_set(len(yaws), len(pitches), world, r, a.how, pitches)[3]) for r in range(world)],
            ["%.1f" % t for t in times], worst, base / worst), flush=True)
 ctx.close()
