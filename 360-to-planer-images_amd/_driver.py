@@ -33,9 +33,9 @@ def shard_blocks(n_items, world, rank):
 
 
 # A rank's job sets every tile of a pitch view up once for all the rank's yaws of that view: in units of one view's
-# drawing, 2.8 (csrc: a workgroup's set-up against one (panorama, yaw) pair; measured on config 2: 8 ranks, tools/sharded_rank_times.py).  A view's own weight
+# drawing, 2.4 (csrc: a workgroup's set-up against one (panorama, yaw) pair; measured on config 2: 8 ranks, tools/sharded_rank_times.py).  A view's own weight
 # grows with its footprint in the panorama, 1 / sin(pitch).
-_SETUP_PER_PITCH_GROUP = 2.8
+_SETUP_PER_PITCH_GROUP = 2.4
 
 
 def _run_cost(first, last, n_yaw, weights):
