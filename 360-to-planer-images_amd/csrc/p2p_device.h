@@ -175,6 +175,9 @@ struct ViewsParams {
     int band_tiles;          // tiles (host copy); 0: no band plan
     int band_per;            // list entries per XCD the grid provides for (>= every first[x + 1] - first[x])
     int band_tail;           // like main_tail: the last band_tail tiles of every XCD's run are drawn by main_tail_parts workgroups
+    const uint32_t* merge_gather_list;  // != nullptr: the plan's gather tiles ([8][merge_gather_n] per-XCD lists, as gather_list / n_list) are
+    int merge_gather_n;                 // drawn by the first 8 * merge_gather_n * (chunks of gather_ppb pairs) workgroups of the band kernel's
+                                        // launch, or of the main kernel's in list order, not by a launch of their own
 };
 
 struct PlanParams {

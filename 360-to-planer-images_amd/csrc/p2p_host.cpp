@@ -89,6 +89,7 @@ struct Options {
     int gather_group = 3;             // (no environment knob)
     int scramble_plan = 0;            // P2P_SCRAMBLE_PLAN (robustness self-test only)
     int coords_all = 0;               // (no environment knob) 1 = the plan pass writes every pixel's quantised coordinates (0: the gather tiles')
+    int merge_gather = 1;               // P2P_MERGE_GATHER: 1 = the gather tiles are drawn by the first workgroups of the band kernel's launch / of the main kernel's in list order
     int early_main = 1;               // P2P_EARLY_MAIN: 1 = a job's first launch sends the main kernel out right behind the plan pass
     int defer_lists = 1;              // P2P_DEFER_LISTS: 1 = a plan without gather tiles makes its main lists at its second launch (0: at once)
     int band = -1;                    // P2P_BAND: 1 = source-band tiles wherever they apply, 0 = never, -1 = the library's rule (choose_band)
@@ -127,6 +128,7 @@ void options_load_locked()
     o.scramble_plan = env_int("P2P_SCRAMBLE_PLAN", o.scramble_plan);
     o.defer_lists = env_int("P2P_DEFER_LISTS", o.defer_lists);
     o.early_main = env_int("P2P_EARLY_MAIN", o.early_main);
+    o.merge_gather = env_int("P2P_MERGE_GATHER", o.merge_gather);
     o.band = env_int("P2P_BAND", o.band);
     o.band_bh = std::min(256, std::max(1, env_int("P2P_BAND_BH", o.band_bh)));
     o.band_cw = std::min(256, std::max(1, env_int("P2P_BAND_CW", o.band_cw)));
@@ -2041,7 +2043,8 @@ int p2p_job_run(p2p_job* j)
         // the LDS-scheme tiles, whichever they turn out to be); the gather tiles' count, the lists and the other kernels
         // follow below.  The kernels write disjoint pixels, in any order.
         std::function<int(const Plan&)> launch_main;
-        if (!float_path && opt.force_rest == 0 && opt.early_main != 0 && opt.scramble_plan == 0)
+        // (not when P2P_MAIN_ORDER names an order: that launch is the one a test or a tool wants to see)
+        if (!float_path && opt.force_rest == 0 && opt.early_main != 0 && opt.scramble_plan == 0 && opt.main_order < 0)
             launch_main = [&](const Plan& Pl) -> int {
                 plan_params(Pl);
                 P.main_list = nullptr;
@@ -2184,6 +2187,14 @@ int p2p_job_run(p2p_job* j)
     if (P.gather_all && !j->plan_ref->coords_full)
         if (int rc = ensure_full_coords(j))
             return rc;
+    // Band plans: the gather kernel's few, long workgroups (the tiles around a pole) are a chain of latencies -- 17 us as a
+    // launch of their own, with the band kernel behind them waiting for the last one; they become the first workgroups of
+    // the band kernel's own launch (with one set of tap registers: the kernel keeps six waves per SIMD).
+    // ... and of the main kernel's, in list order (a one-dimensional grid; not on a job's first launch, which is in grid
+    // order, and not where the gather kernel draws every tile anyway).
+    const bool merged = j->n_gather > 0 && gather_ok && opt.merge_gather != 0 && j->n_odd_pairs == 0 &&
+                        (band ? j->plan_ref->band_tiles > 0
+                              : (P.main_list != nullptr && !early_main && !P.gather_all && any_lds && fast_width));
     if (j->n_gather > 0) {
         if (gather_ok) {
             P.use_pair_list = 0;
@@ -2194,8 +2205,12 @@ int p2p_job_run(p2p_job* j)
             }
             P.gather_list = P.gather_all ? j->d_xcd_all : j->d_xcd_list;
             P.n_list = P.gather_all ? j->xcd_all_stride : j->xcd_stride;
-            if (P.gather_list && P.n_list > 0)
+            if (P.gather_list && P.n_list > 0 && !merged)
                 HIP_TRY(shape_ops(j->shape).views(P, 3, j->ctx->stream));
+            if (merged) {
+                P.merge_gather_list = P.gather_list;
+                P.merge_gather_n = P.n_list;
+            }
             P.gather_list = j->d_gather_list;
         }
         // the table kernel: every pair where the gather kernel does not apply, else the odd pairs

@@ -863,6 +863,9 @@ __device__ __forceinline__ void draw_tight(
 // Per pixel and pair: 2 aligned 12-byte loads; 3 re-alignments and 12 blend instructions per row (class 1) + the 14 of
 // stage 2 -- about 50 instructions whatever the footprint, against 16 + 7 per rot pixel of the footprint in the LDS scheme.
 // ---------------------------------------------------------------------------------------------
+// SINGLE: one set of tap registers (a pair's taps are loaded, waited for, blended: no prefetch inside the wave) -- 28
+// registers less, for the band kernel's merged launch, whose other workgroups must keep their six waves per SIMD.
+template <bool SINGLE = false>
 __device__ __forceinline__ void draw_gather(
     const ViewsParams& P, const uint8_t* __restrict__ src, const YawDesc* __restrict__ ydesc, uint8_t* __restrict__ out,
     const TileGeo& G, uint32_t* stage, int chunk = -1)
@@ -1056,6 +1059,26 @@ __device__ __forceinline__ void draw_gather(
     auto run = [&](auto mode_c, int kbeg, int kend) {
         if (kbeg >= kend)
             return;
+        if (SINGLE) {
+            for (int kk = kbeg; kk < kend; ++kk) {
+                load_taps(mode_c, kk, ta);
+                const uint32_t wB = (uint32_t)__builtin_amdgcn_readlane(cwB, kk);
+                const uint32_t f8 = 8u * (wB & 0xFFu), g8 = 256u - f8;
+                const int cc = (int)(wB >> 8) - 1;
+                uint32_t pix[PXT];
+#pragma unroll
+                for (int j = 0; j < PXT; ++j) {
+                    const bool a_clip = rx[j] == cc, b_clip = rx[j] + 1 == cc;
+                    uint32_t a, b, c, d;
+                    rot_pair(mode_c, ta.U[j], ta.al[j], f8, g8, a_clip, b_clip, a, b);
+                    rot_pair(mode_c, ta.L[j], ta.al[j], f8, g8, a_clip, b_clip, c, d);
+                    pix[j] = blend4_packed(a, b, c, d, tw[j]);
+                }
+                const int pair = pair0 + (int)((uint32_t)__builtin_amdgcn_readlane(cw3, kk) >> 26);
+                store_wave_pixels(SC, pix, out + ((size_t)pair * P.n_pitch + G.pitch_i) * view_bytes, view_bytes);
+            }
+            return;
+        }
         load_taps(mode_c, kbeg, ta);
         // one store that writes nothing: the loop is entered with the vmcnt shape it has inside (see draw_tight)
         __builtin_amdgcn_sched_barrier(0);
@@ -1375,14 +1398,64 @@ __device__ __forceinline__ void draw_rest(
     }
 }
 
+// the plan's list of mode 2 tiles -> (pitch, tile); an entry beyond the plan's slots (never written by the plan
+// pass) is clamped
+// XCD_LISTS (the gather kernel): the list is [8][P.n_list], one work list per XCD, grouped by the tiles' position in
+// the SOURCE so that tiles of different pitch views that read the same part of the panorama meet in one L2
+// (p2p_host.cpp: xcd_lists); gridDim.x == 8 * n_list, ~0 = no tile (returns false).
+template <bool XCD_LISTS>
+__device__ __forceinline__ bool tile_of_list(const ViewsParams& P, const uint32_t* __restrict__ list, uint32_t site, int& pitch_i, int& tile_id,
+                                             uint32_t bx = blockIdx.x, int n_list = -1)
+{
+    const uint32_t tiles = (uint32_t)(((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H));
+    uint32_t idx = bx;
+    if (XCD_LISTS)
+        idx = (bx & 7u) * (uint32_t)(n_list >= 0 ? n_list : P.n_list) + (bx >> 3);
+    uint32_t slot = list[idx];
+    if (XCD_LISTS && slot == ~0u)
+        return false;
+    P2P_AUD_LT(P.audit, site, slot, tiles * (uint32_t)P.n_pitch);
+    if (slot >= tiles * (uint32_t)P.n_pitch)
+        slot = 0u;
+    pitch_i = (int)(slot / tiles);
+    tile_id = (int)(slot - (uint32_t)pitch_i * tiles);
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
+// MERGED (list order only: a one-dimensional grid): the launch's first 8 * merge_gather_n * (chunks of gather_ppb pairs)
+// workgroups draw the plan's gather tiles -- the gather kernel's body with ONE set of tap registers, so that this kernel
+// keeps its registers -- instead of a launch of their own in front of this one: they are few, long chains of memory
+// latencies (the tiles around a pole), and hide behind the LDS-scheme tiles.
+template <bool MERGED>
 __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views_kernel(
     ViewsParams P, const uint8_t* __restrict__ src, const YawDesc* __restrict__ ydesc, uint8_t* __restrict__ out,
     const PieceHdr* __restrict__ hdr, const uint32_t* __restrict__ px, const uint32_t* __restrict__ items)
 {
     __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
+    uint32_t bx = blockIdx.x;
+    if (MERGED) {
+        const uint32_t per_chunk = 8u * (uint32_t)P.merge_gather_n;
+        const uint32_t n_pairs_all = (uint32_t)(P.n_panos * P.n_yaw);
+        const uint32_t gw = per_chunk * ((n_pairs_all + (uint32_t)P.gather_ppb - 1u) / (uint32_t)P.gather_ppb);
+        if (bx < gw) {
+            const uint32_t gchunk = bx / per_chunk;
+            int gp, gt;
+            if (!tile_of_list<true>(P, P.merge_gather_list, AUD_GATHER_LIST, gp, gt, bx - gchunk * per_chunk, P.merge_gather_n))
+                return;
+            const int gtiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
+            const PieceHdr gh = hdr[(size_t)gp * gtiles + gt];
+            const TileGeo GG = tile_geo(P, gh, gp, gt, (int)threadIdx.x);
+            if (GG.mode != 2)
+                return;
+            static_assert(sizeof(tile4) >= (VIEWS_BLOCK / 64) * VIEWS_PXT * 64 * sizeof(uint32_t), "the gather body's staging dwords");
+            draw_gather<true>(P, src, ydesc, out, GG, reinterpret_cast<uint32_t*>(&tile4[0][0]), (int)gchunk);
+            return;
+        }
+        bx -= gw;
+    }
 #if defined(P2P_STAGE_OWN_LDS) || defined(P2P_STORE_INLINE)
     __shared__ __attribute__((aligned(16))) uint32_t stage[(VIEWS_BLOCK / 64) * VIEWS_PXT * 64];  // a dword per pixel
 #else
@@ -1393,7 +1466,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views
     if (P.main_list && P.main_tail > 0) {
         // List order, ONE chunk of pairs, no prefetch workgroups (the host's rule): entry q of the XCD's list -- but its
         // last main_tail entries are drawn by main_tail_parts workgroups each, a part of the pairs each (p2p_host.cpp: main_tail).
-        const uint32_t q = blockIdx.x >> 3, L = (uint32_t)P.main_count[blockIdx.x & 7u];
+        const uint32_t q = bx >> 3, L = (uint32_t)P.main_count[bx & 7u];
         const uint32_t K = (uint32_t)P.main_tail < L ? (uint32_t)P.main_tail : L;
         uint32_t e = q;
         chunk = 0;
@@ -1407,7 +1480,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views
         }
         if (e >= (uint32_t)P.main_stride)
             return;
-        uint32_t slot = P.main_list[(blockIdx.x & 7u) * (uint32_t)P.main_stride + e];
+        uint32_t slot = P.main_list[(bx & 7u) * (uint32_t)P.main_stride + e];
         if (slot == ~0u)
             return;
         P2P_AUD_LT(P.audit, AUD_MAIN_PITCH, slot, (uint32_t)(tiles * P.n_pitch));
@@ -1420,14 +1493,14 @@ __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views
         // (their plan tables and source rows are still in its L2), and so on, then the next main_group entries.
         // With pf_lead > 0 (plan tables beyond the Infinity Cache: config 4) one more workgroup per block, dispatched
         // ahead of the block's last chunk, draws nothing and touches the plan tables of the NEXT block's entries.
-        const uint32_t q = blockIdx.x >> 3, group = (uint32_t)P.main_group, chunks = (uint32_t)P.main_chunks;
+        const uint32_t q = bx >> 3, group = (uint32_t)P.main_group, chunks = (uint32_t)P.main_chunks;
         const uint32_t pf = P.pf_lead > 0 ? 1u : 0u, pf_pos = group * (chunks - 1u);
         const uint32_t per_block = group * chunks + pf;
         const uint32_t blk = q / per_block;
         uint32_t r = q - blk * per_block;
         if (pf && r == pf_pos) {
             constexpr uint32_t LINES = PF_PX_LINES + PF_ITEM_LINES;
-            const uint32_t* mine = P.main_list + (blockIdx.x & 7u) * (uint32_t)P.main_stride;
+            const uint32_t* mine = P.main_list + (bx & 7u) * (uint32_t)P.main_stride;
             uint32_t acc = 0u;
             for (uint32_t i = threadIdx.x; i < group * LINES; i += VIEWS_BLOCK) {
                 const uint32_t tj = i / LINES, l = i - tj * LINES, e = (blk + 1u) * group + tj;
@@ -1448,7 +1521,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views
         const uint32_t e = blk * group + (r - (uint32_t)chunk * group);
         if (e >= (uint32_t)P.main_stride)
             return;
-        uint32_t slot = P.main_list[(blockIdx.x & 7u) * (uint32_t)P.main_stride + e];
+        uint32_t slot = P.main_list[(bx & 7u) * (uint32_t)P.main_stride + e];
         if (slot == ~0u)
             return;
         P2P_AUD_LT(P.audit, AUD_MAIN_PITCH, slot, (uint32_t)(tiles * P.n_pitch));
@@ -1456,7 +1529,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views
         pitch_i = (int)(slot / (uint32_t)tiles);
         tile_id = (int)(slot - (uint32_t)pitch_i * (uint32_t)tiles);
     } else {
-        const BlockRole role = main_block_role(P, (int)blockIdx.x);
+        const BlockRole role = main_block_role(P, (int)bx);
         // heaviest views first (the host orders pitch_order by |pitch - 90| descending): a smoother tail
         pitch_i = pitch_of_block(P, tile_grid_pitch_block(P));
         chunk = tile_grid_chunk(P);
@@ -1519,30 +1592,6 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void remap_views_rest_kernel(
                      items + (size_t)G.slot * LDS_ITEMS_CAP, tile4);
 }
 
-// the plan's list of mode 2 tiles -> (pitch, tile); an entry beyond the plan's slots (never written by the plan
-// pass) is clamped
-// XCD_LISTS (the gather kernel): the list is [8][P.n_list], one work list per XCD, grouped by the tiles' position in
-// the SOURCE so that tiles of different pitch views that read the same part of the panorama meet in one L2
-// (p2p_host.cpp: xcd_lists); gridDim.x == 8 * n_list, ~0 = no tile (returns false).
-template <bool XCD_LISTS>
-__device__ __forceinline__ bool tile_of_list(const ViewsParams& P, const uint32_t* __restrict__ list, uint32_t site, int& pitch_i, int& tile_id,
-                                             uint32_t bx = blockIdx.x, int n_list = -1)
-{
-    const uint32_t tiles = (uint32_t)(((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H));
-    uint32_t idx = bx;
-    if (XCD_LISTS)
-        idx = (bx & 7u) * (uint32_t)(n_list >= 0 ? n_list : P.n_list) + (bx >> 3);
-    uint32_t slot = list[idx];
-    if (XCD_LISTS && slot == ~0u)
-        return false;
-    P2P_AUD_LT(P.audit, site, slot, tiles * (uint32_t)P.n_pitch);
-    if (slot >= tiles * (uint32_t)P.n_pitch)
-        slot = 0u;
-    pitch_i = (int)(slot / tiles);
-    tile_id = (int)(slot - (uint32_t)pitch_i * tiles);
-    return true;
-}
-
 // One workgroup per (mode 2 tile of the plan's list, chunk of pairs).
 #ifndef P2P_GATHER_WAVES
 #define P2P_GATHER_WAVES 4  // two sets of tap registers: 4 waves per SIMD, 16 x 6 KB of loads in flight per CU
@@ -1570,13 +1619,39 @@ __global__ __launch_bounds__(VIEWS_BLOCK, P2P_GATHER_WAVES) void remap_views_gat
 #ifndef P2P_BAND_WAVES
 #define P2P_BAND_WAVES 6  // (at 7 waves per SIMD, 72 registers, the three-item loops spill)
 #endif
-template <bool MASKED>
+// MERGED: the launch's first 8 * band_gather_n * (chunks of gather_ppb pairs) workgroups draw the plan's gather tiles (the
+// gather kernel's body with ONE set of tap registers, so that the kernel keeps its six waves per SIMD): few, long,
+// latency-bound workgroups around a pole -- 17 us as a launch of their own behind which the band kernel waits.
+template <bool MASKED, bool MERGED>
 __global__ __launch_bounds__(VIEWS_BLOCK, P2P_BAND_WAVES) void remap_views_band_kernel(
     ViewsParams P, const uint8_t* __restrict__ src, const YawDesc* __restrict__ ydesc, uint8_t* __restrict__ out,
     const PieceHdr* __restrict__ hdr, const uint32_t* __restrict__ px, const uint32_t* __restrict__ grp, const BandInfo* __restrict__ info)
 {
     __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
-    const uint32_t bx = blockIdx.x;
+    uint32_t bx = blockIdx.x;
+    if (MERGED) {
+        const uint32_t per_chunk = 8u * (uint32_t)P.merge_gather_n;
+        const uint32_t n_pairs = (uint32_t)(P.n_panos * P.n_yaw);
+        const uint32_t gchunks = (n_pairs + (uint32_t)P.gather_ppb - 1u) / (uint32_t)P.gather_ppb;
+        const uint32_t gw = per_chunk * gchunks;
+        if (bx < gw) {
+            if (blockIdx.y != 0)
+                return;
+            const uint32_t gchunk = bx / per_chunk;
+            int pitch_i, tile_id;
+            if (!tile_of_list<true>(P, P.merge_gather_list, AUD_GATHER_LIST, pitch_i, tile_id, bx - gchunk * per_chunk, P.merge_gather_n))
+                return;
+            const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
+            const PieceHdr h = P.hdr[(size_t)pitch_i * tiles + tile_id];
+            const TileGeo G = tile_geo(P, h, pitch_i, tile_id, (int)threadIdx.x);
+            if (G.mode != 2)
+                return;
+            static_assert(sizeof(tile4) >= (VIEWS_BLOCK / 64) * VIEWS_PXT * 64 * sizeof(uint32_t), "the gather body's staging dwords");
+            draw_gather<true>(P, src, ydesc, out, G, reinterpret_cast<uint32_t*>(&tile4[0][0]), (int)gchunk);
+            return;
+        }
+        bx -= gw;
+    }
     const uint32_t xcd = bx & 7u, q = bx >> 3;
     const uint32_t n_tiles = (uint32_t)P.band_tiles;
     uint32_t first = info->first[xcd], last = info->first[xcd + 1];
@@ -1648,13 +1723,18 @@ hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
         int zb = (n_pairs + P.pairs_per_block - 1) / P.pairs_per_block;
         if (TILE_W == 128 && P.main_span > 1)
             zb = (zb + P.main_span - 1) / P.main_span;
-        const dim3 grid(8 * (P.band_per + (P.band_tail > 0 ? (P.main_tail_parts - 1) * P.band_tail : 0)), P.band_tail > 0 ? 1 : zb, 1);
-        if (P.view_mask)
-            hipLaunchKernelGGL(remap_views_band_kernel<true>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.band_hdr, P.band_px,
-                               P.band_grp, P.band_info);
-        else
-            hipLaunchKernelGGL(remap_views_band_kernel<false>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.band_hdr, P.band_px,
-                               P.band_grp, P.band_info);
+        const bool merged = P.merge_gather_list != nullptr && P.merge_gather_n > 0;
+        const int gw = merged ? 8 * P.merge_gather_n * ((n_pairs + P.gather_ppb - 1) / P.gather_ppb) : 0;
+        const dim3 grid(gw + 8 * (P.band_per + (P.band_tail > 0 ? (P.main_tail_parts - 1) * P.band_tail : 0)), P.band_tail > 0 ? 1 : zb, 1);
+#define P2P_LAUNCH_BAND(MASKED, MERGED)                                                                                         \
+        hipLaunchKernelGGL((remap_views_band_kernel<MASKED, MERGED>), grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, \
+                           P.band_hdr, P.band_px, P.band_grp, P.band_info)
+        if (P.view_mask) {
+            if (merged) P2P_LAUNCH_BAND(true, true); else P2P_LAUNCH_BAND(true, false);
+        } else {
+            if (merged) P2P_LAUNCH_BAND(false, true); else P2P_LAUNCH_BAND(false, false);
+        }
+#undef P2P_LAUNCH_BAND
         return hipGetLastError();
     }
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
@@ -1671,8 +1751,11 @@ hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
         grid = dim3(8 * ((P.main_stride + P.main_group - 1) / P.main_group) * (P.main_group * P.main_chunks + (P.pf_lead > 0 ? 1 : 0)), 1, 1);
     else if (which == 0 && P.pf_lead > 0)  // one table-prefetch workgroup in PF_GROUP + 1 (p2p_tile.h: main_block_role)
         grid.x = 8 * (((tiles + 7) / 8 + PF_GROUP - 1) / PF_GROUP) * (PF_GROUP + 1);
-    if (which == 0)
-        hipLaunchKernelGGL(remap_views_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.hdr, P.px, P.items);
+    if (which == 0 && P.main_list && P.merge_gather_list && P.merge_gather_n > 0) {
+        grid.x += 8 * P.merge_gather_n * ((n_pairs + P.gather_ppb - 1) / P.gather_ppb);
+        hipLaunchKernelGGL(remap_views_kernel<true>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.hdr, P.px, P.items);
+    } else if (which == 0)
+        hipLaunchKernelGGL(remap_views_kernel<false>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.hdr, P.px, P.items);
     else
         hipLaunchKernelGGL(remap_views_rest_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc, P.f4tab,
                            P.out, P.hdr, P.px, P.items);

@@ -46,15 +46,16 @@ def test_band_tiles_draw_the_oracles_bytes(gpu, synth, p2p_env, n_panos, tile_sh
     p2p_env("P2P_PLAN_CACHE", "0")
     p2p_env("P2P_TILE_SHAPE", tile_shape)
     p2p_env("P2P_BAND", "1")
-    for (bh, cw), ppb in itertools.product(((16, 8), (4, 8), (8, 32), (24, 4)), ("0", "3")):
+    for (bh, cw), ppb, merge in itertools.product(((16, 8), (4, 8), (8, 32), (24, 4)), ("0", "3"), ("1", "0")):
         p2p_env("P2P_BAND_BH", str(bh))
         p2p_env("P2P_BAND_CW", str(cw))
         p2p_env("P2P_PAIRS_PER_BLOCK", ppb)
+        p2p_env("P2P_MERGE_GATHER", merge)  # the gather tiles as the first workgroups of the band kernel's launch, or as their own
         got, info = _run(gpu, panos, yaws, pitches, ow, oh, fov, maps)
         assert info["band_tiles"] > 0 and 0 < info["n_gather_tiles"] < info["n_tiles"], info
         for i in range(n_panos):
             bad = np.argwhere(got[i] != want[i])
-            assert bad.size == 0, (tile_shape, bh, cw, ppb, i, len(bad), bad[:3])
+            assert bad.size == 0, (tile_shape, bh, cw, ppb, merge, i, len(bad), bad[:3])
 
 
 def test_band_tiles_with_a_view_mask(gpu, synth, p2p_env):

@@ -181,16 +181,18 @@ def test_gather_tiles_in_rows_and_in_blocks_draw_the_same_bytes(gpu, synth, monk
 def test_first_and_second_launch_draw_the_same_bytes(gpu, synth, p2p_env, pitches):
     """A job's first launch sends the main kernel out in grid order right behind the plan pass and, when the plan has no
     gather tile, makes the per-XCD lists only when a second launch asks for them (P2P_EARLY_MAIN, P2P_DEFER_LISTS): the
-    first, the second and the third launch -- grid order, then list order -- draw the oracle's bytes, with either knob off too."""
+    first, the second and the third launch -- grid order, then list order, where the gather tiles ride in the main kernel's
+    launch (P2P_MERGE_GATHER) -- draw the oracle's bytes, with every knob off too."""
     pw, ph, ow, oh, fov = 2048, 1024, 640, 360, 90
     yaws = [0, 33, 90, 200, 301]
     pano = synth.synth_pano(pw, ph, 4400, "N")
     maps = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
     want = oracle_views(pano, yaws, pitches, ow, oh, fov)
     p2p_env("P2P_PLAN_CACHE", "0")
-    for early, defer in itertools.product(("1", "0"), ("1", "0")):
+    for early, defer, merge in itertools.product(("1", "0"), ("1", "0"), ("1", "0")):
         p2p_env("P2P_EARLY_MAIN", early)
         p2p_env("P2P_DEFER_LISTS", defer)
+        p2p_env("P2P_MERGE_GATHER", merge)  # list order: the gather tiles as the first workgroups of the main kernel's launch
         ctx = gpu.Context(0)
         try:
             job = gpu.Job(ctx, pw, ph, 1, yaws, pitches, fov, ow, oh)
@@ -200,7 +202,7 @@ def test_first_and_second_launch_draw_the_same_bytes(gpu, synth, p2p_env, pitche
                 job.run()
                 got = job.get_views(0)
                 bad = np.argwhere(got != want)
-                assert bad.size == 0, (early, defer, launch, len(bad), bad[:3])
+                assert bad.size == 0, (early, defer, merge, launch, len(bad), bad[:3])
             job.close()
         finally:
             ctx.close()
