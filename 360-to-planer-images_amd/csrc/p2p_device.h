@@ -166,6 +166,8 @@ struct ViewsParams {
     const uint32_t* view_mask;
     int mask_words;          // words per pitch: ceil(n_yaw / 32)
     float centre;            // float pixel path only: 0 = the reference's sampling convention, 0.5 = pixel centres
+    const uint4* pair_ctx;   // [slots][pair_ctx_chunks][64] the (panorama, yaw) pair contexts of every tile and chunk of pairs
+    int pair_ctx_chunks;     // (p2p_views.hip: pair_ctx_kernel), or nullptr: every workgroup works its own out
     uint32_t* audit;         // -DP2P_AUDIT builds: the context's violation record (see p2p_audit.h); else nullptr
     // source-band tiles (band plans): the band kernel draws them for every plain-shift yaw instead of the main kernel
     const PieceHdr* band_hdr;
@@ -248,6 +250,8 @@ struct ShapeOps {
     // the band passes after the plan pass: 0 = cut count + scan (then the host reads BandInfo back and allocates),
     // 1 = cut, scatter, tile build, XCD runs
     hipError_t (*band)(const BandParams& B, int stage, hipStream_t st);
+    // the job's pair-context table for the main kernel's tiles (band = 0) or the band tiles (1)
+    hipError_t (*pair_ctx)(const ViewsParams& P, uint4* table, int slots, int chunks, int band, hipStream_t st);
 };
 const ShapeOps& shape_ops_w64();
 const ShapeOps& shape_ops_w128();
@@ -290,6 +294,7 @@ hipError_t launch_plan(const PlanParams& P, hipStream_t st);
 hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st);
 hipError_t launch_float_views(const ViewsParams& P, bool half, int which, hipStream_t st);
 hipError_t launch_band(const BandParams& B, int stage, hipStream_t st);
+hipError_t launch_pair_ctx(const ViewsParams& P, uint4* table, int slots, int chunks, int band, hipStream_t st);
 }  // namespace P2P_SHAPE_NS
 using namespace P2P_SHAPE_NS;
 #define P2P_SHAPE_OPS_NAME2(ns) shape_ops_##ns

@@ -90,6 +90,7 @@ struct Options {
     int scramble_plan = 0;            // P2P_SCRAMBLE_PLAN (robustness self-test only)
     int coords_all = 0;               // (no environment knob) 1 = the plan pass writes every pixel's quantised coordinates (0: the gather tiles')
     int merge_gather = 1;               // P2P_MERGE_GATHER: 1 = the gather tiles are drawn by the first workgroups of the band kernel's launch / of the main kernel's in list order
+    int pair_ctx_table = 1;           // P2P_PAIR_CTX_TABLE: 1 = the pair contexts of every tile come from a table built once per job geometry
     int early_main = 1;               // P2P_EARLY_MAIN: 1 = a job's first launch sends the main kernel out right behind the plan pass
     int defer_lists = 1;              // P2P_DEFER_LISTS: 1 = a plan without gather tiles makes its main lists at its second launch (0: at once)
     int band = -1;                    // P2P_BAND: 1 = source-band tiles wherever they apply, 0 = never, -1 = the library's rule (choose_band)
@@ -128,6 +129,7 @@ void options_load_locked()
     o.scramble_plan = env_int("P2P_SCRAMBLE_PLAN", o.scramble_plan);
     o.defer_lists = env_int("P2P_DEFER_LISTS", o.defer_lists);
     o.early_main = env_int("P2P_EARLY_MAIN", o.early_main);
+    o.pair_ctx_table = env_int("P2P_PAIR_CTX_TABLE", o.pair_ctx_table);
     o.merge_gather = env_int("P2P_MERGE_GATHER", o.merge_gather);
     o.band = env_int("P2P_BAND", o.band);
     o.band_bh = std::min(256, std::max(1, env_int("P2P_BAND_BH", o.band_bh)));
@@ -673,6 +675,14 @@ struct p2p_job {
     int n_gather = 0;                    // tiles the plan marks for gathers
     int n_odd_yaws = 0;                  // yaws that are not a plain shift with one weight (YawDesc.mode != 0)
     uint16_t* d_pitch_order = nullptr;   // [n_pitch] heaviest view first
+    // the pair-context table (p2p_views.hip: pair_ctx_kernel): what every workgroup would work out about its chunk's
+    // (panorama, yaw) pairs, once per (plan, yaw tables, view mask, pairs per workgroup) -- rebuilt when one of them changes
+    uint4* d_pair_ctx = nullptr;
+    const void* pc_plan = nullptr;
+    const void* pc_yaw = nullptr;
+    unsigned long long pc_mask_gen = 0, mask_gen = 1;
+    int pc_ppb = 0, pc_chunks = 0;
+    size_t pc_slots = 0;
     uint32_t* d_view_mask = nullptr;     // sparse view sets (p2p_job_set_view_mask): [n_pitch][mask_words] bits, nullptr = every view
     int mask_words = 0;
     int n_views_wanted = 0;              // views per panorama the job draws (n_yaw * n_pitch without a mask)
@@ -1051,6 +1061,7 @@ void p2p_job_destroy(p2p_job* j)
     (void)dev_free(j->d_odd_pairs);
     (void)dev_free(j->d_pitch_order);
     (void)dev_free(j->d_view_mask);
+    (void)dev_free(j->d_pair_ctx);
     for (hipEvent_t e : j->ev_ring)
         (void)hipEventDestroy(e);
     delete j;
@@ -1570,6 +1581,7 @@ int p2p_job_set_view_mask(p2p_job* j, const uint8_t* mask)
     const p2p_job_desc& d = j->d;
     HIP_TRY(hipSetDevice(j->ctx->device));
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));  // no launch in flight reads the mask that is about to change
+    j->mask_gen++;  // (the pair-context table holds the mask's "not wanted" class)
     if (!mask) {
         (void)dev_free(j->d_view_mask);
         j->d_view_mask = nullptr;
@@ -2165,6 +2177,33 @@ int p2p_job_run(p2p_job* j)
         j->runs++;
         j->ran = true;
         return P2P_OK;
+    }
+    // the pair-context table: not for a job's very first launch (the main kernel is already out), not beyond 64 MB
+    P.pair_ctx = nullptr;
+    P.pair_ctx_chunks = 0;
+    if (opt.pair_ctx_table != 0 && !early_main && opt.force_rest == 0) {
+        const int chunks_all = (j->d.n_panos * j->d.n_yaw + P.pairs_per_block - 1) / P.pairs_per_block;
+        const size_t tslots = band ? (size_t)j->plan_ref->band_tiles : j->n_tiles * (size_t)j->d.n_pitch;
+        const size_t bytes = tslots * (size_t)chunks_all * 64 * sizeof(uint4);
+        if (tslots > 0 && bytes <= ((size_t)64 << 20) && P.pairs_per_block <= 64) {
+            const bool stale = !j->d_pair_ctx || j->pc_plan != j->plan_ref.get() || j->pc_yaw != j->yaw_ref.get() ||
+                               j->pc_mask_gen != j->mask_gen || j->pc_ppb != P.pairs_per_block || j->pc_chunks != chunks_all ||
+                               j->pc_slots != tslots;
+            if (stale) {
+                if (j->d_pair_ctx && (j->pc_slots * (size_t)j->pc_chunks != tslots * (size_t)chunks_all)) {
+                    HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+                    (void)dev_free(j->d_pair_ctx);
+                    j->d_pair_ctx = nullptr;
+                }
+                if (!j->d_pair_ctx)
+                    HIP_TRY(dev_alloc((void**)&j->d_pair_ctx, bytes));
+                HIP_TRY(shape_ops(j->shape).pair_ctx(P, j->d_pair_ctx, (int)tslots, chunks_all, band ? 1 : 0, j->ctx->stream));
+                j->pc_plan = j->plan_ref.get(); j->pc_yaw = j->yaw_ref.get(); j->pc_mask_gen = j->mask_gen;
+                j->pc_ppb = P.pairs_per_block; j->pc_chunks = chunks_all; j->pc_slots = tslots;
+            }
+            P.pair_ctx = j->d_pair_ctx;
+            P.pair_ctx_chunks = chunks_all;
+        }
     }
     if (timed && !early_main)
         HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));

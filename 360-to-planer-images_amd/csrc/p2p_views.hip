@@ -292,6 +292,32 @@ __device__ __forceinline__ PairCtxs pair_contexts(const ViewsParams& P, const Ya
     return X;
 }
 
+// The same contexts from the job's table (ViewsParams::pair_ctx, written by pair_ctx_kernel with the function above): one
+// 16-byte load per lane instead of 83 instructions per wave -- a tile's set-up is worth 2.4 pairs of its 12 on config 2,
+// a whole pair of the 4 a band tile of the reference CLI's default set draws.  Record of lane k: cw0, cw1, cw3 of the
+// k-th pair in class order; the fourth word of lane 0 holds n0 | n1 << 8 | n2 << 16 | n3 << 24, of lane 1 n4 | npairs << 8.
+__device__ __forceinline__ PairCtxs pair_contexts_from_table(const ViewsParams& P, uint32_t slot, int chunk, int t, int ppb_eff)
+{
+    PairCtxs X;
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    if (chunk < P.pair_ctx_chunks)  // (a workgroup that loops over chunks may look one past the last: no pairs there)
+        r = P.pair_ctx[((size_t)slot * (size_t)P.pair_ctx_chunks + (size_t)chunk) * 64u + (size_t)(t & 63)];
+    X.cw0 = r.x;
+    X.cw1 = r.y;
+    X.cw2 = 0;  // (the rest kernel's: it works its contexts out itself)
+    X.cw3 = (int)r.z;
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)r.w, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)r.w, 1);
+    // (whatever the table holds, the counts stay an ascending sequence within a wave's 64 lanes)
+    X.n0 = (int)min(a & 0xFFu, 64u);
+    X.n1 = max(X.n0, (int)min((a >> 8) & 0xFFu, 64u));
+    X.n2 = max(X.n1, (int)min((a >> 16) & 0xFFu, 64u));
+    X.n3 = max(X.n2, (int)min(a >> 24, 64u));
+    X.n4 = max(X.n3, (int)min(b & 0xFFu, 64u));
+    X.npairs = (int)min((b >> 8) & 0xFFu, 64u);
+    X.pair0 = chunk * ppb_eff;
+    return X;
+}
+
 // per-pixel words of the plan -> tap offsets (bytes inside one LDS buffer) and packed weights
 // band_row_bytes > 0: a band tile's words -- the distance field is a live flag, the lower tap sits one LDS row further
 template <int PXT>
@@ -422,7 +448,10 @@ __device__ __forceinline__ void draw_tight(
     constexpr bool SPAN_LOOP = TILE_W == 128;
     const int chunk_end = chunk + (SPAN_LOOP && P.main_span > 1 ? P.main_span : 1);
     // (band tiles: lanes of several pitch views -- no pair is skipped as a whole; unwanted views are dropped per lane below)
-    PairCtxs X = pair_contexts(P, ydesc, G.c0, G.c1, t, chunk, BAND ? -1 : G.pitch_i, ppb);
+    // (from the job's table unless this workgroup draws a PART of the pairs -- the split tail of a list, ppb > 0)
+    const bool ctx_table = P.pair_ctx != nullptr && ppb == 0;
+    PairCtxs X = ctx_table ? pair_contexts_from_table(P, G.slot, chunk, t, P.pairs_per_block)
+                           : pair_contexts(P, ydesc, G.c0, G.c1, t, chunk, BAND ? -1 : G.pitch_i, ppb);
     int nplain = X.n3;
     if (nplain == 0 && chunk + 1 == chunk_end)
         return;
@@ -838,7 +867,8 @@ __device__ __forceinline__ void draw_tight(
             break;
         // the next chunk of this tile: new pair contexts, everything else stands.  The tile buffers keep alternating
         // (the last pair's taps are still being read by slower waves from the buffer this wave does NOT write next).
-        X = pair_contexts(P, ydesc, G.c0, G.c1, t, ch, BAND ? -1 : G.pitch_i, ppb);
+        X = ctx_table ? pair_contexts_from_table(P, G.slot, ch, t, P.pairs_per_block)
+                      : pair_contexts(P, ydesc, G.c0, G.c1, t, ch, BAND ? -1 : G.pitch_i, ppb);
         nplain = X.n3;
         if (X.npairs == 0)
             break;  // past the job's last chunk
@@ -1425,6 +1455,41 @@ __device__ __forceinline__ bool tile_of_list(const ViewsParams& P, const uint32_
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
+// The job's pair-context table: one wave per (tile slot, chunk of pairs) runs pair_contexts and stores what the view
+// kernels' workgroups would each work out again (pair_contexts_from_table).  band != 0: the slots are band tiles.
+__global__ __launch_bounds__(64) void pair_ctx_kernel(ViewsParams P, uint4* __restrict__ table, int band)
+{
+    const uint32_t slot = blockIdx.x;
+    const int chunk = (int)blockIdx.y, t = threadIdx.x;
+    int c0, c1, pitch_i = -1;
+    uint32_t mode;
+    if (band) {
+        const PieceHdr h = P.band_hdr[slot];
+        c0 = h.c0; c1 = h.c1; mode = 1u;
+    } else {
+        const uint32_t tiles = (uint32_t)(((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H));
+        const PieceHdr h = P.hdr[slot];
+        c0 = h.c0; c1 = h.c1; mode = h.mode_items & 3u;
+        pitch_i = (int)(slot / tiles);
+    }
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    if (mode == 1u) {
+        const PairCtxs X = pair_contexts(P, P.ydesc, c0, c1, t, chunk, pitch_i, 0);
+        r.x = X.cw0; r.y = X.cw1; r.z = (uint32_t)X.cw3;
+        r.w = t == 0 ? ((uint32_t)X.n0 | (uint32_t)X.n1 << 8 | (uint32_t)X.n2 << 16 | (uint32_t)X.n3 << 24)
+                     : (t == 1 ? ((uint32_t)X.n4 | (uint32_t)X.npairs << 8) : 0u);
+    }
+    table[((size_t)slot * gridDim.y + (size_t)chunk) * 64u + (size_t)t] = r;
+}
+
+hipError_t launch_pair_ctx(const ViewsParams& P, uint4* table, int slots, int chunks, int band, hipStream_t st)
+{
+    if (slots <= 0 || chunks <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(pair_ctx_kernel, dim3(slots, chunks), dim3(64), 0, st, P, table, band);
+    return hipGetLastError();
+}
+
 // MERGED (list order only: a one-dimensional grid): the launch's first 8 * merge_gather_n * (chunks of gather_ppb pairs)
 // workgroups draw the plan's gather tiles -- the gather kernel's body with ONE set of tap registers, so that this kernel
 // keeps its registers -- instead of a launch of their own in front of this one: they are few, long chains of memory

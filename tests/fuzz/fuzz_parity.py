@@ -14,6 +14,8 @@ synth = importlib.import_module("360-to-planer-images_amd.synth")
 import _args  # named options with hard caps (tests/fuzz/_args.py)
 _p = _args.parser(__doc__, cases=100, seed=2026)
 _p.add_argument("--only", type=int, default=-1, help="re-run one case, checking every yaw")
+_p.add_argument("--launches", type=int, default=2, help="launches per job, each checked: the first goes out in grid order behind the plan "
+                "pass; from the second on the per-XCD lists, the pair-context table and the merged gather launch are in play")
 _p.add_argument("--mode", choices=("default", "big", "real"), default="default",
                 help="big: large geometries; real: real-valued yaw / pitch / FOV, pitch anywhere in [0, 180]")
 _a = _p.parse_args()
@@ -53,18 +55,22 @@ for case in range(int(os.environ.get("FUZZ_FIRST", "0")), n_cases):  # FUZZ_FIRS
     for i, p in enumerate(panos):
         job.set_pano(i, p)
     job.set_maps(rows, U, V)
-    job.run()
     check_yaws = sorted(set([0, n_yaw - 1, int(rng.integers(0, n_yaw))])) if only is None else list(range(n_yaw))
     if only is not None:
         print(dict(pw=pw, ph=ph, ow=ow, oh=oh, fov=fov, yaws=yaws, pitches=pitches, n_panos=n_panos))
-    for i, p in enumerate(panos):
-        got = job.get_views(i)
-        for yi in check_yaws:
-            want = oracle_views(p, [yaws[yi]], pitches, ow, oh, fov)
-            if not np.array_equal(got[yi], want[0]):
-                bad += 1
-                print("MISMATCH", dict(case=case, pw=pw, ph=ph, ow=ow, oh=oh, fov=fov, yaw=yaws[yi], yaw_index=yi, n_yaw=n_yaw, pitches=pitches, pano=i,
-                                       n=int((got[yi] != want[0]).sum())), flush=True)
+    wants = {}
+    for launch in range(max(1, min(4, _a.launches))):
+        job.run()
+        for i, p in enumerate(panos):
+            got = job.get_views(i)
+            for yi in check_yaws:
+                if (i, yi) not in wants:
+                    wants[(i, yi)] = oracle_views(p, [yaws[yi]], pitches, ow, oh, fov)[0]
+                want = wants[(i, yi)]
+                if not np.array_equal(got[yi], want):
+                    bad += 1
+                    print("MISMATCH", dict(case=case, launch=launch, pw=pw, ph=ph, ow=ow, oh=oh, fov=fov, yaw=yaws[yi], yaw_index=yi, n_yaw=n_yaw,
+                                           pitches=pitches, pano=i, n=int((got[yi] != want).sum())), flush=True)
     job.close()
     if case % 10 == 9:
         print("case %d done, %.0f s, mismatches %d" % (case + 1, time.time() - t0, bad), flush=True)

@@ -122,6 +122,12 @@ static hipError_t stub_band(const BandParams& B, int stage, hipStream_t)
         B.info->first[x] = (uint32_t)(nt * x / 8);
     return hipSuccess;
 }
+// the pair-context table: its last record
+static hipError_t stub_pair_ctx(const ViewsParams&, uint4* table, int slots, int chunks, int, hipStream_t)
+{
+    table[(size_t)slots * chunks * 64 - 1] = uint4{0u, 0u, 0u, 0u};
+    return hipSuccess;
+}
 hipError_t launch_scramble(void*, size_t, uint32_t, hipStream_t) { return hipSuccess; }
 hipError_t launch_compact_rows(void* dst, const uint8_t* src, size_t n_bytes, int row_bytes, int src_row, hipStream_t)
 {
@@ -198,12 +204,12 @@ static hipError_t stub_float_views(const ViewsParams& P, bool, int, hipStream_t)
 }
 const ShapeOps& shape_ops_w64()
 {
-    static const ShapeOps ops = {{64, TILE_H, 256, 4, 704}, &stub_plan<64, 256, 704>, &stub_views<64>, &stub_float_views, &stub_band<256>};
+    static const ShapeOps ops = {{64, TILE_H, 256, 4, 704}, &stub_plan<64, 256, 704>, &stub_views<64>, &stub_float_views, &stub_band<256>, &stub_pair_ctx};
     return ops;
 }
 const ShapeOps& shape_ops_w128()
 {
-    static const ShapeOps ops = {{128, TILE_H, 512, 4, 1408}, &stub_plan<128, 512, 1408>, &stub_views<128>, &stub_float_views, &stub_band<512>};
+    static const ShapeOps ops = {{128, TILE_H, 512, 4, 1408}, &stub_plan<128, 512, 1408>, &stub_views<128>, &stub_float_views, &stub_band<512>, &stub_pair_ctx};
     return ops;
 }
 }  // namespace p2p

@@ -189,10 +189,11 @@ def test_first_and_second_launch_draw_the_same_bytes(gpu, synth, p2p_env, pitche
     maps = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
     want = oracle_views(pano, yaws, pitches, ow, oh, fov)
     p2p_env("P2P_PLAN_CACHE", "0")
-    for early, defer, merge in itertools.product(("1", "0"), ("1", "0"), ("1", "0")):
+    for early, defer, merge, table in itertools.product(("1", "0"), ("1", "0"), ("1", "0"), ("1", "0")):
         p2p_env("P2P_EARLY_MAIN", early)
         p2p_env("P2P_DEFER_LISTS", defer)
         p2p_env("P2P_MERGE_GATHER", merge)  # list order: the gather tiles as the first workgroups of the main kernel's launch
+        p2p_env("P2P_PAIR_CTX_TABLE", table)  # the tiles' pair contexts from the job's table (from the second launch on) or worked out per workgroup
         ctx = gpu.Context(0)
         try:
             job = gpu.Job(ctx, pw, ph, 1, yaws, pitches, fov, ow, oh)
@@ -202,7 +203,7 @@ def test_first_and_second_launch_draw_the_same_bytes(gpu, synth, p2p_env, pitche
                 job.run()
                 got = job.get_views(0)
                 bad = np.argwhere(got != want)
-                assert bad.size == 0, (early, defer, merge, launch, len(bad), bad[:3])
+                assert bad.size == 0, (early, defer, merge, table, launch, len(bad), bad[:3])
             job.close()
         finally:
             ctx.close()
