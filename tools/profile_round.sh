@@ -27,7 +27,7 @@ import csv, glob, json, os, re
 out = "$OUT"
 def counters(d, key):
     # key "remap_views_kernel" = the main kernel only (remap_views_rest_kernel and plan_kernel are others)
-    pat = re.compile(r"remap_views_kernel\(") if key == "remap_views_kernel" else re.compile(re.escape(key))
+    pat = re.compile(r"remap_views_kernel[<(]") if key == "remap_views_kernel" else re.compile(re.escape(key))
     vals = {}
     for f in glob.glob(os.path.join(out, d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
