@@ -224,7 +224,7 @@ def secondary_lines(nat, ctx, pano8k, device):
                          "frac_of_hbm_peak": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "plan_ms": plan_ms, "yaw_tables_ms": tables_ms,
                          "kernels": "float_views_kernel" if flags else
-                                    ("remap_views_band_kernel (source-band tiles, %d) + remap_views_gather_kernel (%d tiles around the poles)"
+                                    ("remap_views_band_kernel (source-band tiles, %d; its first workgroups draw the %d gather tiles around the poles)"
                                      % (job.info()["band_tiles"], job.info()["n_gather_tiles"]) if job.info()["band_tiles"] > 0 else
                                      "remap_views_kernel + remap_views_gather_kernel (tiles that do not fit the LDS scheme)")}
             job.close()
