@@ -27,6 +27,7 @@ enum AuditSite : uint32_t {
     AUD_REST_HDR = 0x206,
     AUD_TABLE_LIST = 0x301, AUD_TABLE_PAIR = 0x302, AUD_TABLE_SRC = 0x303, AUD_TABLE_YTAB = 0x304,
     AUD_GATHER_LIST = 0x401, AUD_GATHER_BOX = 0x402, AUD_GATHER_SRC = 0x403, AUD_GATHER_COORD = 0x404,
+    AUD_BAND_TILE = 0x601, AUD_BAND_GRP = 0x602, AUD_BAND_RECT = 0x603,
     AUD_FLOAT_HDR = 0x501, AUD_FLOAT_SRC = 0x502, AUD_FLOAT_LIST = 0x503, AUD_FLOAT_TAP = 0x504,
 };
 

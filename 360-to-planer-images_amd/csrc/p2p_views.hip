@@ -462,8 +462,10 @@ __device__ __forceinline__ void draw_tight(
     // store).  Does this wave hold any group?  A footprint-limited tile -- a minifying view set -- fills only its first
     // waves; the others produce their items, skip stage 2 and need no per-pixel words.
     uint32_t grp_off = 0xFFFFFFFFu;
-    if (BAND)
+    if (BAND) {
         grp_off = grpw[t];
+        P2P_AUD_LT(P.audit, AUD_BAND_GRP, grp_off == 0xFFFFFFFFu ? 0u : grp_off + 11u, (uint32_t)P.n_pitch * (uint32_t)P.view_bytes);
+    }
     const bool wave_draws = !BAND || __ballot(grp_off != 0xFFFFFFFFu) != 0ull;
     if (wave_draws) {
         decode_px<PXT>(pxw, t, tap_up, tap_lo, tw, band_row_bytes);
@@ -1740,6 +1742,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, P2P_BAND_WAVES) void remap_views_band_
     if (e >= L)
         return;
     const uint32_t tile = rev ? last - 1u - e : first + e;
+    P2P_AUD_LT(P.audit, AUD_BAND_TILE, tile, n_tiles);
     const PieceHdr h = hdr[tile];
     TileGeo G{};
     G.mode = 1;
@@ -1751,6 +1754,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, P2P_BAND_WAVES) void remap_views_band_
     G.band_row_items = G.band_row_items > 0 ? G.band_row_items : 1;
     G.slot = tile;
     P2P_AUD_LT(P.audit, AUD_MAIN_HDR, G.n_items, LDS_ITEMS_CAP + 1);
+    P2P_AUD_LT(P.audit, AUD_BAND_RECT, (uint32_t)G.band_row_items * (uint32_t)((G.n_items + G.band_row_items - 1) / G.band_row_items), LDS_ITEMS_CAP + 1);
     draw_tight<true, MASKED>(P, src, ydesc, out, G, px + (size_t)tile * (VIEWS_BLOCK * VIEWS_PXT), nullptr, tile4, nullptr,
                      chunk * (TILE_W == 128 && P.main_span > 1 ? P.main_span : 1), ppb, grp + (size_t)tile * VIEWS_BLOCK);
 }
