@@ -727,23 +727,34 @@ def main():
         w3 = WORKLOADS["cfg3"]
         mine3 = shard_round_robin(w3["n_panos_total"], dist.world, dist.rank)
         sec = {"workload": w3["name"], "scaling": "strong", "panos_per_gpu": len(mine3)}
+        job3, failed = None, 0.0
         try:
-            job3 = nat.Job(ctx, w3["pw"], w3["ph"], max(1, len(mine3)), w3["yaws"], w3["pitches"], w3["fov"], w3["ow"], w3["oh"]) if mine3 else None
-            if job3 is not None:
+            if mine3:
+                job3 = nat.Job(ctx, w3["pw"], w3["ph"], len(mine3), w3["yaws"], w3["pitches"], w3["fov"], w3["ow"], w3["oh"])
                 pano3 = synth.synth_pano(w3["pw"], w3["ph"], 1000 + dist.rank, args.kind)  # (content does not enter the timing)
                 for i in range(len(mine3)):
                     job3.set_pano(i, pano3)
                 job3.time_launches(False)
+                job3.run()
+                ctx.synchronize()
+        except Exception as e:
+            failed, sec["error"] = 1.0, repr(e)
+        # every rank learns whether ALL ranks are ready before anyone enters the barriers of the timed loop: a rank that
+        # failed above must not leave the others waiting in one
+        if dist.max_over_ranks(failed) == 0.0:
             k3 = 6
             el3 = run_timed((lambda: job3.run()) if job3 is not None else (lambda: None), device_sync, dist, k3, 2)
             views3 = w3["n_panos_total"] * len(w3["yaws"]) * len(w3["pitches"])
             sec.update({"steps": k3, "ms_per_step": el3 / k3 * 1e3, "value_Mpix_s": views3 * w3["ow"] * w3["oh"] * k3 / el3 / 1e6,
                         "algorithmic_bytes_per_gpu": algorithmic_bytes(w3, len(mine3)),
                         "frac_of_hbm_peak_per_gpu": algorithmic_bytes(w3, len(mine3)) / (el3 / k3) / 1e9 / HBM_PEAK_GBS})
-            if job3 is not None:
+        else:
+            sec.setdefault("error", "another rank could not set its share up")
+        if job3 is not None:
+            try:
                 job3.close()
-        except Exception as e:  # never takes the headline down (every rank still reaches the barriers inside run_timed
-            sec["error"] = repr(e)  # unless it failed before them: then the other ranks' barrier times out, loudly)
+            except Exception:
+                pass
         out.setdefault("secondary", {})["cfg3_strong"] = sec
     if dist.rank == 0 and dist.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w)
