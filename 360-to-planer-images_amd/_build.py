@@ -6,10 +6,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libp2p_hip.so")
-# the plan pass and the view kernels are built once per tile shape (csrc/p2p_device.h: tile shapes): the *_w128.hip files
-# include their namesakes with the other shape's constants
+# the plan pass and the view kernels are built once per tile shape (csrc/p2p_device.h: tile shapes): the *_w128.hip and
+# *_band.hip files include their namesakes with the other shapes' constants
 SOURCES = [os.path.join(CSRC, f) for f in ("p2p_views.hip", "p2p_plan.hip", "p2p_float.hip", "p2p_views_w128.hip", "p2p_plan_w128.hip",
-                                            "p2p_float_w128.hip", "p2p_maps.hip", "p2p_remap.hip", "p2p_host.cpp")]
+                                            "p2p_float_w128.hip", "p2p_views_band.hip", "p2p_plan_band.hip", "p2p_maps.hip", "p2p_remap.hip",
+                                            "p2p_host.cpp")]
 DEPS = SOURCES + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
     [os.path.join(HERE, "..", "include", "p2p_hip.h")]
 # -ffp-contract=off: the coordinate maths must round exactly where NumPy rounds (no fused a*b+c

@@ -52,7 +52,7 @@ class JobInfo(ctypes.Structure):
         ("pair_chunks", ctypes.c_int32), ("list_order", ctypes.c_int32), ("main_group", ctypes.c_int32),
         ("prefetch_lead", ctypes.c_int32), ("n_odd_yaws", ctypes.c_int32), ("n_tiles", ctypes.c_int64),
         ("n_gather_tiles", ctypes.c_int64), ("timing_events", ctypes.c_int32), ("copy_streams", ctypes.c_int32),
-        ("n_views_wanted", ctypes.c_int32), ("chunks_per_workgroup", ctypes.c_int32), ("band_tiles", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1),
+        ("n_views_wanted", ctypes.c_int32), ("chunks_per_workgroup", ctypes.c_int32), ("band_tiles", ctypes.c_int32), ("lds_items_cap", ctypes.c_int32),
     ]
 
 

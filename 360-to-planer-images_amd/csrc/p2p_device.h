@@ -255,6 +255,7 @@ struct ShapeOps {
 };
 const ShapeOps& shape_ops_w64();
 const ShapeOps& shape_ops_w128();
+const ShapeOps& shape_ops_w64b();  // the band shape: 64 x 16 tiles, LDS buffers of 1000 items (p2p_views_band.hip)
 
 #ifndef P2P_HOST  // device translation units: the constants of THEIR shape
 #ifndef P2P_SHAPE_NS
@@ -285,6 +286,9 @@ constexpr int VIEWS_PXT = TILE_W * TILE_H / VIEWS_BLOCK;  // output pixels per t
 #endif
 constexpr int VIEWS_SLOTS = P2P_SLOTS;  // 16-byte footprint items one thread produces per (panorama, yaw) pair, at most
 constexpr int LDS_ITEMS_CAP = P2P_CAP;  // items (4 rot pixels each) per LDS buffer
+// (a wave produces a slot's 64 items or none of them -- stage 1 does not test the item index per lane: a buffer that ended
+// inside a wave's 64 would have the wave's surplus lanes write into the other buffer, which slower waves still read)
+static_assert(LDS_ITEMS_CAP % 64 == 0, "whole waves of items");
 static_assert(LDS_ITEMS_CAP <= VIEWS_SLOTS * VIEWS_BLOCK && LDS_ITEMS_CAP > (VIEWS_SLOTS - 1) * VIEWS_BLOCK, "slots vs cap");
 constexpr int PXW_UP_BITS = 4 * LDS_ITEMS_CAP <= 4096 ? 12 : 13;  // per-pixel word: bits of the upper tap's LDS offset (dwords)
 constexpr int PXW_DL_BITS = 22 - PXW_UP_BITS;                     //                 bits of (lower tap - upper tap)

@@ -253,13 +253,15 @@ __device__ __forceinline__ void draw_float(
             buf_bytes ^= (uint32_t)sizeof(tile4[0]);
         }
     };
-    static_assert(VIEWS_SLOTS == 2 || VIEWS_SLOTS == 3, "dispatch below");
+    static_assert(VIEWS_SLOTS >= 2 && VIEWS_SLOTS <= 4, "dispatch below");
     if (ns_wave == 0)
         run_ns(std::integral_constant<int, 0>{});
     else if (ns_wave == 1)
         run_ns(std::integral_constant<int, 1>{});
     else if (VIEWS_SLOTS == 2 || ns_wave == 2)
         run_ns(std::integral_constant<int, 2>{});
+    else if (VIEWS_SLOTS == 3 || ns_wave == 3)
+        run_ns(std::integral_constant<int, (VIEWS_SLOTS < 3 ? VIEWS_SLOTS : 3)>{});
     else
         run_ns(std::integral_constant<int, VIEWS_SLOTS>{});
 }

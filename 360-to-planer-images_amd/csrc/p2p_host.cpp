@@ -94,7 +94,7 @@ struct Options {
     int early_main = 1;               // P2P_EARLY_MAIN: 1 = a job's first launch sends the main kernel out right behind the plan pass
     int defer_lists = 1;              // P2P_DEFER_LISTS: 1 = a plan without gather tiles makes its main lists at its second launch (0: at once)
     int band = -1;                    // P2P_BAND: 1 = source-band tiles wherever they apply, 0 = never, -1 = the library's rule (choose_band)
-    int band_bh = 16, band_cw = 8;    // P2P_BAND_BH / P2P_BAND_CW: cell of the source, rows x columns
+    int band_bh = -1, band_cw = -1;   // P2P_BAND_BH / P2P_BAND_CW: cell of the source, rows x columns (-1: by tile shape, band_cell)
     int band_maxw = 27, band_maxh = 7;  // (no environment knob) tap extent of a group beyond which its tile gathers
 };
 
@@ -132,8 +132,8 @@ void options_load_locked()
     o.pair_ctx_table = env_int("P2P_PAIR_CTX_TABLE", o.pair_ctx_table);
     o.merge_gather = env_int("P2P_MERGE_GATHER", o.merge_gather);
     o.band = env_int("P2P_BAND", o.band);
-    o.band_bh = std::min(256, std::max(1, env_int("P2P_BAND_BH", o.band_bh)));
-    o.band_cw = std::min(256, std::max(1, env_int("P2P_BAND_CW", o.band_cw)));
+    o.band_bh = std::min(256, env_int("P2P_BAND_BH", o.band_bh));
+    o.band_cw = std::min(256, env_int("P2P_BAND_CW", o.band_cw));
     g_opt = o;
     g_opt_loaded = true;
     pool_set_budget((size_t)o.pool_mb << 20);
@@ -817,7 +817,17 @@ struct SlotGuard {  // gives the slot back on every return path
     ~SlotGuard() { if (s) slot_release(s); }
 };
 
-const p2p::ShapeOps& shape_ops(int shape) { return shape ? p2p::shape_ops_w128() : p2p::shape_ops_w64(); }
+// tile shapes: 0 = 64 x 16 (LDS buffers of 704 items), 1 = 128 x 16 (1408), 2 = the band shape: 64 x 16 with buffers of 960
+// items (p2p_views_band.hip) -- what a job drawn from source-band tiles gets unless P2P_TILE_SHAPE names one
+const p2p::ShapeOps& shape_ops(int shape) { return shape == 2 ? p2p::shape_ops_w64b() : (shape ? p2p::shape_ops_w128() : p2p::shape_ops_w64()); }
+
+// the source cell of a band plan, rows x columns: 16 x 8, 24 x 16 for the band shape's larger rectangles (CLI default set:
+// 47.1 us with 16 x 8, 46.0 with 24 x 16), unless P2P_BAND_BH / P2P_BAND_CW say otherwise
+void band_cell(const Options& o, int shape, int* bh, int* cw)
+{
+    *bh = o.band_bh > 0 ? o.band_bh : (shape == 2 ? 24 : 16);
+    *cw = o.band_cw > 0 ? o.band_cw : (shape == 2 ? 16 : 8);
+}
 
 // Tile shape of a job (p2p_device.h: tile shapes): 128-wide tiles when the launch's views go well beyond the Infinity
 // Cache and stream to HBM -- whole 128-byte lines per wave store -- (config 4: 18 GB, 6.5 ms against 7.2; config 3 on
@@ -921,7 +931,7 @@ int choose_main_group(const Options& opt, int shape, int span, int chunks)
         return opt.main_group;
     if (span > 1 && span >= chunks)
         return 24;
-    return shape ? 96 : 192;
+    return shape == 1 ? 96 : 192;
 }
 
 }  // namespace
@@ -1531,10 +1541,12 @@ static bool job_band_applies(const p2p_job* j)
     if ((unsigned long long)d.n_pitch * d.oh * ((d.ow + 3) / 4) >= (1ull << 32) - 1ull)
         return false;
     // a single cell must fit a tile's LDS buffer, whatever its groups look like
-    const long rows = o.band_bh + o.band_maxh + 1, ri = ((o.band_cw + o.band_maxw + 3) >> 2) + 1;
+    int bh, cw;
+    band_cell(o, j->shape, &bh, &cw);
+    const long rows = bh + o.band_maxh + 1, ri = ((cw + o.band_maxw + 3) >> 2) + 1;
     if (rows * ri > S.cap || rows > 65535)
         return false;
-    if ((d.pw + o.band_cw - 1) / o.band_cw > 4096)  // (p2p_plan.hip: BAND_MAX_NCX, the cut's cells in LDS)
+    if ((d.pw + cw - 1) / cw > 4096)  // (p2p_plan.hip: BAND_MAX_NCX, the cut's cells in LDS)
         return false;
     return true;
 }
@@ -1560,6 +1572,21 @@ static bool job_wants_band(const p2p_job* j)
     if (!(pairs >= 8 || (pairs >= 4 && d.n_pitch >= 5)))
         return false;
     return j->out_bytes <= ((size_t)128 << 20);
+}
+
+// A job that is drawn from source-band tiles gets the band shape (unless P2P_TILE_SHAPE names one); its yaws may change
+// (p2p_job_set_yaws, p2p_job_set_maps: an odd yaw takes the band plan away), so the shape is settled again before every
+// plan look-up.  Shapes 0 and 2 share the tile raster: nothing else of the job depends on which of the two it is.
+static void job_settle_shape(p2p_job* j)
+{
+    const int base = choose_shape(j->d, j->opt);
+    if (base != 0 || j->opt.tile_shape == 64 || j->opt.tile_shape == 128) {
+        j->shape = base;
+        return;
+    }
+    j->shape = 2;
+    if (!job_wants_band(j))
+        j->shape = 0;
 }
 
 static int job_main_order(const p2p_job* j)
@@ -1628,10 +1655,12 @@ static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& aft
     // device maps: the plan is a function of the key alone -- the context may have it already
     const Options& opt = j->opt;
     const bool band = job_wants_band(j);
+    int cell_bh, cell_cw;
+    band_cell(opt, j->shape, &cell_bh, &cell_cw);
     const int main_order = band ? 0 : job_main_order(j);
     PlanKey key{d.pw, d.ph, d.ow, d.oh, d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16 | P2P_FLAG_PIXEL_CENTRES), j->border,
                 j->fov, j->pitch, j->shape, {opt.gather_blocky_from, main_order != 0, opt.gather_order, opt.gather_group,
-                                             band ? 1 : 0, band ? opt.band_bh : 0, band ? opt.band_cw : 0, band ? opt.band_maxw : 0, band ? opt.band_maxh : 0}};
+                                             band ? 1 : 0, band ? cell_bh : 0, band ? cell_cw : 0, band ? opt.band_maxw : 0, band ? opt.band_maxh : 0}};
     const p2p::TileShape& S = shape_ops(j->shape).shape;
     const bool cached = !j->host_maps && opt.plan_cache != 0 && opt.scramble_plan == 0;
     if (cached) {
@@ -1708,7 +1737,7 @@ static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& aft
     const size_t n_groups_all = (size_t)d.n_pitch * d.oh * ((d.ow + 3) / 4);
     if (band) {
         B.pw = d.pw; B.ph = d.ph; B.ow = d.ow; B.oh = d.oh; B.n_pitch = d.n_pitch;
-        B.g.bh = opt.band_bh; B.g.cw = opt.band_cw;
+        B.g.bh = cell_bh; B.g.cw = cell_cw;
         B.g.ncx = (d.pw + B.g.cw - 1) / B.g.cw;
         B.g.n_bands = (d.ph + B.g.bh - 1) / B.g.bh;
         B.g.maxw = opt.band_maxw; B.g.maxh = opt.band_maxh;
@@ -2045,6 +2074,7 @@ int p2p_job_run(p2p_job* j)
         P.use_pair_list = 0;
     };
     bool early_main = false;
+    job_settle_shape(j);
     if (j->plan_ref && j->plan_ref->band != job_wants_band(j)) {
         // (the yaws changed under a band plan, or away from one: p2p_job_set_yaws / p2p_job_set_maps)
         HIP_TRY(hipStreamSynchronize(j->ctx->stream));
@@ -2115,7 +2145,7 @@ int p2p_job_run(p2p_job* j)
     P.main_tail = 0;
     P.main_tail_parts = opt.main_tail_parts;
     if (P.main_list && pair_chunks == 1 && P.main_span == 1 && P.pf_lead == 0 && j->d.n_panos * j->d.n_yaw >= 4) {
-        const int in_flight = 32 * (j->shape ? 3 : 7);  // workgroups an XCD holds at a time
+        const int in_flight = 32 * (j->shape == 1 ? 3 : (j->shape == 2 ? 5 : 7));  // workgroups an XCD holds at a time
         P.main_tail = opt.main_tail >= 0 ? opt.main_tail : in_flight / 5;
         P.main_tail = std::min(P.main_tail, j->main_stride);
     }
@@ -2128,7 +2158,7 @@ int p2p_job_run(p2p_job* j)
         // the split tail (see main_tail): one chunk of pairs, no span loop
         P.band_tail = 0;
         if (pair_chunks == 1 && P.main_span == 1 && j->d.n_panos * j->d.n_yaw >= 4) {
-            const int in_flight = 32 * (j->shape ? 3 : 7);
+            const int in_flight = 32 * (j->shape == 1 ? 3 : (j->shape == 2 ? 5 : 7));
             P.band_tail = opt.main_tail >= 0 ? opt.main_tail : in_flight / 5;
             P.band_tail = std::min(P.band_tail, std::max(0, Pl.band_tiles / 8));
         }
@@ -2639,6 +2669,7 @@ int p2p_job_get_info(p2p_job* j, p2p_job_info* out)
     if (!j || !out)
         return fail(P2P_ERR_INVALID, "NULL argument");
     memset(out, 0, sizeof(*out));
+    job_settle_shape(j);
     const p2p::TileShape& S = shape_ops(j->shape).shape;
     out->tile_w = S.tile_w;
     out->tile_h = S.tile_h;
@@ -2657,6 +2688,7 @@ int p2p_job_get_info(p2p_job* j, p2p_job_info* out)
     out->timing_events = (int32_t)j->ev_ring.size();
     out->copy_streams = (j->ctx->stream_up != nullptr) + (j->ctx->stream_down != nullptr);
     out->band_tiles = j->plan_ref ? (j->plan_ref->band ? j->plan_ref->band_tiles : 0) : (job_wants_band(j) ? -1 : 0);
+    out->lds_items_cap = S.cap;
     return P2P_OK;
 }
 

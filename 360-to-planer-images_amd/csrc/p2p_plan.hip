@@ -812,9 +812,15 @@ hipError_t launch_plan(const PlanParams& P, hipStream_t st)
 // what the host calls this shape through (p2p_device.h: tile shapes)
 const ShapeOps& P2P_SHAPE_OPS_NAME()
 {
+#ifdef P2P_SHAPE_NO_FLOAT
+    static const ShapeOps ops = {{P2P_SHAPE_NS::TILE_W, P2P_SHAPE_NS::TILE_H, P2P_SHAPE_NS::VIEWS_BLOCK, P2P_SHAPE_NS::VIEWS_PXT, P2P_SHAPE_NS::LDS_ITEMS_CAP},
+                                 &P2P_SHAPE_NS::launch_plan, &P2P_SHAPE_NS::launch_remap_views, nullptr, &P2P_SHAPE_NS::launch_band,
+                                 &P2P_SHAPE_NS::launch_pair_ctx};
+#else
     static const ShapeOps ops = {{P2P_SHAPE_NS::TILE_W, P2P_SHAPE_NS::TILE_H, P2P_SHAPE_NS::VIEWS_BLOCK, P2P_SHAPE_NS::VIEWS_PXT, P2P_SHAPE_NS::LDS_ITEMS_CAP},
                                  &P2P_SHAPE_NS::launch_plan, &P2P_SHAPE_NS::launch_remap_views, &P2P_SHAPE_NS::launch_float_views, &P2P_SHAPE_NS::launch_band,
                                  &P2P_SHAPE_NS::launch_pair_ctx};
+#endif
     return ops;
 }
 

@@ -853,7 +853,7 @@ __device__ __forceinline__ void draw_tight(
         else if constexpr (BAND)
             run_ns_d(ns_c, std::false_type{});
     };
-    static_assert(VIEWS_SLOTS == 2 || VIEWS_SLOTS == 3, "dispatch below");
+    static_assert(VIEWS_SLOTS >= 2 && VIEWS_SLOTS <= 4, "dispatch below");
     for (int ch = chunk;;) {
         if (nplain > 0) {  // (the same for every wave of the workgroup: the loops' barriers stay uniform)
             if (ns_wave == 0)
@@ -862,6 +862,8 @@ __device__ __forceinline__ void draw_tight(
                 run_ns(std::integral_constant<int, 1>{});
             else if (VIEWS_SLOTS == 2 || ns_wave == 2)
                 run_ns(std::integral_constant<int, 2>{});
+            else if (VIEWS_SLOTS == 3 || ns_wave == 3)
+                run_ns(std::integral_constant<int, (VIEWS_SLOTS < 3 ? VIEWS_SLOTS : 3)>{});
             else
                 run_ns(std::integral_constant<int, VIEWS_SLOTS>{});
         }

@@ -4,11 +4,14 @@
 #undef P2P_TILE_ROWS
 #undef P2P_BLOCK
 #undef P2P_CAP
+#undef P2P_SLOTS
+#undef P2P_WAVES
 #undef P2P_SHAPE_NS
 #define P2P_TILE_W 128
 #define P2P_TILE_ROWS 16
 #define P2P_BLOCK 512
 #define P2P_CAP 1408
+#define P2P_SLOTS 3
 #define P2P_SHAPE_NS w128
 // the main kernel's store goes out BEHIND the next pair's loads in this shape (draw_tight): its launches stream 4-18 GB of
 // views to HBM, and a pair's wait for its pieces then does not include the acknowledgement of the store issued just

@@ -298,7 +298,8 @@ typedef struct p2p_job_info {
                                       of a launch are too big to stay cached: config 4) */
     int32_t band_tiles;            /* > 0: the job is drawn from source-band tiles (this many) instead of the main
                                       kernel's per-view tiles; -1: it will be, the plan is not built yet; 0: no */
-    int32_t reserved[1];
+    int32_t lds_items_cap;         /* items (4 source pixels each) of one LDS buffer of the job's tile shape: 704 (64-wide
+                                      tiles), 1408 (128-wide), 960 (the 64-wide shape of band jobs) */
 } p2p_job_info;
 int p2p_job_get_info(p2p_job* job, p2p_job_info* out);
 

@@ -212,4 +212,9 @@ const ShapeOps& shape_ops_w128()
     static const ShapeOps ops = {{128, TILE_H, 512, 4, 1408}, &stub_plan<128, 512, 1408>, &stub_views<128>, &stub_float_views, &stub_band<512>, &stub_pair_ctx};
     return ops;
 }
+const ShapeOps& shape_ops_w64b()
+{
+    static const ShapeOps ops = {{64, TILE_H, 256, 4, 960}, &stub_plan<64, 256, 960>, &stub_views<64>, nullptr, &stub_band<256>, &stub_pair_ctx};
+    return ops;
+}
 }  // namespace p2p

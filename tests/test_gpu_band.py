@@ -32,7 +32,7 @@ def _run(gpu, panos, yaws, pitches, ow, oh, fov, maps, mask=None):
         ctx.close()
 
 
-@pytest.mark.parametrize("tile_shape", ["64", "128"])
+@pytest.mark.parametrize("tile_shape", ["0", "64", "128"])  # (0: the library's choice -- the band shape, p2p_views_band.hip)
 @pytest.mark.parametrize("n_panos", [1, 2])
 def test_band_tiles_draw_the_oracles_bytes(gpu, synth, p2p_env, n_panos, tile_shape):
     """Plain-shift yaws (whole-column and fractional), a pole in view (those tiles stay with the gather kernel), a view
@@ -123,6 +123,35 @@ def test_reference_cli_default_view_set_through_band_tiles_at_8k(gpu, pkg, synth
     assert info["band_tiles"] > 3000, info  # the library's rule
     mx, gt1, anyd = diff_stats(fused, oracle_views_threaded(smooth, yaws, pitches, ow, oh, fov))
     assert mx <= 1, (mx, gt1, anyd)
+
+
+def test_band_kernel_draws_the_same_bytes_every_time(gpu, synth, p2p_env):
+    """The band kernel's workgroups alternate between two LDS buffers with ONE barrier per pair: a wave that wrote past
+    the end of its buffer would change pixels that slower waves are still reading from the other -- in a few runs of
+    many (buffers of 1000 items, not whole waves of them, did exactly that: 3 runs of 14).  The reference CLI's default
+    set at 8K, cold (new context, new plan) and warm, every run against the per-view tiles' bytes
+    (tests/fuzz/band_race.py is the long form)."""
+    pw, ph, ow, oh, fov = 8192, 4096, 800, 800, 90
+    yaws, pitches = [0, 90, 180, 270], [30, 60, 90, 120, 150]
+    pano = synth.synth_pano(pw, ph, 4242, "N")
+    p2p_env("P2P_BAND", "0")
+    (want,), info = _run(gpu, [pano], yaws, pitches, ow, oh, fov, None)
+    assert info["band_tiles"] == 0
+    p2p_env("P2P_BAND", "-1")
+    for _ in range(12):
+        (got,), info = _run(gpu, [pano], yaws, pitches, ow, oh, fov, None)
+        assert info["band_tiles"] > 3000 and info["lds_items_cap"] == 960, info
+        assert np.array_equal(got, want)
+    ctx = gpu.Context(0)
+    try:
+        job = gpu.Job(ctx, pw, ph, 1, yaws, pitches, fov, ow, oh)
+        job.set_pano(0, pano)
+        for _ in range(60):
+            job.run()
+            assert np.array_equal(job.get_views(0), want)
+        job.close()
+    finally:
+        ctx.close()
 
 
 def test_config_2_keeps_the_per_view_tiles(gpu, synth):
