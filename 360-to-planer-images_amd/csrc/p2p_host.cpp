@@ -1571,7 +1571,9 @@ static bool job_wants_band(const p2p_job* j)
         return false;
     if (!(pairs >= 8 || (pairs >= 4 && d.n_pitch >= 5)))
         return false;
-    return j->out_bytes <= ((size_t)128 << 20);
+    // (with fewer than 8 pairs per tile the bound is 80 MB: 4 yaws x 5 pitches of 1152 x 1152 from 8K, 76 MB, 63.5 us
+    // against 71.6; of 1280 x 1280, 94 MB, 80.4 against 73.2 -- profiles/r05_band_rule_sweep.txt)
+    return j->out_bytes <= ((size_t)(pairs >= 8 ? 128 : 80) << 20);
 }
 
 // A job that is drawn from source-band tiles gets the band shape (unless P2P_TILE_SHAPE names one); its yaws may change
