@@ -560,7 +560,11 @@ __device__ __forceinline__ void draw_tight(
         const uint32_t w0 = W.w0;
         const uint32_t wrap_g = W.w1 & 0xFFFFu;
         // one descriptor per panorama: an item word that points outside it loads zeros instead of faulting
+#ifdef P2P_ABLATE_ONE_PANO  // timing experiment (wrong pixels): every resident panorama is the first one -- what sources that never come cold from HBM would give
+        const auto S = make_buf(src, (uint32_t)P.pano_stride);
+#else
         const auto S = make_buf(src + (size_t)(W.w3 & 0x3FFFFFF) * P.pano_stride, (uint32_t)P.pano_stride);
+#endif
         const uint32_t goff = w0 & 0xFFFFFu;
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
