@@ -1563,17 +1563,22 @@ static bool job_wants_band(const p2p_job* j)
     // overflow the LDS (about 1.25 source pixels per output pixel) but not so much that the rectangle is mostly gaps
     // (3.2), with enough (panorama, yaw) pairs per tile to pay its set-up -- 8, or 4 when five pitch views share every
     // source rectangle, as in the reference CLI's defaults -- and views small enough for the write-back stores their
-    // ragged edges need (p2p_tile.h: P2P_BAND_STORE_AUX): 128 MB per launch.  Config 2 (1.07) stays with the per-view tiles.
+    // ragged edges need (p2p_tile.h: P2P_BAND_STORE_AUX): 256 MB per launch.  Config 2 (1.07) stays with the per-view tiles.
     const p2p_job_desc& d = j->d;
     const double r = (double)d.pw * j->fov / (360.0 * d.ow);
     const long long pairs = (long long)d.n_panos * d.n_yaw;
-    if (r < 1.25 || r > 3.2 || j->d_view_mask || j->host_maps)  // (caller maps: their minification is not the FOV's)
+    // (a panorama beyond the Infinity Cache, 16K: the gather kernel's scattered lines come from HBM, and band tiles win up
+    // to 4 source pixels per output pixel -- 12 x 3 views of 1024 x 576 146 us against 180, 4 x 5 of 1024^2 181 against 191)
+    const double r_max = (size_t)d.pw * d.ph * 3 > ((size_t)256 << 20) ? 4.2 : 3.2;
+    if (r < 1.25 || r > r_max || j->d_view_mask || j->host_maps)  // (caller maps: their minification is not the FOV's)
         return false;
     if (!(pairs >= 8 || (pairs >= 4 && d.n_pitch >= 5)))
         return false;
     // (with fewer than 8 pairs per tile the bound is 80 MB: 4 yaws x 5 pitches of 1152 x 1152 from 8K, 76 MB, 63.5 us
     // against 71.6; of 1280 x 1280, 94 MB, 80.4 against 73.2 -- profiles/r05_band_rule_sweep.txt)
-    return j->out_bytes <= ((size_t)(pairs >= 8 ? 128 : 80) << 20);
+    // (with 8 pairs and more no row of the sweep loses by size: 8K 12 x 3 of 1536 x 864, 143 MB, 69.7 us against 76.9; 16K
+    // 12 x 3 of 2048 x 1152, 255 MB, 225 against 256; 398 MB -6 %, 573 MB -1 %)
+    return j->out_bytes <= ((size_t)(pairs >= 8 ? 256 : 80) << 20);
 }
 
 // A job that is drawn from source-band tiles gets the band shape (unless P2P_TILE_SHAPE names one); its yaws may change

@@ -85,6 +85,8 @@ def main():
         bad += case("config 2, noise", 8192, 4096, list(range(0, 360, 30)), [60, 90, 120], 90, 1920, 1080, kind="N", launches=L)
         bad += case("CLI defaults at 8K", 8192, 4096, [0, 90, 180, 270], [30, 60, 90, 120, 150], 90, 800, 800, kind="N", launches=L)
         bad += case("config 5, 45 yaws", 8192, 4096, list(range(0, 360, 8)), [90], 90, 1920, 1080, kind="N", launches=L)
+        bad += case("16K -> 1024x576, 12 x 3", 16384, 8192, list(range(0, 360, 30)), [60, 90, 120], 90, 1024, 576, kind="N", launches=L)
+        bad += case("16K -> 2048x1152, 12 x 3", 16384, 8192, list(range(0, 360, 30)), [60, 90, 120], 90, 2048, 1152, kind="N", launches=L)
     print("band_check: %s" % ("OK" if bad == 0 and d <= want.size // 1000 else "FAILED"), flush=True)
     return 0 if bad == 0 else 1
 
