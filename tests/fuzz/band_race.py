@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Repeatability of the band kernel: the reference CLI's default view set at 8K drawn again and again, cold (a new context
+"""Repeatability of the band kernel (and, at the end, of the other view kernels): the reference CLI's default view set at 8K drawn again and again, cold (a new context
 and plan every time) and warm (one job, many launches), every result against the per-view tiles' bytes.
 GPU box, repo root:   python3 tests/fuzz/band_race.py [cold runs] [warm runs]"""
 import importlib, os, sys
@@ -50,10 +50,31 @@ def main():
                 where[tuple(int(x) for x in r)] = where.get(tuple(int(x) for x in r), 0) + 1
     info = job.info()
     job.close(); ctx.close()
-    print("band tiles %d: cold runs with wrong pixels %d of %d, warm %d of %d" % (info["band_tiles"], bad_cold, cold, bad_warm, warm))
     for k, v in sorted(where.items())[:30]:
         print("   (yaw, pitch, row, col) = %s: %d times" % (k, v))
-    return 1 if bad_cold or bad_warm else 0
+    # the other kernels the same way, each against its own first launch: config 2 through the per-view tiles of either
+    # shape, the CLI set through the gather kernel
+    bad_other = 0
+    for name, env, geo in (("config 2, 64-wide tiles", {}, (8192, 4096, list(range(0, 360, 30)), [60, 90, 120], 1920, 1080)),
+                           ("config 2, 128-wide tiles", {"P2P_TILE_SHAPE": "128"}, (8192, 4096, list(range(0, 360, 30)), [60, 90, 120], 1920, 1080)),
+                           ("CLI set, per-view tiles", {"P2P_BAND": "0"}, (PW, PH, YAWS, PITCHES, OW, OH))):
+        os.environ.update(env); nat.reload_options()
+        pw, ph, yaws, pitches, ow, oh = geo
+        ctx = nat.Context(0); job = nat.Job(ctx, pw, ph, 1, yaws, pitches, FOV, ow, oh); job.set_pano(0, pano)
+        job.run(); ctx.synchronize(); first = job.get_views(0).copy()
+        n_bad = 0
+        for i in range(max(1, warm // 6)):
+            job.run(); ctx.synchronize()
+            n_bad += int(not np.array_equal(job.get_views(0), first))
+        job.close(); ctx.close()
+        for k in env:
+            os.environ.pop(k, None)
+        nat.reload_options()
+        print("%s: launches that differ from the first %d of %d" % (name, n_bad, max(1, warm // 6)))
+        bad_other += n_bad
+    print("band tiles %d: cold runs with wrong pixels %d of %d, warm %d of %d; other kernels: %d launches differ" %
+          (info["band_tiles"], bad_cold, cold, bad_warm, warm, bad_other))
+    return 1 if bad_cold or bad_warm or bad_other else 0
 
 
 if __name__ == "__main__":
