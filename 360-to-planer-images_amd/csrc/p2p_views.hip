@@ -1766,7 +1766,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, P2P_BAND_WAVES) void remap_views_band_
 }
 
 #ifndef P2P_DIRECT_WAVES
-#define P2P_DIRECT_WAVES 4
+#define P2P_DIRECT_WAVES 3  // (140 VGPRs, no scratch; at 4 waves per SIMD 128 with one spilled: the same 21.3-21.7 us for an 800 x 800 legacy view)
 #endif
 __global__ __launch_bounds__(VIEWS_BLOCK, P2P_DIRECT_WAVES) void remap_views_table_kernel(
     ViewsParams P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab, uint8_t* __restrict__ out,
