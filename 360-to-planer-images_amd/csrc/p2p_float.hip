@@ -267,7 +267,10 @@ __device__ __forceinline__ void draw_float(
 }
 
 template <bool HALF>
-__global__ __launch_bounds__(VIEWS_BLOCK, 6) void float_views_kernel(
+#ifndef P2P_FLOAT_HALF_WAVES
+#define P2P_FLOAT_HALF_WAVES 6  // (f16: 80 VGPRs with two spilled; at 5 waves per SIMD none, and config 5 0.840-0.844 ms against 0.829-0.830)
+#endif
+__global__ __launch_bounds__(VIEWS_BLOCK, HALF ? P2P_FLOAT_HALF_WAVES : 6) void float_views_kernel(
     ViewsParams P, const uint8_t* __restrict__ src, uint8_t* __restrict__ out,
     const PieceHdr* __restrict__ hdr, const uint32_t* __restrict__ px, const uint32_t* __restrict__ px2,
     const uint32_t* __restrict__ items)

@@ -1696,7 +1696,8 @@ __global__ __launch_bounds__(VIEWS_BLOCK, P2P_GATHER_WAVES) void remap_views_gat
 // gather kernel's body with ONE set of tap registers, so that the kernel keeps its six waves per SIMD): few, long,
 // latency-bound workgroups around a pole -- 17 us as a launch of their own behind which the band kernel waits.
 template <bool MASKED, bool MERGED>
-__global__ __launch_bounds__(VIEWS_BLOCK, P2P_BAND_WAVES) void remap_views_band_kernel(
+// (MASKED: the per-lane view word and its test cost 9-13 registers -- one wave per SIMD less instead of scratch)
+__global__ __launch_bounds__(VIEWS_BLOCK, (MASKED && P2P_BAND_WAVES > 5) ? 5 : P2P_BAND_WAVES) void remap_views_band_kernel(
     ViewsParams P, const uint8_t* __restrict__ src, const YawDesc* __restrict__ ydesc, uint8_t* __restrict__ out,
     const PieceHdr* __restrict__ hdr, const uint32_t* __restrict__ px, const uint32_t* __restrict__ grp, const BandInfo* __restrict__ info)
 {
