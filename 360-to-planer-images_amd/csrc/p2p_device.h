@@ -69,7 +69,7 @@ struct BandParams {
     BandGeom g;
     const int2* coords;       // the plan pass's quantised coordinates
     uint32_t* cell_count;     // [n_bands * ncx] groups per cell
-    int* cell_cmin;           //   ... their leftmost tap column
+    int* cell_cmin;           //   ... INT32_MAX - their leftmost tap column (0: no group)
     int* cell_cmax1;          //   ... rightmost tap column
     int* cell_rmax1;          //   ... lowest tap row
     uint32_t* cell_off;       //   ... first position in the sorted list

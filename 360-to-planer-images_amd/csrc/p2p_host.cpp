@@ -214,6 +214,62 @@ size_t pool_class(size_t bytes)
 
 size_t caches_evict_all();  // (defined with the contexts' table caches)
 
+// Pinned host blocks for the plan's read-backs (counters, band counts, tile headers): a hipMemcpyAsync into pageable memory
+// is staged and waited for one copy at a time -- three of them were 60 us of a cold band plan.  Process-wide, power-of-two
+// classes from 64 KB; hipHostMalloc itself costs hundreds of microseconds, so blocks come back here (p2p_release_cache
+// frees the idle ones).
+struct PinPool {
+    std::mutex mu;
+    std::vector<std::pair<void*, size_t>> idle;
+};
+PinPool& pin_pool() { static PinPool* P = new PinPool; return *P; }
+hipError_t pin_get(void** out, size_t* cls, size_t bytes)
+{
+    size_t c = (size_t)64 << 10;
+    while (c < bytes)
+        c <<= 1;
+    *cls = c;
+    PinPool& P = pin_pool();
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        for (size_t i = 0; i < P.idle.size(); ++i)
+            if (P.idle[i].second == c) {
+                *out = P.idle[i].first;
+                P.idle.erase(P.idle.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    return hipHostMalloc(out, c, hipHostMallocPortable);
+}
+void pin_put(void* p, size_t cls)
+{
+    if (!p)
+        return;
+    PinPool& P = pin_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (P.idle.size() < 16) {
+        P.idle.emplace_back(p, cls);
+        return;
+    }
+    (void)hipHostFree(p);
+}
+void pin_pool_trim()
+{
+    PinPool& P = pin_pool();
+    std::vector<std::pair<void*, size_t>> drop;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        drop.swap(P.idle);
+    }
+    for (auto& b : drop)
+        (void)hipHostFree(b.first);
+}
+struct PinnedBlock {  // (declare BEFORE a StreamSyncGuard: the stream is drained before the block goes back)
+    void* p = nullptr;
+    size_t cls = 0;
+    ~PinnedBlock() { pin_put(p, cls); }
+};
+
 hipError_t dev_alloc(void** out, size_t bytes)
 {
     *out = nullptr;
@@ -1688,6 +1744,9 @@ static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& aft
     std::vector<uint32_t> tm, tg, ta;
     uint32_t cnt = 0;
     p2p::BandInfo binfo{};
+    // the read-backs land in a pinned block first (pin_get): [BandInfo | counter | headers]
+    PinnedBlock pin;
+    const size_t pin_hdr_off = 128, pin_hdr_max = 65536;  // (larger plans read their headers straight into hh)
     // the band passes' scratch (cells, the groups' cells, the cut's records, the sorted group list): freed on every
     // path, after the stream has been drained (declared before the guard: destroyed after it)
     struct Scratch {
@@ -1696,6 +1755,24 @@ static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& aft
         hipError_t get(void** out, size_t bytes) { hipError_t e = dev_alloc(out, bytes); if (e == hipSuccess) blocks.push_back(*out); return e; }
     } scratch;
     StreamSyncGuard sync_on_exit(st);
+    HIP_TRY(pin_get(&pin.p, &pin.cls, pin_hdr_off + std::min(slots, pin_hdr_max) * sizeof(p2p::PieceHdr)));
+    p2p::BandInfo* const h_binfo = (p2p::BandInfo*)pin.p;
+    uint32_t* const h_cnt = (uint32_t*)((unsigned char*)pin.p + 112);
+    p2p::PieceHdr* const h_hdr = (p2p::PieceHdr*)((unsigned char*)pin.p + pin_hdr_off);
+    static_assert(sizeof(p2p::BandInfo) <= 112, "the pinned block's layout");
+    // the headers into hh: through the pinned block (one asynchronous copy, unpacked after the stream's next
+    // synchronisation by hdr_arrived) or, beyond its size, straight into the vector
+    bool hdr_in_pin = false;
+    auto fetch_headers = [&]() -> hipError_t {
+        hh.resize(slots);
+        hdr_in_pin = slots <= pin_hdr_max;
+        return hipMemcpyAsync(hdr_in_pin ? (void*)h_hdr : (void*)hh.data(), Pl->d_hdr, slots * sizeof(p2p::PieceHdr), hipMemcpyDeviceToHost, st);
+    };
+    auto hdr_arrived = [&]() {
+        if (hdr_in_pin)
+            memcpy(hh.data(), h_hdr, slots * sizeof(p2p::PieceHdr));
+        hdr_in_pin = false;
+    };
     Pl->band = band;
     {
         // ONE block for the plan pass's tables (the device is idle while a fresh geometry's blocks are mapped: six
@@ -1741,6 +1818,7 @@ static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& aft
     Q.centre = (d.flags & P2P_FLAG_PIXEL_CENTRES) ? 0.5f : 0.0f;
     Q.px2 = Pl->d_px2;
     p2p::BandParams& B = Q.band;
+    uint32_t* d_cnt = Pl->d_n_gather;  // (band plans: inside the cell block, see below)
     const size_t n_groups_all = (size_t)d.n_pitch * d.oh * ((d.ow + 3) / 4);
     if (band) {
         B.pw = d.pw; B.ph = d.ph; B.ow = d.ow; B.oh = d.oh; B.n_pitch = d.n_pitch;
@@ -1753,19 +1831,22 @@ static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& aft
         B.view_bytes = (size_t)d.oh * j->out_row;
         B.cost_base = S.tile_w == 128 ? 675u : 600u;  // (xcd_main_lists' cost model)
         const size_t cells = (size_t)B.g.n_bands * B.g.ncx;
-        uint32_t* cellblk = nullptr;  // count, cmax1, rmax1, cur (zeroed), cmin (0x7F..), off
-        HIP_TRY(scratch.get((void**)&cellblk, cells * 6 * sizeof(uint32_t)));
+        // count, cmax1, rmax1, cur, cmin (kept as INT32_MAX - column: zero = no group yet), the plan pass's gather counter
+        // -- ONE memset zeroes them all (four were 40 us of a cold image's 415: a launch and its gap each) --, then off
+        uint32_t* cellblk = nullptr;
+        HIP_TRY(scratch.get((void**)&cellblk, (cells * 6 + 64) * sizeof(uint32_t)));
         B.cell_count = cellblk; B.cell_cmax1 = (int*)(cellblk + cells); B.cell_rmax1 = (int*)(cellblk + 2 * cells);
-        B.cell_cur = cellblk + 3 * cells; B.cell_cmin = (int*)(cellblk + 4 * cells); B.cell_off = cellblk + 5 * cells;
+        B.cell_cur = cellblk + 3 * cells; B.cell_cmin = (int*)(cellblk + 4 * cells); B.cell_off = cellblk + 5 * cells + 64;
+        d_cnt = cellblk + 5 * cells;
+        Q.n_gather = d_cnt;
         HIP_TRY(scratch.get((void**)&B.gcell, n_groups_all * sizeof(uint32_t)));
         HIP_TRY(scratch.get((void**)&B.band_cost, (size_t)B.g.n_bands * (sizeof(unsigned long long) + 2 * sizeof(uint32_t))));
         B.band_tiles = (uint32_t*)(B.band_cost + B.g.n_bands);
         B.band_groups = B.band_tiles + B.g.n_bands;
         HIP_TRY(dev_alloc((void**)&Pl->d_band_info, sizeof(p2p::BandInfo)));
         B.info = Pl->d_band_info;
-        HIP_TRY(hipMemsetAsync(cellblk, 0, cells * 4 * sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(B.cell_cmin, 0x7F, cells * sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(B.info, 0, sizeof(p2p::BandInfo), st));
+        // (BandInfo: every field is written by band_scan_kernel / band_xcd_kernel)
+        HIP_TRY(hipMemsetAsync(cellblk, 0, (cells * 5 + 64) * sizeof(uint32_t), st));
     }
 #ifdef P2P_AUDIT
     if (!band) {
@@ -1780,7 +1861,8 @@ static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& aft
     }
 #endif
     // (the plan pass writes every header, every per-pixel word and every item slot of every tile: nothing to clear)
-    HIP_TRY(hipMemsetAsync(Pl->d_n_gather, 0, sizeof(uint32_t), st));
+    if (!band)
+        HIP_TRY(hipMemsetAsync(Pl->d_n_gather, 0, sizeof(uint32_t), st));
     HIP_TRY(hipEventRecord(ctx->ev_t0, st));
     HIP_TRY(shape_ops(j->shape).plan(Q, st));
     if (!band && after_plan_pass) {
@@ -1791,9 +1873,16 @@ static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& aft
     if (band) {
         // the band passes: count the tiles, read the count back (the tables are sized by it), cut, sort, build
         HIP_TRY(shape_ops(j->shape).band(B, 0, st));
-        HIP_TRY(hipMemcpyAsync(&binfo, B.info, sizeof(binfo), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(&cnt, Pl->d_n_gather, sizeof(cnt), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_binfo, B.info, sizeof(binfo), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
+        // (the headers too: the gather tiles' lists are then made on the host WHILE the device cuts, sorts and builds the
+        // band tiles -- a second and a third round trip behind those kernels were 70 us of a cold image's 415)
+        if (slots <= pin_hdr_max)
+            HIP_TRY(fetch_headers());
         HIP_TRY(hipStreamSynchronize(st));
+        binfo = *h_binfo;
+        cnt = *h_cnt;
+        hdr_arrived();
         if ((size_t)binfo.n_groups > n_groups_all || (size_t)binfo.n_tiles > n_groups_all)
             return fail(P2P_ERR_HIP, "the band passes counted %u tiles, %u groups of %zu", binfo.n_tiles, binfo.n_groups, n_groups_all);
         B.n_tiles = (int)binfo.n_tiles;
@@ -1818,18 +1907,21 @@ static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& aft
     }
     if (band || !after_plan_pass)
         HIP_TRY(hipEventRecord(ctx->ev_t1, st));
-    HIP_TRY(hipMemcpyAsync(&cnt, Pl->d_n_gather, sizeof(cnt), hipMemcpyDeviceToHost, st));
+    if (!band)
+        HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
     // the work lists are made from the plan's headers, once per geometry: they come back with the counter -- unless the
     // plan turns out to have no gather tile and may draw its first launch in grid order (Plan::lists_pending)
     const bool want_main_order = main_order != 0;
     const bool may_defer = want_main_order && opt.defer_lists != 0 && opt.main_order < 0 && opt.scramble_plan == 0;
     Pl->tile_w = shape_ops(j->shape).shape.tile_w;
-    if (want_main_order && !may_defer) {
-        hh.resize(slots);
-        HIP_TRY(hipMemcpyAsync(hh.data(), Pl->d_hdr, slots * sizeof(p2p::PieceHdr), hipMemcpyDeviceToHost, st));
+    if (want_main_order && !may_defer)
+        HIP_TRY(fetch_headers());
+    if (!band) {  // (band plans: the counter came back with the band counts; the device is still building the tiles)
+        HIP_TRY(hipStreamSynchronize(st));
+        cnt = *h_cnt;
+        hdr_arrived();
+        (void)hipEventElapsedTime(&Pl->plan_ms, ctx->ev_t0, ctx->ev_t1);
     }
-    HIP_TRY(hipStreamSynchronize(st));
-    (void)hipEventElapsedTime(&Pl->plan_ms, ctx->ev_t0, ctx->ev_t1);
     if ((size_t)cnt > slots)
         return fail(P2P_ERR_HIP, "the plan pass listed %u gather tiles of %zu", cnt, slots);
     Pl->n_gather = (int)cnt;
@@ -1840,9 +1932,9 @@ static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& aft
         make_main_list = false;
     }
     if ((cnt > 0 || make_main_list) && hh.empty()) {
-        hh.resize(slots);
-        HIP_TRY(hipMemcpyAsync(hh.data(), Pl->d_hdr, slots * sizeof(p2p::PieceHdr), hipMemcpyDeviceToHost, st));
+        HIP_TRY(fetch_headers());
         HIP_TRY(hipStreamSynchronize(st));
+        hdr_arrived();
     }
     if (make_main_list) {  // (tm, tg, ta stay alive until the stream has taken the copies: synchronised below)
         tm = xcd_main_lists(hh, j->n_tiles, &Pl->main_stride, shape_ops(j->shape).shape.tile_w);
@@ -1883,6 +1975,10 @@ static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& aft
     }
     if (make_main_list && cnt == 0)
         HIP_TRY(hipStreamSynchronize(st));  // tm goes out of scope
+    if (band) {
+        HIP_TRY(hipStreamSynchronize(st));
+        (void)hipEventElapsedTime(&Pl->plan_ms, ctx->ev_t0, ctx->ev_t1);
+    }
     if (const int seed = opt.scramble_plan) {
         // Robustness self-test (tests/fuzz/scramble_tables.py), never set in normal use: every table of the plan -- and
         // with bit 30 of the value the job's yaw tables too -- overwritten with pseudo-random words AFTER the plan pass.
@@ -2646,6 +2742,7 @@ int p2p_release_cache(void)
     // pool's idle blocks back to the driver
     (void)caches_evict_all();
     dev_pool_trim();
+    pin_pool_trim();
     return P2P_OK;
 }
 

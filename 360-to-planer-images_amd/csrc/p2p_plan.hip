@@ -67,6 +67,8 @@ __device__ __forceinline__ int wave_reduce(int v)
 
 }  // namespace
 
+constexpr int PLAN_CELL_SLOTS_LOG2 = 7, PLAN_CELL_SLOTS = 1 << PLAN_CELL_SLOTS_LOG2, PLAN_CELL_PROBES = 16;  // (band plans: the tile's cell table)
+
 template <bool CALLER_MAPS>
 __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
 {
@@ -233,6 +235,15 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
             const bool wide = exists && qx1 >= qx0 && (qx1 - qx0 > P.band.g.maxw || qy1 - qy0 > P.band.g.maxh);
             bad |= edge || dead || wide;
         }
+        // A tile's 256 groups fall into a few dozen cells: they are counted in a small LDS table first (keyed by cell,
+        // linear probing) and reach the global cells as one set of atomics per (tile, cell) instead of one per group --
+        // 3.2 M global atomics on the reference CLI's default set otherwise.  A group that finds no slot goes straight
+        // to the global cells.
+        __shared__ uint32_t s_ckey[PLAN_CELL_SLOTS], s_ccnt[PLAN_CELL_SLOTS];
+        __shared__ int s_cminv[PLAN_CELL_SLOTS], s_cmax1[PLAN_CELL_SLOTS], s_crmax1[PLAN_CELL_SLOTS];
+        if (t < PLAN_CELL_SLOTS) {
+            s_ckey[t] = ~0u; s_ccnt[t] = 0u; s_cminv[t] = 0; s_cmax1[t] = 0; s_crmax1[t] = 0;
+        }
         band_ok = __syncthreads_or(bad) == 0 && any_live && !stray && (P.pw & 3) == 0 && !P.float_path;
         // its groups into the cells of the source (or marked: the tile gathers)
         if ((t & 3) == 0) {
@@ -244,14 +255,37 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
                     uint32_t cell = ~0u;
                     if (band_ok) {
                         cell = (uint32_t)(gq_y0[j] / P.band.g.bh) * (uint32_t)P.band.g.ncx + (uint32_t)(gq_x0[j] / P.band.g.cw);
-                        atomicAdd(&P.band.cell_count[cell], 1u);
-                        atomicMin(&P.band.cell_cmin[cell], gq_x0[j]);
-                        atomicMax(&P.band.cell_cmax1[cell], gq_x1[j] + 1);
-                        atomicMax(&P.band.cell_rmax1[cell], gq_y1[j] + 1);
+                        uint32_t h = (cell * 2654435761u) >> (32 - PLAN_CELL_SLOTS_LOG2);
+                        bool found = false;
+                        for (int probe = 0; probe < PLAN_CELL_PROBES && !found; ++probe) {
+                            const uint32_t prev = atomicCAS(&s_ckey[h], ~0u, cell);
+                            found = prev == ~0u || prev == cell;
+                            if (!found)
+                                h = (h + 1u) & (uint32_t)(PLAN_CELL_SLOTS - 1);
+                        }
+                        if (found) {
+                            atomicAdd(&s_ccnt[h], 1u);
+                            atomicMax(&s_cminv[h], INT32_MAX - gq_x0[j]);
+                            atomicMax(&s_cmax1[h], gq_x1[j] + 1);
+                            atomicMax(&s_crmax1[h], gq_y1[j] + 1);
+                        } else {
+                            atomicAdd(&P.band.cell_count[cell], 1u);
+                            atomicMax(&P.band.cell_cmin[cell], INT32_MAX - gq_x0[j]);  // (the minimum, kept inverted: the host zeroes the cells with one memset)
+                            atomicMax(&P.band.cell_cmax1[cell], gq_x1[j] + 1);
+                            atomicMax(&P.band.cell_rmax1[cell], gq_y1[j] + 1);
+                        }
                     }
                     P.band.gcell[((size_t)pitch_i * P.oh + py) * gxn + (size_t)(px >> 2)] = cell;
                 }
             }
+        }
+        __syncthreads();
+        if (t < PLAN_CELL_SLOTS && s_ckey[t] != ~0u) {
+            const uint32_t cell = s_ckey[t];
+            atomicAdd(&P.band.cell_count[cell], s_ccnt[t]);
+            atomicMax(&P.band.cell_cmin[cell], s_cminv[t]);
+            atomicMax(&P.band.cell_cmax1[cell], s_cmax1[t]);
+            atomicMax(&P.band.cell_rmax1[cell], s_crmax1[t]);
         }
     }
     // The LDS scheme needs the whole footprint strictly inside the panorama (no tap is a border tap) and a
@@ -448,7 +482,7 @@ __global__ __launch_bounds__(64) void band_cut_kernel(BandParams B)
     for (int ci = lane; ci < B.g.ncx && ci < BAND_MAX_NCX; ci += 64) {
         uint4 v;
         v.x = B.cell_count[cbase + ci];
-        v.y = (uint32_t)B.cell_cmin[cbase + ci];
+        v.y = (uint32_t)(INT32_MAX - B.cell_cmin[cbase + ci]);
         v.z = (uint32_t)B.cell_cmax1[cbase + ci];
         v.w = (uint32_t)B.cell_rmax1[cbase + ci];
         s_cell[ci] = v;

@@ -71,7 +71,7 @@ static hipError_t stub_plan(const PlanParams& P, hipStream_t)
             if (cell != ~0u)
                 P.band.cell_count[cell]++;
         }
-        P.band.cell_cmin[cells - 1] = 0; P.band.cell_cmax1[cells - 1] = 1; P.band.cell_rmax1[cells - 1] = 1;
+        P.band.cell_cmin[cells - 1] = INT32_MAX; P.band.cell_cmax1[cells - 1] = 1; P.band.cell_rmax1[cells - 1] = 1;
         P.band.cell_cur[cells - 1] = 0; P.band.cell_off[cells - 1] = 0;
         memset(P.coords, 0, (size_t)P.n_pitch * P.oh * P.ow * sizeof(int2));
         P.n_gather[0] = n_gather;

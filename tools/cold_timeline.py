@@ -2,7 +2,7 @@
 """Where does a cold image's device time go?  N first launches of config 2 through fresh contexts (the GPU kept busy in
 between so that the clocks stay up), meant to run under `rocprofv3 --kernel-trace`; `--parse DIR` then prints, per cold
 image, every kernel's start (us after the first one's start) and duration.
-GPU box:  cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/tools/cold_timeline.py 12
+GPU box:  cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/tools/cold_timeline.py 12 [--cli]
           python3 tools/cold_timeline.py --parse $OUT"""
 import csv, glob, importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,7 +25,7 @@ def parse(d):
             cur = []
         if cur is not None:
             cur.append((s, e, short))
-            if len(cur) > 12:
+            if len(cur) > 16:
                 runs.append(cur); cur = None
     if cur:
         runs.append(cur)
@@ -40,10 +40,13 @@ def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--parse":
         return parse(sys.argv[2])
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    cli = "--cli" in sys.argv  # the reference CLI's default view set (a band plan) instead of config 2
     pkg = importlib.import_module("360-to-planer-images_amd"); nat = pkg._native
     synth = importlib.import_module("360-to-planer-images_amd.synth")
     pw, ph, ow, oh, fov = 8192, 4096, 1920, 1080, 90
     yaws, pitches = list(range(0, 360, 30)), [60, 90, 120]
+    if cli:
+        ow, oh, yaws, pitches = 800, 800, [0, 90, 180, 270], [30, 60, 90, 120, 150]
     pano = synth.synth_pano(pw, ph, 1, "S")
     warm_ctx = nat.Context(0)
     warm = nat.Job(warm_ctx, pw, ph, 1, yaws, pitches, fov, ow, oh); warm.set_pano(0, pano)
