@@ -2830,7 +2830,10 @@ static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride
                a.max_pairs_per_block == now.max_pairs_per_block && a.chunk_outer == now.chunk_outer && a.main_order == now.main_order &&
                a.main_group == now.main_group && a.main_span == now.main_span && a.main_tail == now.main_tail && a.main_tail_parts == now.main_tail_parts && a.prefetch_lead == now.prefetch_lead && a.force_rest == now.force_rest &&
                a.gather_ppb == now.gather_ppb && a.gather_all == now.gather_all && a.gather_blocky_from == now.gather_blocky_from &&
-               a.gather_order == now.gather_order && a.gather_group == now.gather_group && a.scramble_plan == now.scramble_plan;
+               a.gather_order == now.gather_order && a.gather_group == now.gather_group && a.scramble_plan == now.scramble_plan &&
+               a.coords_all == now.coords_all && a.merge_gather == now.merge_gather && a.pair_ctx_table == now.pair_ctx_table &&
+               a.early_main == now.early_main && a.defer_lists == now.defer_lists && a.band == now.band && a.band_bh == now.band_bh &&
+               a.band_cw == now.band_cw && a.band_maxw == now.band_maxw && a.band_maxh == now.band_maxh;
     };
     auto same_geometry = [&](const p2p_job* c) {
         const p2p_job_desc& k = c->d;
