@@ -106,6 +106,42 @@ def shard_views(n_yaw, n_pitch, world, rank, how="auto", pitch_deg=None):
     return groups
 
 
+TILE_ROWS = 16  # rows of an output tile (csrc/p2p_device.h: TILE_H): the unit p2p_job_set_rows deals in
+
+
+def shard_rows(oh, world, pitch_deg=None, fov_deg=90.0, ow=None):
+    """One image's output ROWS cut into `world` contiguous bands [(row0, row1)] of whole tile rows -- every rank draws
+    ALL the views, a band of each (p2p_job_set_rows).  A tile's set-up is then spread over all the (panorama, yaw) pairs
+    again (a rank's share of whole views has a few yaws per tile) and the number of views no longer caps the speed-up.
+    A tile row's weight: 1 / sin(polar angle of the row's centre) summed over the pitch views (the footprint in the
+    panorama grows towards a pole); the bands are cut where the running weight passes k / world of the total.  Ranks
+    beyond the number of tile rows get (0, 0): nothing."""
+    import math
+
+    oh, world = int(oh), int(world)
+    n = (oh + TILE_ROWS - 1) // TILE_ROWS
+    pitches = [90.0] if not pitch_deg else [float(p) for p in pitch_deg]
+    focal = (float(ow if ow else oh) / 2.0) / math.tan(math.radians(min(max(float(fov_deg), 1.0), 179.0)) / 2.0)
+    w = []
+    for r in range(n):
+        yc = min(oh, r * TILE_ROWS + TILE_ROWS / 2.0) - oh / 2.0
+        off = math.degrees(math.atan2(yc, focal))
+        w.append(sum(1.0 / max(0.2, math.sin(math.radians(min(max(p + off, 1.0), 179.0)))) for p in pitches))
+    total, cuts, acc, k = sum(w), [0], 0.0, 1
+    for r in range(n):
+        acc += w[r]
+        while k < world and acc >= total * k / world and len(cuts) < world:
+            # (the cut goes behind row r unless stopping before it is closer to the target)
+            cuts.append(r + 1 if (acc - total * k / world) <= w[r] / 2.0 or cuts[-1] == r else r)
+            k += 1
+    while len(cuts) < world:
+        cuts.append(n)
+    cuts.append(n)
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return [(min(oh, a * TILE_ROWS), min(oh, b * TILE_ROWS)) for a, b in zip(cuts[:-1], cuts[1:])]
+
+
 def rank_view_set(n_yaw, n_pitch, world, rank, how="auto", pitch_deg=None):
     """The ONE masked job a rank draws its share of an image with: (yaw_idx, pitch_idx, mask, mine).  yaw_idx and
     pitch_idx are the image's yaw / pitch indices that occur in the rank's share (ascending: the job's own angle
@@ -248,10 +284,13 @@ def release_sharded():
                 c.close()
 
 
-def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0):
-    """Every (yaw, pitch) view of ONE panorama drawn by several GPUs: the pitch-major view list in contiguous runs
-    (shard_views); each device uploads the panorama once, draws its (pitch, yaw subset) groups and downloads them;
-    the host stitches [n_yaw][n_pitch][oh][ow][3].  `devices` may name a device twice (two contexts on one GPU).
+def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0, how="auto"):
+    """Every (yaw, pitch) view of ONE panorama drawn by several GPUs; each device uploads the panorama once, draws its
+    share and downloads it; the host stitches [n_yaw][n_pitch][oh][ow][3].  how = "rows": every device draws a band of
+    rows of EVERY view (shard_rows, p2p_job_set_rows: a tile's set-up spread over all the yaws, no cap by the number of
+    views -- config 2 on 8 ranks: 14 us per rank against 19.8); "views": the pitch-major view list in contiguous runs
+    (shard_views: a masked job per device); "auto": rows when there is a tile row per device.
+    `devices` may name a device twice (two contexts on one GPU).
     A device slot keeps its jobs (device buffers, plan, yaw tables) for the next image of the same geometry, as the
     reference keeps its maps from image to image (P:17-18): a second image pays uploads, view kernels and downloads."""
     pano = _native.as_image(pano, "pano_image")
@@ -260,6 +299,9 @@ def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0):
     out = np.empty((len(yaws), len(pitches), int(oh), int(ow), 3), dtype=np.uint8)
     world = len(devices)
     slots = device_slots(devices)
+    if how == "auto":
+        how = "rows" if world > 1 and (int(oh) + TILE_ROWS - 1) // TILE_ROWS >= world else "views"
+    bands = shard_rows(oh, world, pitches, fov, ow) if how == "rows" else None
 
     # slots of earlier calls that this call does not use (other devices, a second context on one device): their jobs
     # hold panoramas and views, their contexts a stream and cached plans -- both go, unless another call is inside the
@@ -284,7 +326,54 @@ def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0):
         with _slot_lock(slot):
             _one_device_locked(rank, slot)
 
+    def _rows_locked(rank, slot):
+        # this device's band of rows of every view: ONE job over all yaws and pitches, planned for the band alone
+        r0, r1 = bands[rank]
+        geo = (pw, ph, tuple(yaws), tuple(pitches), float(fov), int(ow), int(oh), int(flags), world, rank, "rows", r0, r1)
+        with _ctx_lock:
+            kept = _groups.get(slot)
+        if kept is not None and kept[0] != geo:
+            _close_group(slot)
+            kept = None
+        if r1 <= r0:
+            return
+        ctx = _shared_ctx(slot)
+        n_views = len(yaws) * len(pitches)
+        if kept is None:
+            job = _native.Job(ctx, pw, ph, 1, yaws, pitches, fov, ow, oh, flags=flags)
+            try:
+                job.set_rows(r0, r1)
+                try:
+                    stage = _native.pinned_empty((n_views, r1 - r0, int(ow), 3))
+                except (MemoryError, _native.P2PError, OSError):
+                    stage = np.empty((n_views, r1 - r0, int(ow), 3), np.uint8)
+            except Exception:
+                job.close()
+                raise
+            with _ctx_lock:
+                _groups[slot] = (geo, [(job, stage, None)])
+        with _ctx_lock:
+            job, stage, _ = _groups[slot][1][0]
+        try:
+            job.set_pano(0, pano, wait=False)  # once per device
+            job.run()
+            packed = job.ow % 4 == 0  # (odd widths go through the job's packing buffer: one view at a time)
+            for y in range(len(yaws)):
+                for p in range(len(pitches)):
+                    k = y * len(pitches) + p
+                    if packed:
+                        job.get_view_rows_async(y, p, r0, r1, stage[k])
+                    else:
+                        stage[k] = job.get_view_rows(y, p, r0, r1)
+            job.wait()
+            out[:, :, r0:r1] = stage.reshape(len(yaws), len(pitches), r1 - r0, int(ow), 3)
+        except Exception:
+            _close_group(slot)
+            raise
+
     def _one_device_locked(rank, slot):
+        if bands is not None:
+            return _rows_locked(rank, slot)
         geo = (pw, ph, tuple(yaws), tuple(pitches), float(fov), int(ow), int(oh), int(flags), world, rank)
         yaw_idx, pitch_idx, mask, mine = rank_view_set(len(yaws), len(pitches), world, rank, pitch_deg=pitches)
         with _ctx_lock:

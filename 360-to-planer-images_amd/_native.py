@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "p2p_job_get_views", "p2p_job_kernel_ms", "p2p_job_kernel_ms_last", "p2p_job_device_out", "p2p_job_get_coords",
     "p2p_job_get_yaw_tables", "p2p_job_set_yaws", "p2p_host_alloc", "p2p_host_free", "p2p_release_cache",
     "p2p_reload_options", "p2p_job_get_info", "p2p_job_get_view", "p2p_job_get_view_async", "p2p_job_set_view_mask",
-    "p2p_device_mem_info",
+    "p2p_device_mem_info", "p2p_job_set_rows", "p2p_job_get_view_rows", "p2p_job_get_view_rows_async",
 )
 
 
@@ -174,6 +174,12 @@ def lib():
     L.p2p_job_get_view_async.argtypes = [c_vp, c_int, c_int, c_int, c_vp]
     L.p2p_job_set_view_mask.restype = c_int
     L.p2p_job_set_view_mask.argtypes = [c_vp, c_vp]
+    L.p2p_job_set_rows.restype = c_int
+    L.p2p_job_set_rows.argtypes = [c_vp, c_int, c_int]
+    L.p2p_job_get_view_rows.restype = c_int
+    L.p2p_job_get_view_rows.argtypes = [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]
+    L.p2p_job_get_view_rows_async.restype = c_int
+    L.p2p_job_get_view_rows_async.argtypes = [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]
     L.p2p_device_mem_info.restype = c_int
     L.p2p_device_mem_info.argtypes = [c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]
     L.p2p_job_get_info.restype = c_int
@@ -620,6 +626,23 @@ class Job:
         if m.shape != (self.n_yaw, self.n_pitch):
             raise ValueError("view mask must be [n_yaw][n_pitch] = (%d, %d), got %s" % (self.n_yaw, self.n_pitch, m.shape))
         check(lib().p2p_job_set_view_mask(self._h, m.ctypes.data))
+
+    def set_rows(self, row0, row1):
+        """The job draws only output rows [row0, row1) of every view (whole tile rows of 16; p2p_job_set_rows)."""
+        check(lib().p2p_job_set_rows(self._h, int(row0), int(row1)))
+
+    def get_view_rows(self, yaw_i, pitch_i, row0, row1, index=0):
+        """Rows [row0, row1) of one view, [rows][ow][3] (p2p_job_get_view_rows)."""
+        out = np.empty((int(row1) - int(row0), self.ow, 3), dtype=np.uint8)
+        check(lib().p2p_job_get_view_rows(self._h, int(index), int(yaw_i), int(pitch_i), int(row0), int(row1), out.ctypes.data))
+        return out
+
+    def get_view_rows_async(self, yaw_i, pitch_i, row0, row1, out, index=0):
+        """Enqueue the download of rows [row0, row1) of one view into `out` ([rows][ow][3] uint8, C-contiguous); complete after wait()."""
+        if out.dtype != np.uint8 or out.shape != (int(row1) - int(row0), self.ow, 3) or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous uint8 [row1 - row0][ow][3] array")
+        check(lib().p2p_job_get_view_rows_async(self._h, int(index), int(yaw_i), int(pitch_i), int(row0), int(row1), out.ctypes.data))
+        self._inflight.append(out)
 
     def get_view_async(self, yaw_i, pitch_i, out, index=0):
         """Enqueue the download of one view into `out` ([oh][ow][3] uint8, C-contiguous); complete after wait()."""

@@ -190,6 +190,7 @@ struct PlanParams {
     const float* mapV;
     int2* coords;
     int coords_all;          // 1: the coordinates of every pixel are written; 0: only those of the tiles that gather
+    int ty0, ty1;            // the job draws the tile rows ty0 .. ty1 - 1 of every view (p2p_job_set_rows); the others get mode 0: nobody's
     int coords_only;         // 1: launch_plan runs coords_kernel instead (every pixel's coordinates into an existing plan)
     PieceHdr* hdr;
     uint32_t* px;

@@ -387,12 +387,12 @@ struct PlanKey {  // the reference's key (ow, oh, pitch, pw, ph, fov), for the w
     double fov;
     std::vector<double> pitch;
     int shape;  // tile shape of the tables (0: 64 x 16, 1: 128 x 16)
-    int knobs[9];  // the options that change the tables: gather_blocky_from (header bit), main_order (whether the main
+    int knobs[11];  // the options that change the tables: gather_blocky_from (header bit), main_order (whether the main
                    // list exists), gather_order / gather_group (the XCD lists), band plan or not and its cell / extent
                    // parameters -- a plan built under one setting is never served under another
     bool operator<(const PlanKey& o) const
     {
-        for (int i = 0; i < 9; ++i)
+        for (int i = 0; i < 11; ++i)
             if (knobs[i] != o.knobs[i]) return knobs[i] < o.knobs[i];
         if (shape != o.shape) return shape < o.shape;
         if (pw != o.pw) return pw < o.pw;
@@ -729,6 +729,7 @@ struct p2p_job {
     uint32_t* d_odd_pairs = nullptr;     // (panorama, yaw) pairs whose yaw is not a plain shift with one weight
     int n_odd_pairs = 0;
     int n_gather = 0;                    // tiles the plan marks for gathers
+    int row0 = 0, row1 = 0;              // output rows the job draws, [row0, row1) of every view (p2p_job_set_rows; row1 = oh at creation)
     int n_odd_yaws = 0;                  // yaws that are not a plain shift with one weight (YawDesc.mode != 0)
     uint16_t* d_pitch_order = nullptr;   // [n_pitch] heaviest view first
     // the pair-context table (p2p_views.hip: pair_ctx_kernel): what every workgroup would work out about its chunk's
@@ -1334,6 +1335,8 @@ static int job_create_core(p2p_ctx* ctx, const p2p_job_desc& d, const double* ya
     if (e == hipSuccess) e = hipEventCreateWithFlags(&j->ev_down, hipEventDisableTiming);
     if (e == hipSuccess) e = dev_alloc((void**)&j->d_out, j->out_bytes + 16);
     if (e == hipSuccess) e = dev_alloc((void**)&j->d_pitch, (size_t)d.n_pitch * sizeof(p2p::PitchConst));
+    j->row0 = 0;
+    j->row1 = d.oh;
     j->shape = choose_shape(d, j->opt);
     {
         const p2p::TileShape& S = shape_ops(j->shape).shape;
@@ -1664,6 +1667,27 @@ static int job_main_order(const p2p_job* j)
     return (j->d.n_yaw + ppb - 1) / ppb == 1 ? 1 : 0;
 }
 
+// One image's ROWS shared out to several GPUs (every rank draws all views, a band of rows of each: a tile's set-up is
+// then spread over all the pairs again, and the number of views no longer caps the speed-up).  Whole tile rows; the plan
+// is made for the range (tiles outside it: mode 0, no kernel's), so the next run builds or fetches another plan.
+int p2p_job_set_rows(p2p_job* j, int row0, int row1)
+{
+    if (!j)
+        return fail(P2P_ERR_INVALID, "job is NULL");
+    const int th = shape_ops(j->shape).shape.tile_h;
+    if (row0 < 0 || row1 <= row0 || row1 > j->d.oh || row0 % th != 0 || (row1 % th != 0 && row1 != j->d.oh))
+        return fail(P2P_ERR_INVALID, "rows [%d, %d) of %d: whole tile rows of %d (the last one may be short)", row0, row1, j->d.oh, th);
+    if (row0 == j->row0 && row1 == j->row1)
+        return P2P_OK;
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream));  // no launch in flight reads the plan that is about to go
+    j->row0 = row0;
+    j->row1 = row1;
+    j->plan_ref.reset();
+    j->pc_plan = nullptr;  // (the pair-context table follows the plan's headers: rebuilt, whatever address the next plan gets)
+    return P2P_OK;
+}
+
 int p2p_job_set_view_mask(p2p_job* j, const uint8_t* mask)
 {
     if (!j)
@@ -1723,7 +1747,8 @@ static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& aft
     const int main_order = band ? 0 : job_main_order(j);
     PlanKey key{d.pw, d.ph, d.ow, d.oh, d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16 | P2P_FLAG_PIXEL_CENTRES), j->border,
                 j->fov, j->pitch, j->shape, {opt.gather_blocky_from, main_order != 0, opt.gather_order, opt.gather_group,
-                                             band ? 1 : 0, band ? cell_bh : 0, band ? cell_cw : 0, band ? opt.band_maxw : 0, band ? opt.band_maxh : 0}};
+                                             band ? 1 : 0, band ? cell_bh : 0, band ? cell_cw : 0, band ? opt.band_maxw : 0, band ? opt.band_maxh : 0,
+                                             j->row0, j->row1}};  // (the rows the job draws: p2p_job_set_rows)
     const p2p::TileShape& S = shape_ops(j->shape).shape;
     const bool cached = !j->host_maps && opt.plan_cache != 0 && opt.scramble_plan == 0;
     if (cached) {
@@ -1806,6 +1831,8 @@ static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& aft
     Q.mapU = j->host_maps ? j->d_mapU : nullptr;
     Q.mapV = j->host_maps ? j->d_mapV : nullptr;
     Q.coords = Pl->d_coords;
+    Q.ty0 = j->row0 / S.tile_h;
+    Q.ty1 = (j->row1 + S.tile_h - 1) / S.tile_h;
     Q.coords_all = (band || float_path || opt.coords_all != 0) ? 1 : 0;
     Pl->coords_full = Q.coords_all != 0;
     Q.hdr = Pl->d_hdr;
@@ -1962,7 +1989,8 @@ static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& aft
         HIP_TRY(dev_alloc((void**)&Pl->d_xcd_list, tg.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpyAsync(Pl->d_xcd_list, tg.data(), tg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         Pl->bytes += tg.size() * sizeof(uint32_t);
-        if ((slots - (size_t)cnt) * 4 <= slots) {  // the gather kernel may draw every tile (p2p_job_run: gather_all)
+        // (not for a job that draws a range of rows: "every tile" would be the other ranks' too)
+        if ((slots - (size_t)cnt) * 4 <= slots && j->row0 == 0 && j->row1 == d.oh) {  // the gather kernel may draw every tile (p2p_job_run: gather_all)
             all.resize(slots);
             for (size_t s = 0; s < slots; ++s)
                 all[s] = (uint32_t)s;
@@ -2590,6 +2618,73 @@ int p2p_job_get_view_async(p2p_job* j, int index, int yaw_i, int pitch_i, uint8_
         return rc;
     HIP_TRY(hipEventRecord(j->ev_down, down));
     j->down_pending = true;
+    return P2P_OK;
+}
+
+// rows [row0, row1) of one view, packed (3 * ow bytes per row), behind the last run -- the download that goes with
+// p2p_job_set_rows.  The asynchronous form needs a view width divisible by 4, like p2p_job_get_view_async.
+static int enqueue_rows_copy(p2p_job* j, int index, int yaw_i, int pitch_i, int row0, int row1, uint8_t* out, hipStream_t st)
+{
+    const size_t view = (size_t)j->d.oh * j->out_row;
+    const uint8_t* src = j->d_out + (((size_t)index * j->d.n_yaw + yaw_i) * j->d.n_pitch + pitch_i) * view + (size_t)row0 * j->out_row;
+    const size_t row = (size_t)3 * j->d.ow, rows = (size_t)(row1 - row0);
+    if ((size_t)j->out_row == row) {
+        HIP_TRY(hipMemcpyAsync(out, src, rows * row, hipMemcpyDeviceToHost, st));
+    } else {
+        if (!j->d_pack) {  // sized for a whole panorama's views, as the whole-block download uses it
+            const size_t all = (size_t)j->d.n_yaw * j->d.n_pitch * j->d.oh * row;
+            HIP_TRY(dev_alloc((void**)&j->d_pack, (all + 3) & ~(size_t)3));
+        }
+        HIP_TRY(p2p::launch_compact_rows(j->d_pack, src, rows * row, (int)row, j->out_row, st));
+        HIP_TRY(hipMemcpyAsync(out, j->d_pack, rows * row, hipMemcpyDeviceToHost, st));
+    }
+    return P2P_OK;
+}
+
+static int view_rows_check(p2p_job* j, int index, int yaw_i, int pitch_i, int row0, int row1, uint8_t* out)
+{
+    if (int rc = get_views_check(j, index, out))
+        return rc;
+    if (yaw_i < 0 || yaw_i >= j->d.n_yaw || pitch_i < 0 || pitch_i >= j->d.n_pitch)
+        return fail(P2P_ERR_INVALID, "view (yaw %d, pitch %d) out of range", yaw_i, pitch_i);
+    if (row0 < 0 || row1 <= row0 || row1 > j->d.oh)
+        return fail(P2P_ERR_INVALID, "rows [%d, %d) of %d", row0, row1, j->d.oh);
+    return P2P_OK;
+}
+
+int p2p_job_get_view_rows_async(p2p_job* j, int index, int yaw_i, int pitch_i, int row0, int row1, uint8_t* out)
+{
+    if (int rc = view_rows_check(j, index, yaw_i, pitch_i, row0, row1, out))
+        return rc;
+    if ((size_t)j->out_row != (size_t)3 * j->d.ow)
+        return fail(P2P_ERR_STATE, "asynchronous row downloads need a view width divisible by 4 (the packing buffer is shared); use p2p_job_get_view_rows");
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    hipStream_t down = nullptr;
+    HIP_TRY(ctx_copy_stream(j->ctx, false, &down));
+    if (int rc = mark_run(j))
+        return rc;
+    HIP_TRY(hipStreamWaitEvent(down, j->ev_run, 0));
+    if (int rc = enqueue_rows_copy(j, index, yaw_i, pitch_i, row0, row1, out, down))
+        return rc;
+    HIP_TRY(hipEventRecord(j->ev_down, down));
+    j->down_pending = true;
+    return P2P_OK;
+}
+
+int p2p_job_get_view_rows(p2p_job* j, int index, int yaw_i, int pitch_i, int row0, int row1, uint8_t* out)
+{
+    if (int rc = view_rows_check(j, index, yaw_i, pitch_i, row0, row1, out))
+        return rc;
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    if (j->down_pending) {  // d_pack is shared with the asynchronous path
+        HIP_TRY(hipEventSynchronize(j->ev_down));
+        j->down_pending = false;
+    }
+    StreamSyncGuard sync_on_exit(j->ctx->stream);  // `out` is the caller's
+    if (int rc = enqueue_rows_copy(j, index, yaw_i, pitch_i, row0, row1, out, j->ctx->stream))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+    sync_on_exit.armed = false;
     return P2P_OK;
 }
 

@@ -89,6 +89,28 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void plan_kernel(PlanParams P)
     const int px = x0 + tx;
     const uint32_t slot = (uint32_t)(pitch_i * tiles_x * tiles_y + tile_id);
 
+    // a tile row the job does not draw (p2p_job_set_rows: one image's rows shared out to several GPUs): mode 0, no kernel's
+    if (tile_id / tiles_x < P.ty0 || tile_id / tiles_x >= P.ty1) {
+        if (P.band.gcell != nullptr && (t & 3) == 0) {
+            const size_t gxn = (size_t)((P.ow + 3) >> 2);
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) {
+                const int py = y0 + ty0 + j * ROWSTEP;
+                if (px < P.ow && py < P.oh)
+                    P.band.gcell[((size_t)pitch_i * P.oh + py) * gxn + (size_t)(px >> 2)] = ~0u;
+            }
+        }
+        if (t == 0) {
+            PieceHdr h;
+            h.mode_items = 0u;
+            h.c0 = 0;
+            h.c1 = -1;
+            h.rows = 0u;
+            P.hdr[slot] = h;
+        }
+        return;
+    }
+
     // ---- the pitch-stage coordinate of every pixel of the tile, quantised as cv::remap does ----
     int ix[PXT], iy[PXT], qsx[PXT], qsy[PXT];
     uint32_t fx[PXT], fy[PXT], frac16[PXT];

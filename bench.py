@@ -10,8 +10,8 @@ rank per GPU) the (image x yaw x pitch) batch is dealt to the ranks at IMAGE gra
 every rank draws the metric's own configuration -- one 8K panorama of its own x 36 views, N images
 in all, "scaling": "weak" (per-GPU work fixed as N grows; the N = 1 line is the same workload).
 --workload cfg3 deals config 3's 64 panoramas instead, 64 / N resident per GPU ("strong": the batch
-is fixed); --scaling strong on a single-panorama workload deals its VIEWS (36 views on 8 GPUs: 4 or
-5 each, one masked job per rank).  It is independent work, so there is NO data-path collective;
+is fixed); --scaling strong on a single-panorama workload deals a band of ROWS of every view to each
+rank (--shard views: whole views, 36 on 8 GPUs = 3 to 5 each, one masked job per rank).  It is independent work, so there is NO data-path collective;
 torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the elapsed time.
 value = pixels of the whole job / that time.
 
@@ -479,6 +479,8 @@ def main():
                          "MI355X sits at a low shader clock and needs a few hundred ms of load to reach its working "
                          "clock (a 25-launch run is over in 4 ms).  Reported as preroll_s; 0 turns it off")
     ap.add_argument("--no-preroll", action="store_true")
+    ap.add_argument("--shard", default="rows", choices=["rows", "views"],
+                    help="--scaling strong on one panorama: a band of rows of every view per rank (default) or whole views per rank")
     ap.add_argument("--counters", default="auto", choices=["auto", "measure", "file", "none"],
                     help="roofline.traffic / roofline.valu: measure = rocprofv3 --pmc child runs of this script (one pass "
                          "per counter group, before this process touches the GPU); file = profiles/traffic.json; "
@@ -553,6 +555,17 @@ def main():
         if npg:
             jobs.append(nat.Job(ctx, w["pw"], w["ph"], npg, w["yaws"], w["pitches"], w["fov"], w["ow"], w["oh"], flags=flags))
         views_per_rank = npg * n_yaw * n_pitch
+    elif args.scaling == "strong" and args.shard == "rows":
+        # one panorama, every rank draws a band of ROWS of every view (drv.shard_rows, p2p_job_set_rows): a tile's set-up
+        # stays spread over all the yaws, and the number of views does not cap the speed-up; every rank uploads the panorama
+        r0, r1 = drv.shard_rows(w["oh"], dist.world, w["pitches"], w["fov"], w["ow"])[dist.rank]
+        npg, total_views, seeds = 1, n_yaw * n_pitch, [1000]
+        if r1 > r0:
+            j = nat.Job(ctx, w["pw"], w["ph"], 1, w["yaws"], w["pitches"], w["fov"], w["ow"], w["oh"], flags=flags)
+            j.set_rows(r0, r1)
+            jobs.append(j)
+        views_per_rank = n_yaw * n_pitch * (r1 - r0) / float(w["oh"])  # (in whole views' worth of pixels)
+        sharding = "rows %d..%d of every view of one panorama on this rank, no collective" % (r0, r1)
     elif args.scaling == "strong":
         # one panorama, its pitch-major view list cut into one contiguous run per rank (36 views on 8 GPUs
         # = 5 or 4 consecutive yaws of one pitch view each); every rank uploads the panorama once

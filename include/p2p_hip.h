@@ -252,6 +252,16 @@ int p2p_job_get_view(p2p_job* job, int index, int yaw_i, int pitch_i, uint8_t* o
 /* The same without waiting, on the context's download stream behind the job's last run (view widths divisible by 4);
    `out` is complete after p2p_job_wait / p2p_ctx_synchronize. */
 int p2p_job_get_view_async(p2p_job* job, int index, int yaw_i, int pitch_i, uint8_t* out);
+
+/* One image's ROWS shared out to several GPUs (no reference counterpart: P:252-265 fans one image's yaws out to threads;
+ * with fewer images than GPUs this build deals an image's views -- or, with these calls, a band of rows of EVERY view --
+ * to the devices).  p2p_job_set_rows: the job draws only output rows [row0, row1) of each of its views; row0 and row1
+ * are multiples of 16 (tile rows), row1 may also be the view height; (0, oh) restores the whole view.  The job's next
+ * run plans for that range.  p2p_job_get_view_rows[_async]: rows [row0, row1) of one view, packed 3 * ow bytes per row,
+ * into `out`; the asynchronous form needs a view width divisible by 4 and is waited for with p2p_job_wait. */
+int p2p_job_set_rows(p2p_job* job, int row0, int row1);
+int p2p_job_get_view_rows(p2p_job* job, int index, int yaw_i, int pitch_i, int row0, int row1, uint8_t* out);
+int p2p_job_get_view_rows_async(p2p_job* job, int index, int yaw_i, int pitch_i, int row0, int row1, uint8_t* out);
 /* Wait for everything the job has in flight: uploads, its last run, downloads. */
 int p2p_job_wait(p2p_job* job);
 /* Launch timing, off by default (a job that nobody times creates no timing event and records none).  n >= 1: every

@@ -123,6 +123,15 @@ int main()
         CHECK(p2p_job_get_view_async(job, 0, 0, 0, one.data()) == P2P_ERR_STATE);   // 70 is not divisible by 4: packed downloads only
         CHECK(p2p_job_set_view_mask(job, nullptr) == P2P_OK && p2p_job_get_info(job, &info) == P2P_OK && info.n_views_wanted == 6);
     }
+    {   // a band of rows of every view (one image's rows shared out to several GPUs), its rows back, and the whole view again
+        CHECK(p2p_job_set_rows(job, 8, 32) == P2P_ERR_INVALID && p2p_job_set_rows(job, 0, 40) == P2P_ERR_INVALID);
+        CHECK(p2p_job_set_rows(job, 16, 33) == P2P_OK && p2p_job_run(job) == P2P_OK);
+        std::vector<uint8_t> part((size_t)17 * 70 * 3);
+        CHECK(p2p_job_get_view_rows(job, 1, 2, 1, 16, 33, part.data()) == P2P_OK);
+        CHECK(p2p_job_get_view_rows(job, 1, 2, 1, 16, 34, part.data()) == P2P_ERR_INVALID);
+        CHECK(p2p_job_get_view_rows_async(job, 0, 0, 0, 16, 33, part.data()) == P2P_ERR_STATE);   // 70 is not divisible by 4
+        CHECK(p2p_job_set_rows(job, 0, 33) == P2P_OK && p2p_job_run(job) == P2P_OK);
+    }
     std::vector<int32_t> coords((size_t)2 * 33 * 70 * 2);
     CHECK(p2p_job_get_coords(job, coords.data()) == P2P_OK);
     std::vector<uint32_t> tabs((size_t)3 * 64);

@@ -117,3 +117,32 @@ def test_rank_view_set_of_config_2_on_8_gpus():
     yaw_idx, pitch_idx, mask, mine = drv.rank_view_set(12, 3, 8, 0, "round_robin")  # (the dealing before: 5 of a 3 x 3 grid)
     assert mine == [(0, 0), (8, 0), (4, 1), (0, 2), (8, 2)] and mask.tolist() == [[1, 0, 1], [0, 1, 0], [1, 0, 1]]
     assert drv.rank_view_set(2, 1, 4, 3)[3] == []                            # more ranks than views
+
+
+@pytest.mark.parametrize("oh,world", [(1080, 8), (1080, 3), (800, 8), (270, 4), (40, 8), (16, 2), (4096, 8), (17, 1), (1, 4)])
+def test_row_bands_cover_every_row_exactly_once(oh, world):
+    """_driver.shard_rows (one image's rows shared out to the GPUs: p2p_job_set_rows): contiguous bands of whole tile
+    rows that cover [0, oh) once, in rank order; surplus ranks get empty bands."""
+    import importlib
+    import numpy as np
+    d = importlib.import_module("360-to-planer-images_amd._driver")
+    for pitches, fov in (([60, 90, 120], 90), ([30, 60, 90, 120, 150], 90), (None, 60), ([5], 150)):
+        bands = d.shard_rows(oh, world, pitches, fov, 2 * oh)
+        assert len(bands) == world
+        assert bands[0][0] == 0 and max(b for _, b in bands) == oh
+        for (a0, a1), (b0, b1) in zip(bands[:-1], bands[1:]):
+            assert a1 == b0 and a0 <= a1
+        for a, b in bands:
+            assert a == b or (a % d.TILE_ROWS == 0 and (b % d.TILE_ROWS == 0 or b == oh))
+        covered = np.zeros(oh, int)
+        for a, b in bands:
+            covered[a:b] += 1
+        assert (covered == 1).all()
+
+
+def test_row_bands_of_config_2_on_8_gpus_are_balanced():
+    import importlib
+    d = importlib.import_module("360-to-planer-images_amd._driver")
+    bands = d.shard_rows(1080, 8, [60, 90, 120], 90, 1920)
+    sizes = [b - a for a, b in bands]
+    assert max(sizes) <= 144 and min(sizes) >= 112, sizes  # 68 tile rows on 8 ranks: 7 to 9 each

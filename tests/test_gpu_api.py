@@ -244,14 +244,16 @@ def test_view_sharded_path_two_contexts_on_one_device(gpu, pkg, synth):
     pano = synth.synth_pano(2048, 1024, 3100, "N")
     yaws, pitches = list(range(0, 360, 30)), [60, 90, 120]
     one = pkg.process_views(pano, yaws, pitches, 320, 180, 90)
-    for devices in ([0, 0], [0, 0, 0, 0, 0, 0, 0, 0], [0]):
-        got = d.process_views_sharded(pano, yaws, pitches, 320, 180, 90.0, devices)
-        assert np.array_equal(got, one), devices
+    for how in ("rows", "views", "auto"):  # a band of rows of every view per device | whole views per device
+        for devices in ([0, 0], [0, 0, 0, 0, 0, 0, 0, 0], [0]):
+            got = d.process_views_sharded(pano, yaws, pitches, 320, 180, 90.0, devices, how=how)
+            assert np.array_equal(got, one), (how, devices)
     # 36 views on 8 ranks: each rank's 4 or 5 views are ONE job with a view mask (a 3 x 3 grid with holes); and a view
     # width that is not divisible by 4 (single views through the job's packing buffer)
     one_odd = pkg.process_views(pano, yaws, pitches, 318, 180, 90)
-    got = d.process_views_sharded(pano, yaws, pitches, 318, 180, 90.0, [0] * 8)
-    assert np.array_equal(got, one_odd)
+    for how in ("views", "rows"):
+        got = d.process_views_sharded(pano, yaws, pitches, 318, 180, 90.0, [0] * 8, how=how)
+        assert np.array_equal(got, one_odd), how
     # a caller whose device list changes length from image to image: the contexts kept are those of the LAST call's
     # slots (device, k) -- never one per (rank, device) pair ever used (round 4's advisor finding)
     assert d.live_sharded_contexts() == 8

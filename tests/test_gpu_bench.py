@@ -91,11 +91,16 @@ def test_multi_rank_defaults_config3_share_and_view_sharding(gpu):
     line = _last_json(r.stdout)
     assert line["scaling"] == "strong" and line["config"]["panos_per_gpu"] == 32 and line["config"]["views_per_gpu"] == 32 * 36
     assert "64 panos" in line["config"]["workload"] and line["value"] > 0
-    r = subprocess.run(base + ["--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "10", "--warmup", "2",
-                               "--workload", "cfg2", "--scaling", "strong", "--kind", "N", "--preroll-s", "0.1"],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
-    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-    line = _last_json(r.stdout)
-    assert line["scaling"] == "strong" and line["config"]["views_per_gpu"] == 18 and line["config"]["launches_per_step"] == 1  # one masked job
-    # 36 views x 1920 x 1080 per step, whatever the number of ranks
-    assert abs(line["value"] * line["ms_per_step"] * 1e3 - 36 * 1920 * 1080) / (36 * 1920 * 1080) < 1e-6
+    for shard in ("rows", "views"):  # a band of rows of every view per rank (the default) | whole views per rank
+        r = subprocess.run(base + ["--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "10", "--warmup", "2",
+                                   "--workload", "cfg2", "--scaling", "strong", "--shard", shard, "--kind", "N", "--preroll-s", "0.1"],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        line = _last_json(r.stdout)
+        assert line["scaling"] == "strong" and line["config"]["launches_per_step"] == 1  # one job per rank
+        if shard == "views":
+            assert line["config"]["views_per_gpu"] == 18  # one masked job
+        else:
+            assert abs(line["config"]["views_per_gpu"] - 36 * 544 / 1080.0) < 1e-9  # rows 0..544 of all 36 views on rank 0
+        # 36 views x 1920 x 1080 per step, whatever the number of ranks
+        assert abs(line["value"] * line["ms_per_step"] * 1e3 - 36 * 1920 * 1080) / (36 * 1920 * 1080) < 1e-6
