@@ -18,6 +18,8 @@ _p.add_argument("--launches", type=int, default=2, help="launches per job, each 
                 "pass; from the second on the per-XCD lists, the pair-context table and the merged gather launch are in play")
 _p.add_argument("--mode", choices=("default", "big", "real"), default="default",
                 help="big: large geometries; real: real-valued yaw / pitch / FOV, pitch anywhere in [0, 180]")
+_p.add_argument("--rows", action="store_true", help="after the launches: the first panorama inverted, a random band of tile rows "
+                "(p2p_job_set_rows), one more launch -- the band's rows must be the oracle's for the NEW panorama, every other row the old one's")
 _a = _p.parse_args()
 n_cases, seed = _a.cases, _a.seed
 only = _a.only if _a.only >= 0 else None
@@ -71,6 +73,23 @@ for case in range(int(os.environ.get("FUZZ_FIRST", "0")), n_cases):  # FUZZ_FIRS
                     bad += 1
                     print("MISMATCH", dict(case=case, launch=launch, pw=pw, ph=ph, ow=ow, oh=oh, fov=fov, yaw=yaws[yi], yaw_index=yi, n_yaw=n_yaw,
                                            pitches=pitches, pano=i, n=int((got[yi] != want).sum())), flush=True)
+    if _a.rows and oh >= 16:
+        n_tr = (oh + 15) // 16
+        a_ = int(rng.integers(0, n_tr)); b_ = int(rng.integers(a_ + 1, n_tr + 1))
+        r0, r1 = 16 * a_, min(oh, 16 * b_)
+        inv = 255 - panos[0]
+        job.set_pano(0, inv)
+        job.set_rows(r0, r1)
+        job.run()
+        got = job.get_views(0)
+        for yi in check_yaws:
+            new = oracle_views(inv, [yaws[yi]], pitches, ow, oh, fov)[0]
+            want = wants[(0, yi)].copy()
+            want[:, r0:r1] = new[:, r0:r1]
+            if not np.array_equal(got[yi], want):
+                bad += 1
+                print("MISMATCH (rows %d..%d)" % (r0, r1), dict(case=case, pw=pw, ph=ph, ow=ow, oh=oh, fov=fov, yaw=yaws[yi], pitches=pitches,
+                                                               inside=int((got[yi][:, r0:r1] != want[:, r0:r1]).sum()), outside=int((got[yi] != want).sum())), flush=True)
     job.close()
     if case % 10 == 9:
         print("case %d done, %.0f s, mismatches %d" % (case + 1, time.time() - t0, bad), flush=True)
