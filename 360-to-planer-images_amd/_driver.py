@@ -17,7 +17,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-from . import _native
+try:
+    from . import _native
+except ImportError:  # the tool file executed as a script (python 360-to-planer-images_amd/panorama_to_plane_pitch.py ...): its siblings are plain modules
+    import _native  # type: ignore
 
 
 def shard_round_robin(n_items, world, rank):

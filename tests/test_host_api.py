@@ -268,3 +268,16 @@ def test_integration_stubs_compile_and_bind_exported_entry_points(nat):
         for sym, args in re.findall(r"_p2p\.(p2p_[a-z0-9_]+)\.argtypes = \[(.*?)\n(?=_p2p\.|def |\Z)", b, re.S):
             proto = re.search(r"\bint %s\s*\(([^;]*?)\);" % sym, header, re.S).group(1)
             assert len(re.findall(r"ctypes\.c_\w+", args)) == proto.count(",") + 1, sym
+
+
+@pytest.mark.parametrize("tool", ["panorama_to_plane_pitch.py", "panorama_to_plane.py"])
+def test_the_tool_files_run_as_scripts(tool):
+    """README / INTEGRATION Option A: `python 360-to-planer-images_amd/panorama_to_plane_pitch.py --input_path ...` -- the
+    file executed directly, not imported as a package member: its sibling modules (the binding, the driver) must come in
+    as plain modules.  (--help needs no GPU.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "360-to-planer-images_amd", tool), "--help"],
+                       capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert r.returncode == 0 and "--input_path" in r.stdout, (r.stdout + r.stderr)[-2000:]
