@@ -436,7 +436,6 @@ struct Plan {  // the plan pass's tables (p2p_plan.hip)
     // the quantised coordinates of every pixel (else: of the gather tiles only; ensure_full_coords completes them)
     std::atomic<bool> coords_full{false};
     std::atomic<bool> lists_pending{false};
-    std::vector<p2p::PieceHdr> hdr_host;  // lists_pending: the headers as they came back with the gather count (plan_make_main_lists)
     std::mutex lists_mu;
     std::atomic<int> launches{0};
     int tile_w = 64;
@@ -1781,7 +1780,7 @@ static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& aft
         hipError_t get(void** out, size_t bytes) { hipError_t e = dev_alloc(out, bytes); if (e == hipSuccess) blocks.push_back(*out); return e; }
     } scratch;
     StreamSyncGuard sync_on_exit(st);
-    HIP_TRY(pin_get(&pin.p, &pin.cls, pin_hdr_off + std::min(slots, pin_hdr_max) * sizeof(p2p::PieceHdr) + 512));
+    HIP_TRY(pin_get(&pin.p, &pin.cls, pin_hdr_off + std::min(slots, pin_hdr_max) * sizeof(p2p::PieceHdr)));
     p2p::BandInfo* const h_binfo = (p2p::BandInfo*)pin.p;
     uint32_t* const h_cnt = (uint32_t*)((unsigned char*)pin.p + 112);
     p2p::PieceHdr* const h_hdr = (p2p::PieceHdr*)((unsigned char*)pin.p + pin_hdr_off);
@@ -1790,14 +1789,13 @@ static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& aft
     // synchronisation by hdr_arrived) or, beyond its size, straight into the vector
     bool hdr_in_pin = false;
     auto fetch_headers = [&]() -> hipError_t {
+        hh.resize(slots);
         hdr_in_pin = slots <= pin_hdr_max;
-        if (!hdr_in_pin)
-            hh.resize(slots);
         return hipMemcpyAsync(hdr_in_pin ? (void*)h_hdr : (void*)hh.data(), Pl->d_hdr, slots * sizeof(p2p::PieceHdr), hipMemcpyDeviceToHost, st);
     };
     auto hdr_arrived = [&]() {
         if (hdr_in_pin)
-            hh.assign(h_hdr, h_hdr + slots);
+            memcpy(hh.data(), h_hdr, slots * sizeof(p2p::PieceHdr));
         hdr_in_pin = false;
     };
     Pl->band = band;
@@ -1819,9 +1817,9 @@ static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& aft
         Pl->d_px2 = (uint32_t*)take(b_px2);
         Pl->d_coords = (int2*)take(b_coords);
         Pl->d_hdr = (p2p::PieceHdr*)take(b_hdr);
-        Pl->d_n_gather = (uint32_t*)take(b_cnt);  // (right behind the headers: one copy brings both back)
         Pl->d_px = (uint32_t*)take(b_px);
         Pl->d_items = (uint32_t*)take(b_items);
+        Pl->d_n_gather = (uint32_t*)take(b_cnt);
         Pl->d_gather_list = (uint32_t*)take(b_list);
     }
     Pl->bytes = (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2) +
@@ -1936,26 +1934,18 @@ static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& aft
     }
     if (band || !after_plan_pass)
         HIP_TRY(hipEventRecord(ctx->ev_t1, st));
-    // per-view plans whose lists are made from the headers: headers and counter (it sits right behind them in the plan's
-    // block) in ONE copy -- a second copy is a launch and its gap, 15 us of a first image
-    const size_t hdr_span = (size_t)((const unsigned char*)Pl->d_n_gather - (const unsigned char*)Pl->d_hdr);
-    const bool one_copy = !band && main_order != 0 && slots <= pin_hdr_max && d_cnt == Pl->d_n_gather &&
-                          hdr_span + sizeof(uint32_t) <= pin.cls - pin_hdr_off;
-    if (one_copy) {
-        hdr_in_pin = true;
-        HIP_TRY(hipMemcpyAsync(h_hdr, Pl->d_hdr, hdr_span + sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    } else if (!band)
+    if (!band)
         HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
     // the work lists are made from the plan's headers, once per geometry: they come back with the counter -- unless the
     // plan turns out to have no gather tile and may draw its first launch in grid order (Plan::lists_pending)
     const bool want_main_order = main_order != 0;
     const bool may_defer = want_main_order && opt.defer_lists != 0 && opt.main_order < 0 && opt.scramble_plan == 0;
     Pl->tile_w = shape_ops(j->shape).shape.tile_w;
-    if (want_main_order && !one_copy)  // (also when the lists are deferred: they are made from these headers at the second launch, without another round trip)
+    if (want_main_order && !may_defer)
         HIP_TRY(fetch_headers());
     if (!band) {  // (band plans: the counter came back with the band counts; the device is still building the tiles)
         HIP_TRY(hipStreamSynchronize(st));
-        cnt = one_copy ? *(const uint32_t*)((const unsigned char*)h_hdr + hdr_span) : *h_cnt;
+        cnt = *h_cnt;
         hdr_arrived();
         (void)hipEventElapsedTime(&Pl->plan_ms, ctx->ev_t0, ctx->ev_t1);
     }
@@ -1965,7 +1955,6 @@ static int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& aft
     Pl->built = true;
     bool make_main_list = want_main_order && (size_t)cnt < slots;
     if (make_main_list && may_defer && cnt == 0) {
-        Pl->hdr_host.swap(hh);  // (no gather tile: nothing below reads them)
         Pl->lists_pending = true;
         make_main_list = false;
     }
@@ -2113,16 +2102,11 @@ static int plan_make_main_lists(p2p_job* j, Plan& Pl)
         return P2P_OK;
     hipStream_t st = j->ctx->stream;
     const size_t slots = j->n_tiles * j->d.n_pitch;
-    std::vector<p2p::PieceHdr> hh;
+    std::vector<p2p::PieceHdr> hh(slots);
     std::vector<uint32_t> tm;
     StreamSyncGuard sync_on_exit(st);
-    if (Pl.hdr_host.size() == slots) {
-        hh.swap(Pl.hdr_host);  // (they came back with the first launch's gather count)
-    } else {
-        hh.resize(slots);
-        HIP_TRY(hipMemcpyAsync(hh.data(), Pl.d_hdr, slots * sizeof(p2p::PieceHdr), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-    }
+    HIP_TRY(hipMemcpyAsync(hh.data(), Pl.d_hdr, slots * sizeof(p2p::PieceHdr), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     int stride = 0;
     tm = xcd_main_lists(hh, j->n_tiles, &stride, Pl.tile_w);
     uint32_t* d_list = nullptr;
