@@ -2104,14 +2104,22 @@ static int plan_make_main_lists(p2p_job* j, Plan& Pl)
     const size_t slots = j->n_tiles * j->d.n_pitch;
     std::vector<p2p::PieceHdr> hh(slots);
     std::vector<uint32_t> tm;
+    // (through a pinned block both ways: copies from and to pageable memory are staged and waited for)
+    PinnedBlock pin;
+    const size_t hdr_bytes = slots * sizeof(p2p::PieceHdr);
     StreamSyncGuard sync_on_exit(st);
-    HIP_TRY(hipMemcpyAsync(hh.data(), Pl.d_hdr, slots * sizeof(p2p::PieceHdr), hipMemcpyDeviceToHost, st));
+    HIP_TRY(pin_get(&pin.p, &pin.cls, std::max(hdr_bytes, (size_t)1)));
+    HIP_TRY(hipMemcpyAsync(pin.p, Pl.d_hdr, hdr_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    memcpy(hh.data(), pin.p, hdr_bytes);
     int stride = 0;
     tm = xcd_main_lists(hh, j->n_tiles, &stride, Pl.tile_w);
     uint32_t* d_list = nullptr;
     HIP_TRY(dev_alloc((void**)&d_list, tm.size() * sizeof(uint32_t)));
-    hipError_t e = hipMemcpyAsync(d_list, tm.data(), tm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+    const bool up_pinned = tm.size() * sizeof(uint32_t) <= pin.cls;
+    if (up_pinned)
+        memcpy(pin.p, tm.data(), tm.size() * sizeof(uint32_t));
+    hipError_t e = hipMemcpyAsync(d_list, up_pinned ? pin.p : (const void*)tm.data(), tm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess)
         e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
