@@ -2769,6 +2769,8 @@ int p2p_job_get_coords(p2p_job* j, int32_t* sxsy)
         return fail(P2P_ERR_STATE, "the float pixel paths keep no quantised coordinates");
     if (!j->ran)
         return fail(P2P_ERR_STATE, "p2p_job_run has not been called");
+    if (!j->plan_ref)  // (p2p_job_set_maps / p2p_job_set_rows since: the coordinates' plan is gone, the next run makes another)
+        return fail(P2P_ERR_STATE, "the job's maps or rows changed since its last run: run it again first");
     HIP_TRY(hipSetDevice(j->ctx->device));
     if (j->plan_ref && !j->plan_ref->coords_full)
         if (int rc = ensure_full_coords(j))

@@ -98,8 +98,13 @@ def test_row_ranges_are_whole_tile_rows(gpu, synth):
         for bad in ((8, 32), (0, 40), (32, 32), (48, 16), (-16, 16), (0, 112)):
             with pytest.raises(gpu.P2PError):
                 job.set_rows(*bad)
-        job.set_rows(96, 100)  # (the last tile row is short)
         job.run()
+        assert job.get_coords().shape == (1, 100, 128, 2)
+        job.set_rows(96, 100)  # (the last tile row is short)
+        with pytest.raises(gpu.P2PError):
+            job.get_coords()  # (the plan those coordinates belonged to is gone: run first)
+        job.run()
+        assert job.get_coords().shape == (1, 100, 128, 2)
         with pytest.raises(gpu.P2PError):
             job.get_view_rows(0, 0, 90, 101)
         assert job.get_view_rows(0, 0, 96, 100).shape == (4, 128, 3)
