@@ -111,3 +111,20 @@ def test_row_ranges_are_whole_tile_rows(gpu, synth):
         job.close()
     finally:
         ctx.close()
+
+
+def test_rows_through_the_sharded_driver_incl_the_float_pixel_paths(gpu, synth):
+    """_driver.process_views_sharded, one image on three contexts of one device: a band of rows of every view per context
+    ("rows") and whole views per context ("views") stitch to the single-context result -- uint8 and both float pixel paths."""
+    import importlib
+    d = importlib.import_module("360-to-planer-images_amd._driver")
+    pano = synth.synth_pano(2048, 1024, 3100, "S")
+    yaws, pitches = [0, 33.3, 90, 200], [40, 90, 150]
+    try:
+        for flags in (0, gpu.FLAG_PIXELS_F32, gpu.FLAG_PIXELS_F16):
+            one = d.process_views_sharded(pano, yaws, pitches, 320, 200, 90.0, [0], flags=flags)
+            for how in ("rows", "views"):
+                got = d.process_views_sharded(pano, yaws, pitches, 320, 200, 90.0, [0, 0, 0], flags=flags, how=how)
+                assert np.array_equal(got, one), (flags, how)
+    finally:
+        d.release_sharded()
