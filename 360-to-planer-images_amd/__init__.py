@@ -25,11 +25,13 @@ from .panorama_to_plane_pitch import (
     process_yaw_and_pitchs,
     set_device,
     set_devices,
+    set_exact,
+    set_quality,
 )
 
 __all__ = [
     "check_pitch", "get_pitch_mapping", "get_version", "get_yaw_mapping", "main",
     "precompute_pitch_mapping", "precompute_yaw_mapping", "process_single_image", "process_views",
-    "process_yaw_and_pitchs", "set_device", "set_devices", "panorama_to_plane", "interpolate_color",
+    "process_yaw_and_pitchs", "set_device", "set_devices", "set_exact", "set_quality", "panorama_to_plane", "interpolate_color",
     "get_rotation_matrix", "precompute_mapping",
 ]

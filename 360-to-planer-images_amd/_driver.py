@@ -184,11 +184,15 @@ class DevicePipeline:
         self.slots = [None] * int(slots)  # (key, Job, last ticket)
         self.turn = 0
 
-    def submit(self, pano, yaws, pitches, fov, ow, oh, flags=0):
-        """Enqueue upload -> kernel -> download of every (yaw, pitch) view of `pano`; returns a ticket at once."""
+    def submit(self, pano, yaws, pitches, fov, ow, oh, flags=0, maps=None):
+        """Enqueue upload -> kernel -> download of every (yaw, pitch) view of `pano`; returns a ticket at once.
+        maps = (U, V, maps_key): the tool's exact mode -- the job draws from these pitch maps ([n_pitch][oh][ow] float32,
+        the reference's get_pitch_mapping outputs, P:55-73) instead of evaluating its own; they are uploaded when a slot's
+        job is created and stay with it, as the reference's pitch_mapping_cache keeps them from image to image (P:18)."""
         pano = _native.as_image(pano, "pano_image")
         ph, pw = pano.shape[:2]
-        key = (pw, ph, tuple(float(y) for y in yaws), tuple(float(p) for p in pitches), float(fov), int(ow), int(oh), int(flags))
+        key = (pw, ph, tuple(float(y) for y in yaws), tuple(float(p) for p in pitches), float(fov), int(ow), int(oh), int(flags),
+               None if maps is None else int(maps[2]))
         i = self.turn % len(self.slots)
         self.turn += 1
         slot = self.slots[i]
@@ -199,6 +203,13 @@ class DevicePipeline:
                 slot = None
         if slot is None:
             job = _native.Job(self.ctx, pw, ph, 1, key[2], key[3], fov, ow, oh, flags=flags)
+            if maps is not None:
+                try:
+                    job.set_maps(None, maps[0], maps[1])
+                except Exception:
+                    job.close()
+                    self.slots[i] = None
+                    raise
         else:
             job = slot[1]
         job.set_pano(0, pano, wait=False)
@@ -287,13 +298,14 @@ def release_sharded():
                 c.close()
 
 
-def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0, how="auto"):
+def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0, how="auto", maps=None):
     """Every (yaw, pitch) view of ONE panorama drawn by several GPUs; each device uploads the panorama once, draws its
     share and downloads it; the host stitches [n_yaw][n_pitch][oh][ow][3].  how = "rows": every device draws a band of
     rows of EVERY view (shard_rows, p2p_job_set_rows: a tile's set-up spread over all the yaws, no cap by the number of
     views -- config 2 on 8 ranks: 14 us per rank against 19.8); "views": the pitch-major view list in contiguous runs
     (shard_views: a masked job per device); "auto": rows when there is a tile row per device.
     `devices` may name a device twice (two contexts on one GPU).
+    maps = (U, V, maps_key): the tool's exact mode (DevicePipeline.submit) -- every device's job draws from these pitch maps.
     A device slot keeps its jobs (device buffers, plan, yaw tables) for the next image of the same geometry, as the
     reference keeps its maps from image to image (P:17-18): a second image pays uploads, view kernels and downloads."""
     pano = _native.as_image(pano, "pano_image")
@@ -305,6 +317,7 @@ def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0, ho
     if how == "auto":
         how = "rows" if world > 1 and (int(oh) + TILE_ROWS - 1) // TILE_ROWS >= world else "views"
     bands = shard_rows(oh, world, pitches, fov, ow) if how == "rows" else None
+    maps_id = None if maps is None else int(maps[2])
 
     # slots of earlier calls that this call does not use (other devices, a second context on one device): their jobs
     # hold panoramas and views, their contexts a stream and cached plans -- both go, unless another call is inside the
@@ -332,7 +345,7 @@ def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0, ho
     def _rows_locked(rank, slot):
         # this device's band of rows of every view: ONE job over all yaws and pitches, planned for the band alone
         r0, r1 = bands[rank]
-        geo = (pw, ph, tuple(yaws), tuple(pitches), float(fov), int(ow), int(oh), int(flags), world, rank, "rows", r0, r1)
+        geo = (pw, ph, tuple(yaws), tuple(pitches), float(fov), int(ow), int(oh), int(flags), world, rank, "rows", r0, r1, maps_id)
         with _ctx_lock:
             kept = _groups.get(slot)
         if kept is not None and kept[0] != geo:
@@ -346,6 +359,8 @@ def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0, ho
             job = _native.Job(ctx, pw, ph, 1, yaws, pitches, fov, ow, oh, flags=flags)
             try:
                 job.set_rows(r0, r1)
+                if maps is not None:
+                    job.set_maps(None, maps[0], maps[1])
                 try:
                     stage = _native.pinned_empty((n_views, r1 - r0, int(ow), 3))
                 except (MemoryError, _native.P2PError, OSError):
@@ -377,7 +392,7 @@ def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0, ho
     def _one_device_locked(rank, slot):
         if bands is not None:
             return _rows_locked(rank, slot)
-        geo = (pw, ph, tuple(yaws), tuple(pitches), float(fov), int(ow), int(oh), int(flags), world, rank)
+        geo = (pw, ph, tuple(yaws), tuple(pitches), float(fov), int(ow), int(oh), int(flags), world, rank, maps_id)
         yaw_idx, pitch_idx, mask, mine = rank_view_set(len(yaws), len(pitches), world, rank, pitch_deg=pitches)
         with _ctx_lock:
             kept = _groups.get(slot)
@@ -395,6 +410,8 @@ def process_views_sharded(pano, yaws, pitches, ow, oh, fov, devices, flags=0, ho
             try:
                 if not mask.all():
                     job.set_view_mask(mask)
+                if maps is not None:  # (the job's pitch list is the rank's subset of the image's)
+                    job.set_maps(None, np.ascontiguousarray(maps[0][pitch_idx]), np.ascontiguousarray(maps[1][pitch_idx]))
                 try:
                     stage = _native.pinned_empty((len(mine), int(oh), int(ow), 3))
                 except (MemoryError, _native.P2PError, OSError):

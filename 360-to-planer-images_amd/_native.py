@@ -25,7 +25,7 @@ FLAG_PIXEL_CENTRES = 16  # float paths only: sample through pixel centres (not t
 # every symbol include/p2p_hip.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (
     "p2p_version", "p2p_last_error", "p2p_device_count",
-    "p2p_remap_views_u8", "p2p_remap_views_f64", "p2p_remap_views_maps_u8", "p2p_remap_maps_u8", "p2p_remap_maps_interp_u8",
+    "p2p_remap_views_u8", "p2p_remap_views_f64", "p2p_remap_views_maps_u8", "p2p_remap_views_pitch_maps_f64", "p2p_remap_maps_u8", "p2p_remap_maps_interp_u8",
     "p2p_remap_maps_batch_u8",
     "p2p_build_pitch_map", "p2p_build_yaw_row", "p2p_build_rot_map",
     "p2p_ctx_create", "p2p_ctx_destroy", "p2p_ctx_synchronize", "p2p_ctx_mark", "p2p_ctx_marked_ms",
@@ -96,6 +96,9 @@ def lib():
     L.p2p_remap_views_maps_u8.restype = c_int
     L.p2p_remap_views_maps_u8.argtypes = [c_vp, c_int, c_int, c_i64, c_vp, c_int, c_vp, c_vp, c_int,
                                           c_int, c_int, c_vp, c_int]
+    L.p2p_remap_views_pitch_maps_f64.restype = c_int
+    L.p2p_remap_views_pitch_maps_f64.argtypes = [c_vp, c_int, c_int, c_i64, c_vp, c_int, c_vp, c_vp, c_int, ctypes.c_uint64,
+                                                 c_int, c_int, c_vp, c_int]
     L.p2p_remap_maps_u8.restype = c_int
     L.p2p_remap_maps_u8.argtypes = [c_vp, c_int, c_int, c_i64, c_int, c_vp, c_vp, c_int, c_int, c_vp,
                                     c_int, c_vp, c_int]
@@ -400,6 +403,32 @@ def remap_views_maps(pano, yaw_rows, U, V, device=0):
                                         yaw_rows.ctypes.data, yaw_rows.shape[0],
                                         U.ctypes.data, V.ctypes.data, n_pitch, ow, oh,
                                         out.ctypes.data, int(device)))
+    return out
+
+
+def remap_views_pitch_maps(pano, yaw_deg, U, V, maps_key=0, device=0, pinned=False):
+    """p2p_remap_views_pitch_maps_f64: yaw tables from yaw_deg on the device, caller PITCH maps U, V [n_pitch][oh][ow]
+    (the tool's --exact route).  maps_key names exactly these maps (0: none): a slot that holds them is not sent them again."""
+    pano = as_image(pano, "pano_image")
+    ph, pw = pano.shape[:2]
+    yaw = _f64(yaw_deg)
+    U = np.ascontiguousarray(U, dtype=np.float32)
+    V = np.ascontiguousarray(V, dtype=np.float32)
+    if U.ndim != 3 or U.shape != V.shape:
+        raise ValueError("U and V must both be [n_pitch][oh][ow]")
+    n_pitch, oh, ow = U.shape
+    shape = (yaw.size, n_pitch, oh, ow, 3)
+    out = None
+    if pinned and yaw.size and n_pitch:
+        try:
+            out = pinned_empty(shape)
+        except (MemoryError, P2PError, OSError):
+            out = None
+    if out is None:
+        out = np.empty(shape, dtype=np.uint8)
+    check(lib().p2p_remap_views_pitch_maps_f64(pano.ctypes.data, pw, ph, pano.strides[0], yaw.ctypes.data, yaw.size,
+                                               U.ctypes.data, V.ctypes.data, n_pitch, int(maps_key), ow, oh,
+                                               out.ctypes.data, int(device)))
     return out
 
 

@@ -747,6 +747,7 @@ struct p2p_job {
     int shape = 0;                       // tile shape of the job's plan and kernels (choose_shape)
     p2p::MapGeom geom{};
     bool host_maps = false;
+    unsigned long long maps_key = 0;  // caller's name for the maps the job holds (p2p_remap_views_pitch_maps_f64); 0: none
     bool rows_from_host = false;  // yaw tables were packed from caller float rows, not built from yaw_deg
     bool time_launches = false; // bracket every launch with its own event pair (p2p_job_time_launches / p2p_job_kernel_ms*)
     Options opt;                // the knobs as they stood at p2p_job_create (no environment is read after that)
@@ -1556,6 +1557,7 @@ int p2p_job_set_maps(p2p_job* j, const float* yaw_rows, const float* U, const fl
     if (!j->d_mapV) HIP_TRY(dev_alloc((void**)&j->d_mapV, n_map * sizeof(float)));
     HIP_TRY(hipStreamSynchronize(j->ctx->stream));  // no launch in flight reads the plan that is about to go
     j->plan_ref.reset();  // the plan follows the maps (also when a later step of this call fails): a private one is built
+    j->maps_key = 0;      // (whatever name the old maps had)
     {
         StreamSyncGuard sync_on_exit(j->ctx->stream);  // U and V are the caller's: nothing may still read them after a return
         HIP_TRY(hipMemcpyAsync(j->d_mapU, U, n_map * sizeof(float), hipMemcpyHostToDevice, j->ctx->stream));
@@ -2907,7 +2909,7 @@ int p2p_job_get_info(p2p_job* j, p2p_job_info* out)
 static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride,
                          const double* yaw_deg, int n_yaw, const double* pitch_deg, int n_pitch,
                          double fov_deg, int ow, int oh, uint8_t* out, int device, int flags,
-                         const float* yaw_rows, const float* U, const float* V, int border = 0)
+                         const float* yaw_rows, const float* U, const float* V, int border = 0, unsigned long long maps_key = 0)
 {
     if (!pano || !out)
         return fail(P2P_ERR_INVALID, "NULL image pointer");
@@ -2946,8 +2948,10 @@ static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride
                k.ow == ow && k.oh == oh && k.flags == flags && c->border == border && c->host_maps == (U != nullptr) &&
                std::equal(c->pitch.begin(), c->pitch.end(), pitch_deg);
     };
+    // (caller maps that carry a key: a slot whose job already holds exactly those maps -- and the plan made from them -- first)
+    auto holds_maps = [&](const p2p_job* c) { return same_geometry(c) && (!U || maps_key == 0 || c->maps_key == maps_key); };
     SlotGuard guard;
-    int rc = slot_acquire(device, same_geometry, &guard.s);
+    int rc = slot_acquire(device, holds_maps, &guard.s);
     if (rc != P2P_OK)
         return rc;
     OneShotSlot* slot = guard.s;
@@ -2973,8 +2977,12 @@ static int views_oneshot(const uint8_t* pano, int pw, int ph, int64_t row_stride
     }
     if (rc == P2P_OK)
         rc = p2p_job_set_pano(j, 0, pano, row_stride);
-    if (rc == P2P_OK && U)
+    if (rc == P2P_OK && U && !(maps_key != 0 && j->host_maps && j->maps_key == maps_key && !yaw_rows)) {
+        j->maps_key = 0;
         rc = p2p_job_set_maps(j, yaw_rows, U, V);
+        if (rc == P2P_OK)
+            j->maps_key = maps_key;
+    }
     if (rc == P2P_OK)
         rc = p2p_job_run(j);
     if (rc == P2P_OK)
@@ -3025,6 +3033,16 @@ int p2p_remap_views_maps_u8(const uint8_t* pano, int pw, int ph, int64_t row_str
         return fail(P2P_ERR_INVALID, "bad map arguments");
     return views_oneshot(pano, pw, ph, row_stride, nullptr, n_yaw, nullptr, n_pitch, 90.0, ow, oh, out,
                          device, 0, yaw_rows, U, V);
+}
+
+int p2p_remap_views_pitch_maps_f64(const uint8_t* pano, int pw, int ph, int64_t row_stride,
+                                   const double* yaw_deg, int n_yaw, const float* U, const float* V, int n_pitch,
+                                   uint64_t maps_key, int ow, int oh, uint8_t* out, int device)
+{
+    if (n_yaw < 0 || n_pitch < 0 || (n_yaw > 0 && !yaw_deg) || (n_pitch > 0 && (!U || !V)))
+        return fail(P2P_ERR_INVALID, "bad yaw list / map arguments");
+    return views_oneshot(pano, pw, ph, row_stride, yaw_deg, n_yaw, nullptr, n_pitch, 90.0, ow, oh, out,
+                         device, 0, nullptr, U, V, 0, (unsigned long long)maps_key);
 }
 
 int p2p_remap_maps_u8(const uint8_t* src, int sw, int sh, int64_t row_stride, int cn,

@@ -13,13 +13,22 @@ logging format and error behaviour, so a user of the reference can switch files.
     process_single_image                P:227-280     one resident job per image (all yaws x pitches)
     main                                P:286-356     same walk / logging / error swallowing
     check_pitch                         P:362-376     same messages
-    CLI                                 P:382-488     same flags and defaults (+ additive --device)
+    CLI                                 P:382-488     same flags and defaults (+ additive --device, --devices,
+                                                      --exact, --quality)
 
-All pixel and map arithmetic runs on the GPU.  There is no CPU fallback: without the built
+All pixel arithmetic runs on the GPU, and so do the maps by default.  There is no CPU fallback: without the built
 library or without a HIP device the calls raise.
-Image files are decoded / encoded with Pillow (cv2 is not a dependency here); arrays keep
-cv2's BGR channel order at the API boundary because the reference hands BGR arrays around
-(P:243-244) -- the kernel itself is channel-agnostic.
+
+--exact / process_yaw_and_pitchs(..., exact=True) / set_exact(True): the identical-results mode.  The pitch maps are
+evaluated on the host exactly as the reference evaluates them (P:114-175: NumPy float32 flow, libm, one sgemm; see
+_exact_maps.py), cached under the reference's key (P:62), handed to the device once per geometry, and every pixel is
+drawn from them by the same fixed-point HIP kernels: the reference's bytes on any panorama.  The default evaluates the
+pitch maps on the device (within 1e-5 of the host's), which moves 0.001-0.017 % of cv2.remap's 1/32-px quantisations:
++-1 level on band-limited panoramas, more on hard edges.
+
+Image files are decoded / encoded with Pillow (cv2 is not a dependency here).  At the API boundary arrays keep
+cv2's BGR channel order because the reference hands BGR arrays around (P:243-244); the kernels are channel-agnostic,
+so the file-to-file path (main / process_single_image) keeps Pillow's RGB order end to end and swaps nothing.
 """
 import argparse
 import logging
@@ -35,9 +44,10 @@ if __package__ in (None, ""):  # executed as a script: make the sibling module i
 else:
     from . import _native
 try:
-    from . import _driver
+    from . import _driver, _exact_maps
 except ImportError:  # executed as a script
     import _driver  # type: ignore
+    import _exact_maps  # type: ignore
 
 VERSION = "0.3.2"  # the reference release this file mirrors (P:20)
 
@@ -47,6 +57,8 @@ pitch_mapping_cache = {}
 
 _DEVICE = int(os.environ.get("P2P_DEVICE", "0"))
 _DEVICES = None  # devices the directory walk of main() deals images to (None: just _DEVICE)
+_EXACT = False   # set_exact / --exact: host-evaluated pitch maps, the reference's bytes
+_QUALITY = "u8"  # set_quality / --quality: "u8" (the reference's arithmetic) | "f32" | "f16" (opt-in float resample)
 
 
 def set_device(device):
@@ -61,6 +73,26 @@ def set_devices(devices):
     None or an empty list restores single-device operation."""
     global _DEVICES
     _DEVICES = [int(d) for d in devices] if devices else None
+
+
+def set_exact(on=True):
+    """The identical-results mode for every later call of this module (the CLI's --exact): pitch maps as the reference
+    computes them, on the host; pixels on the GPU from those maps.  Additive to the reference API."""
+    global _EXACT
+    if on and _QUALITY != "u8":
+        raise ValueError("--exact is the reference's fixed-point arithmetic; the float pixel paths have no reference counterpart")
+    _EXACT = bool(on)
+
+
+def set_quality(pixel_path="u8"):
+    """Pixel arithmetic of every later call (the CLI's --quality): "u8" = the reference's two fixed-point cv2.remap stages;
+    "f32" / "f16" = ONE float resample per view with true wrap-around at the seam (not in the reference)."""
+    global _QUALITY
+    if pixel_path not in _PIXEL_PATHS:
+        raise ValueError(f"quality must be one of {sorted(_PIXEL_PATHS)}, got {pixel_path!r}")
+    if pixel_path != "u8" and _EXACT:
+        raise ValueError("--exact is the reference's fixed-point arithmetic; the float pixel paths have no reference counterpart")
+    _QUALITY = pixel_path
 
 
 def get_version():
@@ -93,6 +125,8 @@ def get_yaw_mapping(pano_width, pano_height, yaw_angle):
 
 
 def get_pitch_mapping(output_width, output_height, pitch_angle, pano_width, pano_height, fov_deg=90):
+    if _EXACT:  # the maps the exact mode draws from: the reference's values on this host (their own cache, same key)
+        return _exact_maps.get_pitch_mapping(output_width, output_height, pitch_angle, pano_width, pano_height, fov_deg)
     key = (output_width, output_height, pitch_angle, pano_width, pano_height, fov_deg)
     if key not in pitch_mapping_cache:
         pitch_mapping_cache[key] = precompute_pitch_mapping(
@@ -126,80 +160,156 @@ _PINNED = os.environ.get("P2P_PINNED", "1") != "0"
 _PIXEL_PATHS = {"u8": 0, "f32": _native.FLAG_PIXELS_F32, "f16": _native.FLAG_PIXELS_F16}
 
 
+def _exact_maps_for(pano_image, pitch_angles, output_width, output_height, fov_deg):
+    """(U, V, maps_key) of the exact mode for this panorama's size: the reference's pitch maps (P:55-73, P:114-175),
+    evaluated on the host once per key and named for the device."""
+    shape = np.shape(pano_image)
+    if len(shape) != 3:
+        raise ValueError("pano_image must be (height, width, 3)")
+    for p in pitch_angles:
+        _angle(p, "pitch angle")
+    _angle(fov_deg, "FOV")
+    return _exact_maps.pitch_map_stack(output_width, output_height, list(pitch_angles), int(shape[1]), int(shape[0]), fov_deg)
+
+
 def process_views(pano_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg=90, device=None,
-                  pixel_path="u8", maps=None):
+                  pixel_path=None, maps=None, exact=None):
     """All yaws x pitches of one panorama in one kernel launch.
     Returns uint8 [n_yaw][n_pitch][output_height][output_width][3]; the array lives in page-locked host
     memory (pooled; P2P_PINNED=0 for ordinary memory) so that the copy back from the GPU is one DMA.
     pixel_path: "u8" = the reference's arithmetic (two fixed-point cv2.remap stages, the default and the only
-    parity mode); "f32" / "f16" = the opt-in single float resample with wrap-around (not in the reference).
-    maps: None = the coordinate maps are evaluated on the device (the reference's within +-1 on band-limited
-    panoramas); (yaw_rows, U, V) = the exact route of INTEGRATION.md "Option C": yaw_rows [n_yaw][pano_width] =
+    parity mode); "f32" / "f16" = the opt-in single float resample with wrap-around (not in the reference);
+    None = what set_quality() chose.
+    exact: True = the identical-results mode (see the module docstring): host-evaluated pitch maps, device yaw tables,
+    every pixel on the GPU; None = what set_exact() chose.
+    maps: (yaw_rows, U, V) = the caller's OWN maps, INTEGRATION.md "Option C": yaw_rows [n_yaw][pano_width] =
     row 0 of every get_yaw_mapping()[0] (P:42-52), U / V [n_pitch][H][W] = get_pitch_mapping() outputs (P:55-73) --
     given the reference's own maps the views are the reference's bytes."""
+    pixel_path = _QUALITY if pixel_path is None else pixel_path
+    exact = (_EXACT and maps is None and pixel_path == "u8") if exact is None else bool(exact)
+    dev = _DEVICE if device is None else device
     if maps is not None:
         if pixel_path != "u8":
             raise ValueError("caller maps go through the fixed-point path only")
         yaw_rows, U, V = maps
-        return _native.remap_views_maps(pano_image, yaw_rows, U, V, _DEVICE if device is None else device)
+        return _native.remap_views_maps(pano_image, yaw_rows, U, V, dev)
     yaws = [_angle(y, "yaw angle") for y in yaw_angles]
+    if exact:
+        if pixel_path != "u8":
+            raise ValueError("exact=True is the reference's fixed-point arithmetic; it has no float pixel path")
+        U, V, key = _exact_maps_for(pano_image, pitch_angles, output_width, output_height, fov_deg)
+        return _native.remap_views_pitch_maps(pano_image, yaws, U, V, key, dev, pinned=_PINNED)
     pitches = [_angle(p, "pitch angle") for p in pitch_angles]
     return _native.remap_views_f64(pano_image, yaws, pitches, _angle(fov_deg, "FOV"),
-                                   output_width, output_height, _DEVICE if device is None else device,
+                                   output_width, output_height, dev,
                                    pinned=_PINNED, flags=_PIXEL_PATHS[pixel_path])
 
 
-def process_yaw_and_pitchs(pano_image, yaw_angle, pitch_angles, output_width, output_height, fov_deg=90):
-    """Drop-in for P:181-221: one yaw, several pitches -> list of (output_height, output_width, 3) uint8."""
+def process_yaw_and_pitchs(pano_image, yaw_angle, pitch_angles, output_width, output_height, fov_deg=90, *, exact=None):
+    """Drop-in for P:181-221: one yaw, several pitches -> list of (output_height, output_width, 3) uint8.
+    exact (keyword-only, additive): True = the reference's bytes (host-evaluated pitch maps); None = set_exact()'s choice."""
     logging.debug(f"[Yaw/Pitch] Starting processing for yaw_angle={yaw_angle}")
-    views = process_views(pano_image, [yaw_angle], list(pitch_angles), output_width, output_height, fov_deg)
+    views = process_views(pano_image, [yaw_angle], list(pitch_angles), output_width, output_height, fov_deg, exact=exact)
     return [views[0, i] for i in range(views.shape[1])]
 
 
 # ----------------------------------------------------------------------------------------------
 # image files (Pillow, presented with cv2.imread / cv2.imwrite conventions)
 # ----------------------------------------------------------------------------------------------
-def _imread_bgr(path):
-    """cv2.imread(path) stand-in: HxWx3 uint8 BGR, or None when the file cannot be decoded (P:244-247)."""
-    try:
-        from PIL import Image, ImageOps
+# Per-stage host time of the file-to-file path, for tools/cli_end_to_end.py: None (nothing is recorded) or a dict that
+# collects thread-seconds per stage -- "decode" (file -> RGB array), "to_pinned" (the one copy into page-locked memory;
+# no channel swap), "device_wait" (the writer side waiting for an image's download), "encode" (array -> PNG / JPEG
+# bytes), "write" (bytes -> file).
+stage_seconds = None
+_stage_lock = __import__("threading").Lock()
 
-        with Image.open(str(path)) as im:
-            im = ImageOps.exif_transpose(im)
-            if im.mode in ("I;16", "I;16B", "I;16L", "I"):
-                arr = (np.asarray(im, dtype=np.uint32) >> 8).astype(np.uint8)
-                rgb = np.stack([arr, arr, arr], axis=-1)
-            else:
-                rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
-        return _to_bgr(rgb)
+
+def _stage(name, t0):
+    if stage_seconds is not None:
+        dt = __import__("time").perf_counter() - t0
+        with _stage_lock:
+            stage_seconds[name] = stage_seconds.get(name, 0.0) + dt
+
+
+def _now():
+    return __import__("time").perf_counter() if stage_seconds is not None else 0.0
+
+
+def _decode_rgb(path):
+    """Decode an image file to an RGB HxWx3 uint8 array view (Pillow's memory); raises on any failure."""
+    from PIL import Image, ImageOps
+
+    t0 = _now()
+    with Image.open(str(path)) as im:
+        im = ImageOps.exif_transpose(im)
+        if im.mode in ("I;16", "I;16B", "I;16L", "I"):
+            arr = (np.asarray(im, dtype=np.uint32) >> 8).astype(np.uint8)
+            out = np.stack([arr, arr, arr], axis=-1)
+        else:
+            out = np.asarray(im.convert("RGB"), dtype=np.uint8)
+    _stage("decode", t0)
+    return out
+
+
+def _to_pinned(arr):
+    """A contiguous copy of `arr` (any channel order / strides) in page-locked memory, from which the upload is one
+    DMA; ordinary memory when no device / P2P_PINNED=0 (the compute call reports that)."""
+    t0 = _now()
+    try:
+        if _PINNED:
+            try:
+                dst = _native.pinned_empty(arr.shape)
+                dst[...] = arr
+                return dst
+            except (_native.P2PError, OSError, MemoryError):
+                pass
+        return np.ascontiguousarray(arr)
+    finally:
+        _stage("to_pinned", t0)
+
+
+def _imread_rgb(path):
+    """What the file-to-file path decodes with: HxWx3 uint8 in Pillow's RGB order, page-locked, or None when the file
+    cannot be decoded (P:244-247).  The kernels do not care which channel is which and nobody else sees the array,
+    so no channel is swapped between the decoder and the encoder (cv2.imread's BGR is an artefact of cv2, P:243-244)."""
+    try:
+        return _to_pinned(_decode_rgb(path))
     except Exception:
         return None
 
 
-def _to_bgr(rgb):
-    """RGB -> BGR copy (the one copy decoding needs anyway) straight into page-locked memory, from which
-    the upload is one DMA; ordinary memory when no device / P2P_PINNED=0 (the compute call reports that)."""
-    if _PINNED:
-        try:
-            dst = _native.pinned_empty(rgb.shape)
-            dst[...] = rgb[:, :, ::-1]
-            return dst
-        except (_native.P2PError, OSError, MemoryError):
-            pass
-    return np.ascontiguousarray(rgb[:, :, ::-1])
+def _imread_bgr(path):
+    """cv2.imread(path) stand-in for callers that are handed the array: HxWx3 uint8 BGR, or None (P:244-247)."""
+    try:
+        return _to_pinned(_decode_rgb(path)[:, :, ::-1])
+    except Exception:
+        return None
+
+
+def _imwrite_rgb(path, image):
+    """Encode an RGB HxWx3 uint8 array as .png / .jpg / .jpeg (cv2.imwrite's defaults: JPEG quality 95)."""
+    import io
+
+    from PIL import Image
+
+    t0 = _now()
+    im = Image.fromarray(np.ascontiguousarray(image))
+    buf = io.BytesIO()
+    if Path(path).suffix.lower() in (".jpg", ".jpeg"):
+        im.save(buf, format="JPEG", quality=95)
+    else:
+        im.save(buf, format="PNG", compress_level=1)
+    _stage("encode", t0)
+    t0 = _now()
+    with open(str(path), "wb") as f:
+        f.write(buf.getbuffer())
+    _stage("write", t0)
+    return True
 
 
 def _imwrite_bgr(path, image):
-    """cv2.imwrite(path, image) stand-in for .png / .jpg / .jpeg (cv2 defaults: JPEG quality 95)."""
-    from PIL import Image
-
-    im = Image.fromarray(np.ascontiguousarray(image[:, :, ::-1]))
-    ext = Path(path).suffix.lower()
-    if ext in (".jpg", ".jpeg"):
-        im.save(str(path), format="JPEG", quality=95)
-    else:
-        im.save(str(path), format="PNG", compress_level=1)
-    return True
+    """cv2.imwrite(path, image) stand-in for arrays in cv2's BGR order."""
+    return _imwrite_rgb(path, image[:, :, ::-1])
 
 
 # throughput summary of a main() run (SURVEY section 5: keep the reference's log format, add one Mpix/s + GB/s line)
@@ -220,7 +330,7 @@ def _write_yaw(views_y, yaw_angle, pitch_angles, base_name, output_width, output
     for pi, pitch_angle in enumerate(pitch_angles):
         out_filename = f"{base_name}_{output_width}x{output_height}_yaw_{yaw_angle}_pitch_{pitch_angle}.{output_format}"
         output_file = output_dir / out_filename
-        _imwrite_bgr(output_file, views_y[pi])
+        _imwrite_rgb(output_file, views_y[pi])  # (the image was decoded to RGB and never swapped: _imread_rgb)
         logging.debug(f"Saved {output_file}")
 
 
@@ -240,7 +350,7 @@ def process_single_image(
     comes from ONE kernel launch and the `num_workers` threads encode / write the files, one task
     per yaw (the codecs release the GIL), which is where the time goes once the resampling is on the GPU."""
     logging.info(f"Loading image: {input_image_path}")
-    input_image = _imread_bgr(input_image_path)
+    input_image = _imread_rgb(input_image_path)
     if input_image is None:
         logging.error(f"Failed to read image: {input_image_path}")
         return
@@ -248,13 +358,22 @@ def process_single_image(
                            output_height, num_workers, output_format, fov_deg)
 
 
+def _mode_of(input_image, pitch_angles, output_width, output_height, fov_deg):
+    """(flags, maps) of the module's current mode for one image: maps = (U, V, key) in exact mode, else None."""
+    if _EXACT:
+        return 0, _exact_maps_for(input_image, pitch_angles, output_width, output_height, fov_deg)
+    return _PIXEL_PATHS[_QUALITY], None
+
+
 def _views_of(input_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg, device=None):
     """Every view of one image.  With several devices selected (set_devices) and this single image to draw, the
-    (yaw x pitch) views are cut, pitch-major, into one run per device; otherwise one device."""
+    image is shared out to them -- a band of rows of every view each, or runs of the view list (SURVEY 8(e));
+    otherwise one device."""
     if device is None and _DEVICES and len(_DEVICES) > 1:
+        flags, maps = _mode_of(input_image, pitch_angles, output_width, output_height, fov_deg)
         return _driver.process_views_sharded(input_image, [_angle(y, "yaw angle") for y in yaw_angles],
                                              [_angle(p, "pitch angle") for p in pitch_angles], output_width,
-                                             output_height, _angle(fov_deg, "FOV"), _DEVICES)
+                                             output_height, _angle(fov_deg, "FOV"), _DEVICES, flags=flags, maps=maps)
     if device is None:
         return process_views(input_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg)
     return process_views(input_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg, device=device)
@@ -269,7 +388,7 @@ class _SyncPipeline:
     def __init__(self, device=None):
         self.device = device
 
-    def submit(self, pano, yaws, pitches, fov, ow, oh):
+    def submit(self, pano, yaws, pitches, fov, ow, oh, flags=0, maps=None):
         if self.device is None:
             return process_views(pano, yaws, pitches, ow, oh, fov)
         return process_views(pano, yaws, pitches, ow, oh, fov, device=self.device)
@@ -296,7 +415,9 @@ def _submit_writes(executor, views, input_image_path, output_dir, yaw_angles, pi
         if isinstance(views, Exception):
             raise views
         if hasattr(views, "result"):
+            t0 = _now()
             views = views.result()
+            _stage("device_wait", t0)
     except Exception as e:  # the reference reports task failures per yaw and carries on (P:279-280)
         return [(yaw_angle, e) for yaw_angle in yaw_angles]
     return [(yaw_angle, executor.submit(_write_yaw, views[yi], yaw_angle, pitch_angles, base_name, output_width,
@@ -404,7 +525,7 @@ def main(
             try:
                 with ThreadPoolExecutor(max_workers=n_dec) as decoder, \
                         ThreadPoolExecutor(max_workers=max(1, int(num_workers or 1))) as writers:
-                    decoding = deque(decoder.submit(_imread_bgr, f) for f in image_files[:depth])
+                    decoding = deque(decoder.submit(_imread_rgb, f) for f in image_files[:depth])
                     on_device, writing = deque(), deque()
 
                     def retire(n_keep):
@@ -418,14 +539,16 @@ def main(
                     for k, image_file in enumerate(image_files):
                         decoded = decoding.popleft().result()
                         if k + depth < len(image_files):
-                            decoding.append(decoder.submit(_imread_bgr, image_files[k + depth]))
+                            decoding.append(decoder.submit(_imread_rgb, image_files[k + depth]))
                         logging.info(f"Loading image: {image_file}")
                         if decoded is None:
                             logging.error(f"Failed to read image: {image_file}")
                             continue
                         _count(src_bytes=int(decoded.nbytes))
                         try:
-                            ticket = pipe.submit(decoded, yaws, pitches, _angle(fov_deg, "FOV"), output_width, output_height)
+                            flags, maps = _mode_of(decoded, pitch_angles, output_width, output_height, fov_deg)
+                            ticket = pipe.submit(decoded, yaws, pitches, _angle(fov_deg, "FOV"), output_width, output_height,
+                                                 flags=flags, maps=maps)
                         except Exception as e:
                             ticket = e
                         on_device.append((ticket, image_file))
@@ -500,11 +623,21 @@ def build_arg_parser():
     p.add_argument("--device", type=int, default=None, help="HIP device index (default 0 or $P2P_DEVICE)")
     p.add_argument("--devices", type=int, nargs="+", default=None,
                    help="HIP devices a folder of images is dealt to round-robin (one host thread per device)")
+    p.add_argument("--exact", action="store_true",
+                   help="Identical-results mode: the pitch maps are evaluated on the host exactly as the reference does "
+                        "(NumPy float32, P:114-175) and every pixel is drawn from them on the GPU -- the reference's bytes "
+                        "on any panorama.  Default: maps on the device too (+-1 level on smooth images)")
+    p.add_argument("--quality", choices=sorted(_PIXEL_PATHS), default="u8",
+                   help="Pixel arithmetic: u8 = the reference's two fixed-point cv2.remap stages (default); f32 / f16 = one "
+                        "float resample per view with true wrap-around at the seam (not in the reference)")
     return p
 
 
 def cli(argv=None):
-    args = build_arg_parser().parse_args(argv)
+    parser = build_arg_parser()
+    args = parser.parse_args(argv)
+    if args.exact and args.quality != "u8":
+        parser.error("--exact is the reference's fixed-point arithmetic: it goes with --quality u8 only")
     # logging set-up as P:462-475 (the logs/ directory is created even without file logging)
     log_file_path = Path(__file__).resolve().parent.parent / "logs" / "app.log"
     log_file_path.parent.mkdir(parents=True, exist_ok=True)
@@ -515,6 +648,9 @@ def cli(argv=None):
     if args.device is not None:
         set_device(args.device)
     set_devices(args.devices)
+    set_exact(False)
+    set_quality(args.quality)
+    set_exact(args.exact)
     main(
         input_path=args.input_path,
         output_path=args.output_path,

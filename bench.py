@@ -140,6 +140,19 @@ def run_timed(step, device_sync, dist, steps, warmup):
     return dist.max_over_ranks(t1 - t0)
 
 
+def cpu_model():
+    """The host CPU's model name (the CPU baseline states core count AND model)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+
+    return platform.processor() or platform.machine() or "unknown"
+
+
 # ------------------------------------------------------------------------------------------------
 def cpu_baseline(w, budget_s=12.0):
     """The oracle (CPU restatement of P:181-221 + cv2.remap arithmetic) on a bounded sample of the same
@@ -177,6 +190,7 @@ def cpu_baseline(w, budget_s=12.0):
     dtn = time.perf_counter() - t0
     return {
         "value": len(yaws) * per_yaw / dtn / 1e6, "unit": "Mpix/s", "cores": threads, "kind": "port",
+        "cpu_model": cpu_model(), "host_cores": cores,
         "value_1core": one,
         "sample": "threaded: %d yaws x %d pitches on %d threads in %.1f s; single thread: %d of %d yaws in %.1f s; "
                   "map building included; host has %d cores" % (len(yaws), len(w["pitches"]), threads, dtn, done,
@@ -318,6 +332,56 @@ def host_to_host_lines(pkg, nat, drv, pano8k, device):
     return out
 
 
+def exact_route_line(pkg, nat, w, pano, device):
+    """The identical-results route (--exact) on the metric's configuration: what its FIRST image pays on top of the default
+    route -- the pitch maps evaluated on the host as the reference evaluates them (P:114-175), their upload, the plan made
+    from them -- and what a launch costs in the steady state, where nothing but the kernels run (the maps stay with the
+    job as they stay in the reference's pitch_mapping_cache, P:18)."""
+    import numpy as np
+
+    em = importlib.import_module(PKG + "._exact_maps")
+    em.clear()
+    t0 = time.perf_counter()
+    U, V, key = em.pitch_map_stack(w["ow"], w["oh"], w["pitches"], w["pw"], w["ph"], w["fov"])
+    host_maps_ms = (time.perf_counter() - t0) * 1e3
+    ctx = nat.Context(device)
+    try:
+        job = nat.Job(ctx, w["pw"], w["ph"], 1, w["yaws"], w["pitches"], w["fov"], w["ow"], w["oh"])
+        job.set_pano(0, pano)
+        t0 = time.perf_counter()
+        job.set_maps(None, U, V)
+        upload_ms = (time.perf_counter() - t0) * 1e3
+        ctx.mark(0)
+        job.run()
+        ctx.mark(1)
+        first_run_ms = ctx.marked_ms()
+        plan_ms, tables_ms = job.plan_ms()
+        for _ in range(50):
+            job.run()
+        n = 400
+        ctx.mark(0)
+        for _ in range(n):
+            job.run()
+        ctx.mark(1)
+        steady_us = ctx.marked_ms() / n * 1e3
+        info = job.info()
+        job.close()
+    finally:
+        ctx.close()
+        em.clear()
+    b_alg = algorithmic_bytes(w, 1)
+    return {"workload": w["name"] + ", --exact: pitch maps evaluated on the host (NumPy, the reference's float32 flow), pixels on the GPU",
+            "host_maps_ms": host_maps_ms, "maps_upload_ms": upload_ms, "maps_bytes": int(U.nbytes + V.nbytes),
+            "first_run_ms": first_run_ms, "plan_ms": plan_ms, "yaw_tables_ms": tables_ms,
+            "first_image_ms": host_maps_ms + upload_ms + tables_ms + first_run_ms,
+            "steady_state_us_per_launch": steady_us, "frac_of_hbm_peak": b_alg / (steady_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "n_gather_tiles": info["n_gather_tiles"],
+            "how": "fresh context; host_maps_ms = wall time of _exact_maps.pitch_map_stack for the %d pitch maps; maps_upload_ms = "
+                   "wall time of p2p_job_set_maps (pageable float32 arrays); first_run_ms / steady state = HIP events on the job's "
+                   "stream; the reference pays its own map builders on its first image (0.27 s per pitch map at 1080p, SURVEY 3.5)"
+                   % len(w["pitches"])}
+
+
 def cold_first_image(nat, w, pano, device):
     """What ONE image through a context that has not seen its geometry pays on the device, next to the steady state
     the headline quotes: yaw tables + plan pass + view kernel (the reference's first image pays its map builders,
@@ -407,14 +471,21 @@ def measure_counters(args):
                                env=clean_child_env(tmp))
             except (OSError, subprocess.SubprocessError):
                 continue
-            acc = {}
+            acc, dur = {}, {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
                         if kernel in row.get("Kernel_Name", ""):
                             acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+                            try:  # (one row per counter and dispatch: the dispatch's own duration, once)
+                                dur[row.get("Dispatch_Id")] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                            except (KeyError, TypeError, ValueError):
+                                pass
             for k, v in acc.items():
                 vals[k] = sum(v) / len(v)
+            good = [x for x in dur.values() if x > 0]
+            if good and "SQ_BUSY_CU_CYCLES" in acc:  # the SQ pass: the clock this kernel held while it was counted
+                vals["_sq_pass_kernel_ns"] = sum(good) / len(good)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return vals or None
@@ -701,6 +772,23 @@ def main():
                 "note": "secondary ceilings: the exact two-stage fixed-point emulation keeps the VALU issue ports about "
                         "0.8 busy and moves traffic_rate_GBs through the L2 fabric at the same time (a plain copy "
                         "reaches measured_copy_GBs): co-limited, DESIGN.md 5.2"}
+    # The kernel's own issue floor: its vector instructions, all issued at one wave-instruction per
+    # 4 cycles and SIMD, on the 1024 SIMDs, at the clock the kernel itself holds -- SQ_BUSY_CU_CYCLES (summed over the 256
+    # CUs) over the duration of the counted dispatches; without those timestamps, over this run's mean launch duration.
+    issue = None
+    if counters and counters.get("SQ_INSTS_VALU") and counters.get("SQ_BUSY_CU_CYCLES"):
+        n_cu, n_simd = 256, 1024
+        dur_s = counters["_sq_pass_kernel_ns"] * 1e-9 if counters.get("_sq_pass_kernel_ns") else k_avg_s
+        clock_hz = counters["SQ_BUSY_CU_CYCLES"] / n_cu / dur_s
+        if clock_hz > 0:
+            floor_us = counters["SQ_INSTS_VALU"] * 4.0 / n_simd / clock_hz * 1e6
+            issue = {"issue_floor_us": floor_us, "frac_of_issue_floor": floor_us / (k_avg_s * 1e6),
+                     "clock_ghz_from_busy_cu_cycles": clock_hz / 1e9,
+                     "clock_from": "SQ_BUSY_CU_CYCLES / 256 CUs / " + ("the counted dispatches' own duration (%.1f us under the profiler)"
+                                   % (dur_s * 1e6) if counters.get("_sq_pass_kernel_ns") else "this run's mean launch duration"),
+                     "how": "SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / that clock; frac_of_issue_floor = issue_floor_us / kernel_ms_avg: "
+                            "how much of a launch is vector-instruction issue at a perfect schedule",
+                     "target_0p70_us": b_alg / (0.70 * HBM_PEAK_GBS * 1e9) * 1e6}
     out = {
         "metric": "Mpix/s remapped, 8K equirect->1080p x36 views" if args.workload == "cfg2"
                   else "Mpix/s remapped (%s)" % args.workload,
@@ -718,7 +806,10 @@ def main():
                      "algorithmic_bytes_per_launch": b_alg,
                      "traffic_rate_GBs": (traffic / k_avg_s / 1e9) if (traffic and k_avg_s) else None,
                      "measured_copy_GBs": copy_gbs,
-                     "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None},
+                     "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,
+                     "issue_floor_us": issue["issue_floor_us"] if issue else None,
+                     "frac_of_issue_floor": issue["frac_of_issue_floor"] if issue else None,
+                     "issue_floor": issue},
         "preroll_s": preroll_s, "preroll_launches": preroll_launches,
         "sclk_mhz": {"before_preroll": sclk_before, "after_timed_region": sclk_after},
     }
@@ -727,6 +818,10 @@ def main():
         pano8k = synth.synth_pano(8192, 4096, 1000, args.kind)
         out["cold"] = cold_first_image(nat, w, pano8k, dist.local_rank)
         out["secondary"] = secondary_lines(nat, ctx, pano8k, dist.local_rank)
+        try:
+            out["secondary"]["exact_route"] = exact_route_line(pkg, nat, w, pano8k, dist.local_rank)
+        except Exception as e:  # a secondary line never takes the headline down
+            out["secondary"]["exact_route"] = {"error": repr(e)}
         # the host-buffer lines come from a process of their own, run before this one touched the GPU (h2h below): in
         # THIS process -- torch initialised, a dozen streams created and destroyed by now -- the pipeline's three
         # streams no longer overlap (9.3 ms per image against 4.5: the runtime maps streams onto a handful of

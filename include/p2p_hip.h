@@ -113,6 +113,23 @@ int p2p_remap_views_maps_u8(const uint8_t* pano, int pw, int ph, int64_t row_str
                             int ow, int oh, uint8_t* out, int device);
 
 /*
+ * The tool's --exact route: the yaw tables are built on the device from yaw_deg (P:79-108 uses IEEE operations only:
+ * bit-exact), the PITCH maps are the caller's -- what get_pitch_mapping() (P:55-73) returns on the caller's host,
+ * libm's and BLAS's last bits included -- and every pixel is drawn from them by the fixed-point kernels: the
+ * reference's bytes, also on noise panoramas.
+ *   U, V     : [n_pitch][oh][ow] float32
+ *   maps_key : the caller's name for exactly these maps -- the reference's pitch_mapping_cache keys them by
+ *              (output_width, output_height, pitch_angle, pano_width, pano_height, fov_deg) (P:62) and keeps them for
+ *              the life of the process; a one-shot slot that already holds maps of this name keeps their device copy
+ *              and the plan made from them (a later call with the same key uploads the panorama only).  0: no name,
+ *              the maps are uploaded and planned on every call.  Two different sets of maps must never share a key.
+ */
+int p2p_remap_views_pitch_maps_f64(const uint8_t* pano, int pw, int ph, int64_t row_stride,
+                                   const double* yaw_deg, int n_yaw,
+                                   const float* U, const float* V, int n_pitch, uint64_t maps_key,
+                                   int ow, int oh, uint8_t* out, int device);
+
+/*
  * Replaces panorama_to_plane(pano_array, U, V) (L:182-194) == cv2.remap(src, U, V,
  * INTER_LINEAR, borderMode) (L:179 uses BORDER_REFLECT; P:192-199/212-218 use BORDER_CONSTANT
  * with borderValue 0).  src: uint8 [sh][sw][cn], cn in {1,3,4}; U,V: float32 [oh][ow];

@@ -67,11 +67,13 @@ def test_product_never_imports_the_oracle():
 
 def test_signatures_match_the_reference(pkg):
     m = pkg.panorama_to_plane_pitch
-    def params(f):
-        return [(p.name, p.default) for p in inspect.signature(f).parameters.values()]
+    def params(f):  # what a positional / keyword caller of the reference sees (keyword-ONLY additions are checked apart)
+        return [(p.name, p.default) for p in inspect.signature(f).parameters.values() if p.kind != p.KEYWORD_ONLY]
     E = inspect.Parameter.empty
     assert params(m.process_yaw_and_pitchs) == [("pano_image", E), ("yaw_angle", E), ("pitch_angles", E),
                                                 ("output_width", E), ("output_height", E), ("fov_deg", 90)]
+    kw_only = [(p.name, p.default) for p in inspect.signature(m.process_yaw_and_pitchs).parameters.values() if p.kind == p.KEYWORD_ONLY]
+    assert kw_only == [("exact", None)]  # additive: the identical-results mode (None = set_exact()'s choice, off by default)
     assert params(m.get_yaw_mapping) == [("pano_width", E), ("pano_height", E), ("yaw_angle", E)]
     assert params(m.get_pitch_mapping) == [("output_width", E), ("output_height", E), ("pitch_angle", E),
                                            ("pano_width", E), ("pano_height", E), ("fov_deg", 90)]
@@ -117,6 +119,15 @@ def test_cli_surface_and_defaults(pkg):
         p.parse_args("--input_path x --output_format bmp".split())
     with pytest.raises(SystemExit):
         p.parse_args([])  # --input_path is required
+    # additive flags: off / the reference's arithmetic by default
+    assert a.exact is False and a.quality == "u8"
+    a = p.parse_args("--input_path x --exact".split())
+    assert a.exact is True
+    assert p.parse_args("--input_path x --quality f16".split()).quality == "f16"
+    with pytest.raises(SystemExit):
+        p.parse_args("--input_path x --quality f64".split())
+    with pytest.raises(SystemExit):
+        pkg.panorama_to_plane_pitch.cli("--input_path x --exact --quality f32".split())
 
 
 def test_file_naming_and_error_swallowing(pkg, tmp_path, monkeypatch, caplog):
@@ -132,7 +143,7 @@ def test_file_naming_and_error_swallowing(pkg, tmp_path, monkeypatch, caplog):
 
     def fake_views(pano, yaws, pitches, ow, oh, fov=90):
         calls.append((pano.shape, tuple(yaws), tuple(pitches), ow, oh, fov))
-        assert pano[0, 0].tolist() == [30, 20, 10]  # BGR at the API boundary, like cv2.imread
+        assert pano[0, 0].tolist() == [10, 20, 30]  # file to file nothing swaps channels: the decoder's RGB goes to the encoder as is
         return np.zeros((len(yaws), len(pitches), oh, ow, 3), np.uint8)
 
     monkeypatch.setattr(m, "process_views", fake_views)
