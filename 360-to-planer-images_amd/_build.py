@@ -9,15 +9,19 @@ OUT = os.path.join(HERE, "libp2p_hip.so")
 # the plan pass and the view kernels are built once per tile shape (csrc/p2p_device.h: tile shapes): the *_w128.hip and
 # *_band.hip files include their namesakes with the other shapes' constants
 SOURCES = [os.path.join(CSRC, f) for f in ("p2p_views.hip", "p2p_plan.hip", "p2p_float.hip", "p2p_views_w128.hip", "p2p_plan_w128.hip",
-                                            "p2p_float_w128.hip", "p2p_views_band.hip", "p2p_plan_band.hip", "p2p_maps.hip", "p2p_remap.hip",
-                                            "p2p_host.cpp")]
+                                            "p2p_float_w128.hip", "p2p_views_band.hip", "p2p_plan_band.hip", "p2p_maps.hip", "p2p_remap.hip")]
+# the host side (csrc/p2p_host.h lists the units): the C ABI's entry points + exception barrier, then what they call
+HOST_SOURCES = [os.path.join(CSRC, f) for f in ("p2p_abi.cpp", "p2p_host_pool.cpp", "p2p_host_ctx.cpp", "p2p_host_plan.cpp",
+                                                 "p2p_host_job.cpp", "p2p_host_oneshot.cpp")]
+SOURCES += HOST_SOURCES
 DEPS = SOURCES + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
     [os.path.join(HERE, "..", "include", "p2p_hip.h")]
 # -ffp-contract=off: the coordinate maths must round exactly where NumPy rounds (no fused a*b+c
 # unless written as fmaf).  IEEE divide / sqrt are hipcc's default for fp32.
 # -amdgpu-atomic-optimizer-strategy=DPP: the default (iterative) strategy turns every LDS atomicMin/Max
 # of the footprint reduction into a 64-iteration scalar loop; DPP makes it a 6-step wave reduction.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-Wall",
+# -fvisibility=hidden: the dynamic symbol table holds the C ABI (P2P_EXPORT in p2p_abi.cpp) and nothing else.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-Wall", "-fvisibility=hidden",
          "-mllvm", "-amdgpu-atomic-optimizer-strategy=DPP"]
 
 

@@ -1,5 +1,5 @@
 // p2p_device.h -- structures and launchers shared by the device code (p2p_views / p2p_maps / p2p_remap / p2p_float .hip) and the
-// host side of the C ABI (p2p_host.cpp).  Not part of the public ABI (that is include/p2p_hip.h).
+// host side of the C ABI (p2p_host.h: p2p_abi.cpp + p2p_host_*.cpp).  Not part of the public ABI (that is include/p2p_hip.h).
 #ifndef P2P_DEVICE_H
 #define P2P_DEVICE_H
 
@@ -124,7 +124,7 @@ struct ViewsParams {
     const uint32_t* f4tab;   // [n_yaw][pw] weights of columns c..c+3 (mod pw), one byte each
     int n_yaw, n_pitch, n_panos;
     int pairs_per_block;     // (panorama, yaw) pairs looped over by one workgroup
-    const uint32_t* main_list;  // main kernel: [8][main_stride] the LDS-scheme tiles dealt to the XCDs in source order (p2p_host.cpp:
+    const uint32_t* main_list;  // main kernel: [8][main_stride] the LDS-scheme tiles dealt to the XCDs in source order (p2p_host_plan.cpp:
     int main_stride;            // xcd_main_lists), ~0 = none; nullptr: the grid's own (tile, chunk, pitch view) order
     int main_group, main_chunks;  // list entries an XCD draws for one chunk of pairs before it turns to the next chunk; chunks of pairs
                                   // (main_chunks counts workgroups per tile: chunks of pairs / main_span, rounded up)
@@ -158,7 +158,7 @@ struct ViewsParams {
     const uint32_t* gather_list;  // the plan's mode-2 tiles (pitch * tiles + tile), in no particular order, and how many
     int n_gather;
     int gather_ppb;          // (panorama, yaw) pairs per workgroup of the gather / table kernels
-    int n_list;              // gather kernel: gather_list is [8][n_list], one work list per XCD, ~0 = no tile (p2p_host.cpp: xcd_lists)
+    int n_list;              // gather kernel: gather_list is [8][n_list], one work list per XCD, ~0 = no tile (p2p_host_plan.cpp: xcd_lists)
     int gather_all;          // 1: the gather kernel draws EVERY tile (few of the job's tiles fit the LDS scheme: one launch less)
     // sparse view sets (p2p_job_set_view_mask; the view-sharded multi-GPU path: a rank's 4-5 views of one image in ONE
     // launch): bit (yaw & 31) of word [pitch][yaw >> 5] = the view is drawn; nullptr: all of them.  A view that is not
@@ -239,7 +239,7 @@ hipError_t launch_cubic_tab(short* tab, hipStream_t st);
 //   w128  128 x 16 pixels per workgroup of 512 threads, 1408 items: a wave's store covers whole 128-byte lines (2 rows x
 //         384 bytes instead of 4 x 192), which is what counts when tens of gigabytes of views stream to HBM
 //         (config 4: 6.5 ms against 7.2; config 2 loses 12 %, the CLI's default set 25 %).
-// The host picks a shape per job (p2p_host.cpp: choose_shape) and calls through ShapeOps.
+// The host picks a shape per job (p2p_host_plan.cpp: choose_shape) and calls through ShapeOps.
 struct TileShape {
     int tile_w, tile_h, block, pxt, cap;  // TILE_W, TILE_H, VIEWS_BLOCK, VIEWS_PXT, LDS_ITEMS_CAP of the shape
 };

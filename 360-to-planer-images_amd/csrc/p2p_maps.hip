@@ -245,7 +245,7 @@ __global__ void compact_rows_kernel(uint32_t* __restrict__ dst, const uint8_t* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// launchers (called from p2p_host.cpp through p2p_device.h)
+// launchers (called from the p2p_host_*.cpp units through p2p_device.h)
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_compact_rows(void* dst, const uint8_t* src, size_t n_bytes, int row_bytes, int src_row, hipStream_t st)
 {

@@ -1440,7 +1440,7 @@ __device__ __forceinline__ void draw_rest(
 // pass) is clamped
 // XCD_LISTS (the gather kernel): the list is [8][P.n_list], one work list per XCD, grouped by the tiles' position in
 // the SOURCE so that tiles of different pitch views that read the same part of the panorama meet in one L2
-// (p2p_host.cpp: xcd_lists); gridDim.x == 8 * n_list, ~0 = no tile (returns false).
+// (p2p_host_plan.cpp: xcd_lists); gridDim.x == 8 * n_list, ~0 = no tile (returns false).
 template <bool XCD_LISTS>
 __device__ __forceinline__ bool tile_of_list(const ViewsParams& P, const uint32_t* __restrict__ list, uint32_t site, int& pitch_i, int& tile_id,
                                              uint32_t bx = blockIdx.x, int n_list = -1)
@@ -1538,7 +1538,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views
     int tile_id, pitch_i, chunk, ppb = 0;
     if (P.main_list && P.main_tail > 0) {
         // List order, ONE chunk of pairs, no prefetch workgroups (the host's rule): entry q of the XCD's list -- but its
-        // last main_tail entries are drawn by main_tail_parts workgroups each, a part of the pairs each (p2p_host.cpp: main_tail).
+        // last main_tail entries are drawn by main_tail_parts workgroups each, a part of the pairs each (p2p_host_job.cpp: main_tail).
         const uint32_t q = bx >> 3, L = (uint32_t)P.main_count[bx & 7u];
         const uint32_t K = (uint32_t)P.main_tail < L ? (uint32_t)P.main_tail : L;
         uint32_t e = q;
@@ -1561,7 +1561,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views
         pitch_i = (int)(slot / (uint32_t)tiles);
         tile_id = (int)(slot - (uint32_t)pitch_i * (uint32_t)tiles);
     } else if (P.main_list) {
-        // List order (p2p_host.cpp: xcd_main_lists): workgroup b runs on XCD b & 7 and is that XCD's q-th, q = b >> 3.
+        // List order (p2p_host_plan.cpp: xcd_main_lists): workgroup b runs on XCD b & 7 and is that XCD's q-th, q = b >> 3.
         // The XCD draws main_group entries of its list for one chunk of pairs, the same entries for the next chunk
         // (their plan tables and source rows are still in its L2), and so on, then the next main_group entries.
         // With pf_lead > 0 (plan tables beyond the Infinity Cache: config 4) one more workgroup per block, dispatched

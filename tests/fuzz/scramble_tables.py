@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Robustness self-test: the view kernels on plan tables (and, every other case, yaw tables) that have been
-overwritten with pseudo-random words (P2P_SCRAMBLE_PLAN, csrc/p2p_host.cpp).  They must draw garbage and nothing
+overwritten with pseudo-random words (P2P_SCRAMBLE_PLAN, csrc/p2p_host_plan.cpp).  They must draw garbage and nothing
 worse: no GPU fault, no hang, the process goes on and a clean job afterwards is byte-exact.  Covers the main, gather,
 rest and table kernels (plain and flickering yaws, caller rows that are not a shift, poles, minifying views, odd
 widths, the legacy tool's border modes, the float pixel path).  Run by hand on the GPU box (a hole in the range checks

@@ -1,5 +1,5 @@
 // Host-only stand-in for <hip/hip_runtime.h>, for tests/test_sanitizers.py ONLY: it lets the host side of the C ABI
-// (360-to-planer-images_amd/csrc/p2p_host.cpp: argument checking, job / plan / cache state, stream and event
+// (360-to-planer-images_amd/csrc/p2p_host_*.cpp: argument checking, job / plan / cache state, stream and event
 // bookkeeping) be compiled with g++ -fsanitize=address,undefined and driven without a GPU.  "Device" memory is host
 // memory, copies are memcpy, streams and events are counters; the kernels themselves are not part of this build
 // (tests/sanitize/launch_stubs.cpp).  GPU AddressSanitizer is not available on the target pool, so this is how

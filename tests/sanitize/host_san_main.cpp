@@ -1,12 +1,38 @@
 // Drives the C ABI of include/p2p_hip.h through valid and invalid call sequences in the host-only build
 // (stub HIP runtime, stub launchers) under -fsanitize=address,undefined: every host-side allocation, copy size,
-// index computation and teardown path of 360-to-planer-images_amd/csrc/p2p_host.cpp, from several threads.
+// index computation and teardown path of 360-to-planer-images_amd/csrc/p2p_abi.cpp + p2p_host_*.cpp, from several threads.
 #include "p2p_hip.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <new>
 #include <thread>
 #include <vector>
+
+// ---- an operator new that fails on request (the exception barrier of the C ABI) ----
+// While a thread has armed it, the N-th allocation that thread makes throws std::bad_alloc -- inside whatever
+// std::vector / std::map / std::shared_ptr / std::function of the library (or of the stand-in launchers) asked for it.
+static thread_local long g_fail_at = -1, g_news = 0;
+static thread_local bool g_in_library = false;   // (the harness's own buffers are not the library's allocations)
+static void* counted_alloc(size_t n)
+{
+    if (g_in_library && g_fail_at >= 0 && ++g_news == g_fail_at)
+        throw std::bad_alloc();
+    void* p = malloc(n ? n : 1);
+    if (!p)
+        throw std::bad_alloc();
+    return p;
+}
+void* operator new(size_t n) { return counted_alloc(n); }
+void* operator new[](size_t n) { return counted_alloc(n); }
+void* operator new(size_t n, const std::nothrow_t&) noexcept { try { return counted_alloc(n); } catch (...) { return nullptr; } }
+void* operator new[](size_t n, const std::nothrow_t&) noexcept { try { return counted_alloc(n); } catch (...) { return nullptr; } }
+void operator delete(void* p, const std::nothrow_t&) noexcept { free(p); }
+void operator delete[](void* p, const std::nothrow_t&) noexcept { free(p); }
+void operator delete(void* p) noexcept { free(p); }
+void operator delete[](void* p) noexcept { free(p); }
+void operator delete(void* p, size_t) noexcept { free(p); }
+void operator delete[](void* p, size_t) noexcept { free(p); }
 
 extern "C" int p2p_stub_device_count;
 extern "C" long p2p_stub_live(int what);  // 0: events, 1: streams the library holds right now
@@ -41,9 +67,106 @@ static void one_shot_calls(int seed)
     CHECK(p2p_build_yaw_row(pw, 0.5, row.data(), 0) == P2P_OK);
 }
 
+// One job's life through the resident API; returns at the first call that fails (its status in *rc) after tearing down
+// what exists.  Every status must be P2P_OK or -- with an allocation failure armed -- P2P_ERR_OOM / P2P_ERR_HIP with a
+// message; nothing may abort, leak or leave the library unusable.
+static bool job_life(bool band, int* rc_out)
+{
+    const int pw = 64, ph = 32, ow = 70, oh = 33;
+    std::vector<uint8_t> pano((size_t)pw * ph * 3, 5), views((size_t)2 * 2 * oh * ow * 3), one((size_t)oh * ow * 3);
+    std::vector<float> U((size_t)2 * oh * ow, 3.0f), V((size_t)2 * oh * ow, 4.0f);
+    const int32_t yaws[2] = {0, 90}, pitches[2] = {60, 120};
+    const uint8_t mask[4] = {1, 0, 0, 1};
+    p2p_ctx* ctx = nullptr;
+    p2p_job* job = nullptr;
+    p2p_job_desc d = {pw, ph, 1, 2, yaws, 2, pitches, 90, ow, oh, P2P_FLAG_DEFAULT};
+    g_in_library = true;
+    int rc = p2p_ctx_create(0, &ctx);
+    if (rc == P2P_OK) rc = p2p_job_create(ctx, &d, &job);
+    if (rc == P2P_OK) rc = p2p_job_set_pano(job, 0, pano.data(), 3 * pw);
+    if (rc == P2P_OK) rc = p2p_job_run(job);          // the plan (a band plan with its two-stage build when `band`)
+    if (rc == P2P_OK) rc = p2p_job_run(job);          // the deferred per-XCD lists, the pair-context table
+    if (rc == P2P_OK) rc = p2p_job_get_views(job, 0, views.data());
+    if (rc == P2P_OK) rc = p2p_job_set_view_mask(job, mask);
+    if (rc == P2P_OK) rc = p2p_job_run(job);
+    if (rc == P2P_OK) rc = p2p_job_get_view(job, 0, 1, 1, one.data());
+    if (rc == P2P_OK) rc = p2p_job_set_view_mask(job, nullptr);
+    if (rc == P2P_OK && !band) rc = p2p_job_set_maps(job, nullptr, U.data(), V.data());   // a private plan from caller maps
+    if (rc == P2P_OK) rc = p2p_job_run(job);
+    if (rc == P2P_OK) rc = p2p_job_time_launches(job, 4);
+    if (rc == P2P_OK) rc = p2p_job_run(job);
+    if (rc == P2P_OK) rc = p2p_job_get_views_async(job, 0, views.data());
+    if (rc == P2P_OK) rc = p2p_job_wait(job);
+    g_in_library = false;
+    if (rc != P2P_OK && !*p2p_last_error()) { fprintf(stderr, "a failing call left no message\n"); exit(1); }
+    g_in_library = true;
+    p2p_job_destroy(job);
+    p2p_ctx_destroy(ctx);
+    g_in_library = false;
+    *rc_out = rc;
+    return rc == P2P_OK;
+}
+
+static bool oneshot_life(int* rc_out)
+{
+    const int pw = 68, ph = 32, ow = 70, oh = 33;
+    std::vector<uint8_t> pano((size_t)pw * ph * 3, 5), out((size_t)2 * 2 * oh * ow * 3), dst((size_t)ow * oh * 4);
+    std::vector<float> U((size_t)2 * oh * ow, 3.0f), V((size_t)2 * oh * ow, 4.0f);
+    const int32_t yaws[2] = {0, 90}, pitches[2] = {60, 120};
+    const double yd[2] = {10.0, 20.0};
+    g_in_library = true;
+    int rc = p2p_remap_views_u8(pano.data(), pw, ph, 3 * pw, yaws, 2, pitches, 2, 90, ow, oh, out.data(), 0, 0);
+    if (rc == P2P_OK) rc = p2p_remap_views_pitch_maps_f64(pano.data(), pw, ph, 3 * pw, yd, 2, U.data(), V.data(), 2, 77, ow, oh, out.data(), 0);
+    if (rc == P2P_OK) rc = p2p_remap_views_pitch_maps_f64(pano.data(), pw, ph, 3 * pw, yd, 2, U.data(), V.data(), 2, 77, ow, oh, out.data(), 0);
+    if (rc == P2P_OK) rc = p2p_remap_maps_interp_u8(pano.data(), pw, ph, 3 * pw, 3, U.data(), V.data(), ow, oh, dst.data(), P2P_INTER_CUBIC, P2P_BORDER_WRAP, nullptr, 0);
+    if (rc == P2P_OK) rc = p2p_build_yaw_row(pw, 0.3, U.data(), 0);
+    g_in_library = false;
+    if (rc != P2P_OK && !*p2p_last_error()) { fprintf(stderr, "a failing call left no message\n"); exit(1); }
+    *rc_out = rc;
+    return rc == P2P_OK;
+}
+
+// Sweep: fail the N-th allocation of a job's life for N = 1, 2, ... until a run makes fewer than N allocations.  After every
+// failed run the same life must succeed with nothing armed (the library is still usable, its pools and caches consistent).
+template <class F>
+static void alloc_failure_sweep(const char* what, F life)
+{
+    int rc = 0, failed = 0, oom = 0;
+    CHECK(life(&rc));   // warm: the process-wide pools exist (they are never torn down and would read as leaks of run N)
+    long n = 1;
+    for (;; ++n) {
+        g_news = 0;
+        g_fail_at = n;
+        const bool ok = life(&rc);
+        const bool triggered = g_news >= n;
+        g_fail_at = -1;
+        if (!ok) {
+            ++failed;
+            oom += rc == P2P_ERR_OOM;
+            CHECK(rc == P2P_ERR_OOM || rc == P2P_ERR_HIP);
+            CHECK(life(&rc));   // ... and the library carries on (P:279-280: an error is logged, the pool lives)
+        }
+        if (!triggered)
+            break;
+        CHECK(n < 100000);
+    }
+    CHECK(p2p_release_cache() == P2P_OK);
+    printf("allocation-failure sweep, %s: %ld allocations per life, %d lives failed (%d with P2P_ERR_OOM), every one recovered\n", what, n - 1, failed, oom);
+    fflush(stdout);
+}
+
 int main()
 {
     CHECK(p2p_device_count() == 1);
+    if (!getenv("P2P_SAN_NO_SWEEP")) {
+        alloc_failure_sweep("resident job, per-view plan", [](int* rc) { return job_life(false, rc); });
+        setenv("P2P_BAND", "1", 1);
+        CHECK(p2p_reload_options() == P2P_OK);
+        alloc_failure_sweep("resident job, band plan", [](int* rc) { return job_life(true, rc); });
+        unsetenv("P2P_BAND");
+        CHECK(p2p_reload_options() == P2P_OK);
+        alloc_failure_sweep("one-shot entry points", oneshot_life);
+    }
     // ---- argument errors: every one must come back as a status, nothing may be touched ----
     uint8_t px[48] = {0};
     const int32_t y0[1] = {0}, p_bad[1] = {0}, p_ok[1] = {90};

@@ -1,4 +1,4 @@
-"""GPU parity of the work lists (csrc/p2p_host.cpp: xcd_main_lists, xcd_lists): which XCD draws which tile, and when,
+"""GPU parity of the work lists (csrc/p2p_host_plan.cpp: xcd_main_lists, xcd_lists): which XCD draws which tile, and when,
 must not change a byte.  Every combination of main-kernel order (grid / list / list for several panoramas), turn length
 per chunk of pairs, table-prefetch workgroups and gather-tile order is checked against the CPU restatement of the
 reference's two cv2.remap stages (P:181-221) on a job that has LDS-scheme tiles, gather tiles (a pole in view),

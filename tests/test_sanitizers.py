@@ -1,7 +1,8 @@
 """the CPU-side code under AddressSanitizer + UndefinedBehaviorSanitizer (GPU ASan is not available
 on the target pool, and is not what is asked for).  Two host-only builds, made and run here with gcc:
-  * the host side of the C ABI (360-to-planer-images_amd/csrc/p2p_host.cpp) against a stand-in HIP runtime and
-    stand-in launchers (tests/sanitize/), driven through valid and invalid call sequences from 12 threads;
+  * the host side of the C ABI (360-to-planer-images_amd/csrc/p2p_abi.cpp + p2p_host_*.cpp) against a stand-in HIP runtime and
+    stand-in launchers (tests/sanitize/), driven through valid and invalid call sequences from 12 threads, and with
+    a host allocation failure injected at every allocation of a job's life (the C ABI's exception barrier);
   * oracle/cv_remap_oracle.c on maps full of NaN / infinities / out-of-range values.
 Any sanitizer report fails the test."""
 import os
@@ -13,6 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SAN = os.path.join(ROOT, "tests", "sanitize")
 FLAGS = ["-g", "-O1", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+HOST_UNITS = ("p2p_abi.cpp", "p2p_host_pool.cpp", "p2p_host_ctx.cpp", "p2p_host_plan.cpp", "p2p_host_job.cpp", "p2p_host_oneshot.cpp")
 ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
 
 
@@ -30,12 +32,19 @@ def test_host_shim_under_asan_ubsan(tmp_path):
     subprocess.check_call(["g++", "-std=c++17"] + FLAGS + [
         "-I", os.path.join(SAN, "hip_stub"), "-I", os.path.join(ROOT, "include"),
         "-I", os.path.join(ROOT, "360-to-planer-images_amd", "csrc"),
-        os.path.join(ROOT, "360-to-planer-images_amd", "csrc", "p2p_host.cpp"),
+        *[os.path.join(ROOT, "360-to-planer-images_amd", "csrc", f) for f in HOST_UNITS],
         os.path.join(SAN, "launch_stubs.cpp"), os.path.join(SAN, "host_san_main.cpp"), "-o", exe, "-lpthread"])
-    assert "host sanitizer run OK" in _run(exe)
+    out = _run(exe)
+    assert "host sanitizer run OK" in out
+    # the exception barrier of the C ABI (include/p2p_hip.h: "never throws"): an allocation failure injected at EVERY
+    # allocation of a job's life came back as a status, leaked nothing, aborted nothing, and the next life succeeded
+    for what in ("resident job, per-view plan", "resident job, band plan", "one-shot entry points"):
+        line = [l for l in out.splitlines() if l.startswith("allocation-failure sweep, " + what)]
+        assert line and "every one recovered" in line[0], out[-1500:]
+        assert int(line[0].split(":")[1].split()[0]) > 50, line  # (a sweep that armed nothing would pass trivially)
     # once more with the other tile shape's table sizes (csrc/p2p_device.h: tile shapes; the job picks 128-wide tiles
     # by itself only for launches of several GB)
-    assert "host sanitizer run OK" in _run(exe, P2P_TILE_SHAPE="128")
+    assert "host sanitizer run OK" in _run(exe, P2P_TILE_SHAPE="128", P2P_SAN_NO_SWEEP="1")
 
 
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
