@@ -9,7 +9,7 @@ OUT = os.path.join(HERE, "libp2p_hip.so")
 # the plan pass and the view kernels are built once per tile shape (csrc/p2p_device.h: tile shapes): the *_w128.hip and
 # *_band.hip files include their namesakes with the other shapes' constants
 SOURCES = [os.path.join(CSRC, f) for f in ("p2p_views.hip", "p2p_plan.hip", "p2p_float.hip", "p2p_views_w128.hip", "p2p_plan_w128.hip",
-                                            "p2p_float_w128.hip", "p2p_views_band.hip", "p2p_plan_band.hip", "p2p_maps.hip", "p2p_remap.hip")]
+                                            "p2p_float_w128.hip", "p2p_views_band.hip", "p2p_plan_band.hip", "p2p_maps.hip", "p2p_remap.hip", "p2p_lists.hip")]
 # the host side (csrc/p2p_host.h lists the units): the C ABI's entry points + exception barrier, then what they call
 HOST_SOURCES = [os.path.join(CSRC, f) for f in ("p2p_abi.cpp", "p2p_host_pool.cpp", "p2p_host_ctx.cpp", "p2p_host_plan.cpp",
                                                  "p2p_host_job.cpp", "p2p_host_oneshot.cpp")]

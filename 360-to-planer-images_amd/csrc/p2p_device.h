@@ -131,7 +131,7 @@ struct ViewsParams {
     int main_span;           // main kernel: chunks of pairs ONE workgroup draws, one after the other (>= 1)
     int main_tail;           // list order, one chunk of pairs: the last main_tail entries of every XCD's list are drawn by
     int main_tail_parts;     // main_tail_parts workgroups each, a part of the pairs each (0 = off)
-    int main_count[8];       // entries of each XCD's list
+    const uint32_t* main_count;  // [8] entries of each XCD's list (written with the list by main_lists_kernel: the host knows only the stride)
     int pf_lead;             // main kernel: > 0 = every (PF_GROUP + 1)-th workgroup of an XCD's run draws nothing and touches the plan
                              // tables of the PF_GROUP tiles that start pf_lead groups later (p2p_tile.h: main_block_role)
     int chunk_outer;         // tile grids: 0 = (tile, chunk, pitch view), 1 = (tile, pitch view, chunk) -- see pair_chunk
@@ -217,6 +217,19 @@ struct RemapParams {
     uint8_t cval[4];
     const short* ctab;  // INTER_CUBIC only: [32 * 32][4][4] fixed-point weights (cubic_tab_kernel)
 };
+
+// the main kernel's per-XCD work lists, built on the device from the plan's headers (p2p_lists.hip)
+struct MainListParams {
+    const PieceHdr* hdr;   // [slots] = [n_pitch][tiles]
+    uint32_t slots;
+    uint32_t cost_base;    // a tile costs about cost_base + its footprint's items
+    uint32_t cap;          // entries per XCD the table (and the main kernel's grid) provides for; 8 * cap >= slots
+    uint32_t* order;       // scratch [slots]: the mode-1 tiles by (source band, view, raster)
+    uint32_t* cost;        // scratch [slots]: their costs in that order
+    uint32_t* table;       // out [8][cap]: XCD x's entries, then ~0
+    uint32_t* count;       // out [8]
+};
+hipError_t launch_main_lists(const MainListParams& M, hipStream_t st);
 
 hipError_t launch_yaw_tables(uint32_t* packed, float* rows, int pw, int n_yaw, const double* yaw_rad,
                              hipStream_t st);

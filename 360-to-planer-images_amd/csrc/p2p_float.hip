@@ -55,25 +55,34 @@ __device__ __forceinline__ uint32_t blend_f32(uint32_t a, uint32_t b, uint32_t c
 }
 
 // The float16 form.  A byte needs no conversion at all to be a half: the bit pattern 0x00vv IS the (subnormal)
-// float16 v * 2^-24.  v_perm_b32 puts the two horizontal neighbours of a channel into the two halves of a
-// register, v_dot2_f32_f16 blends them with the float16 weights ((1 - wx) 2^15, wx 2^15) and accumulates in
-// float32 (exact products: checked on the hardware, tools/ubench/cvt_probe.hip); the vertical blend of the two
-// row results is two float32 operations with the row weights pre-scaled by 2^9.  Per channel: 2 perm, 2 dot2,
-// 2 float ops, 1 convert -- what the exact path's packed-integer blend costs.  A pixel with no footprint has
-// both row weights 0 and comes out black.
-__device__ __forceinline__ uint32_t blend_f16(uint32_t a, uint32_t b, uint32_t c, uint32_t d, f16x2 wx2, float wy0s, float wy1s)
+// float16 v * 2^-24.  v_perm_b32 puts the two VERTICAL neighbours of a channel into the two halves of a register,
+// v_dot2_f32_f16 blends them with the pixel's float16 row weights ((1 - wy) 2^15, wy 2^15) and accumulates in float32
+// (exact products: checked on the hardware, tools/ubench/cvt_probe.hip); the horizontal blend of the two column
+// results is two float32 operations with the column weights pre-scaled by 2^9.  Per channel: 2 perm, 2 dot2, 2 float
+// ops, 1 convert -- what the exact path's packed-integer blend costs.  Rows first (round 6): the row weights belong to
+// the pixel, not to the yaw -- ONE packed register per pixel for the whole tile instead of two floats, and nothing to
+// convert to float16 per yaw (the column weights, which change with every yaw's fractional shift, stay float32).
+// A pixel with no footprint has both row weights 0 and comes out black.
+__device__ __forceinline__ uint32_t blend_f16(uint32_t a, uint32_t b, uint32_t c, uint32_t d, f16x2 wy2, float wx0s, float wx1s)
 {
     uint32_t r = 0u;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const uint32_t sel = 0x0C040C00u + 0x00010001u * (uint32_t)k;  // byte k of two pixels as two u16
-        const f16x2 up = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(b, a, sel));
-        const f16x2 lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(d, c, sel));
-        const float hu = __builtin_amdgcn_fdot2(up, wx2, 0.0f, false);
-        const float hl = __builtin_amdgcn_fdot2(lo, wx2, 0.0f, false);
-        r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(hl, wy1s, hu * wy0s), k, r);
+        const f16x2 le = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(c, a, sel));  // left column: upper, lower
+        const f16x2 ri = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(d, b, sel));
+        const float vl = __builtin_amdgcn_fdot2(le, wy2, 0.0f, false);
+        const float vr = __builtin_amdgcn_fdot2(ri, wy2, 0.0f, false);
+        r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(vr, wx1s, vl * wx0s), k, r);
     }
     return r;
+}
+
+// (1 - wy) 2^15 | wy 2^15 as two float16 (round to zero, as v_cvt_pkrtz_f16_f32 does); 0 | 0 for a pixel with no footprint
+__device__ __forceinline__ f16x2 row_weights_f16(float wy, bool live)
+{
+    const float w1 = live ? wy * 32768.0f : 0.0f, w0 = live ? 32768.0f - wy * 32768.0f : 0.0f;
+    return __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(w0, w1));
 }
 
 template <bool HALF>
@@ -99,7 +108,7 @@ __device__ __forceinline__ void draw_float(
     uint32_t tap_up[PXT], tap_lo[PXT];
     float fu[PXT];
     float wyf[PXT];          // float32 path: the row weight
-    float wy0s[PXT], wy1s[PXT];  // float16 path: both row weights, times 2^9 (the column weights carry 2^15)
+    f16x2 wy2[PXT];          // float16 path: both row weights, packed, times 2^15 (the column weights carry 2^9)
     bool live[PXT];
 #pragma unroll
     for (int j = 0; j < PXT; ++j) {
@@ -111,8 +120,7 @@ __device__ __forceinline__ void draw_float(
         fu[j] = (float)(fr & 0xFFFFu) * (1.0f / 65536.0f);
         const float wy = (float)(fr >> 16) * (1.0f / 65536.0f);
         wyf[j] = wy;
-        wy0s[j] = live[j] ? (1.0f - wy) * 512.0f : 0.0f;
-        wy1s[j] = live[j] ? wy * 512.0f : 0.0f;
+        wy2[j] = row_weights_f16(wy, live[j]);
     }
     uint32_t slot_off[VIEWS_SLOTS], slot_g[VIEWS_SLOTS];
     decode_items(itw, t, G.n_items, P.src_pitch, slot_off, slot_g);
@@ -147,7 +155,7 @@ __device__ __forceinline__ void draw_float(
     }
 
     // the way out, as in the exact kernel: pixels -> LDS -> 4 adjacent pixels of one row per lane -> 12 bytes
-    const int wv = t >> 6, ln = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6), ln = t & 63;  // (the wave's index as a scalar: the staging address stays out of the VGPRs)
     uint32_t* const stg = stage + wv * (PXT * 64);
     const int x4 = 4 * (ln & 15), sj = ln >> 4;
     const int srow = ((wv * 64 + x4) >> TILE_LW) + sj * TILE_ROWSTEP, scol = (wv * 64 + x4) & (TILE_W - 1);
@@ -186,12 +194,25 @@ __device__ __forceinline__ void draw_float(
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_raw_buffer_store_b32(0u, __builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0x00020000), 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        for (int k = 0; k < npairs; ++k) {
+        uint8_t* pend_O = out;
+        uint32_t pend_records = 0u;
+        auto flush_pending = [&]() {
+            const uint4 v4 = *reinterpret_cast<const uint4*>(stg + stg_rd);
+            u32x3 o;
+            o.x = __builtin_amdgcn_perm(v4.y, v4.x, 0x04020100u);
+            o.y = __builtin_amdgcn_perm(v4.z, v4.y, 0x05040201u);
+            o.z = __builtin_amdgcn_perm(v4.w, v4.z, 0x06050402u);
+            __builtin_amdgcn_raw_buffer_store_b96(o, __builtin_amdgcn_make_buffer_rsrc(pend_O, 0, (int)pend_records, 0x00020000),
+                                                  (int)out_off12, 0, P2P_STORE_AUX);
+        };
+        // one pair: `cur` holds its source pieces, the next pair's are requested into `nxt` (the two sets swap roles from pair
+        // to pair: no register copies)
+        auto one_pair = [&](int k, const Q16 (&cur)[VIEWS_SLOTS], Q16 (&nxt)[VIEWS_SLOTS]) {
             uint4* tl4 = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(&tile4[0][0]) + buf_bytes);
 #pragma unroll
             for (int sl = 0; sl < NS; ++sl) {
                 // source pixels 0..3 of the piece (byte offsets 0, 3, 6, 9) as dwords
-                const uint32_t d0 = qc[sl].d[0], d1 = qc[sl].d[1], d2 = qc[sl].d[2], d3 = qc[sl].d[3];
+                const uint32_t d0 = cur[sl].d[0], d1 = cur[sl].d[1], d2 = cur[sl].d[2], d3 = cur[sl].d[3];
                 uint4 o;
                 o.x = d0 & 0x00FFFFFFu;
                 o.y = __builtin_amdgcn_perm(d1, d0, 0x0C050403u);
@@ -202,6 +223,7 @@ __device__ __forceinline__ void draw_float(
             uint32_t soff = buf_bytes + 4u * (((uint32_t)__builtin_amdgcn_readlane((int)cw0, k) >> 20) & 3u);
             asm volatile("" : "+s"(soff));
             const float sf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cwf), k));
+            flush_pending();  // the pair before (the first pair: a descriptor of no records)
             __syncthreads();
             const unsigned char* tl = reinterpret_cast<const unsigned char*>(&tile4[0][0]);
             uint32_t ta[PXT][4];
@@ -221,37 +243,41 @@ __device__ __forceinline__ void draw_float(
                 ta[j][3] = lo[1];
             }
             const int kn = k + 1 < npairs ? k + 1 : k;
-            load_pieces(ns_c, kn, qn);
+            load_pieces(ns_c, kn, nxt);
             uint32_t pix[PXT];
 #pragma unroll
             for (int j = 0; j < PXT; ++j) {
                 if (HALF) {
-                    const float w1 = wx[j] * 32768.0f;
-                    const f16x2 wx2 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(32768.0f - w1, w1));
-                    pix[j] = blend_f16(ta[j][0], ta[j][1], ta[j][2], ta[j][3], wx2, wy0s[j], wy1s[j]);
+                    const float w1 = wx[j] * 512.0f;
+                    pix[j] = blend_f16(ta[j][0], ta[j][1], ta[j][2], ta[j][3], wy2[j], 512.0f - w1, w1);
+                    // (one pixel after the other: left to itself the scheduler interleaves the four blends, and the
+                    // kernel's 80 registers -- six waves per SIMD -- no longer hold them)
+                    __builtin_amdgcn_sched_barrier(0);
                 } else {
                     const uint32_t v = blend_f32(ta[j][0], ta[j][1], ta[j][2], ta[j][3], wx[j], wyf[j]);
                     pix[j] = live[j] ? v : 0u;
                 }
             }
-            uint8_t* O = out + ((size_t)(pair0 + k) * P.n_pitch + G.pitch_i) * view_bytes;  // [pano][yaw][pitch][oh][ow][3]
-            // a view the job does not draw is stored through a descriptor of no records: dropped by the hardware
-            const uint32_t records = ((wanted_mask >> k) & 1ull) ? (uint32_t)view_bytes : 0u;
+            // The way out runs ONE PAIR BEHIND (as the exact kernel's, p2p_views.hip): this pair's pixels go into the wave's
+            // staging dwords and stay there; the NEXT pair reads them back, packs and stores them between its stage 1 and its
+            // barrier -- where the wave waits for its LDS writes anyway -- so the staging round trip no longer stands between
+            // the blend and the next pair.  (DS operations of one wave execute in order; the staging dwords are the wave's own.)
 #pragma unroll
             for (int j = 0; j < PXT; ++j)
                 stg[j * 64 + ln] = pix[j];
-            const uint4 v4 = *reinterpret_cast<const uint4*>(stg + stg_rd);
-            u32x3 o;
-            o.x = __builtin_amdgcn_perm(v4.y, v4.x, 0x04020100u);
-            o.y = __builtin_amdgcn_perm(v4.z, v4.y, 0x05040201u);
-            o.z = __builtin_amdgcn_perm(v4.w, v4.z, 0x06050402u);
-            __builtin_amdgcn_raw_buffer_store_b96(o, __builtin_amdgcn_make_buffer_rsrc(O, 0, (int)records, 0x00020000),
-                                                  (int)out_off12, 0, P2P_STORE_AUX);
-#pragma unroll
-            for (int sl = 0; sl < VIEWS_SLOTS; ++sl)
-                qc[sl] = qn[sl];
+            pend_O = out + ((size_t)(pair0 + k) * P.n_pitch + G.pitch_i) * view_bytes;  // [pano][yaw][pitch][oh][ow][3]
+            // a view the job does not draw is stored through a descriptor of no records: dropped by the hardware
+            pend_records = ((wanted_mask >> k) & 1ull) ? (uint32_t)view_bytes : 0u;
             buf_bytes ^= (uint32_t)sizeof(tile4[0]);
+        };
+        int k = 0;
+        for (; k + 1 < npairs; k += 2) {
+            one_pair(k, qc, qn);
+            one_pair(k + 1, qn, qc);
         }
+        if (k < npairs)
+            one_pair(k, qc, qn);
+        flush_pending();  // the last pair's pixels
     };
     static_assert(VIEWS_SLOTS >= 2 && VIEWS_SLOTS <= 4, "dispatch below");
     if (ns_wave == 0)
@@ -350,9 +376,8 @@ __global__ __launch_bounds__(VIEWS_BLOCK) void float_views_rest_kernel(
             __builtin_memcpy(&d, r1 + 3 * x1, 3);
             uint32_t res;
             if (HALF) {
-                const float w1 = wx * 32768.0f;
-                res = blend_f16(a, b, c, d, __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(32768.0f - w1, w1)),
-                                (1.0f - wy) * 512.0f, wy * 512.0f);
+                const float w1 = wx * 512.0f;
+                res = blend_f16(a, b, c, d, row_weights_f16(wy, true), 512.0f - w1, w1);
             } else {
                 res = blend_f32(a, b, c, d, wx, wy);
             }

@@ -174,8 +174,8 @@ struct Plan {  // the plan pass's tables (p2p_plan.hip)
     uint32_t* d_xcd_list = nullptr;      // [8][xcd_stride] the same tiles dealt to the XCDs by source position (xcd_lists), ~0: none
     uint32_t* d_xcd_all = nullptr;       // [8][xcd_all_stride] every tile, likewise (only when most tiles gather: ViewsParams::gather_all)
     uint32_t* d_main_list = nullptr;     // [8][main_stride] the LDS-scheme tiles, dealt to the XCDs in source order (xcd_main_lists)
+    uint32_t* d_main_count = nullptr;    // [8] entries of each XCD's main list (part of d_main_list's block; main_lists_kernel writes both)
     int xcd_stride = 0, xcd_all_stride = 0, main_stride = 0;
-    int main_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // entries of each XCD's main list (the rest of its main_stride is empty)
     int n_gather = 0;
     // band plan (source-band tiles, p2p_device.h): no px / items tables; the band kernel draws band_tiles tiles
     bool band = false;
@@ -184,10 +184,10 @@ struct Plan {  // the plan pass's tables (p2p_plan.hip)
     uint32_t* d_band_grp = nullptr;
     p2p::BandInfo* d_band_info = nullptr;
     int band_tiles = 0, band_groups = 0, band_per = 0;
-    // The main kernel's per-XCD lists are made from the headers on the host (xcd_main_lists).  A plan with no gather
-    // tile does not need them to draw: its FIRST launch goes out in the grid's own order right behind the plan pass, and
-    // the lists are made when a second launch asks for the plan (one image through a fresh context -- the tool on one
-    // file -- never pays the read-back, the sort and the upload: bench.py's cold figures).
+    // The main kernel's per-XCD lists are made from the headers ON THE DEVICE (p2p_lists.hip: no read-back, no host sort,
+    // no upload).  A plan with no gather tile does not need them to draw: its FIRST launch goes out in the grid's own
+    // order right behind the plan pass, and the list kernel is enqueued when a second launch asks for the plan (one image
+    // through a fresh context -- the tool on one file -- does not wait for it: bench.py's cold figures).
     // the quantised coordinates of every pixel (else: of the gather tiles only; ensure_full_coords completes them)
     std::atomic<bool> coords_full{false};
     std::atomic<bool> lists_pending{false};
@@ -304,7 +304,7 @@ struct p2p_job {
     int xcd_stride = 0, xcd_all_stride = 0;
     uint32_t* d_main_list = nullptr;     // the main kernel's per-XCD work lists (see p2p_host::Plan)
     int main_stride = 0;
-    int main_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t* d_main_count = nullptr;
     uint32_t* d_odd_pairs = nullptr;     // (panorama, yaw) pairs whose yaw is not a plain shift with one weight
     int n_odd_pairs = 0;
     int n_gather = 0;                    // tiles the plan marks for gathers

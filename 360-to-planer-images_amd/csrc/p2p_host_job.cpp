@@ -535,9 +535,7 @@ int job_run(p2p_job* j)
         j->d_coords = Pl.d_coords; j->d_hdr = Pl.d_hdr; j->d_px = Pl.d_px; j->d_items = Pl.d_items; j->d_px2 = Pl.d_px2;
         j->d_gather_list = Pl.d_gather_list; j->d_xcd_list = Pl.d_xcd_list; j->d_xcd_all = Pl.d_xcd_all;
         j->xcd_stride = Pl.xcd_stride; j->xcd_all_stride = Pl.xcd_all_stride; j->n_gather = Pl.n_gather;
-        j->d_main_list = Pl.d_main_list; j->main_stride = Pl.main_stride;
-        for (int x = 0; x < 8; ++x)
-            j->main_count[x] = Pl.main_count[x];
+        j->d_main_list = Pl.d_main_list; j->main_stride = Pl.main_stride; j->d_main_count = Pl.d_main_count;
     }
     P.pairs_per_block = choose_pairs_per_block(j->d, shape_ops(j->shape).shape, opt);
     P.chunk_outer = opt.chunk_outer >= 0 ? opt.chunk_outer : (j->d.n_panos > 1 ? 1 : 0);
@@ -551,8 +549,7 @@ int job_run(p2p_job* j)
     // entries drawn for one chunk of pairs before the next chunk: with ONE panorama a short run (the entries' plan tables
     // and source rows are still in L2 for the next chunk), with several all of them (a chunk's panoramas serve every
     // tile before the next ones are touched: see pair_chunk)
-    for (int x = 0; x < 8; ++x)
-        P.main_count[x] = j->main_count[x];
+    P.main_count = j->d_main_count;
     P.main_group = P.chunk_outer ? std::max(1, j->main_stride)
                                  : std::max(1, std::min(j->main_stride, choose_main_group(opt, j->shape, P.main_span, pair_chunks)));
     // table-prefetch workgroups (p2p_tile.h: main_block_role) when one launch's plan tables cannot stay in the Infinity
@@ -566,7 +563,7 @@ int job_run(p2p_job* j)
     // of that is lost.  Shorter workgroups at the end shorten it.  Only where one workgroup draws ALL pairs of its tile.
     P.main_tail = 0;
     P.main_tail_parts = opt.main_tail_parts;
-    if (P.main_list && pair_chunks == 1 && P.main_span == 1 && P.pf_lead == 0 && j->d.n_panos * j->d.n_yaw >= 4) {
+    if (P.main_list && j->shape != 1 && pair_chunks == 1 && P.main_span == 1 && P.pf_lead == 0 && j->d.n_panos * j->d.n_yaw >= 4) {  // (not the 128-wide kernel: p2p_views.hip)
         const int in_flight = 32 * (j->shape == 1 ? 3 : (j->shape == 2 ? 5 : 7));  // workgroups an XCD holds at a time
         P.main_tail = opt.main_tail >= 0 ? opt.main_tail : in_flight / 5;
         P.main_tail = std::min(P.main_tail, j->main_stride);

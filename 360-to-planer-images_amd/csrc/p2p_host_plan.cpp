@@ -18,64 +18,43 @@ uint64_t source_order_key(const p2p::PieceHdr& h)
     return key;
 }
 
-// The main kernel's tiles (mode 1), dealt to the 8 XCDs (workgroup b runs on XCD b & 7).  In the grid's own order --
-// the tile raster of one pitch view after the other -- every view reads its band of the panorama through the XCDs' L2s
-// by itself, and neighbouring pitch views overlap by half (config 2: 60 / 90 / 120 degrees, 59 degrees high each):
-// 244 MB of reads per launch for a 100 MB panorama and 35 MB of tables.  Here the tiles of ALL pitch views are ordered
-// by the band of 64 source rows their footprint is centred in, then by view and raster position, and every XCD takes
-// a contiguous part of that order: the tiles of two views that read the same rows follow each other on one XCD and
-// find them in its L2 (117 MB; config 2 -2 ... -3.5 %, config 4 -4.5 %).  Used for jobs with ONE resident panorama:
-// with several, streamed from HBM, the grid's own order is faster.
-std::vector<uint32_t> xcd_main_lists(const std::vector<p2p::PieceHdr>& hh, size_t tiles, int* stride, int tile_w)
+// The main kernel's per-XCD lists (p2p_lists.hip: main_lists_kernel) for a plan whose headers are on the device: one
+// block [table 8 x cap | count 8 | order, cost: the kernel's scratch], one launch on `st`, nothing read back.  The table's
+// stride is all the host knows: a quarter more than an equal share of ALL the plan's tiles (the runs are of equal work,
+// not of equal length; the kernel keeps every run within it).
+int plan_enqueue_main_lists(Plan& Pl, size_t slots, int tile_w, hipStream_t st)
 {
-    // (band, view, raster position): the slots come in (view, raster) order, so a counting sort by band does it
-    (void)tiles;
-    auto band_of = [](const p2p::PieceHdr& h) { return (size_t)((((h.rows & 0xFFFFu) + (h.rows >> 16)) / 2u) >> 6); };
-    std::vector<size_t> start(1026, 0);
-    for (const p2p::PieceHdr& h : hh)
-        if ((h.mode_items & 3u) == 1u)
-            start[band_of(h) + 1]++;
-    for (size_t b = 1; b < start.size(); ++b)
-        start[b] += start[b - 1];
-    std::vector<std::pair<uint64_t, uint32_t>> order(start.back());
-    for (size_t s = 0; s < hh.size(); ++s)
-        if ((hh[s].mode_items & 3u) == 1u)
-            order[start[band_of(hh[s])]++] = std::make_pair((uint64_t)band_of(hh[s]), (uint32_t)s);
+    const size_t cap = (slots + 7) / 8 + (slots + 31) / 32 + 16;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_table = up(8 * cap * sizeof(uint32_t)), b_count = 256, b_scratch = up(slots * sizeof(uint32_t));
+    unsigned char* blk = nullptr;
+    HIP_TRY(dev_alloc((void**)&blk, b_table + b_count + 2 * b_scratch));
+    p2p::MainListParams M{};
+    M.hdr = Pl.d_hdr;
+    M.slots = (uint32_t)slots;
     // equal WORK per XCD, not equal counts: a tile costs about 600 + its footprint's items (stage 2 and the way out,
     // plus stage 1 per item), and the footprints grow towards the poles -- with equal counts the two XCDs that hold the
     // polar bands finish last (config 3's share: 7.6 ms against 6.5 in grid order)
     // (the constant, swept: config 2, 64-wide tiles, is flat from 200 to 1400 -- 84.6 ... 85.1 us, 86.9 at 0, 86.0 at 3000;
     // config 4, 128-wide tiles of twice the pixels, has a sharp optimum: 450 / 525 / 600 / 675 / 750 / 850 / 1000 give
     // 6.32 / 6.26 / 6.22 / 6.17 / 6.25 / 6.32 / 6.45 ms)
-    const uint32_t cost_base = tile_w == 128 ? 675u : 600u;
-    const size_t n = order.size();
-    std::vector<uint64_t> upto(n + 1, 0);
-    for (size_t i = 0; i < n; ++i)
-        upto[i + 1] = upto[i] + cost_base + (hh[order[i].second].mode_items >> 8);
-    size_t first[9];
-    first[0] = 0;
-    for (int x = 1; x < 8; ++x)
-        first[x] = (size_t)(std::lower_bound(upto.begin(), upto.end(), upto[n] * (uint64_t)x / 8u) - upto.begin());
-    first[8] = n;
-    size_t per = 1;
-    for (int x = 0; x < 8; ++x) {
-        first[x + 1] = std::max(first[x + 1], first[x]);
-        per = std::max(per, first[x + 1] - first[x]);
+    M.cost_base = tile_w == 128 ? 675u : 600u;
+    M.cap = (uint32_t)cap;
+    M.table = (uint32_t*)blk;
+    M.count = (uint32_t*)(blk + b_table);
+    M.order = (uint32_t*)(blk + b_table + b_count);
+    M.cost = (uint32_t*)(blk + b_table + b_count + b_scratch);
+    const hipError_t e = p2p::launch_main_lists(M, st);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(st);
+        (void)dev_free(blk);
+        return fail(P2P_ERR_HIP, "main lists: %s", hipGetErrorString(e));
     }
-    // every XCD's list has the longest one's length, the shorter ones end in empty entries (spreading those over the
-    // list instead: nothing on config 2, 7.31 against 7.02 ms on config 4)
-    std::vector<uint32_t> table(8 * per, ~0u);
-    for (int x = 0; x < 8; ++x) {
-        // an XCD draws its bands from the costlier end (towards a pole) to the cheaper one: the workgroups in flight when
-        // its list runs out are then its shortest (config 2 84.3 / 83.8 / 83.6 -> 82.9 / 83.1 / 83.5 us, config 4 6.10 ->
-        // 6.02 ms, 12 yaws of one 1080p view at pitch 60 33.6 -> 33.2 us)
-        const size_t a = first[x], b = first[x + 1], q = (b - a) / 4;
-        const bool reversed = q > 0 && (upto[b] - upto[b - q]) > (upto[a + q] - upto[a]);
-        for (size_t i = a; i < b; ++i)
-            table[x * per + (i - a)] = order[reversed ? (b - 1 - (i - a)) : i].second;
-    }
-    *stride = (int)per;
-    return table;
+    Pl.d_main_list = M.table;
+    Pl.d_main_count = M.count;
+    Pl.main_stride = (int)cap;
+    Pl.bytes += b_table + b_count + 2 * b_scratch;
+    return P2P_OK;
 }
 
 // The gather kernel's tiles, dealt to the 8 XCDs (workgroup b runs on XCD b & 7 and takes entry b >> 3 of that XCD's
@@ -403,7 +382,7 @@ int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& after_plan
     // return the stream is drained (the guard, destroyed first) before they and the plan's blocks -- back to the pool,
     // where any thread may pick them up at once -- go out of scope
     std::vector<p2p::PieceHdr> hh;
-    std::vector<uint32_t> tm, tg, ta;
+    std::vector<uint32_t> tg, ta;
     uint32_t cnt = 0;
     p2p::BandInfo binfo{};
     // the read-backs land in a pinned block first (pin_get): [BandInfo | counter | headers]
@@ -585,8 +564,6 @@ int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& after_plan
     const bool want_main_order = main_order != 0;
     const bool may_defer = want_main_order && opt.defer_lists != 0 && opt.main_order < 0 && opt.scramble_plan == 0;
     Pl->tile_w = shape_ops(j->shape).shape.tile_w;
-    if (want_main_order && !may_defer)
-        HIP_TRY(fetch_headers());
     if (!band) {  // (band plans: the counter came back with the band counts; the device is still building the tiles)
         HIP_TRY(hipStreamSynchronize(st));
         cnt = *h_cnt;
@@ -602,23 +579,14 @@ int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& after_plan
         Pl->lists_pending = true;
         make_main_list = false;
     }
-    if ((cnt > 0 || make_main_list) && hh.empty()) {
+    if (cnt > 0 && hh.empty()) {  // (the gather tiles' lists are made on the host, from the headers)
         HIP_TRY(fetch_headers());
         HIP_TRY(hipStreamSynchronize(st));
         hdr_arrived();
     }
-    if (make_main_list) {  // (tm, tg, ta stay alive until the stream has taken the copies: synchronised below)
-        tm = xcd_main_lists(hh, j->n_tiles, &Pl->main_stride, shape_ops(j->shape).shape.tile_w);
-        for (int x = 0; x < 8; ++x) {
-            int c = 0;
-            while (c < Pl->main_stride && tm[(size_t)x * Pl->main_stride + c] != ~0u)
-                ++c;
-            Pl->main_count[x] = c;
-        }
-        HIP_TRY(dev_alloc((void**)&Pl->d_main_list, tm.size() * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpyAsync(Pl->d_main_list, tm.data(), tm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        Pl->bytes += tm.size() * sizeof(uint32_t);
-    }
+    if (make_main_list)  // (on the device: one launch, nothing waited for)
+        if (int rc = plan_enqueue_main_lists(*Pl, slots, shape_ops(j->shape).shape.tile_w, st))
+            return rc;
     if (cnt > 0) {
         // the gather kernel's work lists, one per XCD: xcd_lists
         const bool by_source = opt.gather_order != 0;
@@ -645,8 +613,6 @@ int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& after_plan
         }
         HIP_TRY(hipStreamSynchronize(st));  // the vectors go out of scope
     }
-    if (make_main_list && cnt == 0)
-        HIP_TRY(hipStreamSynchronize(st));  // tm goes out of scope
     if (band) {
         HIP_TRY(hipStreamSynchronize(st));
         (void)hipEventElapsedTime(&Pl->plan_ms, ctx->ev_t0, ctx->ev_t1);
@@ -670,6 +636,7 @@ int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& after_plan
         HIP_TRY(p2p::launch_scramble(Pl->d_gather_list, slots * sizeof(uint32_t), sd + 4, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_xcd_list, Pl->d_xcd_list ? 8 * (size_t)Pl->xcd_stride * sizeof(uint32_t) : 0, sd + 10, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_main_list, Pl->d_main_list ? 8 * (size_t)Pl->main_stride * sizeof(uint32_t) : 0, sd + 12, st));
+        HIP_TRY(p2p::launch_scramble(Pl->d_main_count, Pl->d_main_count ? 8 * sizeof(uint32_t) : 0, sd + 17, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_xcd_all, Pl->d_xcd_all ? 8 * (size_t)Pl->xcd_all_stride * sizeof(uint32_t) : 0, sd + 11, st));
         HIP_TRY(p2p::launch_scramble(Pl->d_coords, (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2), sd + 5, st));
         if (Pl->d_px2)
@@ -723,48 +690,16 @@ int ensure_full_coords(p2p_job* j)
     return P2P_OK;
 }
 
-// the deferred half of job_build_plan: the main kernel's per-XCD lists of a plan that has been launched once
+// the deferred half of job_build_plan: the main kernel's per-XCD lists of a plan that has been launched once -- one
+// kernel on the job's stream in front of the launch that asked (round 5: a read-back, a host sort and an upload, 75 us of
+// a geometry's second launch)
 int plan_make_main_lists(p2p_job* j, Plan& Pl)
 {
     std::lock_guard<std::mutex> lk(Pl.lists_mu);
     if (!Pl.lists_pending)
         return P2P_OK;
-    hipStream_t st = j->ctx->stream;
-    const size_t slots = j->n_tiles * j->d.n_pitch;
-    std::vector<p2p::PieceHdr> hh(slots);
-    std::vector<uint32_t> tm;
-    // (through a pinned block both ways: copies from and to pageable memory are staged and waited for)
-    PinnedBlock pin;
-    const size_t hdr_bytes = slots * sizeof(p2p::PieceHdr);
-    StreamSyncGuard sync_on_exit(st);
-    HIP_TRY(pin_get(&pin.p, &pin.cls, std::max(hdr_bytes, (size_t)1)));
-    HIP_TRY(hipMemcpyAsync(pin.p, Pl.d_hdr, hdr_bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    memcpy(hh.data(), pin.p, hdr_bytes);
-    int stride = 0;
-    tm = xcd_main_lists(hh, j->n_tiles, &stride, Pl.tile_w);
-    uint32_t* d_list = nullptr;
-    HIP_TRY(dev_alloc((void**)&d_list, tm.size() * sizeof(uint32_t)));
-    const bool up_pinned = tm.size() * sizeof(uint32_t) <= pin.cls;
-    if (up_pinned)
-        memcpy(pin.p, tm.data(), tm.size() * sizeof(uint32_t));
-    hipError_t e = hipMemcpyAsync(d_list, up_pinned ? pin.p : (const void*)tm.data(), tm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess)
-        e = hipStreamSynchronize(st);
-    if (e != hipSuccess) {
-        (void)dev_free(d_list);
-        return fail(P2P_ERR_HIP, "main lists: %s", hipGetErrorString(e));
-    }
-    sync_on_exit.armed = false;
-    for (int x = 0; x < 8; ++x) {
-        int c = 0;
-        while (c < stride && tm[(size_t)x * stride + c] != ~0u)
-            ++c;
-        Pl.main_count[x] = c;
-    }
-    Pl.main_stride = stride;
-    Pl.d_main_list = d_list;
-    Pl.bytes += tm.size() * sizeof(uint32_t);
+    if (int rc = plan_enqueue_main_lists(Pl, j->n_tiles * (size_t)j->d.n_pitch, Pl.tile_w, j->ctx->stream))
+        return rc;
     Pl.lists_pending = false;
     return P2P_OK;
 }

@@ -1163,7 +1163,10 @@ __device__ __forceinline__ uint32_t rot_pixel_buf(const ViewsParams& P, __amdgpu
 
 // TABLE = true: the body of remap_views_table_kernel -- a mode 2 tile, a few pairs per workgroup; false:
 // remap_views_rest_kernel -- the general loop over the mode 1 tiles.
-template <bool TABLE>
+// BCONST (table kernel only): the job's border mode is BORDER_CONSTANT (the current tool, P:192-199) -- the other modes'
+// cv::borderInterpolate arithmetic (the legacy tool, L:179) is not compiled into that instance, nor the constant
+// mode's tap masks into the other: the mode is the LAUNCH's, not the pixel's.
+template <bool TABLE, bool BCONST = true>
 __device__ __forceinline__ void draw_rest(
     const ViewsParams& P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab,
     const YawDesc* __restrict__ ydesc, const uint32_t* __restrict__ f4tab, uint8_t* __restrict__ out,
@@ -1227,7 +1230,7 @@ __device__ __forceinline__ void draw_rest(
             // writes borderValue when sx >= w || sx+1 < 0 || sy >= h || sy+1 < 0)
             const bool inrange = inside[j] && d.ix[j] >= -1 && d.iy[j] >= -1 && d.ix[j] < P.pw && d.iy[j] < P.ph;
             // other border modes (legacy entry point, L:179) resolve every tap to some pixel
-            d.live[j] = P.border == 0 ? inrange : inside[j];
+            d.live[j] = BCONST ? inrange : inside[j];
         }
     };
     auto direct_pixels = [&](const DirectPx& d, __amdgpu_buffer_rsrc_t S, int yi, uint32_t (&pix)[PXT]) {
@@ -1238,7 +1241,9 @@ __device__ __forceinline__ void draw_rest(
 #pragma unroll
         for (int j = 0; j < PXT; ++j) {
             pix[j] = 0;
-            if (d.live[j] && P.border != 0) {
+            if (!BCONST) {
+                if (!d.live[j])
+                    continue;
                 const int xa = border_interpolate(d.ix[j], P.pw, P.border), xb = border_interpolate(d.ix[j] + 1, P.pw, P.border);
                 const int ya = border_interpolate(d.iy[j], P.ph, P.border), yb = border_interpolate(d.iy[j] + 1, P.ph, P.border);
                 const uint32_t row0 = (uint32_t)ya * pitch, row1 = (uint32_t)yb * pitch;
@@ -1246,6 +1251,8 @@ __device__ __forceinline__ void draw_rest(
                 pix[j] = blend4(rot_pixel_buf(P, S, row0, t0, AUD_TABLE_SRC), rot_pixel_buf(P, S, row0, t1, AUD_TABLE_SRC),
                                 rot_pixel_buf(P, S, row1, t0, AUD_TABLE_SRC), rot_pixel_buf(P, S, row1, t1, AUD_TABLE_SRC),
                                 d.fx[j], d.fy[j]);
+                // (one pixel's taps at a time: four pixels' worth of border arithmetic and loads in flight cost 140 registers)
+                __builtin_amdgcn_sched_barrier(0);
             } else if (d.live[j]) {
                 const bool c0in = d.ix[j] >= 0, c1in = d.ix[j] + 1 < P.pw, r0in = d.iy[j] >= 0, r1in = d.iy[j] + 1 < P.ph;
                 const uint32_t row0 = (uint32_t)(r0in ? d.iy[j] : 0) * pitch, row1 = (uint32_t)(r1in ? d.iy[j] + 1 : 0) * pitch;
@@ -1505,7 +1512,8 @@ hipError_t launch_pair_ctx(const ViewsParams& P, uint4* table, int slots, int ch
 template <bool MERGED>
 __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views_kernel(
     ViewsParams P, const uint8_t* __restrict__ src, const YawDesc* __restrict__ ydesc, uint8_t* __restrict__ out,
-    const PieceHdr* __restrict__ hdr, const uint32_t* __restrict__ px, const uint32_t* __restrict__ items)
+    const PieceHdr* __restrict__ hdr, const uint32_t* __restrict__ px, const uint32_t* __restrict__ items,
+    const uint32_t* __restrict__ main_count)
 {
     __shared__ uint4 tile4[2][LDS_ITEMS_CAP];
     uint32_t bx = blockIdx.x;
@@ -1536,10 +1544,13 @@ __global__ __launch_bounds__(VIEWS_BLOCK, VIEWS_WAVES_PER_SIMD) void remap_views
 #endif
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
     int tile_id, pitch_i, chunk, ppb = 0;
-    if (P.main_list && P.main_tail > 0) {
+    // (64-wide shapes only: the 128-wide kernel is the shape of launches of several GB, which draw several chunks of pairs
+    // per tile -- no split tail there -- and it sits at its 80 registers)
+    if (TILE_W != 128 && P.main_list && P.main_tail > 0) {
         // List order, ONE chunk of pairs, no prefetch workgroups (the host's rule): entry q of the XCD's list -- but its
         // last main_tail entries are drawn by main_tail_parts workgroups each, a part of the pairs each (p2p_host_job.cpp: main_tail).
-        const uint32_t q = bx >> 3, L = (uint32_t)P.main_count[bx & 7u];
+        // (the XCD's count: written with the list by main_lists_kernel -- a scalar load through the restrict-qualified parameter)
+        const uint32_t q = bx >> 3, L = min(main_count[bx & 7u], (uint32_t)P.main_stride);
         const uint32_t K = (uint32_t)P.main_tail < L ? (uint32_t)P.main_tail : L;
         uint32_t e = q;
         chunk = 0;
@@ -1767,8 +1778,9 @@ __global__ __launch_bounds__(VIEWS_BLOCK, (MASKED && P2P_BAND_WAVES > 5) ? 5 : P
 }
 
 #ifndef P2P_DIRECT_WAVES
-#define P2P_DIRECT_WAVES 3  // (140 VGPRs, no scratch; at 4 waves per SIMD 128 with one spilled: the same 21.3-21.7 us for an 800 x 800 legacy view)
+#define P2P_DIRECT_WAVES 5
 #endif
+template <bool BCONST>
 __global__ __launch_bounds__(VIEWS_BLOCK, P2P_DIRECT_WAVES) void remap_views_table_kernel(
     ViewsParams P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab, uint8_t* __restrict__ out,
     const PieceHdr* __restrict__ hdr, const uint32_t* __restrict__ gather_list)
@@ -1778,7 +1790,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, P2P_DIRECT_WAVES) void remap_views_tab
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
     const PieceHdr h = hdr[(size_t)pitch_i * tiles + tile_id];
     const TileGeo G = tile_geo(P, h, pitch_i, tile_id, (int)threadIdx.x);
-    draw_rest<true>(P, src, ytab, nullptr, nullptr, out, G, nullptr, nullptr, nullptr);
+    draw_rest<true, BCONST>(P, src, ytab, nullptr, nullptr, out, G, nullptr, nullptr, nullptr);
 }
 
 // which = 0: the main kernel, 1: the rest, 2: the table kernel, 3: the gather kernel (they write disjoint pixels; the
@@ -1789,8 +1801,10 @@ hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
     if (which == 2 || which == 3) {
         const int np = (which == 2 && P.use_pair_list) ? P.n_odd_pairs : n_pairs;
         const dim3 grid(which == 3 ? 8 * P.n_list : P.n_gather, 1, (np + P.gather_ppb - 1) / P.gather_ppb);
-        if (which == 2)
-            hipLaunchKernelGGL(remap_views_table_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.out, P.hdr, P.gather_list);
+        if (which == 2 && P.border == 0)
+            hipLaunchKernelGGL(remap_views_table_kernel<true>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.out, P.hdr, P.gather_list);
+        else if (which == 2)
+            hipLaunchKernelGGL(remap_views_table_kernel<false>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.out, P.hdr, P.gather_list);
         else
             hipLaunchKernelGGL(remap_views_gather_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.hdr, P.gather_list);
         return hipGetLastError();
@@ -1821,7 +1835,7 @@ hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
     if (which == 0 && TILE_W == 128 && P.main_span > 1)  // a main-kernel workgroup loops over main_span chunks
         zblocks = (zblocks + P.main_span - 1) / P.main_span;
     dim3 grid(8 * ((tiles + 7) / 8), P.chunk_outer ? P.n_pitch : zblocks, P.chunk_outer ? zblocks : P.n_pitch);
-    if (which == 0 && P.main_list && P.main_tail > 0)  // list order, one chunk: every entry once, the last main_tail of every XCD twice
+    if (which == 0 && TILE_W != 128 && P.main_list && P.main_tail > 0)  // list order, one chunk: every entry once, the last main_tail of every XCD twice
         grid = dim3(8 * (P.main_stride + (P.main_tail_parts - 1) * P.main_tail), 1, 1);
     else if (which == 0 && P.main_list)  // list order: (blocks of main_group entries) x chunks, per XCD
         grid = dim3(8 * ((P.main_stride + P.main_group - 1) / P.main_group) * (P.main_group * P.main_chunks + (P.pf_lead > 0 ? 1 : 0)), 1, 1);
@@ -1829,9 +1843,9 @@ hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
         grid.x = 8 * (((tiles + 7) / 8 + PF_GROUP - 1) / PF_GROUP) * (PF_GROUP + 1);
     if (which == 0 && P.main_list && P.merge_gather_list && P.merge_gather_n > 0) {
         grid.x += 8 * P.merge_gather_n * ((n_pairs + P.gather_ppb - 1) / P.gather_ppb);
-        hipLaunchKernelGGL(remap_views_kernel<true>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.hdr, P.px, P.items);
+        hipLaunchKernelGGL(remap_views_kernel<true>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.hdr, P.px, P.items, P.main_count);
     } else if (which == 0)
-        hipLaunchKernelGGL(remap_views_kernel<false>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.hdr, P.px, P.items);
+        hipLaunchKernelGGL(remap_views_kernel<false>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.hdr, P.px, P.items, P.main_count);
     else
         hipLaunchKernelGGL(remap_views_rest_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.ydesc, P.f4tab,
                            P.out, P.hdr, P.px, P.items);

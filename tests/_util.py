@@ -57,3 +57,23 @@ def coords_to_maps(coords):
 def diff_stats(a, b):
     d = np.abs(a.astype(np.int16) - b.astype(np.int16))
     return int(d.max()), float((d > 1).mean()), float((d > 0).mean())
+
+
+_hip = None
+
+
+def poison_views(job, byte=0xA5):
+    """Fill a job's device output block with a byte pattern (straight through the HIP runtime: a test's business, no
+    knob of the library): the block comes out of the library's device memory pool, where an earlier job of the same
+    size may have left the very views the test expects -- a tile that nobody draws would otherwise go unnoticed."""
+    import ctypes
+
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL("libamdhip64.so")
+        _hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+        _hip.hipMemset.restype = ctypes.c_int
+        _hip.hipDeviceSynchronize.restype = ctypes.c_int
+    ptr, n = job.device_out()
+    assert ptr and n > 0
+    assert _hip.hipMemset(ctypes.c_void_p(ptr), int(byte), n) == 0 and _hip.hipDeviceSynchronize() == 0

@@ -3,6 +3,7 @@
 // sizes the real kernels use, so that ASan sees every host-side allocation being addressed, and do no pixel work.
 #define P2P_HOST 1
 #include "p2p_device.h"
+#include <algorithm>
 #include <string.h>
 #include <vector>
 extern "C" int p2p_stub_device_count = 1;
@@ -20,6 +21,49 @@ hipError_t launch_yaw_tables(uint32_t* packed, float* rows, int pw, int n_yaw, c
             if (packed) packed[(size_t)y * pw + c] = 3u * (uint32_t)c;
             if (rows) rows[(size_t)y * pw + c] = (float)c + (float)(yaw_rad[y] * 0.0);
         }
+    return hipSuccess;
+}
+// the main kernel's per-XCD lists: the host algorithm the device kernel (csrc/p2p_lists.hip) replaced -- counting sort by
+// source band, running costs, eight cuts of equal work, every run from its costlier end
+hipError_t launch_main_lists(const MainListParams& M, hipStream_t)
+{
+    auto band_of = [](const PieceHdr& h) { return (size_t)((((h.rows & 0xFFFFu) + (h.rows >> 16)) / 2u) >> 6); };
+    std::vector<size_t> start(1026, 0);
+    for (uint32_t s = 0; s < M.slots; ++s)
+        if ((M.hdr[s].mode_items & 3u) == 1u)
+            start[std::min<size_t>(band_of(M.hdr[s]), 1023) + 1]++;
+    for (size_t b = 1; b < start.size(); ++b)
+        start[b] += start[b - 1];
+    const size_t n = start.back();
+    for (uint32_t s = 0; s < M.slots; ++s)
+        if ((M.hdr[s].mode_items & 3u) == 1u) {
+            const size_t pos = start[std::min<size_t>(band_of(M.hdr[s]), 1023)]++;
+            M.order[pos] = s;
+            M.cost[pos] = M.cost_base + (M.hdr[s].mode_items >> 8);
+        }
+    std::vector<uint64_t> upto(n + 1, 0);
+    for (size_t i = 0; i < n; ++i)
+        upto[i + 1] = upto[i] + M.cost[i];
+    size_t first[9];
+    first[0] = 0;
+    first[8] = n;
+    for (int x = 1; x < 8; ++x) {
+        size_t v = 0;
+        while (v < n && upto[v] < upto[n] * (uint64_t)x / 8u)
+            ++v;
+        v = std::max(v, first[x - 1]);
+        v = std::min(v, first[x - 1] + M.cap);
+        if (n > (size_t)(8 - x) * M.cap)
+            v = std::max(v, n - (size_t)(8 - x) * M.cap);
+        first[x] = v;
+    }
+    for (int x = 0; x < 8; ++x) {
+        const size_t a = first[x], b = first[x + 1], q = (b - a) / 4;
+        const bool reversed = q > 0 && (upto[b] - upto[b - q]) > (upto[a + q] - upto[a]);
+        for (size_t e = 0; e < M.cap; ++e)
+            M.table[(size_t)x * M.cap + e] = e < b - a ? M.order[reversed ? b - 1 - e : a + e] : ~0u;
+        M.count[x] = (uint32_t)(b - a);
+    }
     return hipSuccess;
 }
 hipError_t launch_yaw_pack(uint32_t* packed, const float* rows, size_t n, hipStream_t)
