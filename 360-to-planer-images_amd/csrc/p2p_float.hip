@@ -256,6 +256,7 @@ __device__ __forceinline__ void draw_float(
                 } else {
                     const uint32_t v = blend_f32(ta[j][0], ta[j][1], ta[j][2], ta[j][3], wx[j], wyf[j]);
                     pix[j] = live[j] ? v : 0u;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             // The way out runs ONE PAIR BEHIND (as the exact kernel's, p2p_views.hip): this pair's pixels go into the wave's
