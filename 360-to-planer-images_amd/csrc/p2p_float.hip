@@ -256,7 +256,8 @@ __device__ __forceinline__ void draw_float(
                 } else {
                     const uint32_t v = blend_f32(ta[j][0], ta[j][1], ta[j][2], ta[j][3], wx[j], wyf[j]);
                     pix[j] = live[j] ? v : 0u;
-                    __builtin_amdgcn_sched_barrier(0);
+                    if (TILE_W == 128)  // (the 128-wide instance spills without it; the 64-wide one is 2 % faster left alone)
+                        __builtin_amdgcn_sched_barrier(0);
                 }
             }
             // The way out runs ONE PAIR BEHIND (as the exact kernel's, p2p_views.hip): this pair's pixels go into the wave's
@@ -295,7 +296,7 @@ __device__ __forceinline__ void draw_float(
 
 template <bool HALF>
 #ifndef P2P_FLOAT_HALF_WAVES
-#define P2P_FLOAT_HALF_WAVES 6  // (f16: 80 VGPRs with two spilled; at 5 waves per SIMD none, and config 5 0.840-0.844 ms against 0.829-0.830)
+#define P2P_FLOAT_HALF_WAVES 6  // (f16: 77 VGPRs, no scratch; at 5 waves per SIMD config 5 runs 1 % faster -- 837 against 847 us -- and keeps fewer workgroups per CU)
 #endif
 __global__ __launch_bounds__(VIEWS_BLOCK, HALF ? P2P_FLOAT_HALF_WAVES : 6) void float_views_kernel(
     ViewsParams P, const uint8_t* __restrict__ src, uint8_t* __restrict__ out,

@@ -65,7 +65,6 @@ struct Options {
     long plan_cache_mb = 4096;        // P2P_PLAN_CACHE_MB (a context copies it at p2p_ctx_create)
     // per job
     int plan_cache = 1;               // P2P_PLAN_CACHE
-    int verbose = 0;                  // P2P_VERBOSE
     int tile_shape = 0;               // P2P_TILE_SHAPE: 64 | 128 | 0 = choose_shape's rule
     int pairs_per_block = 0;          // P2P_PAIRS_PER_BLOCK
     int max_pairs_per_block = -1;     // P2P_MAX_PAIRS_PER_BLOCK

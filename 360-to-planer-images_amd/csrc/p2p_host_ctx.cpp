@@ -39,7 +39,7 @@ size_t cache_evict_unused(p2p_ctx* c, size_t budget);
 
 
 
-const char* version(void) { return "0.2.0-gfx950"; }
+const char* version(void) { return "0.3.0-gfx950"; }
 const char* last_error(void) { return g_err; }
 
 int device_count(void)

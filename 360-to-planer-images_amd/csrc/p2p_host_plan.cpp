@@ -655,9 +655,6 @@ int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& after_plan
         return P2P_OK;
     }
     sync_on_exit.armed = false;  // every path above has synchronised the stream
-    if (opt.verbose)
-        fprintf(stderr, "p2p plan: %u of %zu tiles gather (%dx%d views, %d pitches), %.1f us; band tiles %d (%d groups)\n", cnt, slots, d.ow, d.oh, d.n_pitch,
-                Pl->plan_ms * 1e3, Pl->band_tiles, Pl->band_groups);
     if (cached) {
         std::lock_guard<std::mutex> lk(ctx->cache_mu);
         Pl->stamp = ++ctx->cache_clock;

@@ -35,7 +35,6 @@ void options_load_locked()
     o.oneshot_cache_max_mb = std::max(0, env_int("P2P_ONESHOT_CACHE_MAX_MB", (int)o.oneshot_cache_max_mb));
     o.plan_cache_mb = std::max(0, env_int("P2P_PLAN_CACHE_MB", (int)o.plan_cache_mb));
     o.plan_cache = env_int("P2P_PLAN_CACHE", o.plan_cache);
-    o.verbose = env_int("P2P_VERBOSE", o.verbose);
     o.tile_shape = env_int("P2P_TILE_SHAPE", o.tile_shape);
     o.pairs_per_block = env_int("P2P_PAIRS_PER_BLOCK", o.pairs_per_block);
     o.max_pairs_per_block = env_int("P2P_MAX_PAIRS_PER_BLOCK", o.max_pairs_per_block);

@@ -517,7 +517,10 @@ def main(
             # encoded by the shared writer pool, one task per yaw.
             from collections import deque
 
-            depth = 3
+            # Files decoded ahead: 3, more with many workers -- an 8K PNG takes one thread 0.6 s, the GPU 0.1 ms, and with 16
+            # workers the 20 default views of an image are encoded in 0.35 s: three decoders were what the tool waited for
+            # (tools/cli_end_to_end.py).  Each is a page-locked panorama (100 MB at 8K).
+            depth = max(3, min(8, int(num_workers or 1) // 2))
             n_dec = max(1, min(depth, int(num_workers or 1)))
             yaws = [_angle(y, "yaw angle") for y in yaw_angles]
             pitches = [_angle(p, "pitch angle") for p in pitch_angles]

@@ -9,7 +9,7 @@ run() { # label env...
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-28s %.3f ms per launch, frac %.3f' % ('$label', j['roofline']['kernel_ms_avg'], j['roofline']['frac']))"
 }
-run "library's rule" P2P_VERBOSE=0
+run "library's rule" P2P_PLAN_CACHE=1
 run "main_group 48" P2P_MAIN_GROUP=48
 run "main_group 192" P2P_MAIN_GROUP=192
 run "prefetch_lead 0" P2P_PREFETCH_LEAD=0
@@ -19,4 +19,4 @@ run "pairs_per_block 24" P2P_PAIRS_PER_BLOCK=24
 run "pairs_per_block 18" P2P_PAIRS_PER_BLOCK=18
 run "pairs_per_block 48" P2P_MAX_PAIRS_PER_BLOCK=64 P2P_PAIRS_PER_BLOCK=48
 run "tile shape 64" P2P_TILE_SHAPE=64
-run "library's rule" P2P_VERBOSE=0
+run "library's rule" P2P_PLAN_CACHE=1

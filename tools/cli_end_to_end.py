@@ -18,6 +18,8 @@ import sys
 import tempfile
 import time
 
+os.environ.setdefault("TQDM_DISABLE", "1")  # (the tool's progress bars: one per image, not what is measured here)
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
