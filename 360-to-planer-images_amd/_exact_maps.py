@@ -31,6 +31,25 @@ _next_key = [1]
 
 def pitch_mapping(W, H, FOV_rad, pitch_radian, pano_width, pano_height):
     """(U, V) float32 (H, W) with the values of precompute_pitch_mapping (P:114-175)."""
+    c, s = np.cos(pitch_radian), np.sin(pitch_radian)
+    R = np.array([[1, 0, 0], [0, c, -s], [0, s, c]], dtype=np.float32)  # P:142-149
+    return _rotated_ray_map(W, H, FOV_rad, R, pano_width, pano_height)
+
+
+def legacy_mapping(W, H, FOV_rad, yaw_radian, pitch_radian, pano_width, pano_height):
+    """(U, V) float32 (H, W) with the values of the LEGACY tool's precompute_mapping
+    (/root/reference/app/legacy/panorama_to_plane.py:47-157): the same ray map under the combined rotation
+    R_pitch @ R_yaw of get_rotation_matrix (L:21-45), two float32 3x3 arrays multiplied with np.dot."""
+    cy, sy = np.cos(yaw_radian), np.sin(yaw_radian)
+    cp, sp = np.cos(pitch_radian), np.sin(pitch_radian)
+    R_yaw = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], dtype=np.float32)    # L:32-36
+    R_pitch = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]], dtype=np.float32)  # L:38-42
+    return _rotated_ray_map(W, H, FOV_rad, np.dot(R_pitch, R_yaw), pano_width, pano_height)  # L:45
+
+
+def _rotated_ray_map(W, H, FOV_rad, R, pano_width, pano_height):
+    """What both tools' builders share (P:119-175 / L:95-157): pinhole rays, normalised, rotated by the float32 3x3 R,
+    mapped to panorama coordinates."""
     W, H = int(W), int(H)
     focal = (0.5 * W) / np.tan(FOV_rad / 2)                 # P:119, float64 scalar
     x = np.arange(W, dtype=np.float32) - (W / 2.0)          # P:129 for one row of pixels
@@ -44,9 +63,7 @@ def pitch_mapping(W, H, FOV_rad, pitch_radian, pano_width, pano_height):
     np.divide(y[:, None], norm, out=rays[1].reshape(H, W))
     np.divide(z, norm, out=rays[2].reshape(H, W))
     del norm
-    c, s = np.cos(pitch_radian), np.sin(pitch_radian)
-    R = np.array([[1, 0, 0], [0, c, -s], [0, s, c]], dtype=np.float32)  # P:142-149
-    rot = R @ rays                                          # P:155: ONE float32 gemm of the reference's shape
+    rot = R @ rays                                          # P:155 / L:123: ONE float32 gemm of the reference's shape
     del rays
     x_rot, y_rot, z_rot = rot.reshape(3, H, W)              # P:158
     with np.errstate(invalid="ignore"):                     # (z_rot may round above 1: NaN, a black pixel, P:162)

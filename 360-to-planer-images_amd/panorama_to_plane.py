@@ -10,6 +10,11 @@ yaw + pitch rotation per view and a single cv2.remap with BORDER_REFLECT.
                                                             this build's own: images decoded ahead on a thread pool, one upload
                                                             and ONE launch per image for all its yaws, encoders on a second pool
 
+--exact (additive; set_exact(True) from Python): the identical-results mode of this package -- precompute_mapping is
+evaluated on the host exactly as the reference evaluates it (_exact_maps.legacy_mapping follows L:47-157: NumPy float32
+flow, libm, one sgemm) and every pixel is drawn from those maps on the GPU: the reference's bytes.  Default: the maps
+come from the device too (rot_map_kernel, within 1e-5 of the host's).
+
 Image files go through Pillow (cv2 is not a dependency here).  The reference converts BGR -> RGB after
 imread and back before imwrite (L:254, L:275); remap is channel-agnostic, so the files are the same.
 There is no CPU fallback for the maps or the resampling.
@@ -27,11 +32,21 @@ import numpy as np
 
 if __package__ in (None, ""):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _exact_maps  # type: ignore
     import _native  # type: ignore
 else:
-    from . import _native
+    from . import _exact_maps, _native
 
 _DEVICE = int(os.environ.get("P2P_DEVICE", "0"))
+_EXACT = False  # set_exact / --exact
+
+
+def set_exact(on=True):
+    """Maps as the reference computes them, on the host (see the module docstring); pixels on the GPU either way."""
+    global _EXACT
+    if bool(on) != _EXACT:
+        precompute_mapping.cache_clear()  # (the cached maps belong to the other mode)
+    _EXACT = bool(on)
 
 
 def get_rotation_matrix(yaw_radian: float, pitch_radian: float) -> np.ndarray:
@@ -51,7 +66,10 @@ def get_rotation_matrix(yaw_radian: float, pitch_radian: float) -> np.ndarray:
 @lru_cache(maxsize=None)
 def precompute_mapping(W: int, H: int, FOV_rad: float, yaw_radian: float, pitch_radian: float,
                        pano_width: int, pano_height: int) -> Tuple[np.ndarray, np.ndarray]:
-    """L:47-157: (U, V) float32 maps of one view, computed by rot_map_kernel."""
+    """L:47-157: (U, V) float32 maps of one view, computed by rot_map_kernel -- in exact mode on the host, with the
+    reference's own arithmetic."""
+    if _EXACT:
+        return _exact_maps.legacy_mapping(W, H, FOV_rad, yaw_radian, pitch_radian, pano_width, pano_height)
     R = get_rotation_matrix(yaw_radian, pitch_radian)
     return _native.build_rot_map(W, H, float(FOV_rad), R, pano_width, pano_height, _DEVICE)
 
@@ -116,6 +134,9 @@ def build_arg_parser() -> argparse.ArgumentParser:
     parser = argparse.ArgumentParser(description="Convert panorama images to plane projections based on FOV, yaw, and pitch.")
     for flag, kw in _FLAGS:
         parser.add_argument(flag, **(dict(kw, type=check_pitch) if flag == "--pitch" else kw))
+    parser.add_argument("--exact", action="store_true",
+                        help="Identical-results mode: the maps are evaluated on the host exactly as the reference does "
+                             "(NumPy float32, L:47-157); every pixel is still drawn on the GPU")
     return parser
 
 
@@ -220,6 +241,7 @@ def convert_folder(input_path, output_path, yaw_angles, pitch=90, FOV=90, output
 def main(argv=None):
     logging.basicConfig(level=logging.INFO, format="%(asctime)s [%(levelname)s] %(message)s", handlers=[logging.StreamHandler()])
     a = parse_arguments(argv)
+    set_exact(a.exact)
     convert_folder(a.input_path, a.output_path, a.yaw_angles, a.pitch, a.FOV, a.output_width, a.output_height,
                    a.output_format, a.num_workers)
 

@@ -75,3 +75,33 @@ def test_cache_keys_and_stack(em):
     _, _, k3 = em.pitch_map_stack(64, 48, [90, 60], 256, 128, 90)
     assert k3 != k
     em.clear()
+
+
+def test_legacy_maps_are_the_references(em, same_platform_as_golden):
+    """The legacy tool's --exact builder (_exact_maps.legacy_mapping, L:47-157) against the vectors the reference's own
+    precompute_mapping produced (tests/golden/legacy_maps_golden.npz, make_golden_legacy.py)."""
+    import json
+    import os
+
+    from tests.conftest import ROOT
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "legacy_maps_golden.npz"))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    n = 0
+    for e in meta["tiny"]:
+        U, V = em.legacy_mapping(e["W"], e["H"], float(np.radians(e["fov"])), float(np.radians(e["yaw"])),
+                                 float(np.radians(e["pitch"])), e["pw"], e["ph"])
+        gU, gV = z[e["key"] + "_U"], z[e["key"] + "_V"]
+        ok = ~(np.isnan(gU) | np.isnan(gV) | np.isnan(U) | np.isnan(V))
+        dU = np.abs(U - gU)[ok]
+        assert ok.mean() > 0.999 and np.minimum(dU, e["pw"] - 1 - dU).max() <= 2e-3 and np.abs(V - gV)[ok].max() <= 2e-3
+        if same_platform_as_golden:
+            assert np.array_equal(U, gU, equal_nan=True) and np.array_equal(V, gV, equal_nan=True), e
+        n += 1
+    for e in meta["sampled"]:
+        U, V = em.legacy_mapping(e["W"], e["H"], float(np.radians(e["fov"])), float(np.radians(e["yaw"])),
+                                 float(np.radians(e["pitch"])), e["pw"], e["ph"])
+        if same_platform_as_golden:
+            assert _sha(U) == e["sha_U"] and _sha(V) == e["sha_V"], e
+        n += 1
+    assert n >= 6

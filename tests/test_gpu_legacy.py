@@ -100,6 +100,28 @@ def test_legacy_cli_files(gpu, legacy, synth, tmp_path):
     assert np.abs(got.astype(int) - want.astype(int)).max() <= 1      # device map vs NumPy map: 1/32-px flips on a smooth image
 
 
+def test_legacy_cli_exact_on_noise(gpu, legacy, synth, tmp_path):
+    """The legacy tool with --exact: host-evaluated maps (the reference's own arithmetic, L:47-157), pixels on the GPU --
+    the oracle's bytes on a NOISE panorama, every yaw; and back to the device maps afterwards."""
+    from PIL import Image
+
+    src = tmp_path / "in"
+    src.mkdir()
+    pano = synth.synth_pano(1024, 512, 2201, "N")
+    Image.fromarray(pano).save(src / "n.png")
+    out = tmp_path / "out"
+    try:
+        legacy.main(["--input_path", str(src), "--output_path", str(out), "--output_width", "200", "--output_height", "300",
+                     "--pitch", "70", "--yaw_angles", "0", "60", "270", "--num_workers", "2", "--exact"])
+        for yaw in (0, 60, 270):
+            got = np.asarray(Image.open(out / f"n_pitch70_yaw{yaw}_fov90.png").convert("RGB"))
+            U, V = maps.legacy_map(200, 300, float(np.radians(90)), float(np.radians(yaw)), float(np.radians(70)), 1024, 512)
+            assert np.array_equal(got, cpu_ref.remap(pano, U, V, cpu_ref.BORDER_REFLECT)), yaw
+    finally:
+        legacy.set_exact(False)
+    assert legacy._EXACT is False and legacy.precompute_mapping.cache_info().currsize == 0
+
+
 def test_batched_maps_remap_equals_one_call_per_map(gpu, synth):
     """L:259-281: the legacy tool remaps one image through one precomputed map per yaw.  p2p_remap_maps_batch_u8
     draws them all in one launch; same bytes as cv2.remap per map (oracle), incl. a NaN coordinate under

@@ -18,6 +18,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 120 rocprofv3 --pmc $c --output-format csv -d $OUT/calib_$c -- $ROOT/tools/ubench/fetch_calib > /dev/null 2> $OUT/calib_$c.log
 done
 timeout 120 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $OUT/pmc_ea -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-preroll --counters none > /dev/null 2> $OUT/pmc_ea.log
+# the SQ pass bench.py's issue floor comes from (roofline.issue_floor_us): SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / the clock
+# the kernel holds (SQ_BUSY_CU_CYCLES / 256 CUs / the counted dispatches' own duration)
+timeout 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVES SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-preroll --counters none > /dev/null 2> $OUT/pmc_sq.log
 timeout 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum --output-format csv -d $OUT/pmc_tcc -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-preroll --counters none > /dev/null 2> $OUT/pmc_tcc.log
 cd $ROOT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
@@ -41,6 +44,24 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     res["calib"]["stream16_" + c] = counters("calib_" + c, "stream16").get(c)
 res["views"].update(counters("pmc_ea", "remap_views_kernel"))
 res["views"].update(counters("pmc_tcc", "remap_views_kernel"))
+res["views"].update(counters("pmc_sq", "remap_views_kernel"))
+# the counted dispatches' own duration (the clock is derived from it) and the issue floor
+dur = {}
+for f in glob.glob(os.path.join(out, "pmc_sq", "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        if re.search(r"remap_views_kernel[<(]", row["Kernel_Name"]):
+            try:
+                dur[row["Dispatch_Id"]] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+            except (KeyError, ValueError):
+                pass
+v = res["views"]
+if dur and v.get("SQ_BUSY_CU_CYCLES") and v.get("SQ_INSTS_VALU"):
+    ns = sum(dur.values()) / len(dur)
+    clock = v["SQ_BUSY_CU_CYCLES"] / 256.0 / (ns * 1e-9)
+    res["issue_floor"] = {"sq_pass_kernel_us": ns / 1e3, "clock_ghz": clock / 1e9,
+                          "issue_floor_us": v["SQ_INSTS_VALU"] * 4.0 / 1024.0 / clock * 1e6,
+                          "valu_lane_insts_per_output_px": v["SQ_INSTS_VALU"] * 64.0 / (36 * 1920 * 1080),
+                          "how": "SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / (SQ_BUSY_CU_CYCLES / 256 CUs / the counted dispatches' duration)"}
 json.dump(res, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
