@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "p2p_job_get_views", "p2p_job_kernel_ms", "p2p_job_kernel_ms_last", "p2p_job_device_out", "p2p_job_get_coords",
     "p2p_job_get_yaw_tables", "p2p_job_set_yaws", "p2p_host_alloc", "p2p_host_free", "p2p_release_cache",
     "p2p_reload_options", "p2p_job_get_info", "p2p_job_get_view", "p2p_job_get_view_async", "p2p_job_set_view_mask",
-    "p2p_device_mem_info", "p2p_job_set_rows", "p2p_job_get_view_rows", "p2p_job_get_view_rows_async",
+    "p2p_device_mem_info", "p2p_job_set_border", "p2p_job_set_rows", "p2p_job_get_view_rows", "p2p_job_get_view_rows_async",
 )
 
 
@@ -177,6 +177,8 @@ def lib():
     L.p2p_job_get_view_async.argtypes = [c_vp, c_int, c_int, c_int, c_vp]
     L.p2p_job_set_view_mask.restype = c_int
     L.p2p_job_set_view_mask.argtypes = [c_vp, c_vp]
+    L.p2p_job_set_border.restype = c_int
+    L.p2p_job_set_border.argtypes = [c_vp, c_int]
     L.p2p_job_set_rows.restype = c_int
     L.p2p_job_set_rows.argtypes = [c_vp, c_int, c_int]
     L.p2p_job_get_view_rows.restype = c_int
@@ -655,6 +657,10 @@ class Job:
         if m.shape != (self.n_yaw, self.n_pitch):
             raise ValueError("view mask must be [n_yaw][n_pitch] = (%d, %d), got %s" % (self.n_yaw, self.n_pitch, m.shape))
         check(lib().p2p_job_set_view_mask(self._h, m.ctypes.data))
+
+    def set_border(self, border):
+        """cv2 border code of the job's pitch stage (p2p_job_set_border): BORDER_REFLECT makes a resident legacy-tool job."""
+        check(lib().p2p_job_set_border(self._h, int(border)))
 
     def set_rows(self, row0, row1):
         """The job draws only output rows [row0, row1) of every view (whole tile rows of 16; p2p_job_set_rows)."""

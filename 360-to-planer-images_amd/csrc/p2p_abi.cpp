@@ -107,6 +107,7 @@ P2P_ABI_INT(job_share_panos, (p2p_job* job, p2p_job* owner), (job, owner))
 P2P_ABI_INT(job_set_yaws, (p2p_job* job, const int32_t* yaw_deg), (job, yaw_deg))
 P2P_ABI_INT(job_set_yaws_f64, (p2p_job* job, const double* yaw_deg), (job, yaw_deg))
 P2P_ABI_INT(job_set_maps, (p2p_job* job, const float* yaw_rows, const float* U, const float* V), (job, yaw_rows, U, V))
+P2P_ABI_INT(job_set_border, (p2p_job* job, int border_mode), (job, border_mode))
 P2P_ABI_INT(job_set_view_mask, (p2p_job* job, const uint8_t* mask), (job, mask))
 P2P_ABI_INT(job_run, (p2p_job* job), (job))
 P2P_ABI_INT(job_get_views, (p2p_job* job, int index, uint8_t* out), (job, index, out))

@@ -408,6 +408,7 @@ int job_share_panos(p2p_job* job, p2p_job* owner);
 int job_set_yaws(p2p_job* job, const int32_t* yaw_deg);
 int job_set_yaws_f64(p2p_job* job, const double* yaw_deg);
 int job_set_maps(p2p_job* job, const float* yaw_rows, const float* U, const float* V);
+int job_set_border(p2p_job* job, int border_mode);
 int job_set_view_mask(p2p_job* job, const uint8_t* mask);
 int job_run(p2p_job* job);
 int job_get_views(p2p_job* job, int index, uint8_t* out);

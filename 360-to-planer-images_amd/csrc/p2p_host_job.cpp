@@ -367,6 +367,27 @@ int job_set_rows(p2p_job* j, int row0, int row1)
     return P2P_OK;
 }
 
+// The border mode of the job's pitch stage (default BORDER_CONSTANT 0, the current tool's, P:212-218): the legacy tool's
+// cv2.remap(..., borderMode=BORDER_REFLECT) (L:179) as a RESIDENT job -- its maps set once (p2p_job_set_maps), one upload
+// and one launch per image.  The plan follows the mode (another key: the next run builds or fetches it).
+int job_set_border(p2p_job* j, int border_mode)
+{
+    if (!j)
+        return fail(P2P_ERR_INVALID, "job is NULL");
+    if (border_mode < P2P_BORDER_CONSTANT || border_mode > P2P_BORDER_REFLECT_101)
+        return fail(P2P_ERR_INVALID, "unsupported border mode %d", border_mode);
+    if (j->d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16))
+        return fail(P2P_ERR_STATE, "the float pixel path wraps around the seam by itself: it has no border mode");
+    if (border_mode == j->border)
+        return P2P_OK;
+    HIP_TRY(hipSetDevice(j->ctx->device));
+    HIP_TRY(hipStreamSynchronize(j->ctx->stream));  // no launch in flight reads the plan that is about to go
+    j->border = border_mode;
+    j->plan_ref.reset();
+    j->pc_plan = nullptr;
+    return P2P_OK;
+}
+
 int job_set_view_mask(p2p_job* j, const uint8_t* mask)
 {
     if (!j)

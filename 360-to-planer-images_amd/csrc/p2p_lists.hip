@@ -10,7 +10,8 @@
 //
 // Rounds 2-5 made these lists on the host: headers read back, a counting sort, an upload -- 75 us of a geometry's second
 // launch with the GPU idle (158-162 us against 85 in the steady state).  The headers never need to leave HBM: one
-// workgroup of 1024 threads does the same counting sort (stable: a band's tiles stay in (view, raster) order), the same
+// workgroup of 1024 threads does the same counting sort by source band (a band's tiles stay in (view, raster) order up to the
+// turns the lanes of one LDS atomic take), the same
 // running sums of the tiles' costs, the same eight cuts of equal WORK and the same choice of the end an XCD starts from.
 // The host knows only the table's stride (`cap` entries per XCD, a quarter more than an equal share of all tiles) and
 // sizes the grid by it; the entries each XCD really has are written next to the table (`count`), and the main kernel reads
@@ -27,6 +28,7 @@ namespace {
 constexpr int LISTS_BLOCK = 1024;
 constexpr int LISTS_WAVES = LISTS_BLOCK / 64;
 constexpr int BATCH = 8;          // independent loads in flight per lane (see phase A)
+constexpr int LISTS_COST_CAP = 12288;  // tiles whose costs fit the LDS next to the counters (24 KB of the workgroup's 57)
 constexpr int LISTS_BANDS = 512;  // bands of 64 source rows: panoramas below 32767 rows (the C ABI's limit)
 
 __device__ __forceinline__ uint32_t band_of_rows(uint32_t rows)
@@ -65,6 +67,11 @@ __global__ __launch_bounds__(LISTS_BLOCK) void main_lists_kernel(MainListParams 
     __shared__ unsigned long long s_wtot64[LISTS_WAVES];
     __shared__ uint32_t s_wtot32[LISTS_WAVES];
     __shared__ uint32_t s_first[9], s_rev[8];
+    // the tiles' costs in the sorted order, for the running sums and the cuts: in LDS when the plan is small enough (config
+    // 2: 6 120 tiles), else in the block's scratch (a write and two reads of global memory between barriers)
+    __shared__ uint16_t s_cost[LISTS_COST_CAP];
+    const bool cost_in_lds = M.slots <= (uint32_t)LISTS_COST_CAP;
+    auto cost_at = [&](uint32_t i) -> uint32_t { return cost_in_lds ? (uint32_t)s_cost[i] : M.cost[i]; };
     __shared__ unsigned long long s_want[8];
     __shared__ uint32_t s_n;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -123,8 +130,11 @@ __global__ __launch_bounds__(LISTS_BLOCK) void main_lists_kernel(MainListParams 
         s_n = upto_band;
     __syncthreads();
     const uint32_t n = s_n;
-    // C: the stable scatter.  A wave walks its run in slot order; the lanes of a chunk that share a band take consecutive
-    // positions in lane order (DS operations of one wave execute in order: no barrier inside a wave's walk)
+    // C: the scatter.  A wave walks its run in slot order and every lane takes its band's next position with ONE LDS atomic
+    // per chunk of 64 slots (DS operations of one wave execute in order: a later chunk's tiles land behind an earlier
+    // chunk's; inside a chunk the lanes of one band take their turns in the order the LDS serves them).  Round 6's first
+    // version ranked the lanes of a chunk band by band -- a loop of ballots with an LDS round trip per distinct band:
+    // 7.3 us of the kernel's 22.6 (tools/lists_kernel_phases.sh).
     for (uint32_t base = s0; base < s1; base += 64u * BATCH) {
         uint32_t mi[BATCH], rw[BATCH];
         if (base == s0) {
@@ -136,24 +146,16 @@ __global__ __launch_bounds__(LISTS_BLOCK) void main_lists_kernel(MainListParams 
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
             const uint32_t s = base + 64u * (uint32_t)k + (uint32_t)lane;
-            const bool live = (mi[k] & 3u) == 1u;
-            const uint32_t band = band_of_rows(rw[k]);
-            unsigned long long todo = __ballot(live);
-            while (todo) {
-                const int leader = __builtin_ctzll(todo);
-                const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)band, leader);
-                const unsigned long long same = __ballot(live && band == b0);
-                const uint32_t first = s_pos[w][b0];
-                if (live && band == b0) {
-                    const uint32_t pos = first + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-                    if (pos < slots) {
-                        M.order[pos] = s;
-                        M.cost[pos] = M.cost_base + (mi[k] >> 8);
-                    }
+            if ((mi[k] & 3u) == 1u) {
+                const uint32_t pos = atomicAdd(&s_pos[w][band_of_rows(rw[k])], 1u);
+                if (pos < slots) {
+                    const uint32_t c = M.cost_base + (mi[k] >> 8);
+                    M.order[pos] = s;
+                    if (cost_in_lds)
+                        s_cost[pos] = (uint16_t)min(c, 65535u);
+                    else
+                        M.cost[pos] = c;
                 }
-                if (lane == leader)
-                    s_pos[w][b0] = first + (uint32_t)__popcll(same);
-                todo &= ~same;
             }
         }
     }
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(LISTS_BLOCK) void main_lists_kernel(MainListParams 
         uint32_t c[BATCH];
 #pragma unroll
         for (int k = 0; k < BATCH; ++k)
-            c[k] = i0 + (uint32_t)k < b ? M.cost[i0 + (uint32_t)k] : 0u;
+            c[k] = i0 + (uint32_t)k < b ? cost_at(i0 + (uint32_t)k) : 0u;
 #pragma unroll
         for (int k = 0; k < BATCH; ++k)
             mine += c[k];
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(LISTS_BLOCK) void main_lists_kernel(MainListParams 
                 uint32_t c[BATCH];
 #pragma unroll
                 for (int k = 0; k < BATCH; ++k)
-                    c[k] = i0 + (uint32_t)k < b ? M.cost[i0 + (uint32_t)k] : 0u;
+                    c[k] = i0 + (uint32_t)k < b ? cost_at(i0 + (uint32_t)k) : 0u;
 #pragma unroll
                 for (int k = 0; k < BATCH; ++k) {
                     const unsigned long long next = run + c[k];
@@ -230,8 +232,8 @@ __global__ __launch_bounds__(LISTS_BLOCK) void main_lists_kernel(MainListParams 
 #pragma unroll
             for (int k = 0; k < BATCH / 2; ++k) {
                 const uint32_t i = i0 + 64u * (uint32_t)k;
-                ch[k] = i < q ? M.cost[ra + i] : 0u;
-                ct[k] = i < q ? M.cost[rb - q + i] : 0u;
+                ch[k] = i < q ? cost_at(ra + i) : 0u;
+                ct[k] = i < q ? cost_at(rb - q + i) : 0u;
             }
 #pragma unroll
             for (int k = 0; k < BATCH / 2; ++k) {

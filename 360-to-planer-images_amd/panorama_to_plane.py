@@ -182,6 +182,35 @@ def views_of_image(pano, maps_by_yaw):
     return {y: panorama_to_plane(pano, *maps_by_yaw[y]) for y in yaws}
 
 
+class ResidentViews:
+    """Every yaw's view of MANY images of one size: a resident job (p2p_job_set_border + p2p_job_set_maps) that keeps the
+    maps and their plan on the device -- the reference builds its maps once per run too (L:341-363) and then calls
+    panorama_to_plane once per image and yaw (L:259-265).  Per image: one upload, one launch for all yaws, one download."""
+
+    def __init__(self, size, maps_by_yaw, device=None):
+        self.yaws = list(maps_by_yaw)
+        U = np.stack([maps_by_yaw[y][0] for y in self.yaws])
+        V = np.stack([maps_by_yaw[y][1] for y in self.yaws])
+        self.ctx = _native.Context(_DEVICE if device is None else device)
+        try:
+            # ONE yaw of 0 degrees (the yaw stage is then a copy) and the caller's maps as the job's "pitch views"
+            self.job = _native.Job(self.ctx, size[1], size[0], 1, [0.0], [90.0] * len(self.yaws), 90.0, U.shape[2], U.shape[1])
+            self.job.set_border(_native.BORDER_REFLECT)
+            self.job.set_maps(None, U, V)
+        except Exception:
+            self.ctx.close()
+            raise
+
+    def views(self, pano):
+        self.job.set_pano(0, pano)
+        self.job.run()
+        return dict(zip(self.yaws, self.job.get_views(0, pinned=True)[0]))
+
+    def close(self):
+        self.job.close()
+        self.ctx.close()
+
+
 def convert_folder(input_path, output_path, yaw_angles, pitch=90, FOV=90, output_width=1000, output_height=1500,
                    output_format=None, num_workers=None) -> int:
     """The legacy tool's job (L:306-388) for one folder; returns the number of files written.  Images are decoded
@@ -200,7 +229,7 @@ def convert_folder(input_path, output_path, yaw_angles, pitch=90, FOV=90, output
     workers = num_workers if num_workers else max(1, int((os.cpu_count() or 1) * 0.9))
     logging.info(f"Using {workers} worker(s) for processing.")
     logging.info(f"Starting processing of {len(files)} images with {len(yaw_angles)} yaw angles each.")
-    written, maps_for = [], {}
+    written, maps_for, resident = [], {}, {}
     with ThreadPoolExecutor(max_workers=workers) as readers, ThreadPoolExecutor(max_workers=workers) as writers:
         decoded = [(f, readers.submit(_decode_rgb, f)) for f in files]
         try:
@@ -223,10 +252,18 @@ def convert_folder(input_path, output_path, yaw_angles, pitch=90, FOV=90, output
                                                             yaw_radian=float(np.radians(y)), pitch_radian=float(np.radians(pitch)),
                                                             pano_width=size[1], pano_height=size[0]) for y in yaw_angles}
                 fmt = output_format or f.suffix[1:]
-                for yaw, view in views_of_image(pano, maps_for[size]).items():
+                if pano.ndim == 3 and pano.shape[2] == 3 and maps_for[size]:
+                    if size not in resident:
+                        resident[size] = ResidentViews(size, maps_for[size])
+                    views = resident[size].views(pano)
+                else:
+                    views = views_of_image(pano, maps_for[size])
+                for yaw, view in views.items():
                     written.append(writers.submit(_encode_rgb, dst / f"{f.stem}_pitch{pitch}_yaw{yaw}_fov{FOV}.{fmt}", view))
             except Exception as e:
                 logging.error(f"Failed to process {f}: {e}")
+        for r in resident.values():
+            r.close()
         done = 0
         for w in written:
             try:

@@ -247,6 +247,12 @@ int p2p_job_set_yaws_f64(p2p_job* job, const double* yaw_deg);
 /* Optional: use caller float maps instead of in-kernel ones (see p2p_remap_views_maps_u8).  yaw_rows may be
    NULL to keep the yaw tables built from yaw_deg. */
 int p2p_job_set_maps(p2p_job* job, const float* yaw_rows, const float* U, const float* V);
+/* The border mode of the job's pitch stage: P2P_BORDER_CONSTANT (0, the default: the current tool's cv2.remap calls,
+   P:192-199, P:212-218) or one of the other cv2 codes -- the legacy tool's panorama_to_plane is
+   cv2.remap(img, U, V, INTER_LINEAR, BORDER_REFLECT) (L:179).  With p2p_job_set_maps (its maps as the job's "pitch views",
+   one per yaw of L:259-265, a single yaw of 0 degrees in front) the legacy per-image loop becomes a resident job: the
+   maps go up once, every image costs one upload, one launch and one download.  The job's next run plans for the mode. */
+int p2p_job_set_border(p2p_job* job, int border_mode);
 /* Sparse view sets.  mask: uint8 [n_yaw][n_pitch], non-zero = the job draws that (yaw, pitch) view of every panorama;
    NULL = all of them again.  Views that are not wanted are neither computed nor written (their part of the output
    block keeps whatever it held).  What it is for: the view-sharded multi-GPU path -- one task per yaw on ONE shared

@@ -255,6 +255,11 @@ int main()
         CHECK(p2p_job_get_view_rows_async(job, 0, 0, 0, 16, 33, part.data()) == P2P_ERR_STATE);   // 70 is not divisible by 4
         CHECK(p2p_job_set_rows(job, 0, 33) == P2P_OK && p2p_job_run(job) == P2P_OK);
     }
+    {   // the pitch stage's border mode (the legacy tool's resident job): bad codes refused, a change re-plans, and back
+        CHECK(p2p_job_set_border(job, 7) == P2P_ERR_INVALID && p2p_job_set_border(nullptr, 0) == P2P_ERR_INVALID);
+        CHECK(p2p_job_set_border(job, P2P_BORDER_REFLECT) == P2P_OK && p2p_job_run(job) == P2P_OK);
+        CHECK(p2p_job_set_border(job, P2P_BORDER_CONSTANT) == P2P_OK && p2p_job_run(job) == P2P_OK);
+    }
     std::vector<int32_t> coords((size_t)2 * 33 * 70 * 2);
     CHECK(p2p_job_get_coords(job, coords.data()) == P2P_OK);
     std::vector<uint32_t> tabs((size_t)3 * 64);

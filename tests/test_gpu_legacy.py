@@ -122,6 +122,37 @@ def test_legacy_cli_exact_on_noise(gpu, legacy, synth, tmp_path):
     assert legacy._EXACT is False and legacy.precompute_mapping.cache_info().currsize == 0
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_resident_border_job_draws_the_oracles_bytes(gpu, synth, mode):
+    """p2p_job_set_border: the legacy remap as a RESIDENT job (maps set once, several images through it) -- every border
+    mode, three maps as the job's views, two images in turn; and the mode changed on a live job."""
+    pw, ph, ow, oh = 1024, 512, 201, 150
+    rng = np.random.default_rng(77 + mode)
+    U = rng.uniform(-40.0, pw + 40.0, size=(3, oh, ow)).astype(np.float32)      # taps beyond every border
+    V = rng.uniform(-30.0, ph + 30.0, size=(3, oh, ow)).astype(np.float32)
+    panos = [synth.synth_pano(pw, ph, 2300 + i, "N") for i in range(2)]
+    ctx = gpu.Context(0)
+    try:
+        job = gpu.Job(ctx, pw, ph, 1, [0.0], [90.0] * 3, 90.0, ow, oh)
+        job.set_border(mode)
+        job.set_maps(None, U, V)
+        for pano in panos:
+            job.set_pano(0, pano)
+            job.run()
+            got = job.get_views(0)[0]
+            for k in range(3):
+                assert np.array_equal(got[k], cpu_ref.remap(pano, U[k], V[k], mode)), (mode, k)
+        other = cpu_ref.BORDER_WRAP if mode != cpu_ref.BORDER_WRAP else cpu_ref.BORDER_REPLICATE
+        job.set_border(other)
+        job.run()
+        assert np.array_equal(job.get_views(0)[0][1], cpu_ref.remap(panos[1], U[1], V[1], other))
+        with pytest.raises(gpu.P2PError):
+            job.set_border(9)
+        job.close()
+    finally:
+        ctx.close()
+
+
 def test_batched_maps_remap_equals_one_call_per_map(gpu, synth):
     """L:259-281: the legacy tool remaps one image through one precomputed map per yaw.  p2p_remap_maps_batch_u8
     draws them all in one launch; same bytes as cv2.remap per map (oracle), incl. a NaN coordinate under
