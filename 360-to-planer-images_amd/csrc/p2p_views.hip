@@ -1163,10 +1163,10 @@ __device__ __forceinline__ uint32_t rot_pixel_buf(const ViewsParams& P, __amdgpu
 
 // TABLE = true: the body of remap_views_table_kernel -- a mode 2 tile, a few pairs per workgroup; false:
 // remap_views_rest_kernel -- the general loop over the mode 1 tiles.
-// BCONST (table kernel only): the job's border mode is BORDER_CONSTANT (the current tool, P:192-199) -- the other modes'
-// cv::borderInterpolate arithmetic (the legacy tool, L:179) is not compiled into that instance, nor the constant
-// mode's tap masks into the other: the mode is the LAUNCH's, not the pixel's.
-template <bool TABLE, bool BCONST = true>
+// BORDER (table kernel only): the job's border mode, a compile-time constant -- 0 = BORDER_CONSTANT (the current tool,
+// P:192-199) with its tap masks, 1..4 = the other cv2 codes with THAT mode's cv::borderInterpolate arithmetic (the legacy
+// tool, L:179: BORDER_REFLECT): the mode is the LAUNCH's, not the pixel's, and an instance carries one mode's code.
+template <bool TABLE, int BORDER = 0>
 __device__ __forceinline__ void draw_rest(
     const ViewsParams& P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab,
     const YawDesc* __restrict__ ydesc, const uint32_t* __restrict__ f4tab, uint8_t* __restrict__ out,
@@ -1230,7 +1230,7 @@ __device__ __forceinline__ void draw_rest(
             // writes borderValue when sx >= w || sx+1 < 0 || sy >= h || sy+1 < 0)
             const bool inrange = inside[j] && d.ix[j] >= -1 && d.iy[j] >= -1 && d.ix[j] < P.pw && d.iy[j] < P.ph;
             // other border modes (legacy entry point, L:179) resolve every tap to some pixel
-            d.live[j] = BCONST ? inrange : inside[j];
+            d.live[j] = BORDER == 0 ? inrange : inside[j];
         }
     };
     auto direct_pixels = [&](const DirectPx& d, __amdgpu_buffer_rsrc_t S, int yi, uint32_t (&pix)[PXT]) {
@@ -1241,11 +1241,11 @@ __device__ __forceinline__ void draw_rest(
 #pragma unroll
         for (int j = 0; j < PXT; ++j) {
             pix[j] = 0;
-            if (!BCONST) {
+            if (BORDER != 0) {
                 if (!d.live[j])
                     continue;
-                const int xa = border_interpolate(d.ix[j], P.pw, P.border), xb = border_interpolate(d.ix[j] + 1, P.pw, P.border);
-                const int ya = border_interpolate(d.iy[j], P.ph, P.border), yb = border_interpolate(d.iy[j] + 1, P.ph, P.border);
+                const int xa = border_interpolate(d.ix[j], P.pw, BORDER), xb = border_interpolate(d.ix[j] + 1, P.pw, BORDER);
+                const int ya = border_interpolate(d.iy[j], P.ph, BORDER), yb = border_interpolate(d.iy[j] + 1, P.ph, BORDER);
                 const uint32_t row0 = (uint32_t)ya * pitch, row1 = (uint32_t)yb * pitch;
                 const uint32_t t0 = T[xa], t1 = T[xb];
                 pix[j] = blend4(rot_pixel_buf(P, S, row0, t0, AUD_TABLE_SRC), rot_pixel_buf(P, S, row0, t1, AUD_TABLE_SRC),
@@ -1780,7 +1780,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, (MASKED && P2P_BAND_WAVES > 5) ? 5 : P
 #ifndef P2P_DIRECT_WAVES
 #define P2P_DIRECT_WAVES 5
 #endif
-template <bool BCONST>
+template <int BORDER>
 __global__ __launch_bounds__(VIEWS_BLOCK, P2P_DIRECT_WAVES) void remap_views_table_kernel(
     ViewsParams P, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ytab, uint8_t* __restrict__ out,
     const PieceHdr* __restrict__ hdr, const uint32_t* __restrict__ gather_list)
@@ -1790,7 +1790,7 @@ __global__ __launch_bounds__(VIEWS_BLOCK, P2P_DIRECT_WAVES) void remap_views_tab
     const int tiles = ((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H);
     const PieceHdr h = hdr[(size_t)pitch_i * tiles + tile_id];
     const TileGeo G = tile_geo(P, h, pitch_i, tile_id, (int)threadIdx.x);
-    draw_rest<true, BCONST>(P, src, ytab, nullptr, nullptr, out, G, nullptr, nullptr, nullptr);
+    draw_rest<true, BORDER>(P, src, ytab, nullptr, nullptr, out, G, nullptr, nullptr, nullptr);
 }
 
 // which = 0: the main kernel, 1: the rest, 2: the table kernel, 3: the gather kernel (they write disjoint pixels; the
@@ -1801,10 +1801,18 @@ hipError_t launch_remap_views(const ViewsParams& P, int which, hipStream_t st)
     if (which == 2 || which == 3) {
         const int np = (which == 2 && P.use_pair_list) ? P.n_odd_pairs : n_pairs;
         const dim3 grid(which == 3 ? 8 * P.n_list : P.n_gather, 1, (np + P.gather_ppb - 1) / P.gather_ppb);
-        if (which == 2 && P.border == 0)
-            hipLaunchKernelGGL(remap_views_table_kernel<true>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.out, P.hdr, P.gather_list);
-        else if (which == 2)
-            hipLaunchKernelGGL(remap_views_table_kernel<false>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.out, P.hdr, P.gather_list);
+#define P2P_LAUNCH_TABLE(B) \
+    hipLaunchKernelGGL(remap_views_table_kernel<B>, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ytab, P.out, P.hdr, P.gather_list)
+        if (which == 2) {
+            switch (P.border) {
+            case 1: P2P_LAUNCH_TABLE(1); break;
+            case 2: P2P_LAUNCH_TABLE(2); break;
+            case 3: P2P_LAUNCH_TABLE(3); break;
+            case 4: P2P_LAUNCH_TABLE(4); break;
+            default: P2P_LAUNCH_TABLE(0); break;
+            }
+        }
+#undef P2P_LAUNCH_TABLE
         else
             hipLaunchKernelGGL(remap_views_gather_kernel, grid, dim3(VIEWS_BLOCK), 0, st, P, P.src, P.ydesc, P.out, P.hdr, P.gather_list);
         return hipGetLastError();

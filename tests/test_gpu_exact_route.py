@@ -140,3 +140,23 @@ def test_api_exact_from_the_reference_fanout(pkg, synth):
             tool.set_quality("f16")
     finally:
         tool.set_exact(False)
+
+
+def test_exact_maps_through_the_view_sharded_driver(pkg, synth):
+    """One image shared out to several contexts by WHOLE VIEWS (a masked job per context, its pitch subset of the maps) and
+    by rows, with the exact mode's maps: the oracle's bytes either way."""
+    import importlib
+    drv = importlib.import_module("360-to-planer-images_amd._driver")
+    em = importlib.import_module("360-to-planer-images_amd._exact_maps")
+    pano = synth.synth_pano(1024, 512, 1005, "N")
+    yaws, pitches, ow, oh, fov = [0, 45, 90, 200], [50, 90, 130], 160, 120, 90
+    maps = em.pitch_map_stack(ow, oh, pitches, 1024, 512, fov)
+    want = oracle_views(pano, yaws, pitches, ow, oh, fov)
+    try:
+        for how in ("views", "rows"):
+            got = drv.process_views_sharded(pano, [float(y) for y in yaws], [float(p) for p in pitches], ow, oh, float(fov),
+                                            [0, 0, 0], how=how, maps=maps)
+            assert np.array_equal(got, want), how
+    finally:
+        drv.release_sharded()
+        em.clear()
