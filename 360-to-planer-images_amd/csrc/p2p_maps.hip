@@ -107,10 +107,21 @@ __global__ __launch_bounds__(1024) void yaw_desc_kernel(YawDesc* __restrict__ de
     __syncthreads();
     const int s_a = i0, s_b = (i0 + pw - 1) % pw;
     int nb_a = 0, nb_b = 0;
-    for (int c = t; c < pw; c += 1024) {
-        uint32_t te = T[c];
-        nb_a += yaw_delta(te, c, s_a, pw) < 0;
-        nb_b += yaw_delta(te, c, s_b, pw) < 0;
+    // (eight independent loads asked for before the first is used: one round of memory latency per pass instead of eight at
+    // 8192 columns -- the kernel sits on a cold image's critical path, before the job exists)
+    for (int c0 = t; c0 < pw; c0 += 8 * 1024) {
+        uint32_t te[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            te[k] = c0 + 1024 * k < pw ? T[c0 + 1024 * k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = c0 + 1024 * k;
+            if (c < pw) {
+                nb_a += yaw_delta(te[k], c, s_a, pw) < 0;
+                nb_b += yaw_delta(te[k], c, s_b, pw) < 0;
+            }
+        }
     }
     if (nb_a) atomicAdd(&bad[0], nb_a);
     if (nb_b) atomicAdd(&bad[1], nb_b);
@@ -126,21 +137,37 @@ __global__ __launch_bounds__(1024) void yaw_desc_kernel(YawDesc* __restrict__ de
     }
     const int c_last = (pw - 1 - s + pw) % pw;  // the rot column whose source column is pw-1
     int lmin = 64, lmax = -1;
-    for (int c = t; c < pw; c += 1024) {
-        uint32_t w = 0;
+    for (int c0 = t; c0 < pw; c0 += 4 * 1024) {
+        uint32_t te[4][4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            int cm = c + m;
-            if (cm >= pw)
-                cm -= pw;
-            int d = yaw_delta(T[cm], cm, s, pw);
-            w |= (uint32_t)d << (8 * m);
-            if (m == 0 && c != c_last) {
-                lmin = min(lmin, d);
-                lmax = max(lmax, d);
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                int cm = c0 + 1024 * k + m;
+                if (cm >= pw)
+                    cm -= pw;
+                te[k][m] = c0 + 1024 * k < pw ? T[cm] : 0u;
             }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + 1024 * k;
+            if (c >= pw)
+                continue;
+            uint32_t w = 0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                int cm = c + m;
+                if (cm >= pw)
+                    cm -= pw;
+                int d = yaw_delta(te[k][m], cm, s, pw);
+                w |= (uint32_t)d << (8 * m);
+                if (m == 0 && c != c_last) {
+                    lmin = min(lmin, d);
+                    lmax = max(lmax, d);
+                }
+            }
+            F4[c] = w;
         }
-        F4[c] = w;
     }
     atomicMin(&dmin, lmin);
     atomicMax(&dmax, lmax);

@@ -160,3 +160,32 @@ def test_exact_maps_through_the_view_sharded_driver(pkg, synth):
     finally:
         drv.release_sharded()
         em.clear()
+
+
+def test_pitch_maps_entry_point_keys_and_yaws(gpu, synth):
+    """p2p_remap_views_pitch_maps_f64 directly: without a key (maps uploaded and planned per call), with a key (the slot keeps
+    them: other panoramas, other yaw VALUES through the same maps), and a second key with other maps -- always the bytes of
+    the all-caller-maps entry point fed the oracle's yaw rows."""
+    from tests._util import oracle_maps
+    pw, ph, ow, oh, fov = 1024, 512, 222, 148, 80
+    pitches = [40, 90, 141]
+    panos = [synth.synth_pano(pw, ph, 1020 + i, "N") for i in range(2)]
+
+    def want(pano, yaws, U, V):
+        rows, _, _ = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
+        return gpu.remap_views_maps(pano, rows, U, V)
+
+    _, U, V = oracle_maps([0], pitches, ow, oh, pw, ph, fov)
+    _, U2, V2 = oracle_maps([0], [p + 3 for p in pitches], ow, oh, pw, ph, fov)
+    for key in (0, 4242):
+        for pano in panos:
+            for yaws in ([0, 33, 270], [10, 200, 359]):   # same count: the slot's job is re-used, its yaw tables rebuilt
+                got = gpu.remap_views_pitch_maps(pano, yaws, U, V, key)
+                assert np.array_equal(got, want(pano, yaws, U, V)), (key, yaws)
+    got = gpu.remap_views_pitch_maps(panos[0], [0, 33, 270], U2, V2, 4243)     # other maps under another name
+    assert np.array_equal(got, want(panos[0], [0, 33, 270], U2, V2))
+    got = gpu.remap_views_pitch_maps(panos[1], [0, 33, 270], U, V, 4242)       # and the first name still means the first maps
+    assert np.array_equal(got, want(panos[1], [0, 33, 270], U, V))
+    with pytest.raises(ValueError):
+        gpu.remap_views_pitch_maps(panos[0], [0], U, V[:2], 0)
+    gpu.release_cache()
