@@ -14,7 +14,7 @@ logging format and error behaviour, so a user of the reference can switch files.
     main                                P:286-356     same walk / logging / error swallowing
     check_pitch                         P:362-376     same messages
     CLI                                 P:382-488     same flags and defaults (+ additive --device, --devices,
-                                                      --exact, --quality)
+                                                      --exact, --quality, --pixel_centres)
 
 All pixel arithmetic runs on the GPU, and so do the maps by default.  There is no CPU fallback: without the built
 library or without a HIP device the calls raise.
@@ -59,6 +59,7 @@ _DEVICE = int(os.environ.get("P2P_DEVICE", "0"))
 _DEVICES = None  # devices the directory walk of main() deals images to (None: just _DEVICE)
 _EXACT = False   # set_exact / --exact: host-evaluated pitch maps, the reference's bytes
 _QUALITY = "u8"  # set_quality / --quality: "u8" (the reference's arithmetic) | "f32" | "f16" (opt-in float resample)
+_CENTRES = False  # set_quality(..., pixel_centres=True) / --pixel_centres: float paths only, sample through pixel centres
 
 
 def set_device(device):
@@ -84,15 +85,19 @@ def set_exact(on=True):
     _EXACT = bool(on)
 
 
-def set_quality(pixel_path="u8"):
+def set_quality(pixel_path="u8", pixel_centres=False):
     """Pixel arithmetic of every later call (the CLI's --quality): "u8" = the reference's two fixed-point cv2.remap stages;
-    "f32" / "f16" = ONE float resample per view with true wrap-around at the seam (not in the reference)."""
-    global _QUALITY
+    "f32" / "f16" = ONE float resample per view with true wrap-around at the seam (not in the reference).
+    pixel_centres (float paths only, --pixel_centres): rays through the centres of the output pixels and panorama texels
+    centred at i + 0.5 -- the reference samples at integer coordinates (P:122-131), which shifts the picture by half a pixel."""
+    global _QUALITY, _CENTRES
     if pixel_path not in _PIXEL_PATHS:
         raise ValueError(f"quality must be one of {sorted(_PIXEL_PATHS)}, got {pixel_path!r}")
     if pixel_path != "u8" and _EXACT:
         raise ValueError("--exact is the reference's fixed-point arithmetic; the float pixel paths have no reference counterpart")
-    _QUALITY = pixel_path
+    if pixel_centres and pixel_path == "u8":
+        raise ValueError("pixel centres are a convention of the float pixel paths (--quality f32 / f16); u8 is the reference's arithmetic")
+    _QUALITY, _CENTRES = pixel_path, bool(pixel_centres)
 
 
 def get_version():
@@ -160,6 +165,10 @@ _PINNED = os.environ.get("P2P_PINNED", "1") != "0"
 _PIXEL_PATHS = {"u8": 0, "f32": _native.FLAG_PIXELS_F32, "f16": _native.FLAG_PIXELS_F16}
 
 
+def _flags_of(pixel_path):
+    return _PIXEL_PATHS[pixel_path] | (_native.FLAG_PIXEL_CENTRES if (_CENTRES and pixel_path != "u8") else 0)
+
+
 def _exact_maps_for(pano_image, pitch_angles, output_width, output_height, fov_deg):
     """(U, V, maps_key) of the exact mode for this panorama's size: the reference's pitch maps (P:55-73, P:114-175),
     evaluated on the host once per key and named for the device."""
@@ -202,7 +211,7 @@ def process_views(pano_image, yaw_angles, pitch_angles, output_width, output_hei
     pitches = [_angle(p, "pitch angle") for p in pitch_angles]
     return _native.remap_views_f64(pano_image, yaws, pitches, _angle(fov_deg, "FOV"),
                                    output_width, output_height, dev,
-                                   pinned=_PINNED, flags=_PIXEL_PATHS[pixel_path])
+                                   pinned=_PINNED, flags=_flags_of(pixel_path))
 
 
 def process_yaw_and_pitchs(pano_image, yaw_angle, pitch_angles, output_width, output_height, fov_deg=90, *, exact=None):
@@ -362,7 +371,7 @@ def _mode_of(input_image, pitch_angles, output_width, output_height, fov_deg):
     """(flags, maps) of the module's current mode for one image: maps = (U, V, key) in exact mode, else None."""
     if _EXACT:
         return 0, _exact_maps_for(input_image, pitch_angles, output_width, output_height, fov_deg)
-    return _PIXEL_PATHS[_QUALITY], None
+    return _flags_of(_QUALITY), None
 
 
 def _views_of(input_image, yaw_angles, pitch_angles, output_width, output_height, fov_deg, device=None):
@@ -633,6 +642,9 @@ def build_arg_parser():
     p.add_argument("--quality", choices=sorted(_PIXEL_PATHS), default="u8",
                    help="Pixel arithmetic: u8 = the reference's two fixed-point cv2.remap stages (default); f32 / f16 = one "
                         "float resample per view with true wrap-around at the seam (not in the reference)")
+    p.add_argument("--pixel_centres", action="store_true",
+                   help="With --quality f32 / f16 only: sample through pixel centres (the reference samples at integer "
+                        "coordinates, which shifts the picture by half a pixel)")
     return p
 
 
@@ -641,6 +653,8 @@ def cli(argv=None):
     args = parser.parse_args(argv)
     if args.exact and args.quality != "u8":
         parser.error("--exact is the reference's fixed-point arithmetic: it goes with --quality u8 only")
+    if args.pixel_centres and args.quality == "u8":
+        parser.error("--pixel_centres goes with --quality f32 / f16 (u8 is the reference's arithmetic, integer coordinates)")
     # logging set-up as P:462-475 (the logs/ directory is created even without file logging)
     log_file_path = Path(__file__).resolve().parent.parent / "logs" / "app.log"
     log_file_path.parent.mkdir(parents=True, exist_ok=True)
@@ -652,7 +666,7 @@ def cli(argv=None):
         set_device(args.device)
     set_devices(args.devices)
     set_exact(False)
-    set_quality(args.quality)
+    set_quality(args.quality, args.pixel_centres)
     set_exact(args.exact)
     main(
         input_path=args.input_path,
