@@ -117,7 +117,7 @@ def test_cli_quality_flag(tmp_path, synth):
               "--yaw_angles", "10", "--pitch_angles", "75", "--output_width", "320", "--output_height", "200"], tmp_path)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     c = _load(tmp_path / "c" / "q_320x200_yaw_10_pitch_75.png").astype(np.int16)
-    assert (c != outs["f32"]).mean() > 0.2 and np.abs(c - outs["f32"])[:, 2:-2].max() <= 12   # a smooth image, half a pixel apart
+    assert (c != outs["f32"]).mean() > 0.03 and np.abs(c - outs["f32"])[:, 2:-2].max() <= 12   # a smooth image, half a pixel apart
     r = _run(["--input_path", str(tmp_path / "q.png"), "--pixel_centres"], tmp_path)
     assert r.returncode == 2 and "--pixel_centres" in r.stderr
 
