@@ -419,6 +419,35 @@ def test_release_cache_gives_device_memory_back(gpu, synth):
     ctx.close()
 
 
+def test_resource_limits_of_the_header(gpu, synth, p2p_env):
+    """The two resource knobs include/p2p_hip.h documents: P2P_POOL_MB = 0 -- the pool keeps no idle block, a destroyed
+    job's device memory is back at the driver without p2p_release_cache -- and P2P_ONESHOT_CACHE_MAX_MB = 0 -- a one-shot
+    slot keeps no job between calls (and the second call is as right as the first)."""
+    def free_mb():
+        return gpu.device_mem_info(0)[0] / 2**20
+
+    pano = synth.synth_pano(4096, 2048, 3601, "S")
+    gpu.release_cache()
+    p2p_env("P2P_POOL_MB", "0")
+    p2p_env("P2P_PLAN_CACHE", "0")                             # (the context would keep the plan for the next job)
+    before = free_mb()
+    ctx = gpu.Context(0)
+    job = gpu.Job(ctx, 4096, 2048, 1, list(range(0, 360, 30)), [60, 90, 120], 90, 1280, 720)
+    job.set_pano(0, pano)
+    job.run()
+    first = job.get_views(0)
+    assert before - free_mb() > 100                            # 25 MB of panorama, 100 MB of views, the plan
+    job.close()
+    assert before - free_mb() < 32, before - free_mb()         # nothing idles in the pool
+    ctx.close()
+    p2p_env("P2P_ONESHOT_CACHE_MAX_MB", "0")
+    a = gpu.remap_views(pano, list(range(0, 360, 30)), [60, 90, 120], 90, 1280, 720)
+    held = before - free_mb()
+    b = gpu.remap_views(pano, list(range(0, 360, 30)), [60, 90, 120], 90, 1280, 720)
+    assert held < 32 and np.array_equal(a, b) and np.array_equal(a, first), held
+    gpu.release_cache()
+
+
 def test_process_exit_with_live_caches_from_pool_threads(gpu, tmp_path):
     """Cached one-shot jobs, streams and page-locked blocks are alive when the interpreter exits -- from pool
     threads that finished, from a daemon thread that never will, and on sys.exit from the main thread.  Nothing is
