@@ -333,14 +333,16 @@ def _count(views=0, pixels=0, src_bytes=0):
         _stats["src_bytes"] += src_bytes
 
 
-def _write_yaw(views_y, yaw_angle, pitch_angles, base_name, output_width, output_height, output_format, output_dir):
-    """Encode and write every pitch view of one yaw (one task of the writer pool)."""
-    _count(views=len(pitch_angles), pixels=len(pitch_angles) * int(output_width) * int(output_height))
-    for pi, pitch_angle in enumerate(pitch_angles):
-        out_filename = f"{base_name}_{output_width}x{output_height}_yaw_{yaw_angle}_pitch_{pitch_angle}.{output_format}"
-        output_file = output_dir / out_filename
-        _imwrite_rgb(output_file, views_y[pi])  # (the image was decoded to RGB and never swapped: _imread_rgb)
-        logging.debug(f"Saved {output_file}")
+def _write_view(view, yaw_angle, pitch_angle, base_name, output_width, output_height, output_format, output_dir):
+    """Encode and write ONE view (one task of the writer pool).  The reference's parallel unit is the yaw (P:252-265) and
+    its files are written by the caller, one after the other (P:271-278); with the resampling on the GPU the encoder is what
+    the tool waits for, and a yaw's pitch views are independent files: a task each -- 20 tasks per image of the
+    reference's default view set instead of 4, which is what keeps more than a handful of workers busy."""
+    _count(views=1, pixels=int(output_width) * int(output_height))
+    out_filename = f"{base_name}_{output_width}x{output_height}_yaw_{yaw_angle}_pitch_{pitch_angle}.{output_format}"
+    output_file = output_dir / out_filename
+    _imwrite_rgb(output_file, view)  # (the image was decoded to RGB and never swapped: _imread_rgb)
+    logging.debug(f"Saved {output_file}")
 
 
 def process_single_image(
@@ -357,7 +359,7 @@ def process_single_image(
     """Drop-in for P:227-280.  The reference fans one task per yaw out to `num_workers` threads that
     each resample on the CPU and the caller writes the files; here every yaw and pitch of the image
     comes from ONE kernel launch and the `num_workers` threads encode / write the files, one task
-    per yaw (the codecs release the GIL), which is where the time goes once the resampling is on the GPU."""
+    per view (the codecs release the GIL), which is where the time goes once the resampling is on the GPU."""
     logging.info(f"Loading image: {input_image_path}")
     input_image = _imread_rgb(input_image_path)
     if input_image is None:
@@ -414,9 +416,9 @@ def _make_pipeline(device):
 
 def _submit_writes(executor, views, input_image_path, output_dir, yaw_angles, pitch_angles, output_width,
                    output_height, output_format):
-    """One write task per yaw on `executor` (the reference's parallel unit, P:252-265).  `views` is the array, a
-    ticket of the device pipeline (its download may still be in flight), or the exception that replaced them.
-    Returns [(yaw_angle, future-or-exception)], to be drained with _drain_views."""
+    """One write task per VIEW on `executor`, grouped by yaw (the reference's parallel unit and the unit its errors are
+    reported by, P:252-280).  `views` is the array, a ticket of the device pipeline (its download may still be in flight),
+    or the exception that replaced them.  Returns [(yaw_angle, [futures] or exception)], to be drained with _drain_views."""
     base_name = Path(input_image_path).stem
     output_dir = Path(output_dir)
     yaw_angles = list(yaw_angles)
@@ -429,14 +431,15 @@ def _submit_writes(executor, views, input_image_path, output_dir, yaw_angles, pi
             _stage("device_wait", t0)
     except Exception as e:  # the reference reports task failures per yaw and carries on (P:279-280)
         return [(yaw_angle, e) for yaw_angle in yaw_angles]
-    return [(yaw_angle, executor.submit(_write_yaw, views[yi], yaw_angle, pitch_angles, base_name, output_width,
-                                        output_height, output_format, output_dir))
+    return [(yaw_angle, [executor.submit(_write_view, views[yi][pi], yaw_angle, pitch_angle, base_name, output_width,
+                                         output_height, output_format, output_dir)
+                         for pi, pitch_angle in enumerate(pitch_angles)])
             for yi, yaw_angle in enumerate(yaw_angles)]
 
 
 def _submit_views(executor, input_image, input_image_path, output_dir, yaw_angles, pitch_angles, output_width,
                   output_height, output_format, fov_deg, device=None):
-    """One kernel launch for every yaw and pitch of the image, then one write task per yaw on `executor`."""
+    """One kernel launch for every yaw and pitch of the image, then one write task per view on `executor`."""
     yaw_angles = list(yaw_angles)
     _count(src_bytes=int(getattr(input_image, "nbytes", 0)))
     try:
@@ -455,7 +458,14 @@ def _drain_views(tasks):
         try:
             if isinstance(task, Exception):
                 raise task
-            task.result()
+            first_error = None
+            for view_task in task:  # (every file of the yaw is waited for; the first failure is the yaw's)
+                try:
+                    view_task.result()
+                except Exception as e:
+                    first_error = first_error or e
+            if first_error is not None:
+                raise first_error
         except Exception as e:
             logging.error(f"Error processing yaw_angle {yaw_angle}: {e}")
 
