@@ -230,6 +230,7 @@ struct MainListParams {
     uint32_t* count;       // out [8]
 };
 hipError_t launch_main_lists(const MainListParams& M, hipStream_t st);
+hipError_t launch_zero_words(uint32_t* p, uint32_t n, hipStream_t st);  // (instead of hipMemsetAsync in front of a kernel)
 
 hipError_t launch_yaw_tables(uint32_t* packed, float* rows, int pw, int n_yaw, const double* yaw_rad,
                              hipStream_t st);

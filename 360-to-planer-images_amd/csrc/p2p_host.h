@@ -86,7 +86,7 @@ struct Options {
     int merge_gather = 1;               // P2P_MERGE_GATHER: 1 = the gather tiles are drawn by the first workgroups of the band kernel's launch / of the main kernel's in list order
     int pair_ctx_table = 1;           // P2P_PAIR_CTX_TABLE: 1 = the pair contexts of every tile come from a table built once per job geometry
     int early_main = 1;               // P2P_EARLY_MAIN: 1 = a job's first launch sends the main kernel out right behind the plan pass
-    int defer_lists = 1;              // P2P_DEFER_LISTS: 1 = a plan without gather tiles makes its main lists at its second launch (0: at once)
+    int defer_lists = 1;              // P2P_DEFER_LISTS: 1 = a plan without gather tiles draws its first launch in grid order and makes its main lists at its second (0: in front of the first launch's main kernel)
     int band = -1;                    // P2P_BAND: 1 = source-band tiles wherever they apply, 0 = never, -1 = the library's rule (choose_band)
     int band_bh = -1, band_cw = -1;   // P2P_BAND_BH / P2P_BAND_CW: cell of the source, rows x columns (-1: by tile shape, band_cell)
     int band_maxw = 27, band_maxh = 7;  // (no environment knob) tap extent of a group beyond which its tile gathers
@@ -187,9 +187,12 @@ struct Plan {  // the plan pass's tables (p2p_plan.hip)
     // no upload).  A plan with no gather tile does not need them to draw: its FIRST launch goes out in the grid's own
     // order right behind the plan pass, and the list kernel is enqueued when a second launch asks for the plan (one image
     // through a fresh context -- the tool on one file -- does not wait for it: bench.py's cold figures).
+    // P2P_DEFER_LISTS=0: the list kernel and the pair contexts go out between the plan pass and the first main kernel, which
+    // then draws in list order like every later launch (same box: first launch 194-200 -> 229-236 us, second 105-111 -> 85-91).
     // the quantised coordinates of every pixel (else: of the gather tiles only; ensure_full_coords completes them)
     std::atomic<bool> coords_full{false};
     std::atomic<bool> lists_pending{false};
+    bool lists_made = false;             // the main lists went out behind the plan pass, in front of the first launch (p2p_job_run)
     std::mutex lists_mu;
     std::atomic<int> launches{0};
     int tile_w = 64;
@@ -365,9 +368,10 @@ int choose_main_group(const Options& opt, int shape, int span, int chunks);
 bool job_wants_band(const p2p_job* j);
 void job_settle_shape(p2p_job* j);
 int job_main_order(const p2p_job* j);
-int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& after_plan_pass = nullptr);
+int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass = nullptr);
 int ensure_full_coords(p2p_job* j);
 int plan_make_main_lists(p2p_job* j, Plan& Pl);
+int plan_enqueue_main_lists(Plan& Pl, size_t slots, int tile_w, hipStream_t st);
 
 // ---- implementations of the ABI functions: p2p_xyz -> p2p_host::xyz ----
 const char* version();

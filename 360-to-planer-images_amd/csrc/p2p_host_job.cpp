@@ -516,6 +516,57 @@ int job_run(p2p_job* j)
         P.rest_ppb = std::min(16, std::max(1, j->n_odd_pairs));
         P.use_pair_list = 0;
     };
+    // the main kernel's grid: list order (source bands, all pitch views together) unless the plan has no list
+    auto list_params = [&](const Plan& Pl, int main_order) {
+        P.main_list = (main_order == 2 || (main_order == 1 && j->d.n_panos == 1)) ? Pl.d_main_list : nullptr;
+        P.main_stride = Pl.main_stride;
+        P.main_count = Pl.d_main_count;
+        const int pair_chunks = (j->d.n_panos * j->d.n_yaw + P.pairs_per_block - 1) / P.pairs_per_block;
+        // entries drawn for one chunk of pairs before the next chunk: with ONE panorama a short run (the entries' plan
+        // tables and source rows are still in L2 for the next chunk), with several all of them (a chunk's panoramas serve
+        // every tile before the next ones are touched: see pair_chunk)
+        P.main_group = P.chunk_outer ? std::max(1, Pl.main_stride)
+                                     : std::max(1, std::min(Pl.main_stride, choose_main_group(opt, j->shape, P.main_span, pair_chunks)));
+        // The last entries of every XCD's list as two workgroups of half the pairs each: when the list runs out, the
+        // workgroups in flight end over a whole workgroup's life (25 us on config 2) with ever fewer of them left -- half
+        // of that is lost.  Shorter workgroups at the end shorten it.  Only where one workgroup draws ALL pairs of its tile.
+        P.main_tail = 0;
+        P.main_tail_parts = opt.main_tail_parts;
+        if (P.main_list && j->shape != 1 && pair_chunks == 1 && P.main_span == 1 && P.pf_lead == 0 && j->d.n_panos * j->d.n_yaw >= 4) {  // (not the 128-wide kernel: p2p_views.hip)
+            const int in_flight = 32 * (j->shape == 1 ? 3 : (j->shape == 2 ? 5 : 7));  // workgroups an XCD holds at a time
+            P.main_tail = opt.main_tail >= 0 ? opt.main_tail : in_flight / 5;
+            P.main_tail = std::min(P.main_tail, Pl.main_stride);
+        }
+    };
+    // The job's pair-context table (pair_ctx_kernel) for the plan `Pl`: written on `st` when the one the job holds is
+    // of another plan, yaw list, view mask or chunking; sets P.pair_ctx.  Not beyond 64 MB.
+    auto pair_ctx_table = [&](const Plan* Pl, bool band_plan, hipStream_t st) -> int {
+        P.pair_ctx = nullptr;
+        P.pair_ctx_chunks = 0;
+        const int chunks_all = (j->d.n_panos * j->d.n_yaw + P.pairs_per_block - 1) / P.pairs_per_block;
+        const size_t tslots = band_plan ? (size_t)Pl->band_tiles : j->n_tiles * (size_t)j->d.n_pitch;
+        const size_t bytes = tslots * (size_t)chunks_all * 64 * sizeof(uint4);
+        if (tslots == 0 || bytes > ((size_t)64 << 20) || P.pairs_per_block > 64)
+            return P2P_OK;
+        const bool stale = !j->d_pair_ctx || j->pc_plan != Pl || j->pc_yaw != j->yaw_ref.get() ||
+                           j->pc_mask_gen != j->mask_gen || j->pc_ppb != P.pairs_per_block || j->pc_chunks != chunks_all ||
+                           j->pc_slots != tslots;
+        if (stale) {
+            if (j->d_pair_ctx && (j->pc_slots * (size_t)j->pc_chunks != tslots * (size_t)chunks_all)) {
+                HIP_TRY(hipStreamSynchronize(j->ctx->stream));
+                (void)dev_free(j->d_pair_ctx);
+                j->d_pair_ctx = nullptr;
+            }
+            if (!j->d_pair_ctx)
+                HIP_TRY(dev_alloc((void**)&j->d_pair_ctx, bytes));
+            HIP_TRY(shape_ops(j->shape).pair_ctx(P, j->d_pair_ctx, (int)tslots, chunks_all, band_plan ? 1 : 0, st));
+            j->pc_plan = Pl; j->pc_yaw = j->yaw_ref.get(); j->pc_mask_gen = j->mask_gen;
+            j->pc_ppb = P.pairs_per_block; j->pc_chunks = chunks_all; j->pc_slots = tslots;
+        }
+        P.pair_ctx = j->d_pair_ctx;
+        P.pair_ctx_chunks = chunks_all;
+        return P2P_OK;
+    };
     bool early_main = false;
     job_settle_shape(j);
     if (j->plan_ref && j->plan_ref->band != job_wants_band(j)) {
@@ -527,14 +578,33 @@ int job_run(p2p_job* j)
         // One image through a fresh geometry: the main kernel goes out in grid order right behind the plan pass (it draws
         // the LDS-scheme tiles, whichever they turn out to be); the gather tiles' count, the lists and the other kernels
         // follow below.  The kernels write disjoint pixels, in any order.
-        std::function<int(const Plan&)> launch_main;
+        std::function<int(Plan&)> launch_main;
         // (not when P2P_MAIN_ORDER names an order: that launch is the one a test or a tool wants to see)
         if (!float_path && opt.force_rest == 0 && opt.early_main != 0 && opt.scramble_plan == 0 && opt.main_order < 0)
-            launch_main = [&](const Plan& Pl) -> int {
+            launch_main = [&](Plan& Pl) -> int {
                 plan_params(Pl);
                 P.main_list = nullptr;
                 P.main_stride = 0;
                 P.main_group = 1;
+                P.pair_ctx = nullptr;
+                P.pair_ctx_chunks = 0;
+                // P2P_DEFER_LISTS=0: the per-XCD lists and the pair contexts, which need the plan pass only, go out between
+                // the plan pass and the main kernel, and the geometry's first image is drawn as every later one will be.
+                // Not the default: 17 + 5 us in front of a kernel that is, on a cold cache, SLOWER in list order (124 us
+                // against 105 in grid order; the steady state has it the other way round) -- first launch 194-200 ->
+                // 229-236 us, second 105-111 -> 85-91 on one box: the sum is 14 us worse.  The lists on a second stream
+                // next to the main kernel (tools/platform/side_stream_probe.hip): the list kernel's 16 waves and 30 KB of
+                // LDS find no CU with room while the main kernel's seven workgroups per CU are in flight, and run behind it.
+                const int main_order = job_main_order(j);
+                if (main_order != 0 && opt.defer_lists == 0) {
+                    if (int rc = plan_enqueue_main_lists(Pl, j->n_tiles * (size_t)j->d.n_pitch, shape_ops(j->shape).shape.tile_w, j->ctx->stream))
+                        return rc;
+                    Pl.lists_made = true;
+                    list_params(Pl, main_order);
+                    if (opt.pair_ctx_table != 0)
+                        if (int rc = pair_ctx_table(&Pl, false, j->ctx->stream))
+                            return rc;
+                }
                 if (timed)
                     HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
                 HIP_TRY(shape_ops(j->shape).views(P, 0, j->ctx->stream));
@@ -560,35 +630,16 @@ int job_run(p2p_job* j)
     }
     P.pairs_per_block = choose_pairs_per_block(j->d, shape_ops(j->shape).shape, opt);
     P.chunk_outer = opt.chunk_outer >= 0 ? opt.chunk_outer : (j->d.n_panos > 1 ? 1 : 0);
-    // the main kernel's grid: list order (source bands, all pitch views together) unless the plan has no list
-    const int main_order = band ? 0 : job_main_order(j);
-    P.main_list = (main_order == 2 || (main_order == 1 && j->d.n_panos == 1)) ? j->d_main_list : nullptr;
-    P.main_stride = j->main_stride;
     P.main_span = choose_main_span(j->d, shape_ops(j->shape).shape, opt, P.pairs_per_block);
     const int pair_chunks = (j->d.n_panos * j->d.n_yaw + P.pairs_per_block - 1) / P.pairs_per_block;
     P.main_chunks = (pair_chunks + P.main_span - 1) / P.main_span;
-    // entries drawn for one chunk of pairs before the next chunk: with ONE panorama a short run (the entries' plan tables
-    // and source rows are still in L2 for the next chunk), with several all of them (a chunk's panoramas serve every
-    // tile before the next ones are touched: see pair_chunk)
-    P.main_count = j->d_main_count;
-    P.main_group = P.chunk_outer ? std::max(1, j->main_stride)
-                                 : std::max(1, std::min(j->main_stride, choose_main_group(opt, j->shape, P.main_span, pair_chunks)));
     // table-prefetch workgroups (p2p_tile.h: main_block_role) when one launch's plan tables cannot stay in the Infinity
     // Cache next to the panorama (config 4: 565 MB): 2 groups = 64 tiles of lead per XCD
     {
         const size_t table_bytes = plan_table_bytes(j->d, shape_ops(j->shape).shape);
         P.pf_lead = opt.prefetch_lead >= 0 ? opt.prefetch_lead : (table_bytes > ((size_t)128 << 20) ? 2 : 0);
     }
-    // The last entries of every XCD's list as two workgroups of half the pairs each: when the list runs out, the
-    // workgroups in flight end over a whole workgroup's life (25 us on config 2) with ever fewer of them left -- half
-    // of that is lost.  Shorter workgroups at the end shorten it.  Only where one workgroup draws ALL pairs of its tile.
-    P.main_tail = 0;
-    P.main_tail_parts = opt.main_tail_parts;
-    if (P.main_list && j->shape != 1 && pair_chunks == 1 && P.main_span == 1 && P.pf_lead == 0 && j->d.n_panos * j->d.n_yaw >= 4) {  // (not the 128-wide kernel: p2p_views.hip)
-        const int in_flight = 32 * (j->shape == 1 ? 3 : (j->shape == 2 ? 5 : 7));  // workgroups an XCD holds at a time
-        P.main_tail = opt.main_tail >= 0 ? opt.main_tail : in_flight / 5;
-        P.main_tail = std::min(P.main_tail, j->main_stride);
-    }
+    list_params(*j->plan_ref, band ? 0 : job_main_order(j));
     if (band) {
         const Plan& Pl = *j->plan_ref;
         P.band_hdr = Pl.d_band_hdr; P.band_px = Pl.d_band_px; P.band_grp = Pl.d_band_grp; P.band_info = Pl.d_band_info;
@@ -648,33 +699,12 @@ int job_run(p2p_job* j)
         j->ran = true;
         return P2P_OK;
     }
-    // the pair-context table: not for a job's very first launch (the main kernel is already out), not beyond 64 MB
+    // the pair-context table: not for a job's very first launch (the main kernel is already out)
     P.pair_ctx = nullptr;
     P.pair_ctx_chunks = 0;
-    if (opt.pair_ctx_table != 0 && !early_main && opt.force_rest == 0) {
-        const int chunks_all = (j->d.n_panos * j->d.n_yaw + P.pairs_per_block - 1) / P.pairs_per_block;
-        const size_t tslots = band ? (size_t)j->plan_ref->band_tiles : j->n_tiles * (size_t)j->d.n_pitch;
-        const size_t bytes = tslots * (size_t)chunks_all * 64 * sizeof(uint4);
-        if (tslots > 0 && bytes <= ((size_t)64 << 20) && P.pairs_per_block <= 64) {
-            const bool stale = !j->d_pair_ctx || j->pc_plan != j->plan_ref.get() || j->pc_yaw != j->yaw_ref.get() ||
-                               j->pc_mask_gen != j->mask_gen || j->pc_ppb != P.pairs_per_block || j->pc_chunks != chunks_all ||
-                               j->pc_slots != tslots;
-            if (stale) {
-                if (j->d_pair_ctx && (j->pc_slots * (size_t)j->pc_chunks != tslots * (size_t)chunks_all)) {
-                    HIP_TRY(hipStreamSynchronize(j->ctx->stream));
-                    (void)dev_free(j->d_pair_ctx);
-                    j->d_pair_ctx = nullptr;
-                }
-                if (!j->d_pair_ctx)
-                    HIP_TRY(dev_alloc((void**)&j->d_pair_ctx, bytes));
-                HIP_TRY(shape_ops(j->shape).pair_ctx(P, j->d_pair_ctx, (int)tslots, chunks_all, band ? 1 : 0, j->ctx->stream));
-                j->pc_plan = j->plan_ref.get(); j->pc_yaw = j->yaw_ref.get(); j->pc_mask_gen = j->mask_gen;
-                j->pc_ppb = P.pairs_per_block; j->pc_chunks = chunks_all; j->pc_slots = tslots;
-            }
-            P.pair_ctx = j->d_pair_ctx;
-            P.pair_ctx_chunks = chunks_all;
-        }
-    }
+    if (opt.pair_ctx_table != 0 && !early_main && opt.force_rest == 0)
+        if (int rc = pair_ctx_table(j->plan_ref.get(), band, j->ctx->stream))
+            return rc;
     if (timed && !early_main)
         HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
     // The main kernel draws every LDS-scheme tile for every yaw that is a plain shift, the gather kernel every other

@@ -348,7 +348,7 @@ int job_main_order(const p2p_job* j)
 // after_plan_pass: called once the plan pass is enqueued and before anything waits for it (per-view plans only) --
 // p2p_job_run launches the main kernel in grid order there, so that one image through a fresh context has its pixels
 // under way while the host reads the gather count back.
-int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& after_plan_pass)
+int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
 {
     const p2p_job_desc& d = j->d;
     p2p_ctx* ctx = j->ctx;
@@ -496,7 +496,7 @@ int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& after_plan
         HIP_TRY(dev_alloc((void**)&Pl->d_band_info, sizeof(p2p::BandInfo)));
         B.info = Pl->d_band_info;
         // (BandInfo: every field is written by band_scan_kernel / band_xcd_kernel)
-        HIP_TRY(hipMemsetAsync(cellblk, 0, (cells * 5 + 64) * sizeof(uint32_t), st));
+        HIP_TRY(p2p::launch_zero_words(cellblk, (uint32_t)(cells * 5 + 64), st));
     }
 #ifdef P2P_AUDIT
     if (!band) {
@@ -512,7 +512,7 @@ int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& after_plan
 #endif
     // (the plan pass writes every header, every per-pixel word and every item slot of every tile: nothing to clear)
     if (!band)
-        HIP_TRY(hipMemsetAsync(Pl->d_n_gather, 0, sizeof(uint32_t), st));
+        HIP_TRY(p2p::launch_zero_words(Pl->d_n_gather, 1u, st));
     HIP_TRY(hipEventRecord(ctx->ev_t0, st));
     HIP_TRY(shape_ops(j->shape).plan(Q, st));
     if (!band && after_plan_pass) {
@@ -574,7 +574,7 @@ int job_build_plan(p2p_job* j, const std::function<int(const Plan&)>& after_plan
         return fail(P2P_ERR_HIP, "the plan pass listed %u gather tiles of %zu", cnt, slots);
     Pl->n_gather = (int)cnt;
     Pl->built = true;
-    bool make_main_list = want_main_order && (size_t)cnt < slots;
+    bool make_main_list = want_main_order && (size_t)cnt < slots && !Pl->lists_made;  // (made already: p2p_job_run's side stream)
     if (make_main_list && may_defer && cnt == 0) {
         Pl->lists_pending = true;
         make_main_list = false;

@@ -268,6 +268,22 @@ __global__ __launch_bounds__(LISTS_BLOCK) void main_lists_kernel(MainListParams 
         M.count[t] = s_first[t + 1] - s_first[t];
 }
 
+// A few words cleared by a kernel of the job's own stream: hipMemsetAsync goes through the runtime's fill kernel and the
+// barrier around it (15 us in front of a cold image's plan pass, for one counter).
+__global__ __launch_bounds__(256) void zero_words_kernel(uint32_t* __restrict__ p, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+        p[i] = 0u;
+}
+
+hipError_t launch_zero_words(uint32_t* p, uint32_t n, hipStream_t st)
+{
+    if (n == 0u)
+        return hipSuccess;
+    hipLaunchKernelGGL(zero_words_kernel, dim3(std::min((n + 255u) / 256u, 1024u)), dim3(256), 0, st, p, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_main_lists(const MainListParams& M, hipStream_t st)
 {
     hipLaunchKernelGGL(main_lists_kernel, dim3(1), dim3(LISTS_BLOCK), 0, st, M);

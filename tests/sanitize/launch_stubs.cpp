@@ -23,6 +23,11 @@ hipError_t launch_yaw_tables(uint32_t* packed, float* rows, int pw, int n_yaw, c
         }
     return hipSuccess;
 }
+hipError_t launch_zero_words(uint32_t* p, uint32_t n, hipStream_t)
+{
+    memset(p, 0, (size_t)n * sizeof(uint32_t));
+    return hipSuccess;
+}
 // the main kernel's per-XCD lists: the host algorithm the device kernel (csrc/p2p_lists.hip) replaced -- counting sort by
 // source band, running costs, eight cuts of equal work, every run from its costlier end
 hipError_t launch_main_lists(const MainListParams& M, hipStream_t)

@@ -184,10 +184,11 @@ def test_gather_tiles_in_rows_and_in_blocks_draw_the_same_bytes(gpu, synth, monk
 
 @pytest.mark.parametrize("pitches", [[60, 90, 120], [8, 60, 90]], ids=["no gather tile", "a pole in view"])
 def test_first_and_second_launch_draw_the_same_bytes(gpu, synth, p2p_env, pitches):
-    """A job's first launch sends the main kernel out in grid order right behind the plan pass and, when the plan has no
-    gather tile, makes the per-XCD lists only when a second launch asks for them (P2P_EARLY_MAIN, P2P_DEFER_LISTS): the
-    first, the second and the third launch -- grid order, then list order, where the gather tiles ride in the main kernel's
-    launch (P2P_MERGE_GATHER) -- draw the oracle's bytes, with every knob off too."""
+    """A job's first launch sends the main kernel out behind the plan pass without waiting for anything: in grid order,
+    with the per-XCD lists made on the device when a second launch asks (the default), or in list order with the lists and
+    the pair contexts made in between (P2P_DEFER_LISTS=0), or after the gather count has come back (P2P_EARLY_MAIN=0).  The
+    first, the second and the third launch -- where the gather tiles ride in the main kernel's launch
+    (P2P_MERGE_GATHER) -- draw the oracle's bytes into a poisoned block, with every knob either way."""
     pw, ph, ow, oh, fov = 2048, 1024, 640, 360, 90
     yaws = [0, 33, 90, 200, 301]
     pano = synth.synth_pano(pw, ph, 4400, "N")
@@ -205,6 +206,7 @@ def test_first_and_second_launch_draw_the_same_bytes(gpu, synth, p2p_env, pitche
             job.set_maps(*maps)
             job.set_pano(0, pano)
             for launch in range(3):
+                poison_views(job, 0xA5 - launch)  # (a tile that a launch does not draw must show)
                 job.run()
                 got = job.get_views(0)
                 bad = np.argwhere(got != want)
