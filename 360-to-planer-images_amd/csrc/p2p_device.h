@@ -182,6 +182,10 @@ struct ViewsParams {
                                         // launch, or of the main kernel's in list order, not by a launch of their own
 };
 
+// plan_kernel's finish counters: [0] groups that have finished, [32 * (1 + g)] workgroups of group g (workgroup & 63) that
+// have -- 128 bytes apart: 6120 adds to ONE word are 37 us of a 52 us pass, 96 to each of 64 words are not seen
+constexpr int PLAN_TICKET_GROUPS = 64, PLAN_TICKET_WORDS = 32 * (1 + PLAN_TICKET_GROUPS);
+
 struct PlanParams {
     int pw, ph, ow, oh, n_pitch, border;
     MapGeom geom;
@@ -200,6 +204,10 @@ struct PlanParams {
     uint32_t* px2;           // float path: [n_pitch][tiles][256 * VIEWS_PXT] frac(U) | frac(V) << 16, 1/65536 units
     int blocky_from;         // a tile with an output row of 64 pixels across this many source rows is drawn in 16 x 4 blocks (GATHER_BLOCKY_FROM)
     uint32_t* n_gather;      // [0] tiles marked for gathers
+    // Per-view plans: the context's finish counters (PLAN_TICKET_WORDS words, zero between plan passes) and the page-locked
+    // host word the pass's LAST workgroup writes the gather count to (plan_kernel); nullptr: nobody reads it there
+    uint32_t* ticket;
+    uint32_t* n_gather_host;
     uint32_t* gather_list;   // [n_pitch * tiles] the tiles marked for gathers (pitch * tiles + tile), in no particular order
     // band plan (band.gcell != nullptr): a tile all of whose groups can go into source-band tiles gets mode 3 and no
     // tables (px / items are nullptr); its groups are counted into the cells of the source.  The other tiles gather.
@@ -235,7 +243,7 @@ hipError_t launch_zero_words(uint32_t* p, uint32_t n, hipStream_t st);  // (inst
 hipError_t launch_yaw_tables(uint32_t* packed, float* rows, int pw, int n_yaw, const double* yaw_rad,
                              hipStream_t st);
 hipError_t launch_yaw_pack(uint32_t* packed, const float* rows, size_t n, hipStream_t st);
-hipError_t launch_yaw_desc(YawDesc* desc, uint32_t* f4tab, const uint32_t* packed, int pw, int n_yaw,
+hipError_t launch_yaw_desc(YawDesc* desc, uint32_t* f4tab, uint32_t* packed, int pw, int n_yaw, const double* yaw_rad,
                            hipStream_t st);
 hipError_t launch_rot_map(float* U, float* V, int ow, int oh, const MapGeom& g, const float* R9, hipStream_t st);
 hipError_t launch_pitch_map(float* U, float* V, int ow, int oh, const MapGeom& g, float c, float s,

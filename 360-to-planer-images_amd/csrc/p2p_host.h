@@ -86,7 +86,7 @@ struct Options {
     int merge_gather = 1;               // P2P_MERGE_GATHER: 1 = the gather tiles are drawn by the first workgroups of the band kernel's launch / of the main kernel's in list order
     int pair_ctx_table = 1;           // P2P_PAIR_CTX_TABLE: 1 = the pair contexts of every tile come from a table built once per job geometry
     int early_main = 1;               // P2P_EARLY_MAIN: 1 = a job's first launch sends the main kernel out right behind the plan pass
-    int defer_lists = 1;              // P2P_DEFER_LISTS: 1 = a plan without gather tiles draws its first launch in grid order and makes its main lists at its second (0: in front of the first launch's main kernel)
+    int defer_lists = 2;              // P2P_DEFER_LISTS: where a fresh geometry's main lists (and the job's pair contexts) are made -- 0 in front of its first main kernel, 1 right behind it, 2 when a second launch asks
     int band = -1;                    // P2P_BAND: 1 = source-band tiles wherever they apply, 0 = never, -1 = the library's rule (choose_band)
     int band_bh = -1, band_cw = -1;   // P2P_BAND_BH / P2P_BAND_CW: cell of the source, rows x columns (-1: by tile shape, band_cell)
     int band_maxw = 27, band_maxh = 7;  // (no environment knob) tap extent of a group beyond which its tile gathers
@@ -186,9 +186,13 @@ struct Plan {  // the plan pass's tables (p2p_plan.hip)
     // The main kernel's per-XCD lists are made from the headers ON THE DEVICE (p2p_lists.hip: no read-back, no host sort,
     // no upload).  A plan with no gather tile does not need them to draw: its FIRST launch goes out in the grid's own
     // order right behind the plan pass, and the list kernel is enqueued when a second launch asks for the plan (one image
-    // through a fresh context -- the tool on one file -- does not wait for it: bench.py's cold figures).
-    // P2P_DEFER_LISTS=0: the list kernel and the pair contexts go out between the plan pass and the first main kernel, which
-    // then draws in list order like every later launch (same box: first launch 194-200 -> 229-236 us, second 105-111 -> 85-91).
+    // through a fresh context -- the tool on one file -- does not wait for it: bench.py's cold figures; lists_pending).
+    // The device is busy from the plan pass to the end of the second launch either way; what P2P_DEFER_LISTS chooses is
+    // which launch waits for the list kernel and the pair contexts (17 + 5 us).  One box, first / second launch of config 2:
+    //   2 (the default)                                   174-177 / 104-107 us
+    //   1: both right behind the first main kernel        196-207 /  81-84
+    //   0: both between the plan pass and that kernel, which then draws in list order -- slower on a cold cache
+    //                                                     202-207 /  81-89
     // the quantised coordinates of every pixel (else: of the gather tiles only; ensure_full_coords completes them)
     std::atomic<bool> coords_full{false};
     std::atomic<bool> lists_pending{false};
@@ -259,6 +263,10 @@ struct p2p_ctx {
     unsigned long long cache_clock = 0;
     size_t cache_budget = (size_t)4096 << 20;     // P2P_PLAN_CACHE_MB as it stood when the context was created
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // timing of the plan pass / the table kernels
+    // per-view plan passes: the gather counter [PLAN_TICKET_WORDS] and the finish counters [0 .. PLAN_TICKET_WORDS) of
+    // plan_kernel, zero whenever no pass is in flight (the pass's last workgroup leaves them so); one pass at a time
+    uint32_t* d_plan_cnt = nullptr;
+    std::mutex plan_mu;
 };
 
 

@@ -87,6 +87,8 @@ int ctx_create(int device, p2p_ctx** out)
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_t0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_t1);
+    if (e == hipSuccess) e = dev_alloc((void**)&c->d_plan_cnt, (p2p::PLAN_TICKET_WORDS + 32) * sizeof(uint32_t));
+    if (e == hipSuccess) e = p2p::launch_zero_words(c->d_plan_cnt, p2p::PLAN_TICKET_WORDS + 32, c->stream);
 #ifdef P2P_AUDIT
     if (e == hipSuccess) e = dev_alloc((void**)&c->d_audit, p2p::AUDIT_WORDS * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(c->d_audit, 0, p2p::AUDIT_WORDS * sizeof(uint32_t));
@@ -130,6 +132,7 @@ void ctx_destroy(p2p_ctx* c)
         c->yaw_tabs.clear();
     }
     (void)dev_free(c->d_ctab);
+    (void)dev_free(c->d_plan_cnt);
     (void)dev_free(c->d_audit);
     for (void* p : c->scratch)
         (void)dev_free(p);
@@ -262,10 +265,9 @@ int yaw_tabs_get(p2p_ctx* ctx, int pw, const std::vector<double>& yaw_deg, const
     if (rows) {
         HIP_TRY(hipMemcpyAsync(d_rows, rows, n * sizeof(float), hipMemcpyHostToDevice, st));
         HIP_TRY(p2p::launch_yaw_pack(T->d_ytab, d_rows, n, st));
-    } else {
-        HIP_TRY(p2p::launch_yaw_tables(T->d_ytab, nullptr, pw, n_yaw, T->d_yaw_rad, st));
     }
-    HIP_TRY(p2p::launch_yaw_desc(T->d_ydesc, T->d_f4tab, T->d_ytab, pw, n_yaw, st));
+    // (without caller rows the descriptor kernel makes the packed table as it goes: one launch)
+    HIP_TRY(p2p::launch_yaw_desc(T->d_ydesc, T->d_f4tab, T->d_ytab, pw, n_yaw, rows ? nullptr : T->d_yaw_rad, st));
     HIP_TRY(hipEventRecord(ctx->ev_t1, st));
     T->desc.resize(n_yaw);
     HIP_TRY(hipMemcpyAsync(T->desc.data(), T->d_ydesc, T->desc.size() * sizeof(p2p::YawDesc), hipMemcpyDeviceToHost, st));

@@ -590,11 +590,11 @@ int job_run(p2p_job* j)
                 P.pair_ctx_chunks = 0;
                 // P2P_DEFER_LISTS=0: the per-XCD lists and the pair contexts, which need the plan pass only, go out between
                 // the plan pass and the main kernel, and the geometry's first image is drawn as every later one will be.
-                // Not the default: 17 + 5 us in front of a kernel that is, on a cold cache, SLOWER in list order (124 us
-                // against 105 in grid order; the steady state has it the other way round) -- first launch 194-200 ->
-                // 229-236 us, second 105-111 -> 85-91 on one box: the sum is 14 us worse.  The lists on a second stream
-                // next to the main kernel (tools/platform/side_stream_probe.hip): the list kernel's 16 waves and 30 KB of
-                // LDS find no CU with room while the main kernel's seven workgroups per CU are in flight, and run behind it.
+                // Not the default: 17 + 5 us in front of a kernel that is, on a cold cache, SLOWER in list order (the steady
+                // state has it the other way round); Plan::lists_pending has the three orders' times.  The lists on a
+                // second stream NEXT to the main kernel (tools/platform/side_stream_probe.hip): the main kernel's seven
+                // workgroups per CU hold 504 of a SIMD's 512 registers -- no wave of another kernel starts until they
+                // drain, whichever stream was given its work first.
                 const int main_order = job_main_order(j);
                 if (main_order != 0 && opt.defer_lists == 0) {
                     if (int rc = plan_enqueue_main_lists(Pl, j->n_tiles * (size_t)j->d.n_pitch, shape_ops(j->shape).shape.tile_w, j->ctx->stream))
@@ -699,12 +699,17 @@ int job_run(p2p_job* j)
         j->ran = true;
         return P2P_OK;
     }
-    // the pair-context table: not for a job's very first launch (the main kernel is already out)
+    // the pair-context table: not FOR a job's very first launch (the main kernel is already out), but made behind it
+    // when the plan's lists were (P2P_DEFER_LISTS=1)
     P.pair_ctx = nullptr;
     P.pair_ctx_chunks = 0;
-    if (opt.pair_ctx_table != 0 && !early_main && opt.force_rest == 0)
+    if (opt.pair_ctx_table != 0 && opt.force_rest == 0 && (!early_main || (opt.defer_lists == 1 && j->plan_ref->lists_made && !band)))
         if (int rc = pair_ctx_table(j->plan_ref.get(), band, j->ctx->stream))
             return rc;
+    if (early_main) {
+        P.pair_ctx = nullptr;
+        P.pair_ctx_chunks = 0;
+    }
     if (timed && !early_main)
         HIP_TRY(hipEventRecord(j->ev_ring[2 * slot], j->ctx->stream));
     // The main kernel draws every LDS-scheme tile for every yaw that is a plain shift, the gather kernel every other

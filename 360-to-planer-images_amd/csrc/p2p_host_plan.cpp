@@ -402,6 +402,7 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
             return e;
         }
     } scratch;
+    std::unique_lock<std::mutex> one_pass(ctx->plan_mu, std::defer_lock);  // (declared first: given back after the stream has drained)
     StreamSyncGuard sync_on_exit(st);
     HIP_TRY(pin_get(&pin.p, &pin.cls, pin_hdr_off + std::min(slots, pin_hdr_max) * sizeof(p2p::PieceHdr)));
     p2p::BandInfo* const h_binfo = (p2p::BandInfo*)pin.p;
@@ -511,14 +512,30 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
     }
 #endif
     // (the plan pass writes every header, every per-pixel word and every item slot of every tile: nothing to clear)
-    if (!band)
-        HIP_TRY(p2p::launch_zero_words(Pl->d_n_gather, 1u, st));
-    HIP_TRY(hipEventRecord(ctx->ev_t0, st));
+    // Per-view plans: the plan pass's last workgroup writes the gather count into the page-locked block itself
+    // (plan_kernel), and the host waits for the pass's event alone -- no copy in the stream behind the main kernel that is
+    // about to follow, no waiting for that kernel.  The pass counts in the context's own words (zero between passes: no
+    // clearing in front of it either), so one pass per context at a time.
+    constexpr uint32_t kNoCount = 0xFFFFFFFFu;
+    if (!band) {
+        one_pass.lock();
+        Q.n_gather = d_cnt = ctx->d_plan_cnt + p2p::PLAN_TICKET_WORDS;
+        Q.ticket = ctx->d_plan_cnt;
+        Q.n_gather_host = h_cnt;
+        *(volatile uint32_t*)h_cnt = kNoCount;
+    }
+    // (per-view plans: the pass is timed only for a job that asked for launch timing -- an event in front of the pass and
+    // one between it and the main kernel are 5 us each on a cold image's critical path)
+    const bool timed_plan = band || j->time_launches;
+    if (timed_plan)
+        HIP_TRY(hipEventRecord(ctx->ev_t0, st));
     HIP_TRY(shape_ops(j->shape).plan(Q, st));
-    if (!band && after_plan_pass) {
-        HIP_TRY(hipEventRecord(ctx->ev_t1, st));
-        if (int rc = after_plan_pass(*Pl))
-            return rc;
+    if (!band) {
+        if (timed_plan)
+            HIP_TRY(hipEventRecord(ctx->ev_t1, st));
+        if (after_plan_pass)
+            if (int rc = after_plan_pass(*Pl))
+                return rc;
     }
     if (band) {
         // the band passes: count the tiles, read the count back (the tables are sized by it), cut, sort, build
@@ -555,26 +572,43 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
             HIP_TRY(shape_ops(j->shape).band(B, 1, st));
         }
     }
-    if (band || !after_plan_pass)
+    if (band)
         HIP_TRY(hipEventRecord(ctx->ev_t1, st));
-    if (!band)
-        HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
     // the work lists are made from the plan's headers, once per geometry: they come back with the counter -- unless the
     // plan turns out to have no gather tile and may draw its first launch in grid order (Plan::lists_pending)
     const bool want_main_order = main_order != 0;
-    const bool may_defer = want_main_order && opt.defer_lists != 0 && opt.main_order < 0 && opt.scramble_plan == 0;
+    const bool may_defer = want_main_order && opt.defer_lists == 2 && opt.main_order < 0 && opt.scramble_plan == 0;
     Pl->tile_w = shape_ops(j->shape).shape.tile_w;
     if (!band) {  // (band plans: the counter came back with the band counts; the device is still building the tiles)
-        HIP_TRY(hipStreamSynchronize(st));
-        cnt = *h_cnt;
-        hdr_arrived();
-        (void)hipEventElapsedTime(&Pl->plan_ms, ctx->ev_t0, ctx->ev_t1);
+        // the plan pass's last workgroup writes the word; whatever is queued behind the pass is not waited for
+        for (unsigned spins = 1; (cnt = *(volatile uint32_t*)h_cnt) == kNoCount; ++spins) {
+            if ((spins & 2047u) == 0u) {  // (now and then: has the stream drained, or failed, without the word?)
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipSuccess) {
+                    cnt = *(volatile uint32_t*)h_cnt;
+                    break;
+                }
+                if (q != hipErrorNotReady)
+                    return fail(P2P_ERR_HIP, "the plan pass: %s", hipGetErrorString(q));
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        if (cnt == kNoCount)
+            return fail(P2P_ERR_HIP, "the plan pass did not hand its gather count to the host");
+        Pl->plan_ms = 0.0f;
+        if (timed_plan) {
+            HIP_TRY(hipEventSynchronize(ctx->ev_t1));
+            (void)hipEventElapsedTime(&Pl->plan_ms, ctx->ev_t0, ctx->ev_t1);
+        }
+        one_pass.unlock();
     }
     if ((size_t)cnt > slots)
         return fail(P2P_ERR_HIP, "the plan pass listed %u gather tiles of %zu", cnt, slots);
     Pl->n_gather = (int)cnt;
     Pl->built = true;
-    bool make_main_list = want_main_order && (size_t)cnt < slots && !Pl->lists_made;  // (made already: p2p_job_run's side stream)
+    bool make_main_list = want_main_order && (size_t)cnt < slots && !Pl->lists_made;  // (made already: in front of the first main kernel)
     if (make_main_list && may_defer && cnt == 0) {
         Pl->lists_pending = true;
         make_main_list = false;
@@ -584,9 +618,11 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
         HIP_TRY(hipStreamSynchronize(st));
         hdr_arrived();
     }
-    if (make_main_list)  // (on the device: one launch, nothing waited for)
+    if (make_main_list) {  // (on the device: one launch, nothing waited for)
         if (int rc = plan_enqueue_main_lists(*Pl, slots, shape_ops(j->shape).shape.tile_w, st))
             return rc;
+        Pl->lists_made = true;
+    }
     if (cnt > 0) {
         // the gather kernel's work lists, one per XCD: xcd_lists
         const bool by_source = opt.gather_order != 0;
@@ -654,7 +690,7 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
         j->plan_ref = Pl;
         return P2P_OK;
     }
-    sync_on_exit.armed = false;  // every path above has synchronised the stream
+    sync_on_exit.armed = false;  // every copy above has been waited for (kernels may still run: they own no host memory)
     if (cached) {
         std::lock_guard<std::mutex> lk(ctx->cache_mu);
         Pl->stamp = ++ctx->cache_clock;

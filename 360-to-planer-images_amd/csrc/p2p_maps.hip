@@ -89,15 +89,19 @@ __device__ __forceinline__ int yaw_delta(uint32_t te, int c, int s, int pw)
 }
 
 // (1024 threads per yaw: the two passes over the table are chains of dependent loads, 8 rounds each at 8192 columns)
+// EVAL: the packed table is not read but MADE here, in the first pass (yaw_table_kernel's arithmetic, entry for entry) --
+// the two kernels were a launch and a dependency apart (3 + 6 us of the 30 a job's yaw tables cost a cold image).
+template <bool EVAL>
 __global__ __launch_bounds__(1024) void yaw_desc_kernel(YawDesc* __restrict__ desc, uint32_t* __restrict__ f4tab,
-                                                       const uint32_t* __restrict__ packed, int pw)
+                                                       uint32_t* packed, int pw, const double* __restrict__ yaw_rad)
 {
     __shared__ int bad[2];
     __shared__ int dmin, dmax;
     const int yi = blockIdx.x, t = threadIdx.x;
-    const uint32_t* T = packed + (size_t)yi * pw;
+    uint32_t* T = packed + (size_t)yi * pw;
     uint32_t* F4 = f4tab + (size_t)yi * pw;
-    const int i0 = (int)(T[0] & 0xFFFFFu) / 3;
+    const double yr = EVAL ? yaw_rad[yi] : 0.0;
+    const int i0 = (int)((EVAL ? pack_yaw_entry(yaw_row_eval(0, pw, yr)) : T[0]) & 0xFFFFFu) / 3;
     if (t < 2)
         bad[t] = 0;
     if (t == 0) {
@@ -112,8 +116,16 @@ __global__ __launch_bounds__(1024) void yaw_desc_kernel(YawDesc* __restrict__ de
     for (int c0 = t; c0 < pw; c0 += 8 * 1024) {
         uint32_t te[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            te[k] = c0 + 1024 * k < pw ? T[c0 + 1024 * k] : 0u;
+        for (int k = 0; k < 8; ++k) {
+            const int c = c0 + 1024 * k;
+            if (EVAL) {
+                te[k] = c < pw ? pack_yaw_entry(yaw_row_eval(c, pw, yr)) : 0u;
+                if (c < pw)
+                    T[c] = te[k];
+            } else {
+                te[k] = c < pw ? T[c] : 0u;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int c = c0 + 1024 * k;
@@ -125,6 +137,8 @@ __global__ __launch_bounds__(1024) void yaw_desc_kernel(YawDesc* __restrict__ de
     }
     if (nb_a) atomicAdd(&bad[0], nb_a);
     if (nb_b) atomicAdd(&bad[1], nb_b);
+    if (EVAL)
+        __threadfence_block();  // (the second pass reads neighbours' entries from the table this workgroup has just written)
     __syncthreads();
     const bool ok_a = bad[0] == 0, ok_b = bad[1] == 0;
     const int s = ok_a ? s_a : s_b;
@@ -296,10 +310,14 @@ hipError_t launch_yaw_pack(uint32_t* packed, const float* rows, size_t n, hipStr
     return hipGetLastError();
 }
 
-hipError_t launch_yaw_desc(YawDesc* desc, uint32_t* f4tab, const uint32_t* packed, int pw, int n_yaw,
+hipError_t launch_yaw_desc(YawDesc* desc, uint32_t* f4tab, uint32_t* packed, int pw, int n_yaw, const double* yaw_rad,
                            hipStream_t st)
 {
-    hipLaunchKernelGGL(yaw_desc_kernel, dim3(n_yaw), dim3(1024), 0, st, desc, f4tab, packed, pw);
+    // yaw_rad != nullptr: the packed table is written by this launch too (no launch_yaw_tables in front of it)
+    if (yaw_rad)
+        hipLaunchKernelGGL(yaw_desc_kernel<true>, dim3(n_yaw), dim3(1024), 0, st, desc, f4tab, packed, pw, yaw_rad);
+    else
+        hipLaunchKernelGGL(yaw_desc_kernel<false>, dim3(n_yaw), dim3(1024), 0, st, desc, f4tab, packed, pw, yaw_rad);
     return hipGetLastError();
 }
 

@@ -222,6 +222,8 @@ def secondary_lines(nat, ctx, pano8k, device):
             job = nat.Job(ctx, w["pw"], w["ph"], n_panos, w["yaws"], w["pitches"], w["fov"], w["ow"], w["oh"], flags=flags)
             for i in range(n_panos):
                 job.set_pano(i, pano)
+            job.time_launches(1)   # (the plan pass is timed for a job that asks: plan_ms below)
+            job.run()
             job.time_launches(False)
             for _ in range(max(2, launches // 4)):
                 job.run()
@@ -372,6 +374,7 @@ def exact_route_line(pkg, nat, w, pano, device):
         t0 = time.perf_counter()
         job.set_maps(None, U, V)
         upload_ms = (time.perf_counter() - t0) * 1e3
+        job.time_launches(1)  # (plan_ms: the plan pass is timed for a job that asks)
         ctx.mark(0)
         job.run()
         ctx.mark(1)
@@ -410,25 +413,35 @@ def cold_first_image(nat, w, pano, device):
     """What ONE image through a context that has not seen its geometry pays on the device, next to the steady state
     the headline quotes: yaw tables + plan pass + view kernel (the reference's first image pays its map builders,
     P:79-175, the same way).  A fresh context, so that nothing comes from the table caches."""
-    ctx = nat.Context(device)
-    try:
-        job = nat.Job(ctx, w["pw"], w["ph"], 1, w["yaws"], w["pitches"], w["fov"], w["ow"], w["oh"])
-        job.set_pano(0, pano)
-        job.time_launches(1)
-        ctx.mark(0)
-        job.run()   # plan pass (device), its gather-tile count read back (host), the view kernel
-        ctx.mark(1)
-        first = ctx.marked_ms()
-        plan_ms, tables_ms = job.plan_ms()
-        k = job.kernel_ms()
-        job.close()
-        return {"plan_ms": plan_ms, "yaw_tables_ms": tables_ms, "first_run_ms": first, "view_kernel_ms_in_first_run": k,
-                "cold_one_image_ms": tables_ms + first,
-                "how": "fresh context and job; first_run_ms = HIP events around the first p2p_job_run (one allocation for the "
-                       "plan's tables, plan pass, the main kernel in grid order right behind it, the gather count read back; "
-                       "the per-XCD work lists are made when a second launch asks for them); yaw tables are built at job creation"}
-    finally:
-        ctx.close()
+    def one(timed):
+        ctx = nat.Context(device)
+        try:
+            job = nat.Job(ctx, w["pw"], w["ph"], 1, w["yaws"], w["pitches"], w["fov"], w["ow"], w["oh"])
+            job.set_pano(0, pano)
+            if timed:
+                job.time_launches(1)
+            ctx.mark(0)
+            job.run()   # plan pass (device), its gather-tile count handed to the host, the view kernel behind the pass
+            ctx.mark(1)
+            first = ctx.marked_ms()
+            plan_ms, tables_ms = job.plan_ms()
+            k = job.kernel_ms() if timed else None
+            job.close()
+            return first, plan_ms, tables_ms, k
+        finally:
+            ctx.close()
+
+    first, _, tables_ms, _ = one(False)          # the product's path: no event inside the run
+    first_t, plan_ms, tables_t, k = one(True)    # the same with the plan pass and the view kernel bracketed by events
+    return {"plan_ms": plan_ms, "yaw_tables_ms": tables_ms, "first_run_ms": first, "view_kernel_ms_in_first_run": k,
+            "cold_one_image_ms": tables_ms + first, "first_run_ms_with_timing_events": first_t,
+            "how": "fresh context and job, twice: first_run_ms = HIP events around the first p2p_job_run of a job that records "
+                   "no event of its own (one allocation for the plan's tables, the plan pass, the main kernel in grid order "
+                   "right behind it; the pass's last workgroup hands the gather count to the host through page-locked memory, "
+                   "so neither a copy nor that kernel is waited for; the per-XCD work lists are made when a second launch asks "
+                   "for them); plan_ms / view_kernel_ms_in_first_run / first_run_ms_with_timing_events from a second fresh "
+                   "context with p2p_job_time_launches on (four more events inside the run); yaw tables are built at job "
+                   "creation (always timed)"}
 
 
 def read_sclk_mhz():

@@ -294,7 +294,9 @@ int p2p_job_wait(p2p_job* job);
 int p2p_job_time_launches(p2p_job* job, int n);
 /* Device time it took to build the job's plan (the pitch maps' tables, once per geometry: the reference's
    pitch_mapping_cache, P:17-18, P:55-73) and its yaw tables (yaw_mapping_cache, P:42-52), in ms.  The context keeps
-   both by geometry, so these are the times of whichever job built them first.  After the first p2p_job_run. */
+   both by geometry, so these are the times of whichever job built them first.  After the first p2p_job_run.  The plan
+   pass is timed only when the job that built the plan had launch timing on (p2p_job_time_launches before its first
+   run: two events around the pass, 10 us of a cold image's device time); otherwise *plan_ms is 0. */
 int p2p_job_plan_ms(p2p_job* job, float* plan_ms, float* tables_ms);
 /* Device time of the last p2p_job_run's view kernel(s), from HIP events on the job's stream. */
 int p2p_job_kernel_ms(p2p_job* job, float* ms);

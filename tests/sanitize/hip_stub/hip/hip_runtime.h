@@ -12,7 +12,7 @@
 #include <string.h>
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorNotReady = 600 };
 typedef struct p2p_stub_stream* hipStream_t;
 typedef struct p2p_stub_event* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
@@ -55,6 +55,7 @@ static inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, siz
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)calloc(1, sizeof(p2p_stub_stream)); if (*s) p2p_stub_count(1, 1); return *s ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipStreamSynchronize(hipStream_t s) { return s ? hipSuccess : hipErrorInvalidValue; }
+static inline hipError_t hipStreamQuery(hipStream_t s) { return s ? hipSuccess : hipErrorInvalidValue; }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { if (s) p2p_stub_count(1, -1); free(s); return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) { return s && e ? hipSuccess : hipErrorInvalidValue; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)calloc(1, sizeof(p2p_stub_event)); if (*e) p2p_stub_count(0, 1); return *e ? hipSuccess : hipErrorOutOfMemory; }

@@ -76,8 +76,10 @@ hipError_t launch_yaw_pack(uint32_t* packed, const float* rows, size_t n, hipStr
     for (size_t k = 0; k < n; ++k) packed[k] = 3u * (uint32_t)rows[k];
     return hipSuccess;
 }
-hipError_t launch_yaw_desc(YawDesc* desc, uint32_t* f4tab, const uint32_t* packed, int pw, int n_yaw, hipStream_t)
+hipError_t launch_yaw_desc(YawDesc* desc, uint32_t* f4tab, uint32_t* packed, int pw, int n_yaw, const double* yaw_rad, hipStream_t st)
 {
+    if (yaw_rad)  // (the descriptor kernel makes the packed table as it goes)
+        (void)launch_yaw_tables(packed, nullptr, pw, n_yaw, yaw_rad, st);
     for (int y = 0; y < n_yaw; ++y) {
         desc[y] = YawDesc{(int)(packed[(size_t)y * pw] / 3u), y % 3 == 2 ? 1 : 0, 0, -1};
         memset(f4tab + (size_t)y * pw, 0, (size_t)pw * sizeof(uint32_t));
@@ -123,7 +125,7 @@ static hipError_t stub_plan(const PlanParams& P, hipStream_t)
         P.band.cell_cmin[cells - 1] = INT32_MAX; P.band.cell_cmax1[cells - 1] = 1; P.band.cell_rmax1[cells - 1] = 1;
         P.band.cell_cur[cells - 1] = 0; P.band.cell_off[cells - 1] = 0;
         memset(P.coords, 0, (size_t)P.n_pitch * P.oh * P.ow * sizeof(int2));
-        P.n_gather[0] = n_gather;
+        P.n_gather[0] = n_gather;  // (band plans read the count back with a copy; the host word is the per-view plans')
         return hipSuccess;
     }
     // a mix of LDS-scheme and gather tiles with pseudo-random footprints (wild ones too: the host's work-list builders
@@ -142,6 +144,10 @@ static hipError_t stub_plan(const PlanParams& P, hipStream_t)
     }
     memset(P.coords, 0, (size_t)P.n_pitch * P.oh * P.ow * sizeof(int2));
     P.n_gather[0] = n_gather;
+    if (P.n_gather_host) {  // (the plan pass's last workgroup hands the count over itself and leaves the counters zero)
+        *P.n_gather_host = n_gather;
+        P.n_gather[0] = 0u;
+    }
     return hipSuccess;
 }
 // the band passes: stage 0 counts (a few tiles, every banded group), stage 1 touches the last word of every table

@@ -185,17 +185,18 @@ def test_gather_tiles_in_rows_and_in_blocks_draw_the_same_bytes(gpu, synth, monk
 @pytest.mark.parametrize("pitches", [[60, 90, 120], [8, 60, 90]], ids=["no gather tile", "a pole in view"])
 def test_first_and_second_launch_draw_the_same_bytes(gpu, synth, p2p_env, pitches):
     """A job's first launch sends the main kernel out behind the plan pass without waiting for anything: in grid order,
-    with the per-XCD lists made on the device when a second launch asks (the default), or in list order with the lists and
-    the pair contexts made in between (P2P_DEFER_LISTS=0), or after the gather count has come back (P2P_EARLY_MAIN=0).  The
-    first, the second and the third launch -- where the gather tiles ride in the main kernel's launch
-    (P2P_MERGE_GATHER) -- draw the oracle's bytes into a poisoned block, with every knob either way."""
+    with the per-XCD lists (and the job's pair contexts) made on the device behind the gather count's copy while the host
+    wakes up (P2P_DEFER_LISTS=1, the default) or when a second launch asks (2), or in list order with both made in between
+    (0), or after the gather count has come back (P2P_EARLY_MAIN=0).  The first, the second and the third launch -- where
+    the gather tiles ride in the main kernel's launch (P2P_MERGE_GATHER) -- draw the oracle's bytes into a poisoned block,
+    with every knob every way."""
     pw, ph, ow, oh, fov = 2048, 1024, 640, 360, 90
     yaws = [0, 33, 90, 200, 301]
     pano = synth.synth_pano(pw, ph, 4400, "N")
     maps = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
     want = oracle_views(pano, yaws, pitches, ow, oh, fov)
     p2p_env("P2P_PLAN_CACHE", "0")
-    for early, defer, merge, table in itertools.product(("1", "0"), ("1", "0"), ("1", "0"), ("1", "0")):
+    for early, defer, merge, table in itertools.product(("1", "0"), ("1", "0", "2"), ("1", "0"), ("1", "0")):
         p2p_env("P2P_EARLY_MAIN", early)
         p2p_env("P2P_DEFER_LISTS", defer)
         p2p_env("P2P_MERGE_GATHER", merge)  # list order: the gather tiles as the first workgroups of the main kernel's launch

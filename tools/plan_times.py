@@ -19,6 +19,7 @@ for name, (pw, ph, ow, oh, fov, yaws, pitches) in GEOS.items():
     for _ in range(n):
         job = nat.Job(ctx, pw, ph, 1, yaws, pitches, fov, ow, oh)
         job.set_pano(0, pano)
+        job.time_launches(1)  # (the plan pass is timed for jobs that ask)
         job.run()
         a, b = job.plan_ms()
         pl.append(a); tb.append(b)
