@@ -335,6 +335,49 @@ def test_one_shot_pool_is_bounded_and_survives_many_threads(gpu, pkg, synth, mon
     assert np.array_equal(pkg.process_views(pano, yaws[:2], [60], 96, 64)[1, 0], want[1, 0])
 
 
+def test_threads_build_different_plans_on_one_context(gpu, synth):
+    """Several threads create jobs of DIFFERENT geometries on one context and run them at the same time: every plan pass
+    counts its gather tiles in words that belong to the context (one pass at a time, csrc/p2p_host_plan.cpp) and hands the
+    count to the host itself -- each job draws what the same job draws alone on a context of its own, poles (gather tiles)
+    and all, on its first, second and third launch."""
+    pano = synth.synth_pano(2048, 1024, 7117, "N")
+    geos = [(320, 200, [60, 90, 120], 90), (256, 256, [5, 90], 100), (400, 144, [30, 150], 75), (192, 320, [90], 120),
+            (333, 217, [1, 45, 179], 90), (640, 360, [60, 90, 120], 90)]
+    yaws = [0, 47, 90, 201.5, 300]
+
+    def draw(ctx, geo, launches):
+        ow, oh, pitches, fov = geo
+        job = gpu.Job(ctx, 2048, 1024, 1, yaws, pitches, fov, ow, oh)
+        try:
+            job.set_pano(0, pano)
+            out = []
+            for _ in range(launches):
+                job.run()
+                out.append(job.get_views(0).copy())
+            return out
+        finally:
+            job.close()
+
+    want = []
+    for geo in geos:
+        ctx = gpu.Context(0)
+        try:
+            want.append(draw(ctx, geo, 1)[0])
+        finally:
+            ctx.close()
+    shared = gpu.Context(0)
+    try:
+        for rnd in range(3):
+            with ThreadPoolExecutor(max_workers=len(geos)) as ex:
+                got = list(ex.map(lambda g: draw(shared, g, 3), geos))
+            for gi, views in enumerate(got):
+                for li, v in enumerate(views):
+                    assert np.array_equal(v, want[gi]), (rnd, gi, li, int((v != want[gi]).sum()))
+            gpu.release_cache()   # (the next round builds every plan again)
+    finally:
+        shared.close()
+
+
 @pytest.mark.parametrize("flags_name", ["u8", "f16"])
 def test_view_mask_draws_exactly_the_wanted_views(gpu, synth, flags_name):
     """p2p_job_set_view_mask: a sparse (yaw, pitch) set -- a rank's share of one image in the view-sharded path -- in
