@@ -150,6 +150,34 @@ def test_api_exact_from_the_reference_fanout(pkg, synth):
         tool.set_exact(False)
 
 
+def test_exact_mode_over_a_random_sequence_of_geometries(pkg, synth):
+    """One process, the module's exact mode, forty calls whose geometry changes from call to call and comes back: view sizes
+    (odd ones too), FOVs, pitch lists that share angles, real-valued yaws, three panorama sizes, pole pitches -- the one-shot
+    slots keep maps under the names _exact_maps gives them, the contexts keep plans by geometry, and every view is the
+    oracle's bytes on noise whatever the call before it was."""
+    tool = pkg.panorama_to_plane_pitch
+    rng = np.random.default_rng(20260604)
+    panos = {pw: synth.synth_pano(pw, pw // 2, 1100 + pw, "N") for pw in (512, 1024, 1536)}
+    geos = []
+    for _ in range(8):
+        ow, oh = int(rng.integers(17, 260)), int(rng.integers(17, 200))
+        n_p = int(rng.integers(1, 4))
+        pitches = sorted(set(int(x) for x in rng.choice([1, 20, 45, 60, 90, 120, 150, 179], n_p, replace=False)))
+        geos.append((ow, oh, pitches, int(rng.choice([60, 90, 110])), int(rng.choice(list(panos)))))
+    tool.set_exact(True)
+    try:
+        for call in range(40):
+            gi = int(rng.integers(0, len(geos)))
+            ow, oh, pitches, fov, pw = geos[gi]
+            yaw = float(np.round(rng.uniform(-30, 400), 1)) if call % 3 else int(rng.integers(0, 360))
+            got = tool.process_yaw_and_pitchs(panos[pw], yaw, pitches, ow, oh, fov)
+            want = oracle_views(panos[pw], [yaw], pitches, ow, oh, fov)[0]
+            for pi in range(len(pitches)):
+                assert np.array_equal(got[pi], want[pi]), (call, gi, yaw, pitches[pi], ow, oh, fov, pw)
+    finally:
+        tool.set_exact(False)
+
+
 def test_exact_maps_through_the_view_sharded_driver(pkg, synth):
     """One image shared out to several contexts by WHOLE VIEWS (a masked job per context, its pitch subset of the maps) and
     by rows, with the exact mode's maps: the oracle's bytes either way."""
