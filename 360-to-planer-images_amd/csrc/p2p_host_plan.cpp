@@ -595,8 +595,23 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
             __builtin_ia32_pause();
 #endif
         }
-        if (cnt == kNoCount)
-            return fail(P2P_ERR_HIP, "the plan pass did not hand its gather count to the host");
+        if (cnt == kNoCount || (size_t)cnt > slots) {
+            // The stream has drained without a (credible) word: the context's counters were not zero when the pass began
+            // (a lost write: DESIGN.md section 5.7).  The headers say which tiles gather; the counters are cleared again and the
+            // plan does without its unordered gather list (the per-XCD lists are made from the headers anyway).
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(p2p::launch_zero_words(ctx->d_plan_cnt, p2p::PLAN_TICKET_WORDS + 32, st));
+            HIP_TRY(fetch_headers());
+            HIP_TRY(hipStreamSynchronize(st));
+            hdr_arrived();
+            std::vector<uint32_t> marked;
+            for (size_t s = 0; s < slots; ++s)
+                if ((hh[s].mode_items & 3u) == 2u)
+                    marked.push_back((uint32_t)s);
+            cnt = (uint32_t)marked.size();
+            if (cnt > 0)
+                HIP_TRY(hipMemcpy(Pl->d_gather_list, marked.data(), marked.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
         Pl->plan_ms = 0.0f;
         if (timed_plan) {
             HIP_TRY(hipEventSynchronize(ctx->ev_t1));

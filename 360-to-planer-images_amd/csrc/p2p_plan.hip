@@ -69,6 +69,17 @@ __device__ __forceinline__ int wave_reduce(int v)
 
 constexpr int PLAN_CELL_SLOTS_LOG2 = 7, PLAN_CELL_SLOTS = 1 << PLAN_CELL_SLOTS_LOG2, PLAN_CELL_PROBES = 16;  // (band plans: the tile's cell table)
 
+// A tile for the gather kernels goes into the plan's list.  The counter is the context's (zero between plan passes); were it
+// ever not -- this pool has lost writes to fresh device memory under allocation churn, DESIGN.md section 5.7 -- the entry is
+// dropped rather than written past the list, and the host sees a count it cannot believe.
+__device__ __forceinline__ void list_gather_tile(const PlanParams& P, uint32_t slot)
+{
+    const uint32_t at = atomicAdd(P.n_gather, 1u);
+    const uint32_t slots = (uint32_t)P.n_pitch * (uint32_t)(((P.ow + TILE_W - 1) / TILE_W) * ((P.oh + TILE_H - 1) / TILE_H));
+    if (at < slots)
+        P.gather_list[at] = slot;
+}
+
 template <bool CALLER_MAPS>
 __device__ __forceinline__ void plan_tile(const PlanParams& P)
 {
@@ -380,7 +391,7 @@ __device__ __forceinline__ void plan_tile(const PlanParams& P)
     if (band) {  // no tables: mode 3 tiles are drawn from the band tiles, the others from the coordinates
         if (t == 0) {
             if (!band_ok)
-                P.gather_list[atomicAdd(P.n_gather, 1u)] = slot;
+                list_gather_tile(P, slot);
             PieceHdr h;
             h.mode_items = (band_ok ? 3u : 2u) | (uint32_t)(fl & 4);
             h.c0 = any_live ? c0 : 0;
@@ -427,7 +438,7 @@ __device__ __forceinline__ void plan_tile(const PlanParams& P)
         itw[k] = 0u;
     if (t == 0) {
         if (!ok)  // tiles for the gather kernels, listed
-            P.gather_list[atomicAdd(P.n_gather, 1u)] = slot;
+            list_gather_tile(P, slot);
         PieceHdr h;
         h.mode_items = (ok ? (1u | n_items << 8) : 2u) | (uint32_t)(fl & 4);
         h.c0 = any_live ? c0 : 0;

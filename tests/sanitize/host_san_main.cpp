@@ -35,6 +35,7 @@ void operator delete(void* p, size_t) noexcept { free(p); }
 void operator delete[](void* p, size_t) noexcept { free(p); }
 
 extern "C" int p2p_stub_device_count;
+extern "C" int p2p_stub_drop_count;
 extern "C" long p2p_stub_live(int what);  // 0: events, 1: streams the library holds right now
 
 #define CHECK(cond) do { if (!(cond)) { fprintf(stderr, "CHECK failed line %d: %s (%s)\n", __LINE__, #cond, p2p_last_error()); exit(1); } } while (0)
@@ -349,6 +350,21 @@ int main()
     CHECK(p2p_release_cache() == P2P_OK);
     one_shot_calls(99);  // the pool's contexts survive a release
     CHECK(p2p_release_cache() == P2P_OK);
+    {   // a plan pass whose count never reaches the host (a lost write on the device): the headers say which tiles gather
+        p2p_stub_drop_count = 1;
+        p2p_job* jd = nullptr;
+        const int32_t yd[2] = {0, 77}, pd[2] = {45, 100};
+        p2p_job_desc dd = {64, 32, 1, 2, yd, 2, pd, 90, 70, 33, P2P_FLAG_DEFAULT};
+        std::vector<uint8_t> pano_d((size_t)64 * 32 * 3, 5), views_d((size_t)2 * 2 * 33 * 70 * 3);
+        CHECK(p2p_job_create(ctx, &dd, &jd) == P2P_OK && p2p_job_set_pano(jd, 0, pano_d.data(), 192) == P2P_OK);
+        CHECK(p2p_job_run(jd) == P2P_OK && p2p_job_run(jd) == P2P_OK && p2p_job_get_views(jd, 0, views_d.data()) == P2P_OK);
+        p2p_job_info info;
+        CHECK(p2p_job_get_info(jd, &info) == P2P_OK && info.n_gather_tiles > 0);  // (the stub's plan marks a third of the tiles)
+        p2p_job_destroy(jd);
+        p2p_stub_drop_count = 0;
+        CHECK(p2p_job_create(ctx, &dd, &jd) == P2P_OK && p2p_job_set_pano(jd, 0, pano_d.data(), 192) == P2P_OK && p2p_job_run(jd) == P2P_OK);
+        p2p_job_destroy(jd);
+    }
     p2p_ctx_destroy(ctx);
     p2p_stub_device_count = 0;
     CHECK(p2p_device_count() == 0 && p2p_remap_views_u8(px, 4, 4, 12, y0, 1, p_ok, 1, 90, 4, 4, px, 0, 0) == P2P_ERR_NO_DEVICE);

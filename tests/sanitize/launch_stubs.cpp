@@ -7,6 +7,7 @@
 #include <string.h>
 #include <vector>
 extern "C" int p2p_stub_device_count = 1;
+extern "C" int p2p_stub_drop_count = 0;  // 1: the plan pass "loses" the word it hands to the host (job_build_plan falls back to the headers)
 #include <atomic>
 static std::atomic<long> g_stub_live[2];
 extern "C" long p2p_stub_live(int what) { return g_stub_live[what & 1].load(); }
@@ -144,7 +145,7 @@ static hipError_t stub_plan(const PlanParams& P, hipStream_t)
     }
     memset(P.coords, 0, (size_t)P.n_pitch * P.oh * P.ow * sizeof(int2));
     P.n_gather[0] = n_gather;
-    if (P.n_gather_host) {  // (the plan pass's last workgroup hands the count over itself and leaves the counters zero)
+    if (P.n_gather_host && !p2p_stub_drop_count) {  // (the plan pass's last workgroup hands the count over itself and leaves the counters zero)
         *P.n_gather_host = n_gather;
         P.n_gather[0] = 0u;
     }
