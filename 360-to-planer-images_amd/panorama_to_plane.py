@@ -34,8 +34,9 @@ if __package__ in (None, ""):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import _exact_maps  # type: ignore
     import _native  # type: ignore
+    import _png  # type: ignore
 else:
-    from . import _exact_maps, _native
+    from . import _exact_maps, _native, _png
 
 _DEVICE = int(os.environ.get("P2P_DEVICE", "0"))
 _EXACT = False  # set_exact / --exact
@@ -158,13 +159,22 @@ def _decode_rgb(path):
 
 
 def _encode_rgb(path, image):
-    """cv2.imwrite's defaults (L:275-278): JPEG quality 95, PNG otherwise."""
-    from PIL import Image
-
+    """cv2.imwrite's defaults (L:275-278): JPEG quality 95; PNG rows filtered with SUB, deflated at Z_BEST_SPEED / Z_RLE
+    (_png.py)."""
     if Path(path).suffix.lower() in (".jpg", ".jpeg"):
+        from PIL import Image
+
         Image.fromarray(image).save(str(path), format="JPEG", quality=95)
     else:
-        Image.fromarray(image).save(str(path), format="PNG", compress_level=1)
+        try:
+            data = _png.encode_png(image)
+        except ValueError:  # (not a uint8 image of 1 to 4 channels: Pillow's general encoder)
+            from PIL import Image
+
+            Image.fromarray(image).save(str(path), format="PNG", compress_level=1)
+        else:
+            with open(str(path), "wb") as f:
+                f.write(data)
     logging.info(f"Saved output image to {path}")
 
 
