@@ -162,13 +162,12 @@ struct PlanKey {  // the reference's key (ow, oh, pitch, pw, ph, fov), for the w
 
 struct Plan {  // the plan pass's tables (p2p_plan.hip)
     int device = 0;
-    void* d_block = nullptr;             // the one allocation the next seven pointers are parts of
+    void* d_block = nullptr;             // the one allocation the next six pointers are parts of
     int2* d_coords = nullptr;            // [n_pitch][oh][ow] quantised coordinates
     p2p::PieceHdr* d_hdr = nullptr;      // [n_pitch][tiles]
     uint32_t* d_px = nullptr;            // [n_pitch][tiles][256 * VIEWS_PXT]
     uint32_t* d_items = nullptr;         // [n_pitch][tiles][LDS_ITEMS_CAP]
     uint32_t* d_px2 = nullptr;           // float pixel path only: 16-bit coordinate fractions
-    uint32_t* d_n_gather = nullptr;
     uint32_t* d_gather_list = nullptr;   // [n_pitch * tiles] tiles the plan marks for gathers (in the order the plan pass met them)
     uint32_t* d_xcd_list = nullptr;      // [8][xcd_stride] the same tiles dealt to the XCDs by source position (xcd_lists), ~0: none
     uint32_t* d_xcd_all = nullptr;       // [8][xcd_all_stride] every tile, likewise (only when most tiles gather: ViewsParams::gather_all)
@@ -208,7 +207,7 @@ struct Plan {  // the plan pass's tables (p2p_plan.hip)
     {
         DeviceRestore keep;
         (void)hipSetDevice(device);
-        (void)dev_free(d_block);  // coords, hdr, px, items, px2, n_gather, gather_list: parts of it
+        (void)dev_free(d_block);  // coords, hdr, px, items, px2, gather_list: parts of it
         (void)dev_free(d_xcd_list); (void)dev_free(d_xcd_all); (void)dev_free(d_main_list);
         (void)dev_free(d_band_hdr); (void)dev_free(d_band_px); (void)dev_free(d_band_grp); (void)dev_free(d_band_info);
     }

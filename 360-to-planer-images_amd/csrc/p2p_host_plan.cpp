@@ -432,9 +432,9 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
         const size_t b_hdr = up(slots * sizeof(p2p::PieceHdr));
         const size_t b_px = band ? 0 : up(slots * S.block * S.pxt * sizeof(uint32_t));
         const size_t b_items = band ? 0 : up(slots * S.cap * sizeof(uint32_t));
-        const size_t b_cnt = 256, b_list = up(slots * sizeof(uint32_t));
+        const size_t b_list = up(slots * sizeof(uint32_t));
         unsigned char* blk = nullptr;
-        HIP_TRY(dev_alloc((void**)&blk, b_px2 + b_coords + b_hdr + b_px + b_items + b_cnt + b_list));
+        HIP_TRY(dev_alloc((void**)&blk, b_px2 + b_coords + b_hdr + b_px + b_items + b_list));
         Pl->d_block = blk;
         size_t off = 0;
         auto take = [&](size_t b) { unsigned char* p = b ? blk + off : nullptr; off += b; return p; };
@@ -443,7 +443,6 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
         Pl->d_hdr = (p2p::PieceHdr*)take(b_hdr);
         Pl->d_px = (uint32_t*)take(b_px);
         Pl->d_items = (uint32_t*)take(b_items);
-        Pl->d_n_gather = (uint32_t*)take(b_cnt);
         Pl->d_gather_list = (uint32_t*)take(b_list);
     }
     Pl->bytes = (size_t)d.n_pitch * d.oh * d.ow * sizeof(int2) +
@@ -463,13 +462,12 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
     Q.px = Pl->d_px;
     Q.items = Pl->d_items;
     Q.blocky_from = opt.gather_blocky_from;
-    Q.n_gather = Pl->d_n_gather;
     Q.gather_list = Pl->d_gather_list;
     Q.float_path = float_path;
     Q.centre = (d.flags & P2P_FLAG_PIXEL_CENTRES) ? 0.5f : 0.0f;
     Q.px2 = Pl->d_px2;
     p2p::BandParams& B = Q.band;
-    uint32_t* d_cnt = Pl->d_n_gather;  // (band plans: inside the cell block, see below)
+    uint32_t* d_cnt = nullptr;  // the gather tiles' counter: the context's (per-view plans) or inside the cell block (band plans), see below
     const size_t n_groups_all = (size_t)d.n_pitch * d.oh * ((d.ow + 3) / 4);
     if (band) {
         B.pw = d.pw; B.ph = d.ph; B.ow = d.ow; B.oh = d.oh; B.n_pitch = d.n_pitch;
