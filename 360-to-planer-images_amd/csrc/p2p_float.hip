@@ -63,18 +63,47 @@ __device__ __forceinline__ uint32_t blend_f32(uint32_t a, uint32_t b, uint32_t c
 // the pixel, not to the yaw -- ONE packed register per pixel for the whole tile instead of two floats, and nothing to
 // convert to float16 per yaw (the column weights, which change with every yaw's fractional shift, stay float32).
 // A pixel with no footprint has both row weights 0 and comes out black.
+// One pixel's six vertical blends, a.x * w.x + a.y * w.y in float32 each.  Written out as v_dot2_f32_f16 with the constant
+// 0 as its addend: from the builtin the compiler makes the two-source v_dot2c_f32_f16, whose addend is its destination,
+// and a v_mov_b32 0 in front of every one of them (48 of the loop's 306 vector instructions: config 5's f16 launch 871
+// -> 790 us on one box).  The compiler does not know what an asm statement's instructions are, so the hazard it would
+// have covered is covered here: on gfx940 and later a dot instruction's result may be read by another kind of vector
+// instruction three wait states later at the earliest (LLVM's GCNHazardRecognizer: DotWriteDifferentVALURead) -- the
+// s_nop behind the last of the six; the five in front of it are further than that from whatever follows the statement.
+__device__ __forceinline__ void dot2_f16_x6(const f16x2 (&p)[6], f16x2 w, float (&v)[6])
+{
+#ifdef P2P_FLOAT_DOT2_BUILTIN
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        v[k] = __builtin_amdgcn_fdot2(p[k], w, 0.0f, false);
+#else
+    asm("v_dot2_f32_f16 %0, %6, %12, 0\n\t"
+        "v_dot2_f32_f16 %1, %7, %12, 0\n\t"
+        "v_dot2_f32_f16 %2, %8, %12, 0\n\t"
+        "v_dot2_f32_f16 %3, %9, %12, 0\n\t"
+        "v_dot2_f32_f16 %4, %10, %12, 0\n\t"
+        "v_dot2_f32_f16 %5, %11, %12, 0\n\t"
+        "s_nop 2"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(w));
+#endif
+}
+
 __device__ __forceinline__ uint32_t blend_f16(uint32_t a, uint32_t b, uint32_t c, uint32_t d, f16x2 wy2, float wx0s, float wx1s)
 {
-    uint32_t r = 0u;
+    f16x2 p[6];
+    float v[6];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const uint32_t sel = 0x0C040C00u + 0x00010001u * (uint32_t)k;  // byte k of two pixels as two u16
-        const f16x2 le = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(c, a, sel));  // left column: upper, lower
-        const f16x2 ri = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(d, b, sel));
-        const float vl = __builtin_amdgcn_fdot2(le, wy2, 0.0f, false);
-        const float vr = __builtin_amdgcn_fdot2(ri, wy2, 0.0f, false);
-        r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(vr, wx1s, vl * wx0s), k, r);
+        p[2 * k] = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(c, a, sel));      // left column: upper, lower
+        p[2 * k + 1] = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(d, b, sel));  // right column
     }
+    dot2_f16_x6(p, wy2, v);
+    uint32_t r = 0u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(v[2 * k + 1], wx1s, v[2 * k] * wx0s), k, r);
     return r;
 }
 
@@ -231,6 +260,8 @@ __device__ __forceinline__ void draw_float(
 #pragma unroll
             for (int j = 0; j < PXT; ++j) {
                 // fraction of the pixel's own coordinate + fraction of the yaw shift; a carry moves the taps one column on
+                // (the sum with one added, v_fract_f32 for the weight and bit 30 of the pattern for the carry: ten vector
+                // instructions fewer per iteration and not a microsecond faster -- docs/experiments.md)
                 float xs = fu[j] + sf;
                 const bool carry = xs >= 1.0f;
                 wx[j] = carry ? xs - 1.0f : xs;
