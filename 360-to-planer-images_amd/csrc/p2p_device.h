@@ -66,6 +66,10 @@ struct BandInfo {      // device-side summary, read back once per geometry
 };
 struct BandParams {
     int pw, ph, ow, oh, n_pitch;
+    // band_scan_kernel hands the counts the host sizes the band tables by to page-locked memory itself (nullptr: the host
+    // copies BandInfo back): [0] tiles, [1] groups, [2] the plan pass's gather tiles (*n_gather), [3] 1 once the three are there
+    uint32_t* host_words;
+    const uint32_t* n_gather;
     BandGeom g;
     const int2* coords;       // the plan pass's quantised coordinates
     uint32_t* cell_count;     // [n_bands * ncx] groups per cell
@@ -208,6 +212,7 @@ struct PlanParams {
     // host word the pass's LAST workgroup writes the gather count to (plan_kernel); nullptr: nobody reads it there
     uint32_t* ticket;
     uint32_t* n_gather_host;
+    PieceHdr* hdr_host;      // band plans: every tile's header a second time, in page-locked host memory (nullptr: not wanted)
     uint32_t* gather_list;   // [n_pitch * tiles] the tiles marked for gathers (pitch * tiles + tile), in no particular order
     // band plan (band.gcell != nullptr): a tile all of whose groups can go into source-band tiles gets mode 3 and no
     // tables (px / items are nullptr); its groups are counted into the cells of the source.  The other tiles gather.

@@ -173,6 +173,10 @@ struct Plan {  // the plan pass's tables (p2p_plan.hip)
     uint32_t* d_xcd_all = nullptr;       // [8][xcd_all_stride] every tile, likewise (only when most tiles gather: ViewsParams::gather_all)
     uint32_t* d_main_list = nullptr;     // [8][main_stride] the LDS-scheme tiles, dealt to the XCDs in source order (xcd_main_lists)
     uint32_t* d_main_count = nullptr;    // [8] entries of each XCD's main list (part of d_main_list's block; main_lists_kernel writes both)
+    // what job_build_plan leaves behind without waiting for the stream: the host copies of the gather lists (their uploads
+    // may still be queued) and the band passes' device scratch (their kernels may still be running); gone with the plan
+    std::vector<uint32_t> h_xcd_list, h_xcd_all;
+    std::vector<void*> build_blocks;
     int xcd_stride = 0, xcd_all_stride = 0, main_stride = 0;
     int n_gather = 0;
     // band plan (source-band tiles, p2p_device.h): no px / items tables; the band kernel draws band_tiles tiles
@@ -210,6 +214,8 @@ struct Plan {  // the plan pass's tables (p2p_plan.hip)
         (void)dev_free(d_block);  // coords, hdr, px, items, px2, gather_list: parts of it
         (void)dev_free(d_xcd_list); (void)dev_free(d_xcd_all); (void)dev_free(d_main_list);
         (void)dev_free(d_band_hdr); (void)dev_free(d_band_px); (void)dev_free(d_band_grp); (void)dev_free(d_band_info);
+        for (void* b : build_blocks)
+            (void)dev_free(b);
     }
 };
 

@@ -382,7 +382,6 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
     // return the stream is drained (the guard, destroyed first) before they and the plan's blocks -- back to the pool,
     // where any thread may pick them up at once -- go out of scope
     std::vector<p2p::PieceHdr> hh;
-    std::vector<uint32_t> tg, ta;
     uint32_t cnt = 0;
     p2p::BandInfo binfo{};
     // the read-backs land in a pinned block first (pin_get): [BandInfo | counter | headers]
@@ -392,13 +391,16 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
     // path, after the stream has been drained (declared before the guard: destroyed after it)
     struct Scratch {
         std::vector<void*> blocks;
+        size_t total = 0;
         ~Scratch() { for (void* b : blocks) (void)dev_free(b); }
         hipError_t get(void** out, size_t bytes)
         {
             blocks.reserve(blocks.size() + 1);  // (first: a block that cannot be listed would never be freed)
             hipError_t e = dev_alloc(out, bytes);
-            if (e == hipSuccess)
+            if (e == hipSuccess) {
                 blocks.push_back(*out);
+                total += bytes;
+            }
             return e;
         }
     } scratch;
@@ -408,7 +410,7 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
     p2p::BandInfo* const h_binfo = (p2p::BandInfo*)pin.p;
     uint32_t* const h_cnt = (uint32_t*)((unsigned char*)pin.p + 112);
     p2p::PieceHdr* const h_hdr = (p2p::PieceHdr*)((unsigned char*)pin.p + pin_hdr_off);
-    static_assert(sizeof(p2p::BandInfo) <= 112, "the pinned block's layout");
+    static_assert(sizeof(p2p::BandInfo) <= 96, "the pinned block's layout: [BandInfo 0..96 | band_scan_kernel's words 96..112 | counter 112 | headers 128..]");
     // the headers into hh: through the pinned block (one asynchronous copy, unpacked after the stream's next
     // synchronisation by hdr_arrived) or, beyond its size, straight into the vector
     bool hdr_in_pin = false;
@@ -515,6 +517,35 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
     // about to follow, no waiting for that kernel.  The pass counts in the context's own words (zero between passes: no
     // clearing in front of it either), so one pass per context at a time.
     constexpr uint32_t kNoCount = 0xFFFFFFFFu;
+    // Spin until the device has written a word of the page-locked block (it starts as kNoCount); now and then: has the
+    // stream drained, or failed, without it?  P2P_OK also when it drained without the word: the caller looks at the word.
+    auto wait_for_word = [&](volatile uint32_t* w, const char* what) -> int {
+        for (unsigned spins = 1; *w == kNoCount; ++spins) {
+            if ((spins & 2047u) == 0u) {
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipSuccess)
+                    break;
+                if (q != hipErrorNotReady)
+                    return fail(P2P_ERR_HIP, "%s: %s", what, hipGetErrorString(q));
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        return P2P_OK;
+    };
+    volatile uint32_t* const h_words = (volatile uint32_t*)((unsigned char*)pin.p + 96);  // (band plans: band_scan_kernel's four words)
+    if (band) {
+        h_words[0] = h_words[1] = h_words[2] = 0u;
+        h_words[3] = kNoCount;
+        B.host_words = (uint32_t*)h_words;
+        B.n_gather = d_cnt;
+        if (slots <= pin_hdr_max) {  // the headers straight into the page-locked block (hdr_arrived unpacks them)
+            Q.hdr_host = h_hdr;
+            hh.resize(slots);
+            hdr_in_pin = true;
+        }
+    }
     if (!band) {
         one_pass.lock();
         Q.n_gather = d_cnt = ctx->d_plan_cnt + p2p::PLAN_TICKET_WORDS;
@@ -522,9 +553,10 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
         Q.n_gather_host = h_cnt;
         *(volatile uint32_t*)h_cnt = kNoCount;
     }
-    // (per-view plans: the pass is timed only for a job that asked for launch timing -- an event in front of the pass and
-    // one between it and the main kernel are 5 us each on a cold image's critical path)
-    const bool timed_plan = band || j->time_launches;
+    // (the pass -- a band plan's passes -- is timed only for a job that asked for launch timing: an event in front of the
+    // pass and one between it and the main kernel are 5 us each on a cold image's critical path, and a band plan's time
+    // could only be read after waiting for the whole stream)
+    const bool timed_plan = j->time_launches;
     if (timed_plan)
         HIP_TRY(hipEventRecord(ctx->ev_t0, st));
     HIP_TRY(shape_ops(j->shape).plan(Q, st));
@@ -536,18 +568,26 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
                 return rc;
     }
     if (band) {
-        // the band passes: count the tiles, read the count back (the tables are sized by it), cut, sort, build
+        // the band passes: count the tiles, hand the counts to the host (the tables are sized by them), cut, sort, build.
+        // band_scan_kernel writes the three counts into the page-locked block itself and the plan pass has written every
+        // header there (plans of up to 65536 tiles): no copy in the stream, and the host waits for one word -- it makes the
+        // gather tiles' lists from the headers WHILE the device cuts, sorts and builds the band tiles.
         HIP_TRY(shape_ops(j->shape).band(B, 0, st));
-        HIP_TRY(hipMemcpyAsync(h_binfo, B.info, sizeof(binfo), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
-        // (the headers too: the gather tiles' lists are then made on the host WHILE the device cuts, sorts and builds the
-        // band tiles -- a second and a third round trip behind those kernels were 70 us of a cold image's 415)
-        if (slots <= pin_hdr_max)
-            HIP_TRY(fetch_headers());
-        HIP_TRY(hipStreamSynchronize(st));
-        binfo = *h_binfo;
-        cnt = *h_cnt;
-        hdr_arrived();
+        if (int rc = wait_for_word(h_words + 3, "the band passes"))
+            return rc;
+        if (h_words[3] != 1u) {  // (the stream drained without the flag: read the counts back the old way)
+            HIP_TRY(hipMemcpyAsync(h_binfo, B.info, sizeof(binfo), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            binfo = *h_binfo;
+            cnt = *h_cnt;
+        } else {
+            binfo.n_tiles = h_words[0];
+            binfo.n_groups = h_words[1];
+            cnt = h_words[2];
+        }
+        if (hdr_in_pin)  // (the plan pass wrote them there, two kernels ago)
+            hdr_arrived();
         if ((size_t)binfo.n_groups > n_groups_all || (size_t)binfo.n_tiles > n_groups_all)
             return fail(P2P_ERR_HIP, "the band passes counted %u tiles, %u groups of %zu", binfo.n_tiles, binfo.n_groups, n_groups_all);
         B.n_tiles = (int)binfo.n_tiles;
@@ -570,7 +610,7 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
             HIP_TRY(shape_ops(j->shape).band(B, 1, st));
         }
     }
-    if (band)
+    if (band && timed_plan)
         HIP_TRY(hipEventRecord(ctx->ev_t1, st));
     // the work lists are made from the plan's headers, once per geometry: they come back with the counter -- unless the
     // plan turns out to have no gather tile and may draw its first launch in grid order (Plan::lists_pending)
@@ -579,20 +619,9 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
     Pl->tile_w = shape_ops(j->shape).shape.tile_w;
     if (!band) {  // (band plans: the counter came back with the band counts; the device is still building the tiles)
         // the plan pass's last workgroup writes the word; whatever is queued behind the pass is not waited for
-        for (unsigned spins = 1; (cnt = *(volatile uint32_t*)h_cnt) == kNoCount; ++spins) {
-            if ((spins & 2047u) == 0u) {  // (now and then: has the stream drained, or failed, without the word?)
-                const hipError_t q = hipStreamQuery(st);
-                if (q == hipSuccess) {
-                    cnt = *(volatile uint32_t*)h_cnt;
-                    break;
-                }
-                if (q != hipErrorNotReady)
-                    return fail(P2P_ERR_HIP, "the plan pass: %s", hipGetErrorString(q));
-            }
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
-        }
+        if (int rc = wait_for_word((volatile uint32_t*)h_cnt, "the plan pass"))
+            return rc;
+        cnt = *(volatile uint32_t*)h_cnt;
         if (cnt == kNoCount || (size_t)cnt > slots) {
             // The stream has drained without a (credible) word: the context's counters were not zero when the pass began
             // (a lost write: DESIGN.md section 5.7).  The headers say which tiles gather; the counters are cleared again and the
@@ -646,6 +675,7 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
         if (marked.size() != (size_t)cnt) {
             return fail(P2P_ERR_HIP, "the plan's headers mark %zu gather tiles, its counter %u", marked.size(), cnt);
         }
+        std::vector<uint32_t>& tg = Pl->h_xcd_list;  // (kept with the plan: the upload below is not waited for)
         tg = xcd_lists(marked, hh, d.pw, by_source, opt.gather_group, &Pl->xcd_stride);
         HIP_TRY(dev_alloc((void**)&Pl->d_xcd_list, tg.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpyAsync(Pl->d_xcd_list, tg.data(), tg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
@@ -655,16 +685,21 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
             all.resize(slots);
             for (size_t s = 0; s < slots; ++s)
                 all[s] = (uint32_t)s;
+            std::vector<uint32_t>& ta = Pl->h_xcd_all;
             ta = xcd_lists(all, hh, d.pw, by_source, opt.gather_group, &Pl->xcd_all_stride);
             HIP_TRY(dev_alloc((void**)&Pl->d_xcd_all, ta.size() * sizeof(uint32_t)));
             HIP_TRY(hipMemcpyAsync(Pl->d_xcd_all, ta.data(), ta.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
             Pl->bytes += ta.size() * sizeof(uint32_t);
         }
-        HIP_TRY(hipStreamSynchronize(st));  // the vectors go out of scope
     }
     if (band) {
-        HIP_TRY(hipStreamSynchronize(st));
-        (void)hipEventElapsedTime(&Pl->plan_ms, ctx->ev_t0, ctx->ev_t1);
+        // (nothing is waited for: the band tiles are still being built when p2p_job_run enqueues the view kernel behind them;
+        // the passes' scratch goes with the plan)
+        Pl->plan_ms = 0.0f;
+        if (timed_plan) {
+            HIP_TRY(hipStreamSynchronize(st));
+            (void)hipEventElapsedTime(&Pl->plan_ms, ctx->ev_t0, ctx->ev_t1);
+        }
     }
     if (const int seed = opt.scramble_plan) {
         // Robustness self-test (tests/fuzz/scramble_tables.py), never set in normal use: every table of the plan -- and
@@ -703,7 +738,12 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
         j->plan_ref = Pl;
         return P2P_OK;
     }
-    sync_on_exit.armed = false;  // every copy above has been waited for (kernels may still run: they own no host memory)
+    // every copy into host memory above has been waited for; kernels and uploads may still be queued: what they use stays
+    // with the plan
+    Pl->build_blocks.reserve(scratch.blocks.size());
+    Pl->build_blocks.swap(scratch.blocks);
+    Pl->bytes += scratch.total;
+    sync_on_exit.armed = false;
     if (cached) {
         std::lock_guard<std::mutex> lk(ctx->cache_mu);
         Pl->stamp = ++ctx->cache_clock;

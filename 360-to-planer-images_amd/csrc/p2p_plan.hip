@@ -118,6 +118,8 @@ __device__ __forceinline__ void plan_tile(const PlanParams& P)
             h.c1 = -1;
             h.rows = 0u;
             P.hdr[slot] = h;
+            if (P.hdr_host != nullptr)
+                P.hdr_host[slot] = h;
         }
         return;
     }
@@ -398,6 +400,8 @@ __device__ __forceinline__ void plan_tile(const PlanParams& P)
             h.c1 = any_live ? c1 : -1;
             h.rows = any_live ? ((uint32_t)(r0 + 1) & 0xFFFFu) | (uint32_t)(r1 + 1) << 16 : 0u;
             P.hdr[slot] = h;
+            if (P.hdr_host != nullptr)  // (the host makes the gather tiles' lists from the headers while the band tiles are built)
+                P.hdr_host[slot] = h;
         }
         return;
     }
@@ -636,6 +640,16 @@ __global__ __launch_bounds__(1024) void band_scan_kernel(BandParams B)
         B.info->n_groups = run_g;
         B.info->pad[0] = (uint32_t)run_c;
         B.info->pad[1] = (uint32_t)(run_c >> 32);
+        if (B.host_words != nullptr) {
+            // what the host waits for, straight into its page-locked block: no copy, no synchronisation of the stream (the plan
+            // pass's gather counter was settled a kernel ago); the flag goes last, behind the acknowledged three
+            __hip_atomic_store(B.host_words + 0, run_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(B.host_words + 1, run_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(B.host_words + 2, __hip_atomic_load(B.n_gather, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(B.host_words + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

@@ -290,6 +290,16 @@ int main()
         std::vector<int32_t> cb((size_t)2 * 33 * 70 * 2);
         CHECK(p2p_job_get_coords(jb, cb.data()) == P2P_OK);
         p2p_job_destroy(jb);
+        {   // ... and one whose counts never reach the host's page-locked block: read back with copies, the same plan
+            p2p_stub_drop_count = 1;
+            const int32_t pb2[2] = {61, 119};
+            db.pitch_deg = pb2;
+            p2p_job_info ib2;
+            CHECK(p2p_job_create(ctx, &db, &jb) == P2P_OK && p2p_job_set_pano(jb, 0, pano.data(), 192) == P2P_OK && p2p_job_run(jb) == P2P_OK);
+            CHECK(p2p_job_get_info(jb, &ib2) == P2P_OK && ib2.band_tiles == ib.band_tiles && ib2.n_gather_tiles == ib.n_gather_tiles);
+            p2p_job_destroy(jb);
+            p2p_stub_drop_count = 0;
+        }
         unsetenv("P2P_BAND");
         CHECK(p2p_reload_options() == P2P_OK);
     }

@@ -114,6 +114,8 @@ static hipError_t stub_plan(const PlanParams& P, hipStream_t)
         for (size_t s = 0; s < tiles * P.n_pitch; ++s) {
             const bool gathers = s % 5 == 0;
             P.hdr[s] = PieceHdr{gathers ? 2u : 3u, 0, 7, 0x00020001u};
+            if (P.hdr_host)
+                P.hdr_host[s] = P.hdr[s];
             if (gathers)
                 P.gather_list[n_gather++] = (uint32_t)s;
         }
@@ -163,6 +165,9 @@ static hipError_t stub_band(const BandParams& B, int stage, hipStream_t)
         B.band_tiles[B.g.n_bands - 1] = 0; B.band_groups[B.g.n_bands - 1] = 0; B.band_cost[B.g.n_bands - 1] = 0;
         B.info->n_groups = groups;
         B.info->n_tiles = (groups + BLOCK - 1) / BLOCK;
+        if (B.host_words && !p2p_stub_drop_count) {  // (band_scan_kernel hands the counts to the host itself)
+            B.host_words[0] = B.info->n_tiles; B.host_words[1] = groups; B.host_words[2] = *B.n_gather; B.host_words[3] = 1u;
+        }
         return hipSuccess;
     }
     const size_t nt = (size_t)B.n_tiles;
