@@ -368,7 +368,7 @@ size_t caches_evict_all();
 void cache_trim(p2p_ctx* c);  // (cache_mu held by the caller)
 int job_adopt_yaw_tabs(p2p_job* j, std::shared_ptr<YawTabs> yt);
 int yaw_tabs_get(p2p_ctx* ctx, int pw, const std::vector<double>& yaw_deg, const float* rows, float* d_rows,
-                 bool use_cache, std::shared_ptr<YawTabs>* out);
+                 bool use_cache, std::shared_ptr<YawTabs>* out, const std::function<void()>& while_device_works = nullptr);
 
 // ---- shapes, chunking, plans, work lists (p2p_host_plan.cpp) ----
 const p2p::ShapeOps& shape_ops(int shape);
@@ -384,6 +384,7 @@ int job_main_order(const p2p_job* j);
 int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass = nullptr);
 int ensure_full_coords(p2p_job* j);
 int plan_make_main_lists(p2p_job* j, Plan& Pl);
+void plan_block_prefetch(p2p_job* j) noexcept;
 int plan_enqueue_main_lists(Plan& Pl, size_t slots, int tile_w, hipStream_t st);
 
 // ---- implementations of the ABI functions: p2p_xyz -> p2p_host::xyz ----

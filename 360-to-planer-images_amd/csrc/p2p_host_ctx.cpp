@@ -232,8 +232,10 @@ int job_adopt_yaw_tabs(p2p_job* j, std::shared_ptr<YawTabs> yt)
 // Yaw tables for a list of yaw angles (degrees) or for caller float rows: built by yaw_table_kernel /
 // yaw_pack_kernel + yaw_desc_kernel on the context's stream.  rows == nullptr: looked up in / entered into the
 // context's cache (the reference's yaw_mapping_cache, P:17, P:42-52); caller rows make private tables.
+// while_device_works: called once the table kernels are queued and before they are waited for (host work that may as
+// well happen meanwhile: p2p_job_create fetches the block of the job's plan); not called when the tables were cached.
 int yaw_tabs_get(p2p_ctx* ctx, int pw, const std::vector<double>& yaw_deg, const float* rows, float* d_rows,
-                        bool use_cache, std::shared_ptr<YawTabs>* out)
+                        bool use_cache, std::shared_ptr<YawTabs>* out, const std::function<void()>& while_device_works)
 {
     const int n_yaw = (int)yaw_deg.size();
     YawKey key{pw, yaw_deg};
@@ -271,6 +273,8 @@ int yaw_tabs_get(p2p_ctx* ctx, int pw, const std::vector<double>& yaw_deg, const
     HIP_TRY(hipEventRecord(ctx->ev_t1, st));
     T->desc.resize(n_yaw);
     HIP_TRY(hipMemcpyAsync(T->desc.data(), T->d_ydesc, T->desc.size() * sizeof(p2p::YawDesc), hipMemcpyDeviceToHost, st));
+    if (while_device_works)
+        while_device_works();
     HIP_TRY(hipStreamSynchronize(st));  // yr (and the caller's rows) are stack-lifetime host buffers
     sync_on_exit.armed = false;
     (void)hipEventElapsedTime(&T->tables_ms, ctx->ev_t0, ctx->ev_t1);

@@ -138,7 +138,8 @@ int job_create_core(p2p_ctx* ctx, const p2p_job_desc& d, const double* yaw_deg, 
         return fail(e == hipErrorOutOfMemory ? P2P_ERR_OOM : P2P_ERR_HIP, "p2p_job_create: %s", hipGetErrorString(e));
     // the yaw tables: the context's, if it has built them for these angles before (P:42-52)
     std::shared_ptr<YawTabs> yt;
-    int rc = yaw_tabs_get(ctx, d.pw, j->yaw, nullptr, nullptr, j->opt.plan_cache != 0, &yt);
+    // (while the device makes them, the host fetches the block the job's first run will want for its plan)
+    int rc = yaw_tabs_get(ctx, d.pw, j->yaw, nullptr, nullptr, j->opt.plan_cache != 0, &yt, [j]() { plan_block_prefetch(j); });
     if (rc == P2P_OK)
         rc = job_adopt_yaw_tabs(j, yt);
     if (rc != P2P_OK)

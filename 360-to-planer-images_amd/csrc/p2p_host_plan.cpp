@@ -342,6 +342,67 @@ int job_main_order(const p2p_job* j)
 }
 
 
+// the ONE block job_build_plan allocates for a plan's tables, carved at 256-byte boundaries
+struct PlanBlock {
+    size_t b_px2, b_coords, b_hdr, b_px, b_items, b_list;
+    size_t total() const { return b_px2 + b_coords + b_hdr + b_px + b_items + b_list; }
+};
+static PlanBlock plan_block_layout(const p2p_job_desc& d, const p2p::TileShape& S, size_t slots, bool band, bool float_path)
+{
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    PlanBlock L;
+    L.b_px2 = float_path ? up(slots * S.block * S.pxt * sizeof(uint32_t)) : 0;
+    L.b_coords = up((size_t)d.n_pitch * d.oh * d.ow * sizeof(int2));
+    L.b_hdr = up(slots * sizeof(p2p::PieceHdr));
+    L.b_px = band ? 0 : up(slots * S.block * S.pxt * sizeof(uint32_t));
+    L.b_items = band ? 0 : up(slots * S.cap * sizeof(uint32_t));
+    L.b_list = up(slots * sizeof(uint32_t));
+    return L;
+}
+
+// the key a job's plan is kept under in its context (PlanKey: the reference's cache key for the whole pitch list, plus what
+// shapes the tables)
+static PlanKey plan_key_of(const p2p_job* j, bool band, int cell_bh, int cell_cw, int main_order)
+{
+    const p2p_job_desc& d = j->d;
+    const Options& opt = j->opt;
+    return PlanKey{d.pw, d.ph, d.ow, d.oh, d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16 | P2P_FLAG_PIXEL_CENTRES), j->border,
+                   j->fov, j->pitch, j->shape, {opt.gather_blocky_from, main_order != 0, opt.gather_order, opt.gather_group,
+                                                band ? 1 : 0, band ? cell_bh : 0, band ? cell_cw : 0, band ? opt.band_maxw : 0, band ? opt.band_maxh : 0,
+                                                j->row0, j->row1}};  // (the rows the job draws: p2p_job_set_rows)
+}
+
+// p2p_job_create, while the device makes the job's yaw tables: the block the job's first p2p_job_run will ask the pool for
+// is fetched from the driver now and handed to the pool (hipMalloc is 12 us whatever the size: a fresh geometry's first
+// image no longer waits for it).  A prediction -- the plan the job would build if it ran now; a job that changes its mind
+// (p2p_job_set_maps, a view mask) finds the pool without that block, as before.  Nothing when the context has the plan.
+void plan_block_prefetch(p2p_job* j) noexcept
+{
+    try {
+        if (options().pool_mb <= 0)
+            return;
+        job_settle_shape(j);
+        const bool band = job_wants_band(j);
+        int cell_bh, cell_cw;
+        band_cell(j->opt, j->shape, &cell_bh, &cell_cw);
+        const int main_order = band ? 0 : job_main_order(j);
+        if (j->opt.plan_cache != 0) {
+            const PlanKey key = plan_key_of(j, band, cell_bh, cell_cw, main_order);
+            std::lock_guard<std::mutex> lk(j->ctx->cache_mu);
+            if (j->ctx->plans.find(key) != j->ctx->plans.end())
+                return;
+        }
+        const bool float_path = (j->d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16)) != 0;
+        const PlanBlock L = plan_block_layout(j->d, shape_ops(j->shape).shape, j->n_tiles * (size_t)j->d.n_pitch, band, float_path);
+        void* blk = nullptr;
+        if (dev_alloc(&blk, L.total()) == hipSuccess)
+            (void)dev_free(blk);
+        else
+            (void)hipGetLastError();
+    } catch (...) {
+    }
+}
+
 // Build the job's plan (p2p_plan.hip) for its current maps: once per job geometry, like the yaw tables.  It
 // depends on the maps only, never on pixel data -- the device counterpart of the reference's
 // pitch_mapping_cache (P:17-18, P:55-73), which lives as long as the process.
@@ -361,10 +422,7 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
     int cell_bh, cell_cw;
     band_cell(opt, j->shape, &cell_bh, &cell_cw);
     const int main_order = band ? 0 : job_main_order(j);
-    PlanKey key{d.pw, d.ph, d.ow, d.oh, d.flags & (P2P_FLAG_PIXELS_F32 | P2P_FLAG_PIXELS_F16 | P2P_FLAG_PIXEL_CENTRES), j->border,
-                j->fov, j->pitch, j->shape, {opt.gather_blocky_from, main_order != 0, opt.gather_order, opt.gather_group,
-                                             band ? 1 : 0, band ? cell_bh : 0, band ? cell_cw : 0, band ? opt.band_maxw : 0, band ? opt.band_maxh : 0,
-                                             j->row0, j->row1}};  // (the rows the job draws: p2p_job_set_rows)
+    const PlanKey key = plan_key_of(j, band, cell_bh, cell_cw, main_order);
     const p2p::TileShape& S = shape_ops(j->shape).shape;
     const bool cached = !j->host_maps && opt.plan_cache != 0 && opt.scramble_plan == 0;
     if (cached) {
@@ -428,15 +486,10 @@ int job_build_plan(p2p_job* j, const std::function<int(Plan&)>& after_plan_pass)
     {
         // ONE block for the plan pass's tables (the device is idle while a fresh geometry's blocks are mapped: six
         // allocations were a third of the first image's device-side time), carved at 256-byte boundaries
-        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-        const size_t b_px2 = float_path ? up(slots * S.block * S.pxt * sizeof(uint32_t)) : 0;
-        const size_t b_coords = up((size_t)d.n_pitch * d.oh * d.ow * sizeof(int2));
-        const size_t b_hdr = up(slots * sizeof(p2p::PieceHdr));
-        const size_t b_px = band ? 0 : up(slots * S.block * S.pxt * sizeof(uint32_t));
-        const size_t b_items = band ? 0 : up(slots * S.cap * sizeof(uint32_t));
-        const size_t b_list = up(slots * sizeof(uint32_t));
+        const PlanBlock L = plan_block_layout(d, S, slots, band, float_path);
+        const size_t b_px2 = L.b_px2, b_coords = L.b_coords, b_hdr = L.b_hdr, b_px = L.b_px, b_items = L.b_items, b_list = L.b_list;
         unsigned char* blk = nullptr;
-        HIP_TRY(dev_alloc((void**)&blk, b_px2 + b_coords + b_hdr + b_px + b_items + b_list));
+        HIP_TRY(dev_alloc((void**)&blk, L.total()));
         Pl->d_block = blk;
         size_t off = 0;
         auto take = [&](size_t b) { unsigned char* p = b ? blk + off : nullptr; off += b; return p; };

@@ -437,8 +437,8 @@ def cold_first_image(nat, w, pano, device):
     return {"plan_ms": plan_ms, "yaw_tables_ms": tables_ms, "first_run_ms": first, "view_kernel_ms_in_first_run": k,
             "cold_one_image_ms": tables_ms + first, "first_run_ms_with_timing_events": first_t,
             "how": "fresh context and job, twice: first_run_ms = HIP events around the first p2p_job_run of a job that records "
-                   "no event of its own (one allocation for the plan's tables, the plan pass, the main kernel in grid order "
-                   "right behind it; the pass's last workgroup hands the gather count to the host through page-locked memory, "
+                   "no event of its own (the plan pass, the main kernel in grid order right behind it -- the block for the plan's "
+                   "tables was fetched from the driver at job creation, while the device made the yaw tables; the pass's last workgroup hands the gather count to the host through page-locked memory, "
                    "so neither a copy nor that kernel is waited for; the per-XCD work lists are made when a second launch asks "
                    "for them); plan_ms / view_kernel_ms_in_first_run / first_run_ms_with_timing_events from a second fresh "
                    "context with p2p_job_time_launches on (four more events inside the run); yaw tables are built at job "
