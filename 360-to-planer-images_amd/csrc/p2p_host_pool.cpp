@@ -145,7 +145,9 @@ hipError_t pin_get(void** out, size_t* cls, size_t bytes)
                 return hipSuccess;
             }
     }
-    return hipHostMalloc(out, c, hipHostMallocPortable);
+    // (portable and mapped: the plan pass of ANY device writes its counts and headers into these blocks through the block's own
+    // address -- job_build_plan)
+    return hipHostMalloc(out, c, hipHostMallocPortable | hipHostMallocMapped);
 }
 void pin_put(void* p, size_t cls) noexcept
 {

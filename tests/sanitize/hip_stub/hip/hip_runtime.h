@@ -16,7 +16,7 @@ enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErr
 typedef struct p2p_stub_stream* hipStream_t;
 typedef struct p2p_stub_event* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
-enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocPortable = 1 };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocPortable = 1, hipHostMallocMapped = 2 };
 struct int2 { int x, y; };
 struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
