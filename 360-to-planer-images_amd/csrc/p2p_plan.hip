@@ -46,13 +46,15 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* s_scan
 
 // min / max over the 64 lanes of a wave, in every lane: a Hillis-Steele scan inside each row of 16 lanes (DPP
 // row_shr), the rows' totals passed on by row_bcast, the wave's total read from lane 63.  Lanes that a step gives
-// no source keep their value.
+// no source keep their value: the DPP move's `old` operand is the operation's identity, so that min / max with it changes
+// nothing -- and so that the compiler folds the move into the operation (v_min_i32_dpp; with `old` = the value itself it
+// emitted v_mov + v_mov_dpp + v_min + s_nop per step).
 template <bool MAX>
 __device__ __forceinline__ int wave_reduce(int v)
 {
 #define P2P_DPP_STEP(ctrl, row_mask)                                                  \
     {                                                                                 \
-        const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, row_mask, 0xf, false);  \
+        const int o = __builtin_amdgcn_update_dpp(MAX ? INT32_MIN : INT32_MAX, v, ctrl, row_mask, 0xf, false);  \
         v = MAX ? max(v, o) : min(v, o);                                              \
     }
     P2P_DPP_STEP(0x111, 0xf)  // row_shr:1
