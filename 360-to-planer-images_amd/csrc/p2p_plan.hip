@@ -258,11 +258,12 @@ __device__ __forceinline__ void plan_tile(const PlanParams& P)
             const bool exists = (px & ~3) < P.ow && py < P.oh;
             int qx0 = inrange[j] ? ix[j] : INT32_MAX, qx1 = inrange[j] ? ix[j] : INT32_MIN;
             int qy0 = inrange[j] ? iy[j] : INT32_MAX, qy1 = inrange[j] ? iy[j] : INT32_MIN;
+// (every lane of a quad has a source; the identity as the move's `old` value lets the compiler fold move and operation)
 #define P2P_QUAD_STEP(ctrl)                                                                          \
-            qx0 = min(qx0, __builtin_amdgcn_update_dpp(qx0, qx0, ctrl, 0xf, 0xf, false));            \
-            qx1 = max(qx1, __builtin_amdgcn_update_dpp(qx1, qx1, ctrl, 0xf, 0xf, false));            \
-            qy0 = min(qy0, __builtin_amdgcn_update_dpp(qy0, qy0, ctrl, 0xf, 0xf, false));            \
-            qy1 = max(qy1, __builtin_amdgcn_update_dpp(qy1, qy1, ctrl, 0xf, 0xf, false));
+            qx0 = min(qx0, __builtin_amdgcn_update_dpp(INT32_MAX, qx0, ctrl, 0xf, 0xf, false));      \
+            qx1 = max(qx1, __builtin_amdgcn_update_dpp(INT32_MIN, qx1, ctrl, 0xf, 0xf, false));      \
+            qy0 = min(qy0, __builtin_amdgcn_update_dpp(INT32_MAX, qy0, ctrl, 0xf, 0xf, false));      \
+            qy1 = max(qy1, __builtin_amdgcn_update_dpp(INT32_MIN, qy1, ctrl, 0xf, 0xf, false));
             P2P_QUAD_STEP(0xB1)  // quad_perm:[1,0,3,2]
             P2P_QUAD_STEP(0x4E)  // quad_perm:[2,3,0,1]
 #undef P2P_QUAD_STEP
