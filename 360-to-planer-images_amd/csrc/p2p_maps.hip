@@ -21,7 +21,14 @@ __device__ __forceinline__ float yaw_row_eval(int col, int pw, double yaw_rad)
     float u = (float)col;
     float phi = __fdiv_rn(TWO_PI_F * u, (float)pw);  // P:95 (float32)
     double pr = (double)phi + yaw_rad;                // P:98: float32 + np.float64 -> float64
-    double m = fmod(pr, TWO_PI_D);                    // NumPy's floored '%'
+    // NumPy's floored '%': fmod, then the sign fix.  fmod is exact by definition; for 0 <= pr < 4 pi -- every column of a
+    // yaw in [0, 360) degrees -- so are pr itself and pr - 2 pi (y / 2 <= x <= 2 y: the difference of two doubles that close
+    // is representable), and the general routine, a long loop in double precision, is only entered by lanes outside that range
+    double m;
+    if (pr >= 0.0 && pr < 2.0 * TWO_PI_D)
+        m = pr >= TWO_PI_D ? pr - TWO_PI_D : pr;
+    else
+        m = fmod(pr, TWO_PI_D);
     if (m != 0.0) {
         if (m < 0.0)
             m += TWO_PI_D;
