@@ -135,7 +135,7 @@ __device__ __forceinline__ void draw_float(
 
     // ---- this thread's pixels ----
     uint32_t tap_up[PXT], tap_lo[PXT];
-    float fu[PXT];
+    float fu[PXT], fus[PXT];  // the column fraction, and (float16 path) 512 times it
     float wyf[PXT];          // float32 path: the row weight
     f16x2 wy2[PXT];          // float16 path: both row weights, packed, times 2^15 (the column weights carry 2^9)
     bool live[PXT];
@@ -147,6 +147,7 @@ __device__ __forceinline__ void draw_float(
         tap_lo[j] = tap_up[j] + (dl << 2);
         live[j] = dl != 0u;
         fu[j] = (float)(fr & 0xFFFFu) * (1.0f / 65536.0f);
+        fus[j] = fu[j] * 512.0f;
         const float wy = (float)(fr >> 16) * (1.0f / 65536.0f);
         wyf[j] = wy;
         wy2[j] = row_weights_f16(wy, live[j]);
@@ -257,15 +258,22 @@ __device__ __forceinline__ void draw_float(
             const unsigned char* tl = reinterpret_cast<const unsigned char*>(&tile4[0][0]);
             uint32_t ta[PXT][4];
             float wx[PXT];
+            // (float16 path: fractions and weights times 512 = 2^9 throughout -- the scale the dot products' results are
+            // short of; a power of two, so the sums and differences are the unscaled ones' times 512 exactly -- and the two tap
+            // advances of a pair, with and without the carry, ready in registers: one select per pixel instead of select + add)
+            const float sfs = HALF ? sf * 512.0f : sf;
+            const float one = HALF ? 512.0f : 1.0f;
+            uint32_t soff4 = soff + 4u;
+            asm volatile("" : "+v"(soff4));
 #pragma unroll
             for (int j = 0; j < PXT; ++j) {
                 // fraction of the pixel's own coordinate + fraction of the yaw shift; a carry moves the taps one column on
                 // (the sum with one added, v_fract_f32 for the weight and bit 30 of the pattern for the carry: ten vector
                 // instructions fewer per iteration and not a microsecond faster -- docs/experiments.md)
-                float xs = fu[j] + sf;
-                const bool carry = xs >= 1.0f;
-                wx[j] = carry ? xs - 1.0f : xs;
-                const uint32_t adv = soff + (carry ? 4u : 0u);
+                float xs = (HALF ? fus[j] : fu[j]) + sfs;
+                const bool carry = xs >= one;
+                wx[j] = carry ? xs - one : xs;
+                const uint32_t adv = HALF ? (carry ? soff4 : soff) : soff + (carry ? 4u : 0u);
                 const uint32_t* up = reinterpret_cast<const uint32_t*>(tl + (tap_up[j] + adv));
                 const uint32_t* lo = reinterpret_cast<const uint32_t*>(tl + (tap_lo[j] + adv));
                 ta[j][0] = up[0];
@@ -279,7 +287,7 @@ __device__ __forceinline__ void draw_float(
 #pragma unroll
             for (int j = 0; j < PXT; ++j) {
                 if (HALF) {
-                    const float w1 = wx[j] * 512.0f;
+                    const float w1 = wx[j];  // (times 512 already)
                     pix[j] = blend_f16(ta[j][0], ta[j][1], ta[j][2], ta[j][3], wy2[j], 512.0f - w1, w1);
                     // (one pixel after the other: left to itself the scheduler interleaves the four blends, and the
                     // kernel's 80 registers -- six waves per SIMD -- no longer hold them)
