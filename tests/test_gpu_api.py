@@ -335,6 +335,32 @@ def test_one_shot_pool_is_bounded_and_survives_many_threads(gpu, pkg, synth, mon
     assert np.array_equal(pkg.process_views(pano, yaws[:2], [60], 96, 64)[1, 0], want[1, 0])
 
 
+def test_plan_pass_is_timed_only_for_jobs_that_ask(gpu, synth):
+    """p2p_job_plan_ms (include/p2p_hip.h): the yaw tables are always timed; the plan pass only when the job that built the plan
+    had launch timing on before its first run -- two events around the pass are 10 us of a cold image's device time.  Both a
+    per-view plan and a band plan (the reference CLI's default view set); the views do not depend on it."""
+    pano = synth.synth_pano(2048, 1024, 7201, "S")
+    for geo in ((320, 180, [0, 90, 180, 270], [60, 90, 120]), (200, 200, [0, 90, 180, 270], [30, 60, 90, 120, 150])):
+        ow, oh, yaws, pitches = geo
+        views = []
+        for timed in (False, True):
+            ctx = gpu.Context(0)   # (a context of its own: the plan comes out of no cache)
+            try:
+                job = gpu.Job(ctx, 2048, 1024, 1, yaws, pitches, 90, ow, oh)
+                job.set_pano(0, pano)
+                if timed:
+                    job.time_launches(1)
+                job.run()
+                plan_ms, tables_ms = job.plan_ms()
+                assert tables_ms > 0.0
+                assert (plan_ms > 0.0) == timed, (geo, timed, plan_ms)
+                views.append(job.get_views(0).copy())
+                job.close()
+            finally:
+                ctx.close()
+        assert np.array_equal(views[0], views[1])
+
+
 def test_threads_build_different_plans_on_one_context(gpu, synth):
     """Several threads create jobs of DIFFERENT geometries on one context and run them at the same time: every plan pass
     counts its gather tiles in words that belong to the context (one pass at a time, csrc/p2p_host_plan.cpp) and hands the
