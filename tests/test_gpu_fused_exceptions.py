@@ -1,9 +1,14 @@
 """The fused mode's KNOWN exceptions to "+-1 per channel", pinned (arithmetic contract).  With device-evaluated
-maps (the default mode) two things are allowed to differ from the oracle's NumPy maps by more than one level, and
+maps (the default mode) three things are allowed to differ from the oracle's NumPy maps by more than one level, and
 nothing else is:
   * the pole pixel -- one output pixel per view whose ray has x = 0 exactly and points less than a source row past a
     pole: its azimuth is arctan2(+-0, z'), z' a rounding residue of the pitch rotation (P:155's sgemm, P:164), and the
     SIGN of that residue picks one of two columns half a panorama apart.  Any colour of the pole row may come out;
+  * the seam row (round 6) -- an output ROW whose rays, rotated by the pitch, have y' = 0 exactly (tan(pitch) * focal length is
+    that row's y: FOV 120, pitch 30, W / 2 divisible by 3), so that the azimuth of its pixels with x' > 0 is arctan2(+-0, x')
+    and the sign of the residue puts a pixel at U = 0 or at U = 2 pi, clipped to the last column (P:164-173; the reference
+    does not interpolate across the seam): column 0 or column pw - 1 of the panorama, neighbours on the sphere, a few levels
+    apart.  The reference's own choice per pixel hangs on its BLAS;
   * steep gradients under a wide FOV on a small panorama: a coordinate that lands on the other side of a 1/32-pixel
     rounding tie moves a byte by 2-3 levels where neighbouring source pixels differ by a dozen -- on at most 1e-5 of
     the bytes of a view set.
@@ -21,6 +26,8 @@ CASES = [
     ("pole pixel", 1024, 372, 183, 90, [285, 252], [9, 54], 825),
     ("fov 150 at the nadir", 1024, 188, 230, 150, [358, 3, 187], [105, 179], 751),
     ("fov 20 next to both poles", 512, 135, 353, 20, [116, 35, 182], [10, 157], 739),
+    # round 6's last fuzz round (profiles/r06_fuzz_round.txt: case 35 of seed 313): row 93 of the pitch-30 view is the seam
+    ("the seam row", 1024, 474, 344, 120, [297, 314], [30, 129], 735),
 ]
 
 
@@ -36,6 +43,12 @@ def pole_pixels(U, V, ow, ph):
     return m
 
 
+def seam_pixels(U, pw):
+    """Mask of the output pixels the oracle's own map puts ON the seam: U = 0 or U = pw - 1 (clipped), P:164-173."""
+    with np.errstate(invalid="ignore"):
+        return (U < 1.0 / 32) | (U > pw - 1 - 1.0 / 32)
+
+
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_fused_mode_differs_by_more_than_one_only_where_it_is_known_to(gpu, synth, case):
     _, pw, ow, oh, fov, yaws, pitches, seed = case
@@ -48,14 +61,21 @@ def test_fused_mode_differs_by_more_than_one_only_where_it_is_known_to(gpu, synt
     outside = 0
     for pi in range(len(pitches)):
         pole = pole_pixels(U[pi], V[pi], ow, ph)
+        seam = seam_pixels(U[pi], pw)
+        # (the seam is a property of a whole row, or of nothing: a view whose map merely touches column 0 is not excused)
+        seam_row = seam & (seam.sum(axis=1, keepdims=True) >= ow // 4)
         for yi in range(len(yaws)):
             big = d[yi, pi] > 1
             at_pole = big & pole
             assert at_pole.sum() <= 1, ("more than one pole pixel differs in a view", yaws[yi], pitches[pi], np.argwhere(at_pole)[:4].tolist())
-            rest = big & ~pole
+            at_seam = big & seam_row & ~pole
+            assert d[yi, pi][seam_row].max(initial=0) <= 8, ("the seam row: more than two neighbouring columns apart", yaws[yi], pitches[pi])
+            rest = big & ~pole & ~seam_row
             outside += int(rest.sum())
-            assert d[yi, pi][~pole].max() <= 4, ("a difference beyond a flipped 1/32-pixel coordinate", yaws[yi], pitches[pi],
-                                                 int(d[yi, pi][~pole].max()), np.argwhere(rest)[:4].tolist())
+            assert d[yi, pi][~pole & ~seam_row].max() <= 4, ("a difference beyond a flipped 1/32-pixel coordinate", yaws[yi], pitches[pi],
+                                                              int(d[yi, pi][~pole & ~seam_row].max()), np.argwhere(rest)[:4].tolist())
+            if case[0] == "the seam row" and pitches[pi] == 30:
+                assert at_seam.sum() >= 1 and np.unique(np.argwhere(at_seam)[:, 0]).size == 1  # (not vacuous: one row, and it differs)
     n_px = d.size
     assert outside <= max(1, int(1e-5 * n_px * 3)), ("fused mode: pixels off by more than 1 outside the pole pixel", outside, n_px)
 
