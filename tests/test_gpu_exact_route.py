@@ -178,6 +178,18 @@ def test_exact_mode_over_a_random_sequence_of_geometries(pkg, synth):
         tool.set_exact(False)
 
 
+def test_exact_mode_on_the_seam_row_and_the_pole_pixel(pkg, synth):
+    """The geometries where device-evaluated maps are KNOWN to differ from NumPy's (tests/test_gpu_fused_exceptions.py: an
+    output row whose rays land exactly on the seam, FOV 120 / pitch 30 / W = 474; the pixel that looks a fraction of a row
+    past a pole): with the host-evaluated maps of the exact mode the views are the oracle's bytes there too, on noise."""
+    tool = pkg.panorama_to_plane_pitch
+    for pw, ow, oh, fov, yaws, pitches, seed in ((1024, 474, 344, 120, [297, 314], [30, 129], 735),
+                                                (1024, 372, 183, 90, [285, 252], [9, 54], 825)):
+        pano = synth.synth_pano(pw, pw // 2, seed, "N")
+        got = tool.process_views(pano, yaws, pitches, ow, oh, fov, exact=True)
+        assert np.array_equal(got, oracle_views(pano, yaws, pitches, ow, oh, fov)), (pw, ow, oh, fov)
+
+
 def test_exact_maps_through_the_view_sharded_driver(pkg, synth):
     """One image shared out to several contexts by WHOLE VIEWS (a masked job per context, its pitch subset of the maps) and
     by rows, with the exact mode's maps: the oracle's bytes either way."""
