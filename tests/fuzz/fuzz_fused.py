@@ -6,7 +6,8 @@ import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from _util import oracle_views
+from _util import oracle_maps, oracle_views
+from test_gpu_fused_exceptions import pole_pixels, seam_pixels  # the masks of the mode's pinned exceptions
 pkg = importlib.import_module("360-to-planer-images_amd"); nat = pkg._native
 synth = importlib.import_module("360-to-planer-images_amd.synth")
 import _args  # named options with hard caps (tests/fuzz/_args.py)
@@ -28,6 +29,18 @@ for case in range(int(os.environ.get("FUZZ_FIRST", "0")), n_cases):  # FUZZ_FIRS
     worst = max(worst, m)
     if m > 1:
         over += 1
-        print("case %d: max diff %d (%d bytes > 1 of %d), differing %.4f  " % (case, m, big, d.size, frac),
+        # where: the pole pixel, the seam row, or elsewhere (tests/test_gpu_fused_exceptions.py has the definitions)
+        _, U, V = oracle_maps(yaws, pitches, ow, oh, pw, ph, fov)
+        px = d.max(axis=-1) > 1  # [yaw][pitch][oh][ow]
+        n_pole = n_seam = n_else = 0
+        for pi in range(len(pitches)):
+            pole = pole_pixels(U[pi], V[pi], ow, ph)
+            seam = seam_pixels(U[pi], pw)
+            seam = seam & (seam.sum(axis=1, keepdims=True) >= ow // 4)
+            for yi in range(len(yaws)):
+                n_pole += int((px[yi, pi] & pole).sum()); n_seam += int((px[yi, pi] & seam & ~pole).sum())
+                n_else += int((px[yi, pi] & ~pole & ~seam).sum())
+        print("case %d: max diff %d (%d bytes > 1 of %d; pixels: %d pole, %d seam row, %d elsewhere), differing %.4f  "
+              % (case, m, big, d.size, n_pole, n_seam, n_else, frac),
               dict(pw=pw, ow=ow, oh=oh, fov=fov, yaws=yaws, pitches=pitches), flush=True)
 print("fuzz_fused finished: %d cases, worst difference %d, %d cases above 1, %.0f s" % (n_cases, worst, over, time.time() - t0))
