@@ -2,8 +2,8 @@
 """Where does the fused mode (device-evaluated maps) differ from the oracle by more than one level in ONE case of
 tests/fuzz/fuzz_fused.py?  Prints, per view, the differing pixels' oracle coordinates, rows and columns, and how many of the
 plan's quantised coordinates differ from the oracle's (p2p_job_get_coords).  The case is fuzz_fused's: panorama seed 700 + case.
-    python3 tests/fuzz/fused_case_report.py PW OW OH FOV "YAWS" "PITCHES" SEED
-    e.g. 1024 474 344 120 "297 314" "30 129" 735    (round 6: the seam row, tests/test_gpu_fused_exceptions.py)
+    python3 tests/fuzz/fused_case_report.py --pw 1024 --ow 474 --oh 344 --fov 120 --yaws 297 314 --pitches 30 129 --pano-seed 735
+    (the defaults: round 6's seam row, tests/test_gpu_fused_exceptions.py; named options only, as everywhere under tests/fuzz/)
 Uses the oracle (test infrastructure): lives under tests/."""
 import importlib, sys, os
 import numpy as np
@@ -11,11 +11,15 @@ ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from _util import oracle_views, oracle_maps
 pkg=importlib.import_module("360-to-planer-images_amd"); nat=pkg._native
 synth=importlib.import_module("360-to-planer-images_amd.synth")
-a=sys.argv[1:]
-pw,ow,oh,fov=(int(x) for x in a[:4]) if len(a)>=7 else (1024,474,344,120)
-yaws=[int(x) for x in a[4].split()] if len(a)>=7 else [297,314]
-pitches=[int(x) for x in a[5].split()] if len(a)>=7 else [30,129]
-seed=int(a[6]) if len(a)>=7 else 735
+import argparse
+_p = argparse.ArgumentParser(description=__doc__, allow_abbrev=False, formatter_class=argparse.RawDescriptionHelpFormatter)
+_p.add_argument("--pw", type=int, default=1024); _p.add_argument("--ow", type=int, default=474); _p.add_argument("--oh", type=int, default=344)
+_p.add_argument("--fov", type=int, default=120); _p.add_argument("--pano-seed", type=int, default=735)
+_p.add_argument("--yaws", type=int, nargs="+", default=[297, 314]); _p.add_argument("--pitches", type=int, nargs="+", default=[30, 129])
+_a = _p.parse_args()
+if not (16 <= _a.pw <= 16384 and 1 <= _a.ow <= 4096 and 1 <= _a.oh <= 4096 and len(_a.yaws) <= 16 and len(_a.pitches) <= 16):
+    _p.error("sizes out of range (pw 16..16384, views up to 4096 x 4096, at most 16 yaws and 16 pitches)")
+pw,ow,oh,fov,yaws,pitches,seed=_a.pw,_a.ow,_a.oh,_a.fov,list(_a.yaws),list(_a.pitches),_a.pano_seed
 ph=pw//2
 pano=synth.synth_pano(pw,ph,seed,"S")
 got=nat.remap_views(pano,yaws,pitches,fov,ow,oh)
