@@ -16,3 +16,4 @@ run float       tests/fuzz/fuzz_float.py --cases ${FZ_FLOAT:-120} --seed $((SEED
 run oneshot     tests/fuzz/fuzz_oneshot.py --cases ${FZ_ONESHOT:-100} --threads 4 --seed $((SEED + 16))
 run scramble    tests/fuzz/scramble_tables.py --cases 30 --seed $((SEED + 17))
 run rows        tests/fuzz/fuzz_parity.py --cases ${FZ_REAL:-200} --seed $((SEED + 18)) --rows
+run exact       tests/fuzz/fuzz_exact.py --cases ${FZ_EXACT:-200} --seed $((SEED + 19))
